@@ -1,0 +1,170 @@
+/*
+ * instance_stixels_core.h -- C ABI of the MI355X (gfx950) Instance-Stixels column-DP core.
+ *
+ * This is the drop-in boundary of the hot path: plain pointers and sizes, no C++ or torch
+ * types.  It is what the reference's host class `Stixels`
+ * (/root/reference/InstanceStixels/include/InstanceStixels/Stixels.hpp:40-96) needs from the
+ * device side: the three kernel launches of `Stixels::Compute`
+ * (/root/reference/InstanceStixels/src/Stixels.cu:509-590) plus the buffer management of
+ * `Stixels::Initialize` / `Finish` (Stixels.cu:43-283).  The header-compatible `Stixels`
+ * class in include/InstanceStixels/Stixels.hpp is implemented only in terms of these
+ * entry points.
+ *
+ * All functions return 0 on success and a negative IS_E* code on failure; the failing HIP
+ * error string is available from is_last_error().  Nothing here falls back to a CPU path.
+ */
+#ifndef INSTANCE_STIXELS_CORE_H_
+#define INSTANCE_STIXELS_CORE_H_
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IS_OK 0
+#define IS_EINVAL (-1)  /* bad argument / unsupported shape */
+#define IS_EHIP (-2)    /* HIP runtime failure, see is_last_error() */
+#define IS_ENOMEM (-3)
+
+#define IS_GROUND 0
+#define IS_OBJECT 1
+#define IS_SKY 2
+
+#define IS_DOWNSAMPLE_FACTOR 8       /* configuration.h:31 */
+#define IS_MAX_STIXELS_PER_COLUMN 200 /* configuration.h:32 */
+#define IS_INSTANCE_CLASSES 8        /* Stixels.cu:47 (Cityscapes classes 11..18) */
+#define IS_FIRST_INSTANCE_CLASS 11   /* StixelsKernels.cu:926 */
+
+/* Same fields, order and layout as `struct StixelParameters`
+ * (/root/reference/InstanceStixels/include/InstanceStixels/types.h:145-184). */
+typedef struct is_stixel_params {
+    int vhor;
+    int rows;
+    int rows_power2;
+    int rows_power2_segmentation;
+    int cols; /* = realcols, Stixels.cu:213 */
+    int max_dis;
+    float rows_log;
+    float pnexists_given_sky_log;
+    float normalization_sky;
+    float inv_sigma2_sky;
+    float puniform_sky;
+    float nopnexists_given_sky_log;
+    float pnexists_given_ground_log;
+    float puniform;
+    float nopnexists_given_ground_log;
+    float pnexists_given_object_log;
+    float nopnexists_given_object_log;
+    float baseline;
+    float focal;
+    float range_objects_z;
+    float pord;
+    float epsilon;
+    float pgrav;
+    float pblg;
+    float max_dis_log;
+    int max_sections;
+    int width_margin;
+    int segmentation_classes;
+    int segmentation_channels;
+    float prior_weight;
+    float disparity_weight;
+    float segmentation_weight;
+    float instance_weight;
+    int column_step;
+    float clustering_eps;
+    int clustering_min_pts;
+    int clustering_size_filter;
+    float invalid_disparity;
+} is_stixel_params;
+
+/* Same layout as `struct Section` (types.h:186-194), 32 bytes. */
+typedef struct is_section {
+    int type; /* IS_GROUND / IS_OBJECT / IS_SKY, -1 = terminator */
+    int vB, vT;
+    float disparity;
+    int semantic_class;
+    float cost;
+    float instance_meanx;
+    float instance_meany;
+} is_section;
+
+/* Device-side instance-candidate arrays of ONE image, laid out as the reference's
+ * d_instance_* members (Stixels.cu:56-74; filled at StixelsKernels.cu:926-942).
+ * class_offset = class_id * realcols * max_sections.  Any pointer may be NULL to skip it.
+ * Order inside a class is canonical (column ascending, then section index ascending)
+ * instead of the reference's atomic arrival order. */
+typedef struct is_instance_buffers {
+    float* d_centerofmass;     /* [8][realcols*max_sections][2]  (meanx, meany) */
+    int32_t* d_indices;        /* [8][realcols*max_sections][2]  (column, section index) */
+    uint8_t* d_core_candidates; /* [8][realcols*max_sections]    (bool)   */
+    int32_t* d_instances_per_class; /* [8] */
+} is_instance_buffers;
+
+typedef struct is_ctx is_ctx;
+
+/* Replaces the device half of Stixels::Initialize (Stixels.cu:53-74, 136-210): uploads the
+ * frame-independent LUTs and allocates all scratch for up to `max_batch` images per call.
+ *   obj_cost_lut         host, [max_dis][max_dis]   (Stixels.cu:122-129)
+ *   obj_disparity_range  host, [max_dis]            (Stixels.cu:111-115)
+ * `params->vhor` is ignored here (it is a per-frame value, Stixels.cu:532). */
+int is_ctx_create(const is_stixel_params* params, const float* obj_cost_lut,
+                  const float* obj_disparity_range, int max_batch, int device,
+                  is_ctx** out_ctx);
+
+/* Replaces Stixels::Finish (Stixels.cu:250-283). */
+int is_ctx_destroy(is_ctx* ctx);
+
+/* Replaces the JoinColumns launch (Stixels.cu:509-511, kernel StixelsKernels.cu:980-1095).
+ *   d_disparity_big  device, [n_images][rows][full_cols] row-major, image row 0 = top
+ *   d_joined         device, [n_images][realcols][rows], row 0 = image bottom
+ * `stream` is a hipStream_t (NULL = default stream). */
+int is_join_columns(is_ctx* ctx, const float* d_disparity_big, int full_cols, int median_join,
+                    float* d_joined, int n_images, void* stream);
+
+/* Replaces the ComputeObjectLUT + StixelsKernel<PAIRWISE> launches (Stixels.cu:535-590) for
+ * a batch of `n_images` independent images that share the configuration of the context.
+ *   d_joined            device, [n_images][realcols][rows]                 (read only)
+ *   d_segmentation      device, [n_images][realcols][channels][rows_power2_segmentation]
+ *                       int32, layout of tools/CNN_training/models/wrappers.py:35-61.  Read
+ *                       only: unlike the reference the input is NOT modified.
+ *   h_ground_function, h_normalization_ground, h_inv_sigma2_ground
+ *                       host, [n_images][rows]  (Stixels::PrecomputeGround, Stixels.cu:790-817)
+ *   h_vhor              host, [n_images], library convention rows-vhor_image-1 (Stixels.cu:377)
+ *   d_sections          device, [n_images][realcols][max_sections] is_section
+ *   instances           per image (array of n_images) or NULL
+ *   d_cost_table        optional device out, [n_images][realcols][rows][3] final DP costs
+ *   d_index_table       optional device out, [n_images][realcols][rows][3] int32, vB*3+prev
+ * Asynchronous with respect to the host: work is queued on `stream`. */
+int is_compute(is_ctx* ctx, const float* d_joined, const int32_t* d_segmentation,
+               const float* h_ground_function, const float* h_normalization_ground,
+               const float* h_inv_sigma2_ground, const int* h_vhor, int pairwise,
+               int n_images, is_section* d_sections, const is_instance_buffers* instances,
+               float* d_cost_table, int32_t* d_index_table, void* stream);
+
+/* Thin wrappers over the HIP runtime so that the plain-C++ host class needs no HIP headers
+ * (the reference's callers are all .cu files; ours may be plain C++). */
+int is_device_malloc(void** ptr, size_t bytes);
+int is_device_free(void* ptr);
+int is_memcpy_h2d(void* dst, const void* src, size_t bytes, void* stream);
+int is_memcpy_d2h(void* dst, const void* src, size_t bytes, void* stream);
+int is_memset(void* dst, int value, size_t bytes, void* stream);
+int is_stream_synchronize(void* stream);
+int is_device_synchronize(void);
+
+/* Introspection used by bench.py / tests. */
+const char* is_last_error(void);
+const char* is_version(void);
+/* Average duration (ms) of the DP kernel launches recorded by the last is_compute call on
+ * this context, measured with HIP events on the launch stream; <0 if timing is disabled. */
+int is_set_kernel_timing(is_ctx* ctx, int enabled);
+int is_get_kernel_times_ms(is_ctx* ctx, float* prepare_ms, float* dp_ms, float* backtrace_ms);
+size_t is_scratch_bytes(const is_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* INSTANCE_STIXELS_CORE_H_ */

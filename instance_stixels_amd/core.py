@@ -1,0 +1,186 @@
+"""ctypes binding of the HIP column-DP core (include/instance_stixels_core.h).
+
+This is the product path: it loads instance_stixels_amd/lib/libis_core.so and fails loudly if the
+library is missing -- there is no CPU fallback.  PyTorch is used only as the owner of device
+memory / streams (plumbing); every compute call goes through the C ABI.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+from .config import StixelParams, SECTION_DTYPE, INSTANCE_CLASSES
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libis_core.so")
+_LIB = None
+
+EXPORTS = [
+    "is_ctx_create", "is_ctx_destroy", "is_join_columns", "is_compute", "is_device_malloc",
+    "is_device_free", "is_memcpy_h2d", "is_memcpy_d2h", "is_memset", "is_stream_synchronize",
+    "is_device_synchronize", "is_last_error", "is_version", "is_set_kernel_timing",
+    "is_get_kernel_times_ms", "is_scratch_bytes",
+]
+
+
+class InstanceBuffers(ctypes.Structure):
+    _fields_ = [("d_centerofmass", ctypes.c_void_p), ("d_indices", ctypes.c_void_p),
+                ("d_core_candidates", ctypes.c_void_p), ("d_instances_per_class", ctypes.c_void_p)]
+
+
+class CoreError(RuntimeError):
+    pass
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise CoreError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
+                "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        L = ctypes.CDLL(LIB_PATH)
+        vp, ci, cf = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
+        L.is_ctx_create.argtypes = [ctypes.POINTER(StixelParams), vp, vp, ci, ci,
+                                    ctypes.POINTER(vp)]
+        L.is_ctx_destroy.argtypes = [vp]
+        L.is_join_columns.argtypes = [vp, vp, ci, ci, vp, ci, vp]
+        L.is_compute.argtypes = [vp, vp, vp, vp, vp, vp, vp, ci, ci, vp, vp, vp, vp, vp]
+        L.is_device_malloc.argtypes = [ctypes.POINTER(vp), ctypes.c_size_t]
+        L.is_device_free.argtypes = [vp]
+        L.is_memcpy_h2d.argtypes = [vp, vp, ctypes.c_size_t, vp]
+        L.is_memcpy_d2h.argtypes = [vp, vp, ctypes.c_size_t, vp]
+        L.is_memset.argtypes = [vp, ci, ctypes.c_size_t, vp]
+        L.is_stream_synchronize.argtypes = [vp]
+        L.is_last_error.restype = ctypes.c_char_p
+        L.is_version.restype = ctypes.c_char_p
+        L.is_set_kernel_timing.argtypes = [vp, ci]
+        L.is_get_kernel_times_ms.argtypes = [vp, ctypes.POINTER(cf), ctypes.POINTER(cf),
+                                             ctypes.POINTER(cf)]
+        L.is_scratch_bytes.argtypes = [vp]
+        L.is_scratch_bytes.restype = ctypes.c_size_t
+        _LIB = L
+    return _LIB
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise CoreError(f"{what} failed (rc={rc}): {lib().is_last_error().decode()}")
+
+
+def _hp(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+class Core:
+    """One `is_ctx`: the device half of Stixels::Initialize .. Finish for a fixed configuration."""
+
+    def __init__(self, params: StixelParams, obj_cost_lut, obj_disparity_range, max_batch=1,
+                 device=0):
+        self.params = StixelParams.from_buffer_copy(params)
+        self.max_batch = int(max_batch)
+        self.device = int(device)
+        lut = np.ascontiguousarray(obj_cost_lut, np.float32)
+        odr = np.ascontiguousarray(obj_disparity_range, np.float32)
+        D = self.params.max_dis
+        assert lut.size == D * D and odr.size == D
+        self._ctx = ctypes.c_void_p()
+        _check(lib().is_ctx_create(ctypes.byref(self.params), _hp(lut), _hp(odr), self.max_batch,
+                                   self.device, ctypes.byref(self._ctx)), "is_ctx_create")
+
+    def close(self):
+        if self._ctx:
+            lib().is_ctx_destroy(self._ctx)
+            self._ctx = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def scratch_bytes(self):
+        return int(lib().is_scratch_bytes(self._ctx))
+
+    def set_kernel_timing(self, enabled=True):
+        _check(lib().is_set_kernel_timing(self._ctx, int(enabled)), "is_set_kernel_timing")
+
+    def kernel_times_ms(self):
+        a, b, c = ctypes.c_float(), ctypes.c_float(), ctypes.c_float()
+        _check(lib().is_get_kernel_times_ms(self._ctx, ctypes.byref(a), ctypes.byref(b),
+                                            ctypes.byref(c)), "is_get_kernel_times_ms")
+        return dict(prepare_ms=a.value, dp_ms=b.value, backtrace_ms=c.value)
+
+    # ---- raw-pointer API (device pointers as ints) -------------------------------------
+    def join_columns_ptr(self, d_big, full_cols, median_join, d_joined, n_images, stream=0):
+        _check(lib().is_join_columns(self._ctx, d_big, int(full_cols), int(bool(median_join)),
+                                     d_joined, int(n_images), stream), "is_join_columns")
+
+    def compute_ptr(self, d_joined, d_seg, ground_function, normalization_ground,
+                    inv_sigma2_ground, vhor, pairwise, n_images, d_sections, instances=None,
+                    d_cost_table=None, d_index_table=None, stream=0):
+        H = self.params.rows
+        gf = np.ascontiguousarray(ground_function, np.float32).reshape(n_images, H)
+        ng = np.ascontiguousarray(normalization_ground, np.float32).reshape(n_images, H)
+        ig = np.ascontiguousarray(inv_sigma2_ground, np.float32).reshape(n_images, H)
+        vh = np.ascontiguousarray(vhor, np.int32).reshape(n_images)
+        inst = None
+        if instances is not None:
+            arr = (InstanceBuffers * n_images)(*instances)
+            inst = ctypes.cast(arr, ctypes.c_void_p)
+        _check(lib().is_compute(self._ctx, d_joined, d_seg, _hp(gf), _hp(ng), _hp(ig), _hp(vh),
+                                int(bool(pairwise)), int(n_images), d_sections, inst,
+                                d_cost_table, d_index_table, stream), "is_compute")
+
+    # ---- torch-tensor convenience API ----------------------------------------------------
+    def run(self, disparity_big=None, joined=None, segmentation=None, ground_function=None,
+            normalization_ground=None, inv_sigma2_ground=None, vhor=None, pairwise=False,
+            median_join=False, want_tables=False, want_instances=True):
+        """Runs a batch given numpy inputs; returns numpy outputs (one sync at the end).
+
+        disparity_big [n][H][W] or joined [n][C][H]; segmentation [n][C][CH][P2S]."""
+        import torch
+        p = self.params
+        C, H, S = p.cols, p.rows, p.max_sections
+        dev = torch.device("cuda", self.device)
+        seg = torch.from_numpy(np.ascontiguousarray(segmentation, np.int32)).to(dev)
+        n = seg.shape[0]
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        if joined is None:
+            big = torch.from_numpy(np.ascontiguousarray(disparity_big, np.float32)).to(dev)
+            assert big.shape[0] == n and big.shape[1] == H
+            d_joined = torch.empty((n, C, H), dtype=torch.float32, device=dev)
+            self.join_columns_ptr(big.data_ptr(), big.shape[2], median_join, d_joined.data_ptr(), n,
+                                  stream)
+        else:
+            d_joined = torch.from_numpy(np.ascontiguousarray(joined, np.float32)).to(dev)
+        sections = torch.empty((n, C, S, 8), dtype=torch.int32, device=dev)
+        cost = torch.empty((n, C, H, 3), dtype=torch.float32, device=dev) if want_tables else None
+        index = torch.empty((n, C, H, 3), dtype=torch.int32, device=dev) if want_tables else None
+        inst_t, inst_s = None, None
+        if want_instances:
+            com = torch.zeros((n, INSTANCE_CLASSES, C * S, 2), dtype=torch.float32, device=dev)
+            idx = torch.zeros((n, INSTANCE_CLASSES, C * S, 2), dtype=torch.int32, device=dev)
+            core = torch.zeros((n, INSTANCE_CLASSES, C * S), dtype=torch.uint8, device=dev)
+            per = torch.zeros((n, INSTANCE_CLASSES), dtype=torch.int32, device=dev)
+            inst_t = (com, idx, core, per)
+            inst_s = [InstanceBuffers(com[i].data_ptr(), idx[i].data_ptr(), core[i].data_ptr(),
+                                      per[i].data_ptr()) for i in range(n)]
+        self.compute_ptr(d_joined.data_ptr(), seg.data_ptr(), ground_function,
+                         normalization_ground, inv_sigma2_ground, vhor, pairwise, n,
+                         sections.data_ptr(), inst_s,
+                         cost.data_ptr() if cost is not None else None,
+                         index.data_ptr() if index is not None else None, stream)
+        torch.cuda.synchronize(dev)
+        out = dict(joined=d_joined.cpu().numpy(),
+                   sections=sections.cpu().numpy().view(SECTION_DTYPE).reshape(n, C, S))
+        if want_tables:
+            out["cost_table"] = cost.cpu().numpy()
+            out["index_table"] = index.cpu().numpy()
+        if want_instances:
+            out["inst_centerofmass"] = inst_t[0].cpu().numpy()
+            out["inst_indices"] = inst_t[1].cpu().numpy()
+            out["inst_core"] = inst_t[2].cpu().numpy()
+            out["inst_per_class"] = inst_t[3].cpu().numpy()
+        return out

@@ -1,0 +1,326 @@
+/*
+ * is_core.hip -- C ABI of the gfx950 column-DP core (include/instance_stixels_core.h).
+ *
+ * Owns what the device half of the reference's Stixels::Initialize / Compute / Finish owns
+ * (/root/reference/InstanceStixels/src/Stixels.cu:43-283, 449-637): frame-independent LUTs,
+ * per-column scratch (boundary records + object LUT), DP tables, and the launch sequence.
+ * There is no CPU fallback: every failure is reported through the return code.
+ */
+#include <hip/hip_runtime.h>
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "instance_stixels_core.h"
+#include "is_device.h"
+#include "is_numerics.h"
+
+extern "C" {
+size_t isk_prepare_lds_bytes(const DevParams* P);
+size_t isk_unary_lds_bytes(const DevParams* P);
+size_t isk_pairwise_lds_bytes(const DevParams* P, int nwaves);
+hipError_t isk_launch_join(const float*, float*, int, int, int, int, int, int, float, int, hipStream_t);
+hipError_t isk_launch_prepare(const DevParams*, int, const float*, const int32_t*, const float*,
+                              const int*, const float*, RowRec*, float*, hipStream_t);
+hipError_t isk_launch_priors(const DevParams*, const float*, PriorRec*, int, hipStream_t);
+hipError_t isk_launch_dp_unary(const DevParams*, int, int, const RowRec*, const float*, const float*,
+                               const int*, float*, int32_t*, hipStream_t);
+hipError_t isk_launch_dp_pairwise(const DevParams*, int, int, const RowRec*, const float*,
+                                  const PriorRec*, const float*, const int*, float*, int32_t*,
+                                  hipStream_t);
+hipError_t isk_launch_backtrace(const DevParams*, int, int, const RowRec*, const float*,
+                                const int32_t*, is_section*, hipStream_t);
+hipError_t isk_launch_compact(const DevParams*, const is_section*, float*, int32_t*, uint8_t*,
+                              int32_t*, hipStream_t);
+hipError_t isk_set_lds_limits(const DevParams*, int);
+}
+
+static thread_local char g_err[512] = "";
+
+static int fail_hip(hipError_t e, const char* what, const char* file, int line) {
+    snprintf(g_err, sizeof(g_err), "%s returned %s (%d) at %s:%d", what, hipGetErrorString(e),
+             (int)e, file, line);
+    return IS_EHIP;
+}
+static int fail_arg(const char* msg) {
+    snprintf(g_err, sizeof(g_err), "invalid argument: %s", msg);
+    return IS_EINVAL;
+}
+#define HIP_TRY(expr)                                                    \
+    do {                                                                 \
+        hipError_t e__ = (expr);                                         \
+        if (e__ != hipSuccess) return fail_hip(e__, #expr, __FILE__, __LINE__); \
+    } while (0)
+
+struct is_ctx {
+    is_stixel_params params;
+    DevParams dp;
+    int device;
+    int max_batch;
+    int nwaves_unary, nwaves_pairwise;
+    /* frame-independent device tables */
+    float* d_obj_cost_lut;   /* [D][D]  */
+    float* d_odr;            /* [D]     object_disparity_range */
+    float* d_pwinv;          /* [H+1]   prior_weight * (float)(1.0/h) */
+    /* per-call device inputs */
+    float* d_ground;         /* [max_batch][3][H] */
+    int* d_vhor;             /* [max_batch] */
+    float* h_ground_pinned;
+    int* h_vhor_pinned;
+    hipEvent_t staging_free; /* recorded after the H2D copies of the last call */
+    bool staging_pending;
+    /* scratch */
+    RowRec* d_recs;          /* [max_batch*C][H+1] */
+    float* d_lutT;           /* [max_batch*C][H+1][D] */
+    PriorRec* d_priors;      /* [max_batch][H] */
+    float* d_cost_table;     /* [max_batch*C][H][3] */
+    int32_t* d_index_table;  /* [max_batch*C][H][3] */
+    size_t scratch_bytes;
+    /* timing */
+    bool timing;
+    hipEvent_t ev[4];
+    bool ev_valid;
+};
+
+static int ilog2_exact(int n) {
+    int l = 0;
+    while ((1 << l) < n) l++;
+    return l;
+}
+
+const char* is_last_error(void) { return g_err; }
+const char* is_version(void) { return "instance_stixels_amd-core 0.1 (gfx950)"; }
+
+int is_device_malloc(void** ptr, size_t bytes) { HIP_TRY(hipMalloc(ptr, bytes)); return IS_OK; }
+int is_device_free(void* ptr) { HIP_TRY(hipFree(ptr)); return IS_OK; }
+int is_memcpy_h2d(void* dst, const void* src, size_t bytes, void* stream) {
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+    return IS_OK;
+}
+int is_memcpy_d2h(void* dst, const void* src, size_t bytes, void* stream) {
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    return IS_OK;
+}
+int is_memset(void* dst, int value, size_t bytes, void* stream) {
+    HIP_TRY(hipMemsetAsync(dst, value, bytes, (hipStream_t)stream));
+    return IS_OK;
+}
+int is_stream_synchronize(void* stream) { HIP_TRY(hipStreamSynchronize((hipStream_t)stream)); return IS_OK; }
+int is_device_synchronize(void) { HIP_TRY(hipDeviceSynchronize()); return IS_OK; }
+
+size_t is_scratch_bytes(const is_ctx* ctx) { return ctx ? ctx->scratch_bytes : 0; }
+
+int is_ctx_create(const is_stixel_params* p, const float* obj_cost_lut,
+                  const float* obj_disparity_range, int max_batch, int device, is_ctx** out_ctx) {
+    if (!p || !obj_cost_lut || !obj_disparity_range || !out_ctx) return fail_arg("null pointer");
+    if (max_batch < 1) return fail_arg("max_batch < 1");
+    if (p->column_step != IS_DOWNSAMPLE_FACTOR)
+        return fail_arg("column_step must be 8 (assert at StixelsKernels.cu:318)");
+    if (p->rows < 8 || p->rows % 8 != 0) return fail_arg("rows must be a positive multiple of 8");
+    if (p->rows * 3 + 2 >= 32768) return fail_arg("rows too large for the int16 index convention");
+    if (p->max_dis < 2 || p->max_dis > 1024) return fail_arg("max_dis out of range [2, 1024]");
+    if (p->segmentation_classes != 19 || p->segmentation_channels != 21)
+        return fail_arg("the class model is Cityscapes: 19 classes + 2 offset channels (Cityscapes.h)");
+    if (p->cols < 1) return fail_arg("cols (realcols) < 1");
+    if (p->max_sections < 2) return fail_arg("max_sections < 2");
+    const int P2 = 1 << ilog2_exact(p->rows + 1);
+    const int P2S = 1 << ilog2_exact(p->rows / 8 + 1);
+    if (p->rows_power2 != P2 || p->rows_power2_segmentation != P2S)
+        return fail_arg("rows_power2 / rows_power2_segmentation inconsistent with rows (Stixels.cu:131-133)");
+
+    HIP_TRY(hipSetDevice(device));
+    is_ctx* c = (is_ctx*)calloc(1, sizeof(is_ctx));
+    if (!c) return IS_ENOMEM;
+    c->params = *p;
+    c->device = device;
+    c->max_batch = max_batch;
+
+    DevParams& d = c->dp;
+    d.H = p->rows; d.C = p->cols; d.D = p->max_dis; d.P2 = P2; d.P2S = P2S;
+    d.CH = p->segmentation_channels; d.K = p->segmentation_classes; d.S = p->max_sections;
+    d.ntiles = (d.H + IS_TILE - 1) / IS_TILE;
+    d.log2P2 = ilog2_exact(P2);
+    d.invalid = p->invalid_disparity;
+    d.pnex_sky_log = p->pnexists_given_sky_log; d.norm_sky = p->normalization_sky;
+    d.inv_sigma2_sky = p->inv_sigma2_sky; d.puniform_sky = p->puniform_sky;
+    d.nopnex_sky_log = p->nopnexists_given_sky_log;
+    d.pnex_gnd_log = p->pnexists_given_ground_log; d.puniform = p->puniform;
+    d.nopnex_gnd_log = p->nopnexists_given_ground_log;
+    d.dw = p->disparity_weight; d.pw = p->prior_weight; d.sw = p->segmentation_weight;
+    d.iw = p->instance_weight;
+    d.rows_log = p->rows_log; d.max_dis_log = p->max_dis_log; d.epsilon = p->epsilon;
+    d.pgrav = p->pgrav; d.pblg = p->pblg; d.pord = p->pord; d.max_disf = (float)p->max_dis;
+    d.log2c = is_logf(2.0f);
+    d.nlog07 = -is_logf(0.7f);
+    d.nlog03 = -is_logf(0.3f);
+    d.first_g = d.log2c + d.rows_log;                       /* StixelsKernels.cu:196-199 */
+    d.first_o_below = d.rows_log + d.log2c + d.max_dis_log; /* :189-194 */
+    d.first_o_above = d.rows_log + 0.0f + d.max_dis_log;
+    d.size_filter = p->clustering_size_filter;
+    d.column_step = p->column_step;
+
+    /* waves per DP workgroup: the LUT tile is 64*(D+1) floats; keep >= 16 waves per CU */
+    c->nwaves_unary = (d.D <= 128) ? 4 : 8;
+    c->nwaves_pairwise = 4;
+    if (isk_unary_lds_bytes(&d) > 160 * 1024 || isk_pairwise_lds_bytes(&d, c->nwaves_pairwise) > 160 * 1024 ||
+        isk_prepare_lds_bytes(&d) > 160 * 1024) {
+        free(c);
+        return fail_arg("shape needs more than 160 KiB of LDS per workgroup");
+    }
+
+    const size_t H = d.H, C = d.C, D = d.D, B = max_batch;
+    size_t total = 0;
+#define ALLOC(ptr, bytes)                                     \
+    do {                                                      \
+        HIP_TRY(hipMalloc((void**)&(ptr), (bytes)));          \
+        total += (bytes);                                     \
+    } while (0)
+    ALLOC(c->d_obj_cost_lut, sizeof(float) * D * D);
+    ALLOC(c->d_odr, sizeof(float) * D);
+    ALLOC(c->d_pwinv, sizeof(float) * (H + 1));
+    ALLOC(c->d_ground, sizeof(float) * B * 3 * H);
+    ALLOC(c->d_vhor, sizeof(int) * B);
+    ALLOC(c->d_recs, sizeof(RowRec) * B * C * (H + 1));
+    ALLOC(c->d_lutT, sizeof(float) * B * C * (H + 1) * D);
+    ALLOC(c->d_priors, sizeof(PriorRec) * B * H);
+    ALLOC(c->d_cost_table, sizeof(float) * B * C * H * 3);
+    ALLOC(c->d_index_table, sizeof(int32_t) * B * C * H * 3);
+#undef ALLOC
+    c->scratch_bytes = total;
+    HIP_TRY(hipHostMalloc((void**)&c->h_ground_pinned, sizeof(float) * B * 3 * H));
+    HIP_TRY(hipHostMalloc((void**)&c->h_vhor_pinned, sizeof(int) * B));
+    HIP_TRY(hipEventCreateWithFlags(&c->staging_free, hipEventDisableTiming));
+    for (int i = 0; i < 4; i++) HIP_TRY(hipEventCreate(&c->ev[i]));
+
+    HIP_TRY(hipMemcpy(c->d_obj_cost_lut, obj_cost_lut, sizeof(float) * D * D, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->d_odr, obj_disparity_range, sizeof(float) * D, hipMemcpyHostToDevice));
+    {
+        /* prior_weight * inverse_height with inverse_height = (float)(1./(vT+1-vB)),
+         * StixelsKernels.cu:485, 608, 716-719 */
+        float* t = (float*)malloc(sizeof(float) * (H + 1));
+        t[0] = 0.0f;
+        for (size_t h = 1; h <= H; h++) {
+            const float inverse_height = (float)(1. / (double)h);
+            t[h] = p->prior_weight * inverse_height;
+        }
+        hipError_t e = hipMemcpy(c->d_pwinv, t, sizeof(float) * (H + 1), hipMemcpyHostToDevice);
+        free(t);
+        HIP_TRY(e);
+    }
+    HIP_TRY(isk_set_lds_limits(&d, c->nwaves_pairwise));
+    *out_ctx = c;
+    return IS_OK;
+}
+
+int is_ctx_destroy(is_ctx* c) {
+    if (!c) return IS_OK;
+    hipSetDevice(c->device);
+    hipDeviceSynchronize();
+    hipFree(c->d_obj_cost_lut); hipFree(c->d_odr); hipFree(c->d_pwinv); hipFree(c->d_ground);
+    hipFree(c->d_vhor); hipFree(c->d_recs); hipFree(c->d_lutT); hipFree(c->d_priors);
+    hipFree(c->d_cost_table); hipFree(c->d_index_table);
+    hipHostFree(c->h_ground_pinned); hipHostFree(c->h_vhor_pinned);
+    hipEventDestroy(c->staging_free);
+    for (int i = 0; i < 4; i++) hipEventDestroy(c->ev[i]);
+    free(c);
+    return IS_OK;
+}
+
+int is_join_columns(is_ctx* c, const float* d_big, int full_cols, int median_join, float* d_joined,
+                    int n_images, void* stream) {
+    if (!c || !d_big || !d_joined) return fail_arg("null pointer");
+    if (n_images < 1) return fail_arg("n_images < 1");
+    const is_stixel_params& p = c->params;
+    if (p.column_step > 16) return fail_arg("column_step > 16");
+    if (p.width_margin + p.cols * p.column_step > full_cols)
+        return fail_arg("full_cols smaller than width_margin + realcols*column_step");
+    HIP_TRY(isk_launch_join(d_big, d_joined, p.rows, full_cols, p.cols, p.column_step,
+                            p.width_margin, median_join, p.invalid_disparity, n_images,
+                            (hipStream_t)stream));
+    return IS_OK;
+}
+
+int is_set_kernel_timing(is_ctx* c, int enabled) {
+    if (!c) return fail_arg("null ctx");
+    c->timing = enabled != 0;
+    c->ev_valid = false;
+    return IS_OK;
+}
+
+int is_get_kernel_times_ms(is_ctx* c, float* prepare_ms, float* dp_ms, float* backtrace_ms) {
+    if (!c) return fail_arg("null ctx");
+    if (!c->timing || !c->ev_valid) return fail_arg("kernel timing not enabled / no call recorded");
+    HIP_TRY(hipEventSynchronize(c->ev[3]));
+    float a = 0, b = 0, d = 0;
+    HIP_TRY(hipEventElapsedTime(&a, c->ev[0], c->ev[1]));
+    HIP_TRY(hipEventElapsedTime(&b, c->ev[1], c->ev[2]));
+    HIP_TRY(hipEventElapsedTime(&d, c->ev[2], c->ev[3]));
+    if (prepare_ms) *prepare_ms = a;
+    if (dp_ms) *dp_ms = b;
+    if (backtrace_ms) *backtrace_ms = d;
+    return IS_OK;
+}
+
+int is_compute(is_ctx* c, const float* d_joined, const int32_t* d_seg, const float* h_gf,
+               const float* h_ng, const float* h_is2, const int* h_vhor, int pairwise, int n_images,
+               is_section* d_sections, const is_instance_buffers* instances, float* d_cost_table,
+               int32_t* d_index_table, void* stream_) {
+    if (!c || !d_joined || !d_seg || !h_gf || !h_ng || !h_is2 || !h_vhor || !d_sections)
+        return fail_arg("null pointer");
+    if (n_images < 1 || n_images > c->max_batch) return fail_arg("n_images outside [1, max_batch]");
+    hipStream_t stream = (hipStream_t)stream_;
+    const DevParams& P = c->dp;
+    const size_t H = P.H;
+    const int ncols = n_images * P.C;
+
+    /* stage the per-frame ground model (the reference does 3 blocking cudaMemcpy per frame,
+     * Stixels.cu:479-493); pinned + async here, guarded against reuse by an event */
+    if (c->staging_pending) HIP_TRY(hipEventSynchronize(c->staging_free));
+    for (int i = 0; i < n_images; i++) {
+        float* dst = c->h_ground_pinned + (size_t)i * 3 * H;
+        memcpy(dst, h_gf + (size_t)i * H, sizeof(float) * H);
+        memcpy(dst + H, h_ng + (size_t)i * H, sizeof(float) * H);
+        memcpy(dst + 2 * H, h_is2 + (size_t)i * H, sizeof(float) * H);
+        c->h_vhor_pinned[i] = h_vhor[i];
+    }
+    HIP_TRY(hipMemcpyAsync(c->d_ground, c->h_ground_pinned, sizeof(float) * n_images * 3 * H,
+                           hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(c->d_vhor, c->h_vhor_pinned, sizeof(int) * n_images,
+                           hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipEventRecord(c->staging_free, stream));
+    c->staging_pending = true;
+
+    float* ct = d_cost_table ? d_cost_table : c->d_cost_table;
+    int32_t* it = d_index_table ? d_index_table : c->d_index_table;
+
+    if (c->timing) HIP_TRY(hipEventRecord(c->ev[0], stream));
+    HIP_TRY(isk_launch_prepare(&P, ncols, d_joined, d_seg, c->d_ground, c->d_vhor,
+                               c->d_obj_cost_lut, c->d_recs, c->d_lutT, stream));
+    if (pairwise) HIP_TRY(isk_launch_priors(&P, c->d_ground, c->d_priors, n_images, stream));
+    if (c->timing) HIP_TRY(hipEventRecord(c->ev[1], stream));
+    if (pairwise)
+        HIP_TRY(isk_launch_dp_pairwise(&P, ncols, c->nwaves_pairwise, c->d_recs, c->d_lutT,
+                                       c->d_priors, c->d_odr, c->d_vhor, ct, it, stream));
+    else
+        HIP_TRY(isk_launch_dp_unary(&P, ncols, c->nwaves_unary, c->d_recs, c->d_lutT, c->d_pwinv,
+                                    c->d_vhor, ct, it, stream));
+    if (c->timing) HIP_TRY(hipEventRecord(c->ev[2], stream));
+    HIP_TRY(isk_launch_backtrace(&P, ncols, pairwise ? 1 : 0, c->d_recs, ct, it, d_sections, stream));
+    if (instances) {
+        for (int i = 0; i < n_images; i++) {
+            const is_instance_buffers& ib = instances[i];
+            if (!ib.d_centerofmass && !ib.d_indices && !ib.d_core_candidates && !ib.d_instances_per_class)
+                continue;
+            HIP_TRY(isk_launch_compact(&P, d_sections + (size_t)i * P.C * P.S, ib.d_centerofmass,
+                                       ib.d_indices, ib.d_core_candidates, ib.d_instances_per_class,
+                                       stream));
+        }
+    }
+    if (c->timing) {
+        HIP_TRY(hipEventRecord(c->ev[3], stream));
+        c->ev_valid = true;
+    }
+    return IS_OK;
+}

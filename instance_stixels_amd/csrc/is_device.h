@@ -1,0 +1,72 @@
+/*
+ * is_device.h -- device-side data layout of the gfx950 column-DP core.
+ *
+ * HBM layout per stixel column (see DESIGN.md "Data layout"):
+ *   RowRec recs[rows+1]      one 128-byte record per prefix index v (0..rows): every quantity
+ *                            the DP needs at a segment boundary, so that a segment (vB, vT)
+ *                            costs one record at vT+1 (held in VGPRs by the lane that owns
+ *                            vT) and one record at vB (wave-uniform -> scalar loads -> SGPRs).
+ *   float   lutT[rows+1][D]  object data-cost prefix table, transposed w.r.t. the reference's
+ *                            d_object_lut[fn][v] (Stixels.cu:159-160) so that the vB-side
+ *                            gather of a wave stays inside one 4*D-byte row.
+ */
+#ifndef IS_DEVICE_H_
+#define IS_DEVICE_H_
+
+#include <stdint.h>
+
+#define IS_TILE 64          /* rows (vT values) per DP tile = one wavefront */
+#define IS_N_ON 8           /* non-instance object classes 2..9   (Cityscapes.h:69) */
+#define IS_N_OI 8           /* instance object classes     11..18 (Cityscapes.h:75) */
+
+/* Full-resolution exclusive prefix values at row index v (v = 0..rows).
+ * F_c[v] = sum_{j<v} x_c[j/8] in wrapping int32: DownsampledSum(c, vB, vT) of
+ * Cityscapes.h:28-42 equals F_c[vT+1] - F_c[vB] exactly (ring arithmetic mod 2^32). */
+struct __attribute__((aligned(128))) RowRec {
+    int32_t Fg0, Fg1;        /* classes 0 (road), 1 (sidewalk)            */
+    int32_t Fon[IS_N_ON];    /* classes 2..9                                */
+    int32_t Foi[IS_N_OI];    /* classes 11..18                              */
+    int32_t Fsky;            /* class 10                                    */
+    int32_t Fnic;            /* squared offset channels, x + y (StixelsKernels.cu:62-70) */
+    float G;                 /* ground data-cost prefix (Blelloch association)  */
+    float K;                 /* sky data-cost prefix    (Blelloch association)  */
+    float S;                 /* disparity prefix        (Blelloch association)  */
+    float V;                 /* valid-pixel count prefix (exact)                */
+    int64_t MX, MY, MX2, MY2; /* instance-centre prefix sums (StixelsKernels.cu:401-409) */
+};
+static_assert(sizeof(RowRec) == 128, "RowRec must be one 128-byte line");
+
+/* Per-vB transition priors of the pairwise model that do not depend on the DP state
+ * (StixelsKernels.cu:88-199); one 32-byte record per vB, read with scalar loads. */
+struct __attribute__((aligned(32))) PriorRec {
+    float pc;        /* GetPriorCost(vB, rows)                      :40-42   */
+    float g_from;    /* GetPriorCostGround(pc)                      :185-187 */
+    float s_from_g;  /* GetPriorCostSkyFromGround                   :98-106  */
+    float o_from_s;  /* GetPriorCostObjectFromSky if fn > epsilon   :173-183 */
+    float og_hi;     /* GetPriorCostObjectFromGround, fn > g+eps    :132-135 */
+    float og_lo;     /*                               fn < g-eps    :136-139 */
+    float og_mid;    /*                               otherwise     :140-142 */
+    float g_prev;    /* max(0, ground_function[vB-1])               :127-130 */
+};
+static_assert(sizeof(PriorRec) == 32, "PriorRec must be 32 bytes");
+
+struct DevParams {
+    int H, C, D, P2, P2S, CH, K, S;
+    int ntiles;        /* ceil(H / IS_TILE) */
+    int log2P2;
+    float invalid;
+    /* sky / ground data terms (StixelsKernels.cu:201-234) */
+    float pnex_sky_log, norm_sky, inv_sigma2_sky, puniform_sky, nopnex_sky_log;
+    float pnex_gnd_log, puniform, nopnex_gnd_log;
+    /* weights */
+    float dw, pw, sw, iw;
+    /* pairwise model */
+    float rows_log, max_dis_log, epsilon, pgrav, pblg, pord, max_disf;
+    float log2c, nlog07, nlog03; /* is_logf(2), -is_logf(0.7), -is_logf(0.3) */
+    float first_g;  /* GetPriorCostGroundFirst  :196-199 */
+    float first_o_below, first_o_above; /* GetPriorCostObjectFirst :189-194 */
+    int size_filter;
+    int column_step;
+};
+
+#endif /* IS_DEVICE_H_ */

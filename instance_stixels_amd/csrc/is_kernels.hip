@@ -1,0 +1,1082 @@
+/*
+ * is_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the Instance-Stixels
+ * column DP.  Nothing here is translated from the reference's CUDA: the reference runs one
+ * 1024-thread block per column with a barrier per vB and 126 global loads per (vB, vT) pair
+ * (/root/reference/InstanceStixels/src/StixelsKernels.cu:600-839); this file restructures
+ * the same arithmetic (bit-exactly, see DESIGN.md "Exact rewrites") as
+ *
+ *   k_join_columns      A3   StixelsKernels.cu:980-1095   LDS-transposed, coalesced both ways
+ *   k_prepare_columns   A4-A6 StixelsKernels.cu:236-296, 371-469, 959-978 and
+ *                            StixelsKernels.h:73-103: per-row boundary records + object LUT
+ *   k_prior_tables      A9   StixelsKernels.cu:88-199 (DP-state independent part)
+ *   k_dp_unary          A7-A9 StixelsKernels.cu:477-839, PAIRWISE=false: independent
+ *                            (column, 64-row tile) work items, one lane per vT, vB-side
+ *                            operands in SGPRs via scalar loads, vT-side LUT rows in LDS
+ *   k_dp_pairwise       A7-A9 PAIRWISE=true: one workgroup per column walking the tiles
+ *   k_backtrace         A10  StixelsKernels.cu:843-955
+ *   k_compact_instances A10  StixelsKernels.cu:926-942 in canonical order
+ *
+ * Numerics contract: IEEE fp32, no contraction (-ffp-contract=off), correctly rounded
+ * division, no fast-math; integer sums in wrapping int32 / int64 like the reference.
+ */
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "instance_stixels_core.h"
+#include "is_device.h"
+#include "is_numerics.h"
+
+#define IS_INF (__builtin_inff())
+
+typedef const __attribute__((address_space(4))) RowRec* crec_t;     /* scalar-load view */
+typedef const __attribute__((address_space(4))) PriorRec* cprior_t;
+
+/* ====================================================================================== */
+/* A3  JoinColumns                                                                         */
+/* ====================================================================================== */
+#define JOIN_ROWS 64
+#define JOIN_COLS 32
+
+__device__ __forceinline__ float join_median(float* tmp_row, int n) {
+    /* partial selection sort exactly as StixelsKernels.cu:1007-1022 / 1038-1053 */
+    for (int i = 0; i < (n / 2) + 1; i++) {
+        int min_idx = i;
+        for (int j = i + 1; j < n; j++)
+            if (tmp_row[j] < tmp_row[min_idx]) min_idx = j;
+        const float tmp = tmp_row[i];
+        tmp_row[i] = tmp_row[min_idx];
+        tmp_row[min_idx] = tmp;
+    }
+    float median = tmp_row[n / 2];
+    if (n % 2 == 0) median = (median + tmp_row[(n / 2) - 1]) / 2.0f;
+    return median;
+}
+
+__device__ __forceinline__ float join_one(const float* __restrict__ src, int step, bool median,
+                                          float invalid) {
+    float v[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) v[i] = (i < step) ? src[i] : 0.0f;
+    if (median) {
+        if (invalid >= 0) {
+            float t[16];
+            int n = 0;
+#pragma unroll
+            for (int i = 0; i < 16; i++)
+                if (i < step && v[i] != invalid) t[n++] = v[i];
+            return (n > 0) ? join_median(t, n) : invalid;
+        }
+        return join_median(v, step);
+    }
+    float mean = 0.0f;
+    if (invalid >= 0) {
+        int bad = 0;
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+            if (i < step) {
+                if (v[i] != invalid) mean += v[i]; else bad++;
+            }
+        return (bad != step) ? mean / (float)(step - bad) : invalid;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; i++)
+        if (i < step) mean += v[i];
+    return mean / (float)step;
+}
+
+__global__ __launch_bounds__(256) void k_join_columns(const float* __restrict__ big,
+                                                      float* __restrict__ joined, int H, int W,
+                                                      int C, int step, int margin, int median,
+                                                      float invalid) {
+    __shared__ float tile[JOIN_COLS][JOIN_ROWS + 1];
+    const int img = blockIdx.z;
+    const int row0 = blockIdx.x * JOIN_ROWS;
+    const int col0 = blockIdx.y * JOIN_COLS;
+    const float* src = big + (size_t)img * H * W;
+    float* dst = joined + (size_t)img * C * H;
+    const int tx = threadIdx.x % JOIN_COLS, ty = threadIdx.x / JOIN_COLS; /* 32 x 8 */
+    for (int r = ty; r < JOIN_ROWS; r += 256 / JOIN_COLS) {
+        const int row = row0 + r, col = col0 + tx;
+        float val = 0.0f;
+        if (row < H && col < C)
+            val = join_one(src + (size_t)row * W + col * step + margin, step, median != 0, invalid);
+        tile[tx][r] = val;
+    }
+    __syncthreads();
+    const int rr = threadIdx.x % JOIN_ROWS, cc = threadIdx.x / JOIN_ROWS; /* 64 x 4 */
+    for (int c = cc; c < JOIN_COLS; c += 256 / JOIN_ROWS) {
+        const int row = row0 + rr, col = col0 + c;
+        if (row < H && col < C) dst[(size_t)col * H + (H - 1 - row)] = tile[c][rr];
+    }
+}
+
+/* ====================================================================================== */
+/* A4-A6  per-column preparation                                                           */
+/* ====================================================================================== */
+#define PREP_THREADS 256
+
+/* Exclusive prefix of index i (0 <= i < n) with the association of the reference's
+ * work-efficient block scan ComputePrefixSum (StixelsKernels.h:73-103): the up-sweep builds a
+ * pairwise tree, the down-sweep gives a right child `parent + left subtree sum`, i.e. the
+ * left-sibling sums on the root-to-leaf path are added top-down starting from 0.
+ * pyr holds the tree: level b (n>>b nodes) at offset 2n - (2n>>b). */
+__device__ __forceinline__ float blelloch_prefix(const float* pyr, int n, int log2n, int i) {
+    float acc = 0.0f;
+    for (int b = log2n - 1; b >= 0; b--) {
+        const int node = i >> b;
+        if (node & 1) acc = acc + pyr[(2 * n - ((2 * n) >> b)) + node - 1];
+    }
+    return acc;
+}
+
+__device__ __forceinline__ void blelloch_build(float* pyr, int n, int log2n) {
+    for (int b = 1; b <= log2n; b++) {
+        const float* lo = pyr + (2 * n - ((2 * n) >> (b - 1)));
+        float* hi = pyr + (2 * n - ((2 * n) >> b));
+        for (int j = threadIdx.x; j < (n >> b); j += PREP_THREADS) hi[j] = lo[2 * j + 1] + lo[2 * j];
+        __syncthreads();
+    }
+}
+
+/* Exact exclusive block scan of one int64 per thread (any association is exact). */
+__device__ __forceinline__ int64_t block_excl_scan_i64(int64_t v, int64_t* s_wave /*[4]*/) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int64_t inc = v;
+#pragma unroll
+    for (int j = 1; j < 64; j <<= 1) {
+        const int64_t n = __shfl_up(inc, j, 64);
+        if (lane >= j) inc += n;
+    }
+    __syncthreads(); /* s_wave may still be read by the previous call */
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    int64_t base = 0;
+    for (int w = 0; w < wave; w++) base += s_wave[w];
+    return base + inc - v;
+}
+
+__device__ __forceinline__ float data_cost_sky(float d, const DevParams& P) {
+    /* GetDataCostSky, StixelsKernels.cu:201-215 */
+    float data_cost = P.pnex_sky_log;
+    if (d != P.invalid) {
+        const float pgaussian = P.norm_sky + d * d * P.inv_sigma2_sky;
+        const float p_data = __builtin_fminf(P.puniform_sky, pgaussian);
+        data_cost = p_data + P.nopnex_sky_log;
+    }
+    return data_cost;
+}
+__device__ __forceinline__ float data_cost_ground(float fn, float d, float norm_g, float inv_s2_g,
+                                                  const DevParams& P) {
+    /* GetDataCostGround, StixelsKernels.cu:217-234 */
+    float data_cost = P.pnex_gnd_log;
+    if (d != P.invalid) {
+        const float model_diff = (d - fn);
+        const float pgaussian = norm_g + model_diff * model_diff * inv_s2_g;
+        const float p_data = __builtin_fminf(P.puniform, pgaussian);
+        data_cost = p_data + P.nopnex_gnd_log;
+    }
+    return data_cost;
+}
+
+/* full-resolution prefix from the 1/8-resolution exclusive prefix ps (see RowRec) */
+__device__ __forceinline__ int32_t full_prefix(const int32_t* ps, int v) {
+    const int k = v >> 3, m = v & 7;
+    int32_t r = (int32_t)((uint32_t)ps[k] * 8u);
+    if (m) r = (int32_t)((uint32_t)r + (uint32_t)(ps[k + 1] - ps[k]) * (uint32_t)m);
+    return r;
+}
+
+__global__ __launch_bounds__(PREP_THREADS) void k_prepare_columns(
+    const DevParams P, const float* __restrict__ joined, const int32_t* __restrict__ seg,
+    const float* __restrict__ ground /*[img][3][H]*/, const int* __restrict__ vhor_arr,
+    const float* __restrict__ obj_cost_lut, RowRec* __restrict__ recs, float* __restrict__ lutT) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int H = P.H, D = P.D, P2 = P.P2, P2S = P.P2S, CH = P.CH, K = P.K;
+    float* s_d = (float*)smem;                          /* [P2]   disparity column        */
+    float* s_pyr = s_d + P2;                            /* [2*P2] scan tree                */
+    int32_t* s_seg = (int32_t*)(s_pyr + 2 * P2);        /* [CH][P2S]                       */
+    int64_t* s_wave = (int64_t*)(s_seg + CH * P2S);     /* [4]                             */
+
+    const int colg = blockIdx.x;
+    const int img = colg / P.C, col = colg % P.C;
+    const int vhor = vhor_arr[img];
+    const float* gfun = ground + (size_t)img * 3 * H;
+    const float* gnorm = gfun + H;
+    const float* gis2 = gnorm + H;
+    const float* dcol = joined + (size_t)colg * H;
+    const int32_t* scol = seg + (size_t)colg * CH * P2S;
+    RowRec* rcol = recs + (size_t)colg * (H + 1);
+    float* lcol = lutT + (size_t)colg * (H + 1) * D;
+    const int tid = threadIdx.x;
+
+    for (int i = tid; i < P2; i += PREP_THREADS) s_d[i] = (i < H) ? dcol[i] : 0.0f;
+    for (int i = tid; i < CH * P2S; i += PREP_THREADS) s_seg[i] = scol[i];
+    __syncthreads();
+
+    /* ---- instance-centre values per row from the RAW offsets (StixelsKernels.cu:401-409);
+     * thread t owns rows [t*R, t*R+R).  mx = 8*col + 3.5 + offx + 0.5 is an exact integer;
+     * my = trunc(row - offy + 0.5): n for n >= 0, n + 1 for n < 0 (truncation toward zero). */
+    const int R = (H + PREP_THREADS - 1) / PREP_THREADS;
+    const int r_lo = tid * R;
+    const int32_t* offy = s_seg + K * P2S;
+    const int32_t* offx = s_seg + (K + 1) * P2S;
+    int64_t sum_mx = 0, sum_my = 0, sum_mx2 = 0, sum_my2 = 0;
+    for (int r = r_lo; r < r_lo + R && r < H; r++) {
+        const double fx = ((double)(P.column_step * col) + 0.5 * ((double)P.column_step - 1.0)) +
+                          (double)offx[r >> 3] + 0.5;
+        const int64_t mx = (int64_t)fx;
+        const int32_t n32 = (int32_t)((uint32_t)r - (uint32_t)offy[r >> 3]);
+        const int64_t my = (int64_t)((double)n32 + 0.5);
+        sum_mx += mx;
+        sum_my += my;
+        sum_mx2 = (int64_t)((uint64_t)sum_mx2 + (uint64_t)mx * (uint64_t)mx);
+        sum_my2 = (int64_t)((uint64_t)sum_my2 + (uint64_t)my * (uint64_t)my);
+    }
+    int64_t base_mx = block_excl_scan_i64(sum_mx, s_wave);
+    int64_t base_my = block_excl_scan_i64(sum_my, s_wave);
+    int64_t base_mx2 = block_excl_scan_i64(sum_mx2, s_wave);
+    int64_t base_my2 = block_excl_scan_i64(sum_my2, s_wave);
+    /* the owner of rows [r_lo, r_lo+R) writes the exclusive prefix at those indices; the owner
+     * of row H-1 also writes index H (the total) */
+    for (int r = r_lo; r < r_lo + R && r < H; r++) {
+        RowRec* o = rcol + r;
+        o->MX = base_mx; o->MY = base_my; o->MX2 = base_mx2; o->MY2 = base_my2;
+        const double fx = ((double)(P.column_step * col) + 0.5 * ((double)P.column_step - 1.0)) +
+                          (double)offx[r >> 3] + 0.5;
+        const int64_t mx = (int64_t)fx;
+        const int32_t n32 = (int32_t)((uint32_t)r - (uint32_t)offy[r >> 3]);
+        const int64_t my = (int64_t)((double)n32 + 0.5);
+        base_mx += mx;
+        base_my += my;
+        base_mx2 = (int64_t)((uint64_t)base_mx2 + (uint64_t)mx * (uint64_t)mx);
+        base_my2 = (int64_t)((uint64_t)base_my2 + (uint64_t)my * (uint64_t)my);
+    }
+    if (r_lo <= H - 1 && H - 1 < r_lo + R) {
+        RowRec* o = rcol + H;
+        o->MX = base_mx; o->MY = base_my; o->MX2 = base_mx2; o->MY2 = base_my2;
+    }
+    __syncthreads();
+
+    /* ---- square the offset channels in place (StixelsKernels.cu:411-416), then exclusive
+     * prefix of every channel at 1/8 resolution (:462-469); integer, so any order is exact */
+    for (int i = tid; i < 2 * P2S; i += PREP_THREADS) {
+        const uint32_t x = (uint32_t)s_seg[K * P2S + i];
+        s_seg[K * P2S + i] = (int32_t)(x * x);
+    }
+    __syncthreads();
+    if (tid < CH) {
+        int32_t* ch = s_seg + tid * P2S;
+        uint32_t run = 0;
+        for (int k = 0; k < P2S; k++) {
+            const uint32_t x = (uint32_t)ch[k];
+            ch[k] = (int32_t)run;
+            run += x;
+        }
+    }
+    __syncthreads();
+    for (int v = tid; v <= H; v += PREP_THREADS) {
+        RowRec* o = rcol + v;
+        o->Fg0 = full_prefix(s_seg + 0 * P2S, v);
+        o->Fg1 = full_prefix(s_seg + 1 * P2S, v);
+#pragma unroll
+        for (int c = 0; c < IS_N_ON; c++) o->Fon[c] = full_prefix(s_seg + (2 + c) * P2S, v);
+#pragma unroll
+        for (int c = 0; c < IS_N_OI; c++) o->Foi[c] = full_prefix(s_seg + (11 + c) * P2S, v);
+        o->Fsky = full_prefix(s_seg + 10 * P2S, v);
+        o->Fnic = (int32_t)((uint32_t)full_prefix(s_seg + (K + 1) * P2S, v) +
+                            (uint32_t)full_prefix(s_seg + K * P2S, v));
+    }
+
+    /* ---- fp32 prefixes with the reference's block-scan association (:452-461) */
+    /* S: disparity (valid-masked when invalid >= 0, :382-389) */
+    for (int i = tid; i < P2; i += PREP_THREADS) {
+        float x = 0.0f;
+        if (i < H) {
+            const float d = s_d[i];
+            if (P.invalid >= 0) {
+                const int va = d != P.invalid;
+                x = ((float)va) * d;
+            } else {
+                x = d;
+            }
+        }
+        s_pyr[i] = x;
+    }
+    __syncthreads();
+    blelloch_build(s_pyr, P2, P.log2P2);
+    for (int v = tid; v <= H; v += PREP_THREADS) rcol[v].S = blelloch_prefix(s_pyr, P2, P.log2P2, v);
+    __syncthreads();
+    /* V: valid count */
+    for (int i = tid; i < P2; i += PREP_THREADS)
+        s_pyr[i] = (i < H && P.invalid >= 0) ? (float)(s_d[i] != P.invalid) : 0.0f;
+    __syncthreads();
+    blelloch_build(s_pyr, P2, P.log2P2);
+    for (int v = tid; v <= H; v += PREP_THREADS) rcol[v].V = blelloch_prefix(s_pyr, P2, P.log2P2, v);
+    __syncthreads();
+    /* G: ground data cost, +inf at / above the horizon (:435-446) */
+    for (int i = tid; i < P2; i += PREP_THREADS) {
+        float x = 0.0f;
+        if (i < H)
+            x = (i >= vhor) ? IS_INF : data_cost_ground(gfun[i], s_d[i], gnorm[i], gis2[i], P);
+        s_pyr[i] = x;
+    }
+    __syncthreads();
+    blelloch_build(s_pyr, P2, P.log2P2);
+    for (int v = tid; v <= H; v += PREP_THREADS) rcol[v].G = blelloch_prefix(s_pyr, P2, P.log2P2, v);
+    __syncthreads();
+    /* K: sky data cost, 0 below the horizon (:424-433) */
+    for (int i = tid; i < P2; i += PREP_THREADS) {
+        float x = 0.0f;
+        if (i < H) x = (i < vhor) ? 0.0f : data_cost_sky(s_d[i], P);
+        s_pyr[i] = x;
+    }
+    __syncthreads();
+    blelloch_build(s_pyr, P2, P.log2P2);
+    for (int v = tid; v <= H; v += PREP_THREADS) rcol[v].K = blelloch_prefix(s_pyr, P2, P.log2P2, v);
+
+    /* ---- object data-cost prefix table (ComputeObjectLUT, :236-296, 959-978).  Association:
+     * 32-lane Kogge-Stone with the running carry added into lane 0 first, 32-row blocks chained
+     * serially.  One half-wavefront plays the reference's warp; the two halves of a wavefront
+     * work on two different fn. */
+    const int l32 = tid & 31;
+    const int hw = tid >> 5;
+    const int nhw = PREP_THREADS / 32;
+    for (int fn0 = 0; fn0 < D; fn0 += nhw) {
+        const int fn = fn0 + hw;
+        const bool fn_ok = fn < D;
+        const int fnc = fn_ok ? fn : D - 1;
+        float add = 0.0f;
+        if (fn_ok && l32 == 0) lcol[fn] = 0.0f; /* arr[0] = 0, :283-285 */
+        for (int i = 0; i < H; i += 32) {
+            const int row = i + l32;
+            int dis = 0;
+            if (row < H) dis = (int)s_d[row];
+            dis = min(max(dis, 0), D - 1); /* memory safety outside the input domain (Q8) */
+            float cost = obj_cost_lut[fnc * D + dis];
+            if (l32 == 0) cost += add;
+#pragma unroll
+            for (int j = 1; j < 32; j <<= 1) {
+                const float n = __shfl_up(cost, j, 32);
+                if (l32 >= j) cost += n;
+            }
+            if (fn_ok && row < H) lcol[(size_t)(row + 1) * D + fn] = cost;
+            add = __shfl(cost, 31, 32);
+        }
+    }
+}
+
+/* ====================================================================================== */
+/* Pairwise transition priors that depend only on vB and the frame's ground model          */
+/* ====================================================================================== */
+__device__ __forceinline__ float neg_fastlog_div(float v, float v2) { /* :35-38 */
+    return -is_logf(v) + is_logf(v2);
+}
+
+__global__ void k_prior_tables(const DevParams P, const float* __restrict__ ground,
+                               PriorRec* __restrict__ priors, int n_images) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_images * P.H) return;
+    const int img = idx / P.H, vB = idx % P.H;
+    const float* gfun = ground + (size_t)img * 3 * P.H;
+    PriorRec r;
+    r.pc = neg_fastlog_div(1.0f, (float)(P.H - vB));
+    r.g_from = P.nlog03 + r.pc;
+    float gprev = (vB > 0) ? gfun[vB - 1] : 0.0f;
+    r.s_from_g = (gprev < 1.0f) ? r.pc : IS_INF;
+    r.o_from_s = neg_fastlog_div(1.0f, P.max_disf - P.epsilon) + r.pc;
+    const float base = P.nlog07 + r.pc;
+    if (gprev < 0.0f) gprev = 0.0f;
+    r.g_prev = gprev;
+    r.og_hi = base + neg_fastlog_div(P.pgrav, P.max_disf - gprev - P.epsilon);
+    r.og_lo = base + neg_fastlog_div(P.pblg, gprev - P.epsilon);
+    r.og_mid = base + neg_fastlog_div(1.0f - P.pgrav - P.pblg, 2.0f * P.epsilon);
+    priors[idx] = r;
+}
+
+/* ====================================================================================== */
+/* Segment evaluation shared by both DP kernels                                            */
+/* ====================================================================================== */
+struct SegTerms {
+    float seg_g, seg_o, seg_s; /* semantic + instance terms of the three geometric classes */
+    float gd, sd;              /* ground / sky data terms                                   */
+    float mean;                /* un-floored, clamped (>= 0) object mean disparity          */
+    int fni;                   /* floor(mean), clamped to [0, D-1]                          */
+};
+
+/* `my` = record at vT+1 (per lane), `rb` = record at vB (wave-uniform, scalar loads).
+ * Exact rewrites w.r.t. Cityscapes.h:44-118 / StixelsKernels.cu:62-86:
+ *   DownsampledSum(c) = my.F_c - rb.F_c;
+ *   min_c (k + float(S_c)) = k + float(min_c S_c) for classes sharing the additive term k
+ *   (int -> float conversion and fp32 addition are monotone). */
+template <bool HAS_INVALID>
+__device__ __forceinline__ SegTerms eval_segment(const RowRec& my, crec_t rb, int h, int D,
+                                                 float iw) {
+    SegTerms t;
+    const int32_t s_g = min(my.Fg0 - rb->Fg0, my.Fg1 - rb->Fg1);
+    int32_t s_on = my.Fon[0] - rb->Fon[0];
+#pragma unroll
+    for (int c = 1; c < IS_N_ON; c++) s_on = min(s_on, my.Fon[c] - rb->Fon[c]);
+    int32_t s_oi = my.Foi[0] - rb->Foi[0];
+#pragma unroll
+    for (int c = 1; c < IS_N_OI; c++) s_oi = min(s_oi, my.Foi[c] - rb->Foi[c]);
+    const int32_t s_sky = my.Fsky - rb->Fsky;
+    const int32_t s_nic = my.Fnic - rb->Fnic;
+
+    const float nic = iw * (float)s_nic; /* ComputeNonInstanceOffsetCost, :62-70, :496-499 */
+    /* ComputeInstanceOffsetCost, :72-86 */
+    const float meanx = (float)(my.MX - rb->MX);
+    const float meany = (float)(my.MY - rb->MY);
+    const float meanx2 = (float)(my.MX2 - rb->MX2);
+    const float meany2 = (float)(my.MY2 - rb->MY2);
+    const float height = (float)h;
+    const float ic = iw * (meanx2 - meanx * meanx / height + meany2 - meany * meany / height);
+
+    t.seg_g = (float)s_g + nic;
+    const float on = (0.0f + nic) + (float)s_on;
+    const float oi = (0.0f + ic) + (float)s_oi;
+    t.seg_o = (oi < on) ? oi : on;
+    t.seg_s = (float)s_sky + nic;
+
+    t.gd = my.G - rb->G;
+    t.sd = my.K - rb->K;
+    float mean; /* ComputeMean, :47-60 */
+    if (HAS_INVALID) {
+        const float valid_dif = my.V - rb->V;
+        mean = (valid_dif == 0) ? 0 : (my.S - rb->S) / valid_dif;
+    } else {
+        mean = (my.S - rb->S) / (float)h;
+    }
+    if (mean < 0) mean = 0; /* :525-527 */
+    t.mean = mean;
+    int fni = (int)__builtin_floorf(mean);
+    t.fni = min(max(fni, 0), D - 1); /* memory safety outside the input domain (Q8) */
+    return t;
+}
+
+__device__ __forceinline__ RowRec load_rec(const RowRec* p) {
+    RowRec r;
+    const int4* s = (const int4*)p;
+    int4* d = (int4*)&r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) d[i] = s[i];
+    return r;
+}
+
+/* ====================================================================================== */
+/* A7-A9  unary DP: one workgroup = (column, 64-row tile)                                  */
+/* ====================================================================================== */
+/* In unary mode the predecessor cost is never added: cost_table[vT][t] is the
+ * minimum over vB of a single-segment cost, so all (vB, vT) pairs are independent and the only
+ * order that matters is the strict-< tie rule (smallest vB wins).  index_table holds the winning
+ * vB (or -1); the predecessor TYPE is resolved in k_backtrace from the final cost_table. */
+template <bool HAS_INVALID>
+__global__ __launch_bounds__(256) void k_dp_unary(const DevParams P, int ncols,
+                                                  const RowRec* __restrict__ recs,
+                                                  const float* __restrict__ lutT,
+                                                  const float* __restrict__ pwinv,
+                                                  const int* __restrict__ vhor_arr,
+                                                  float* __restrict__ cost_table,
+                                                  int32_t* __restrict__ index_table) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int H = P.H, D = P.D;
+    const int DP = D + 1; /* padded row: conflict-free when lanes share fni */
+    float* s_tile = (float*)smem;             /* [64][D+1] lutT rows tile_lo+1 .. tile_lo+64 */
+    float* s_pwinv = s_tile + IS_TILE * DP;   /* [H+1]     prior_weight * (1/h)               */
+
+    /* XCD-aware order: blocks b, b+8, ... share an XCD/L2; keep all tiles of a column on one
+     * XCD (they gather from the same lutT) and start with the tallest tiles. */
+    const int nxcd = 8;
+    const int xcd = blockIdx.x % nxcd, q = blockIdx.x / nxcd;
+    const int tile = P.ntiles - 1 - (q % P.ntiles);
+    const int colg = (q / P.ntiles) * nxcd + xcd;
+    if (colg >= ncols) return;
+    const int img = colg / P.C;
+    const int vhor = vhor_arr[img];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int nw = blockDim.x >> 6;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile_lo = tile * IS_TILE;
+    const RowRec* rcol = recs + (size_t)colg * (H + 1);
+    const float* lcol = lutT + (size_t)colg * (H + 1) * D;
+
+    for (int i = tid; i < IS_TILE * D; i += blockDim.x) {
+        const int r = i / D, f = i - r * D;
+        const int v = min(tile_lo + 1 + r, H);
+        s_tile[r * DP + f] = lcol[(size_t)v * D + f];
+    }
+    for (int i = tid; i <= H; i += blockDim.x) s_pwinv[i] = pwinv[i];
+
+    const int vT = tile_lo + lane;
+    const int vTc = min(vT, H - 1);
+    const RowRec my = load_rec(rcol + vTc + 1);
+    __syncthreads();
+
+    float best_g = IS_INF, best_o = IS_INF, best_s = IS_INF;
+    int vb_g = -1, vb_o = 0 /* index_table[vT*3+OBJECT] = OBJECT at vB = 0, :592 */, vb_s = -1;
+    const float* my_tile = s_tile + lane * DP;
+    const int vB_end = min(tile_lo + IS_TILE - 1, H - 1);
+
+    for (int vB = w; vB <= vB_end; vB += nw) {
+        crec_t rb = (crec_t)(rcol + vB);
+        const int h = vTc + 1 - vB;
+        const bool live = (h > 0) && (vT < H);
+        const int hc = max(h, 1);
+        const SegTerms t = eval_segment<HAS_INVALID>(my, rb, hc, D, P.iw);
+        const float od = my_tile[t.fni] - lcol[(size_t)vB * D + t.fni];
+        const float pwih = s_pwinv[hc];
+        /* cost = dw*data + pw*(1/h) + sw*seg, left to right (:716-719, 762-765, 820-823) */
+        const float cost_o = P.dw * od + pwih + P.sw * t.seg_o;
+        if (live && cost_o < best_o) { best_o = cost_o; vb_o = vB; }
+        if (vB == 0 || vB <= vhor) { /* ground: vB-1 < vhor (:687); vB = 0 needs vT <= vhor (:542-545) */
+            const float cost_g = P.dw * t.gd + pwih + P.sw * t.seg_g;
+            const bool ok = live && (vB > 0 || vT <= vhor);
+            if (ok && cost_g < best_g) { best_g = cost_g; vb_g = vB; }
+        } else { /* sky: vB-1 >= vhor (:729) */
+            const float cost_s = P.dw * t.sd + pwih + P.sw * t.seg_s;
+            if (live && cost_s < best_s) { best_s = cost_s; vb_s = vB; }
+        }
+    }
+
+    /* merge the waves' partial minima: min cost, ties -> smallest vB (= first strict minimum
+     * of the reference's ascending-vB loop) */
+    __syncthreads();
+    float* m_cost = (float*)smem;                  /* [nw][3][64] (aliases the LUT tile) */
+    int* m_vb = (int*)(m_cost + nw * 3 * 64);      /* [nw][3][64] */
+    m_cost[(w * 3 + 0) * 64 + lane] = best_g; m_vb[(w * 3 + 0) * 64 + lane] = vb_g;
+    m_cost[(w * 3 + 1) * 64 + lane] = best_o; m_vb[(w * 3 + 1) * 64 + lane] = vb_o;
+    m_cost[(w * 3 + 2) * 64 + lane] = best_s; m_vb[(w * 3 + 2) * 64 + lane] = vb_s;
+    __syncthreads();
+    if (tid < 3 * 64) {
+        const int type = tid >> 6;
+        float c = m_cost[(0 * 3 + type) * 64 + lane];
+        int vb = m_vb[(0 * 3 + type) * 64 + lane];
+        for (int ww = 1; ww < nw; ww++) {
+            const float c2 = m_cost[(ww * 3 + type) * 64 + lane];
+            const int vb2 = m_vb[(ww * 3 + type) * 64 + lane];
+            const bool take = (c2 < c) || (c2 == c && vb2 >= 0 && (vb < 0 || vb2 < vb));
+            if (take) { c = c2; vb = vb2; }
+        }
+        if (vT < H) {
+            const size_t o = ((size_t)colg * H + vT) * 3 + type;
+            cost_table[o] = c;
+            index_table[o] = vb;
+        }
+    }
+}
+
+/* ====================================================================================== */
+/* A7-A9  pairwise DP: one workgroup per column walks the tiles bottom-up                  */
+/* ====================================================================================== */
+/* Per finished row r (= vB-1 of later segments): final costs and the object-chain terms that
+ * depend on the DP state (previous_mean of the best OBJECT segment ending at r). */
+struct __attribute__((aligned(32))) PredRec {
+    float cG, cO, cS;  /* cost_table[r*3 + {G,O,S}]                                        */
+    float pm;          /* previous_mean, clamped >= 0 (:675-685)                           */
+    float oo_hi;       /* GetPriorCostObjectFromObject, fn > pm + dif (:159-162)           */
+    float oo_lo;       /*                                fn < pm - dif (:163-166)          */
+    float pm_hi, pm_lo; /* pm + dif, pm - dif                                               */
+};
+
+template <bool HAS_INVALID>
+__device__ __forceinline__ float mean_between(const RowRec* rcol, int vB, int vT) {
+    /* ComputeMean(vB, vT) from the boundary records, :47-60 */
+    const float s1 = rcol[vT + 1].S, s0 = rcol[vB].S;
+    if (HAS_INVALID) {
+        const float valid_dif = rcol[vT + 1].V - rcol[vB].V;
+        return (valid_dif == 0) ? 0 : (s1 - s0) / valid_dif;
+    }
+    return (s1 - s0) / (float)(vT + 1 - vB);
+}
+
+/* Builds the PredRec of finished row r from its final costs and winning object start. */
+template <bool HAS_INVALID>
+__device__ __forceinline__ PredRec make_pred(const DevParams& P, const RowRec* rcol,
+                                             const float* __restrict__ odr, int vhor, int r,
+                                             float cG, float cO, float cS, int obj_vB, float pc_next) {
+    PredRec p;
+    p.cG = cG; p.cO = cO; p.cS = cS;
+    float pm = mean_between<HAS_INVALID>(rcol, obj_vB, r);
+    if (pm < 0) pm = 0;
+    p.pm = pm;
+    /* GetPriorCostObjectFromObject(vB = r+1, ...), :146-171 */
+    float base = (r < vhor) ? P.nlog07 : P.log2c;
+    base += pc_next;
+    int k = (int)pm;
+    k = min(max(k, 0), P.D - 1);
+    float dif = odr[k];
+    if (dif < 0.0f) dif = 0.0f;
+    p.pm_hi = pm + dif;
+    p.pm_lo = pm - dif;
+    p.oo_hi = base + neg_fastlog_div(P.pord, P.max_disf - pm - dif);
+    p.oo_lo = base + neg_fastlog_div(1.0f - P.pord, p.pm_lo);
+    return p;
+}
+
+struct PairBest {
+    float g, o, s;
+    int ig, io, is; /* vB*3 + prev type */
+};
+
+/* One (vB >= 1, vT) evaluation of the pairwise model for the lane owning vT. */
+template <bool HAS_INVALID>
+__device__ __forceinline__ void pairwise_step(const DevParams& P, const RowRec& my, crec_t rb,
+                                              cprior_t pr, const PredRec& pd, int vB, int vhor,
+                                              int h, bool live, float od_hi, float od_lo_base,
+                                              const SegTerms& t, PairBest& b) {
+    const float pw = P.pw;
+    if (vB - 1 < vhor) { /* ground, :687-728 */
+        const float prev_cost = pr->g_from;
+        const float p1 = pd.cG + pw * prev_cost;
+        const float p2 = pd.cO + pw * prev_cost;
+        const float mp = __builtin_fminf(p1, p2);
+        const float cost = P.dw * t.gd + pw * mp + P.sw * t.seg_g;
+        if (live && cost < b.g) {
+            b.g = cost;
+            b.ig = vB * 3 + ((p1 < p2) ? IS_GROUND : IS_OBJECT);
+        }
+    } else { /* sky, :729-775 */
+        const float p1 = pd.cG + pw * pr->s_from_g;
+        const float so = (pd.pm < P.epsilon) ? IS_INF : (P.log2c + pr->pc); /* :88-96 */
+        const float p2 = pd.cO + pw * so;
+        const float mp = __builtin_fminf(p1, p2);
+        const float cost = P.dw * t.sd + pw * mp + P.sw * t.seg_s;
+        if (live && cost < b.s) {
+            b.s = cost;
+            b.is = vB * 3 + ((p1 < p2) ? IS_GROUND : IS_OBJECT);
+        }
+    }
+    /* object, :777-837 */
+    const float fn = t.mean;
+    float og; /* GetPriorCostObjectFromGround, :120-144 */
+    if (fn > (pr->g_prev + P.epsilon)) og = pr->og_hi;
+    else if (fn < (pr->g_prev - P.epsilon)) og = pr->og_lo;
+    else og = pr->og_mid;
+    float oo; /* GetPriorCostObjectFromObject, :146-171 */
+    if (fn > pd.pm_hi) oo = pd.oo_hi;
+    else if (fn < pd.pm_lo) oo = pd.oo_lo;
+    else oo = IS_INF;
+    const float os = (fn > P.epsilon) ? pr->o_from_s : IS_INF; /* :173-183 */
+    const float p1 = pd.cG + pw * og;
+    const float p2 = pd.cO + pw * oo;
+    const float p3 = pd.cS + pw * os;
+    const float mp = __builtin_fminf(__builtin_fminf(p1, p2), p3);
+    const float od = od_hi - od_lo_base;
+    const float cost = P.dw * od + pw * mp + P.sw * t.seg_o;
+    if (live && cost < b.o) {
+        b.o = cost;
+        int min_prev = IS_OBJECT;
+        if (p1 < p2) min_prev = IS_GROUND;
+        if (p3 < __builtin_fminf(p1, p2)) min_prev = IS_SKY;
+        b.io = vB * 3 + min_prev;
+    }
+}
+
+template <bool HAS_INVALID>
+__global__ __launch_bounds__(256) void k_dp_pairwise(
+    const DevParams P, int ncols, const RowRec* __restrict__ recs, const float* __restrict__ lutT,
+    const PriorRec* __restrict__ priors, const float* __restrict__ odr,
+    const int* __restrict__ vhor_arr, float* __restrict__ cost_table,
+    int32_t* __restrict__ index_table) {
+    extern __shared__ __attribute__((aligned(32))) char smem[];
+    const int H = P.H, D = P.D;
+    const int DP = D + 1;
+    const int nw = blockDim.x >> 6;
+    PredRec* s_pred = (PredRec*)smem;                        /* [H] finished rows          */
+    float* s_tile = (float*)(s_pred + H);                    /* [64][D+1]                  */
+    float* m_cost = s_tile + IS_TILE * DP;                   /* [nw][3][64]                */
+    int* m_idx = (int*)(m_cost + nw * 3 * 64);               /* [nw][3][64]                */
+
+    const int colg = blockIdx.x;
+    if (colg >= ncols) return;
+    const int img = colg / P.C;
+    const int vhor = vhor_arr[img];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const RowRec* rcol = recs + (size_t)colg * (H + 1);
+    const float* lcol = lutT + (size_t)colg * (H + 1) * D;
+    const PriorRec* pcol = priors + (size_t)img * H;
+
+    for (int tile = 0; tile < P.ntiles; tile++) {
+        const int tile_lo = tile * IS_TILE;
+        __syncthreads(); /* previous tile fully consumed */
+        for (int i = tid; i < IS_TILE * D; i += blockDim.x) {
+            const int r = i / D, f = i - r * D;
+            const int v = min(tile_lo + 1 + r, H);
+            s_tile[r * DP + f] = lcol[(size_t)v * D + f];
+        }
+        const int vT = tile_lo + lane;
+        const int vTc = min(vT, H - 1);
+        const RowRec my = load_rec(rcol + vTc + 1);
+        const float* my_tile = s_tile + lane * DP;
+        __syncthreads();
+
+        PairBest b;
+        b.g = b.o = b.s = IS_INF;
+        b.ig = b.is = -1;
+        b.io = IS_OBJECT; /* :592 */
+
+        /* ---- phase 1: segments starting in earlier tiles (their predecessors are final),
+         * vB strided over the waves */
+        for (int vB = w; vB <= tile_lo && vB < H; vB += nw) {
+            crec_t rb = (crec_t)(rcol + vB);
+            const int h = vTc + 1 - vB;
+            const bool live = vT < H;
+            const SegTerms t = eval_segment<HAS_INVALID>(my, rb, h, D, P.iw);
+            const float od_hi = my_tile[t.fni];
+            const float od_lo = lcol[(size_t)vB * D + t.fni];
+            if (vB == 0) { /* first segment, :481-594 */
+                const bool below = vT <= vhor;
+                if (below) {
+                    const float cost = P.dw * t.gd + P.pw * P.first_g + P.sw * t.seg_g;
+                    if (live && cost < b.g) { b.g = cost; b.ig = IS_GROUND; }
+                }
+                const float prior = below ? P.first_o_below : P.first_o_above;
+                const float cost = P.dw * (od_hi - od_lo) + P.pw * prior + P.sw * t.seg_o;
+                if (live && cost < b.o) b.o = cost;
+            } else {
+                const PredRec pd = s_pred[vB - 1];
+                pairwise_step<HAS_INVALID>(P, my, rb, (cprior_t)(pcol + vB), pd, vB, vhor, h, live,
+                                           od_hi, od_lo, t, b);
+            }
+        }
+        m_cost[(w * 3 + 0) * 64 + lane] = b.g; m_idx[(w * 3 + 0) * 64 + lane] = b.ig;
+        m_cost[(w * 3 + 1) * 64 + lane] = b.o; m_idx[(w * 3 + 1) * 64 + lane] = b.io;
+        m_cost[(w * 3 + 2) * 64 + lane] = b.s; m_idx[(w * 3 + 2) * 64 + lane] = b.is;
+        __syncthreads();
+
+        /* ---- phase 2: wave 0 merges (min cost, ties -> smallest vB) and walks the diagonal
+         * block sequentially: step vB needs the final row vB-1 of this same tile */
+        if (w == 0) {
+            for (int type = 0; type < 3; type++) {
+                float c = m_cost[(0 * 3 + type) * 64 + lane];
+                int ix = m_idx[(0 * 3 + type) * 64 + lane];
+                for (int ww = 1; ww < nw; ww++) {
+                    const float c2 = m_cost[(ww * 3 + type) * 64 + lane];
+                    const int ix2 = m_idx[(ww * 3 + type) * 64 + lane];
+                    /* a finite cost always comes with an index whose vB part orders ties */
+                    const bool take = (c2 < c) || (c2 == c && c2 < IS_INF && (ix2 / 3) < (ix / 3));
+                    if (take) { c = c2; ix = ix2; }
+                }
+                if (type == 0) { b.g = c; b.ig = ix; }
+                else if (type == 1) { b.o = c; b.io = ix; }
+                else { b.s = c; b.is = ix; }
+            }
+            const int n_rows = min(IS_TILE, H - tile_lo);
+            for (int s = 0; s < n_rows; s++) {
+                const int r = tile_lo + s; /* row that becomes final now */
+                if (s > 0) {
+                    const int vB = r;
+                    crec_t rb = (crec_t)(rcol + vB);
+                    const int h = vTc + 1 - vB;
+                    const bool live = (vT < H) && (h > 0);
+                    const int hc = max(h, 1);
+                    const SegTerms t = eval_segment<HAS_INVALID>(my, rb, hc, D, P.iw);
+                    const float od_hi = my_tile[t.fni];
+                    const float od_lo = lcol[(size_t)vB * D + t.fni];
+                    const PredRec pd = s_pred[vB - 1];
+                    pairwise_step<HAS_INVALID>(P, my, rb, (cprior_t)(pcol + vB), pd, vB, vhor, hc, live,
+                                               od_hi, od_lo, t, b);
+                }
+                /* lane s now holds the final values of row r: publish its PredRec */
+                const float cG = __shfl(b.g, s, 64), cO = __shfl(b.o, s, 64), cS = __shfl(b.s, s, 64);
+                const int io = __shfl(b.io, s, 64);
+                if (lane == 0) {
+                    const float pc_next = (r + 1 < H) ? ((cprior_t)(pcol + r + 1))->pc : 0.0f;
+                    s_pred[r] = make_pred<HAS_INVALID>(P, rcol, odr, vhor, r, cG, cO, cS, io / 3, pc_next);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            }
+            if (vT < H) {
+                const size_t o = ((size_t)colg * H + vT) * 3;
+                cost_table[o + 0] = b.g; cost_table[o + 1] = b.o; cost_table[o + 2] = b.s;
+                index_table[o + 0] = b.ig; index_table[o + 1] = b.io; index_table[o + 2] = b.is;
+            }
+        }
+    }
+}
+
+/* ====================================================================================== */
+/* A10  back-tracing, one lane per column                                                  */
+/* ====================================================================================== */
+__device__ __forceinline__ float bt_mean(const RowRec* rcol, int vB, int vT, float invalid) {
+    const float s1 = rcol[vT + 1].S, s0 = rcol[vB].S;
+    if (invalid >= 0) {
+        const float valid_dif = rcol[vT + 1].V - rcol[vB].V;
+        return (valid_dif == 0) ? 0 : (s1 - s0) / valid_dif;
+    }
+    return (s1 - s0) / (float)(vT + 1 - vB);
+}
+
+__global__ __launch_bounds__(64) void k_backtrace(const DevParams P, int ncols, int pairwise,
+                                                  const RowRec* __restrict__ recs,
+                                                  const float* __restrict__ cost_table,
+                                                  const int32_t* __restrict__ index_table,
+                                                  is_section* __restrict__ sections) {
+    const int colg = blockIdx.x * blockDim.x + threadIdx.x;
+    if (colg >= ncols) return;
+    const int H = P.H;
+    const RowRec* rcol = recs + (size_t)colg * (H + 1);
+    const float* ct = cost_table + (size_t)colg * H * 3;
+    const int32_t* it = index_table + (size_t)colg * H * 3;
+    is_section* out = sections + (size_t)colg * P.S;
+
+    int vT = H - 1;
+    const float last_ground = ct[vT * 3 + IS_GROUND];
+    const float last_object = ct[vT * 3 + IS_OBJECT];
+    const float last_sky = ct[vT * 3 + IS_SKY];
+    int type = IS_OBJECT; /* :854-861 */
+    if (last_ground < last_object) type = IS_GROUND;
+    if (last_sky < __builtin_fminf(last_ground, last_object)) type = IS_SKY;
+
+    int i = 0;
+    int prev_vT;
+    do {
+        const int raw = it[vT * 3 + type];
+        int vB, prev_type;
+        if (pairwise) {
+            vB = raw / 3;
+            prev_type = raw % 3;
+        } else {
+            /* unary: index_table holds the winning vB; the predecessor type is the arg-min of
+             * the FINAL cost_table[vB-1] with the tie rules of :723-727, 769-773, 828-835 */
+            vB = raw;
+            prev_type = IS_OBJECT;
+            if (vB > 0) {
+                const float cG = ct[(vB - 1) * 3 + IS_GROUND];
+                const float cO = ct[(vB - 1) * 3 + IS_OBJECT];
+                if (cG < cO) prev_type = IS_GROUND;
+                if (type == IS_OBJECT) {
+                    const float cS = ct[(vB - 1) * 3 + IS_SKY];
+                    if (cS < __builtin_fminf(cG, cO)) prev_type = IS_SKY;
+                }
+            }
+        }
+        prev_vT = vB - 1;
+        const RowRec a = load_rec(rcol + vT + 1);
+        const RowRec bq = load_rec(rcol + vB);
+        is_section sec;
+        sec.vT = vT;
+        sec.type = type;
+        sec.vB = vB;
+        sec.disparity = bt_mean(rcol, vB, vT, P.invalid);
+        sec.cost = __builtin_fminf(ct[vT * 3 + type], 1e4f);
+        const int hgt = vT + 1 - vB;
+        sec.instance_meanx = (float)(a.MX - bq.MX) / (float)hgt;
+        sec.instance_meany = (float)(a.MY - bq.MY) / (float)hgt;
+        if (sec.type == IS_GROUND) { /* GetGroundSegmentationClass, Cityscapes.h:52-59 */
+            const float cost_road = (float)(a.Fg0 - bq.Fg0);
+            const float cost_sidewalk = (float)(a.Fg1 - bq.Fg1);
+            sec.semantic_class = (cost_road < cost_sidewalk) ? 0 : 1;
+        } else if (sec.type == IS_SKY || sec.disparity < 1.0f) { /* :894-902 */
+            sec.type = IS_SKY;
+            sec.semantic_class = 10;
+        } else { /* GetObjectSegmentationClass, Cityscapes.h:85-111 */
+            const float meanx = (float)(a.MX - bq.MX);
+            const float meany = (float)(a.MY - bq.MY);
+            const float meanx2 = (float)(a.MX2 - bq.MX2);
+            const float meany2 = (float)(a.MY2 - bq.MY2);
+            const float height = (float)hgt;
+            const float ic = P.iw * (meanx2 - meanx * meanx / height + meany2 - meany * meany / height);
+            const float nic = P.iw * (float)(a.Fnic - bq.Fnic);
+            float min_cost = IS_INF;
+            int min_class = 2;
+#pragma unroll
+            for (int c = 0; c < IS_N_ON; c++) {
+                float cs = 0.0f;
+                cs += nic;
+                cs += (float)(a.Fon[c] - bq.Fon[c]);
+                if (min_cost > cs) { min_cost = cs; min_class = 2 + c; }
+            }
+#pragma unroll
+            for (int c = 0; c < IS_N_OI; c++) {
+                float cs = 0.0f;
+                cs += ic;
+                cs += (float)(a.Foi[c] - bq.Foi[c]);
+                if (min_cost > cs) { min_cost = cs; min_class = 11 + c; }
+            }
+            sec.semantic_class = min_class;
+        }
+        out[i] = sec;
+        type = prev_type;
+        vT = prev_vT;
+        i++;
+    } while (prev_vT != -1 && i < P.S - 1); /* the reference asserts i < max_sections (:950) */
+    is_section term;
+    term.type = -1; term.vB = 0; term.vT = 0; term.disparity = 0.0f;
+    term.semantic_class = 0; term.cost = 0.0f; term.instance_meanx = 0.0f; term.instance_meany = 0.0f;
+    out[i] = term;
+}
+
+/* ====================================================================================== */
+/* Instance candidates in canonical (column, section) order, reference layout              */
+/* (StixelsKernels.cu:926-942; one workgroup per image)                                    */
+/* ====================================================================================== */
+__global__ __launch_bounds__(256) void k_compact_instances(
+    const DevParams P, const is_section* __restrict__ sections, float* __restrict__ com,
+    int32_t* __restrict__ indices, uint8_t* __restrict__ core, int32_t* __restrict__ per_class) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int* s_cnt = (int*)smem; /* [C][8] counts, then exclusive offsets */
+    const int C = P.C, S = P.S;
+    const is_section* sec = sections; /* already offset to the image by the host */
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        int cnt[IS_INSTANCE_CLASSES];
+#pragma unroll
+        for (int k = 0; k < IS_INSTANCE_CLASSES; k++) cnt[k] = 0;
+        for (int i = 0; i < S; i++) {
+            const is_section s = sec[(size_t)c * S + i];
+            if (s.type == -1) break;
+            if (s.type == IS_OBJECT && s.semantic_class >= IS_FIRST_INSTANCE_CLASS) {
+                const int k = s.semantic_class - IS_FIRST_INSTANCE_CLASS;
+#pragma unroll
+                for (int kk = 0; kk < IS_INSTANCE_CLASSES; kk++)
+                    if (kk == k) cnt[kk]++;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < IS_INSTANCE_CLASSES; k++) s_cnt[c * IS_INSTANCE_CLASSES + k] = cnt[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < IS_INSTANCE_CLASSES) {
+        int run = 0;
+        for (int c = 0; c < C; c++) {
+            const int n = s_cnt[c * IS_INSTANCE_CLASSES + threadIdx.x];
+            s_cnt[c * IS_INSTANCE_CLASSES + threadIdx.x] = run;
+            run += n;
+        }
+        if (per_class) per_class[threadIdx.x] = run;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        int off[IS_INSTANCE_CLASSES];
+#pragma unroll
+        for (int k = 0; k < IS_INSTANCE_CLASSES; k++) off[k] = s_cnt[c * IS_INSTANCE_CLASSES + k];
+        for (int i = 0; i < S; i++) {
+            const is_section s = sec[(size_t)c * S + i];
+            if (s.type == -1) break;
+            if (s.type == IS_OBJECT && s.semantic_class >= IS_FIRST_INSTANCE_CLASS) {
+                const int k = s.semantic_class - IS_FIRST_INSTANCE_CLASS;
+                int idx = 0;
+#pragma unroll
+                for (int kk = 0; kk < IS_INSTANCE_CLASSES; kk++)
+                    if (kk == k) idx = off[kk]++;
+                const size_t slot = (size_t)k * C * S + idx;
+                if (com) { com[slot * 2] = s.instance_meanx; com[slot * 2 + 1] = s.instance_meany; }
+                if (indices) { indices[slot * 2] = c; indices[slot * 2 + 1] = i; }
+                if (core) core[slot] = (s.vT + 1 - s.vB) >= P.size_filter;
+            }
+        }
+    }
+}
+
+/* ====================================================================================== */
+/* launch helpers (called from is_core.hip)                                                */
+/* ====================================================================================== */
+extern "C" {
+
+size_t isk_prepare_lds_bytes(const DevParams* P) {
+    return sizeof(float) * (size_t)P->P2 * 3 + sizeof(int32_t) * (size_t)P->CH * P->P2S + 64;
+}
+size_t isk_unary_lds_bytes(const DevParams* P) {
+    const size_t a = sizeof(float) * ((size_t)IS_TILE * (P->D + 1) + (size_t)P->H + 1);
+    const size_t b = (size_t)8 * 3 * 64 * 8; /* merge area for up to 8 waves */
+    return (a > b ? a : b) + 16;
+}
+size_t isk_pairwise_lds_bytes(const DevParams* P, int nwaves) {
+    return sizeof(PredRec) * (size_t)P->H + sizeof(float) * (size_t)IS_TILE * (P->D + 1) +
+           (size_t)nwaves * 3 * 64 * 8 + 32;
+}
+
+hipError_t isk_launch_join(const float* big, float* joined, int H, int W, int C, int step,
+                           int margin, int median, float invalid, int n_images,
+                           hipStream_t stream) {
+    dim3 grid((H + JOIN_ROWS - 1) / JOIN_ROWS, (C + JOIN_COLS - 1) / JOIN_COLS, n_images);
+    hipLaunchKernelGGL(k_join_columns, grid, dim3(256), 0, stream, big, joined, H, W, C, step,
+                       margin, median, invalid);
+    return hipGetLastError();
+}
+
+hipError_t isk_launch_prepare(const DevParams* P, int ncols, const float* joined,
+                              const int32_t* seg, const float* ground, const int* vhor,
+                              const float* obj_cost_lut, RowRec* recs, float* lutT,
+                              hipStream_t stream) {
+    hipLaunchKernelGGL(k_prepare_columns, dim3(ncols), dim3(PREP_THREADS),
+                       isk_prepare_lds_bytes(P), stream, *P, joined, seg, ground, vhor,
+                       obj_cost_lut, recs, lutT);
+    return hipGetLastError();
+}
+
+hipError_t isk_launch_priors(const DevParams* P, const float* ground, PriorRec* priors,
+                             int n_images, hipStream_t stream) {
+    const int n = n_images * P->H;
+    hipLaunchKernelGGL(k_prior_tables, dim3((n + 255) / 256), dim3(256), 0, stream, *P, ground,
+                       priors, n_images);
+    return hipGetLastError();
+}
+
+hipError_t isk_launch_dp_unary(const DevParams* P, int ncols, int nwaves, const RowRec* recs,
+                               const float* lutT, const float* pwinv, const int* vhor,
+                               float* cost_table, int32_t* index_table, hipStream_t stream) {
+    const int groups = (ncols + 7) / 8;
+    const dim3 grid(groups * 8 * P->ntiles);
+    const size_t lds = isk_unary_lds_bytes(P);
+    if (P->invalid >= 0)
+        hipLaunchKernelGGL(k_dp_unary<true>, grid, dim3(nwaves * 64), lds, stream, *P, ncols, recs,
+                           lutT, pwinv, vhor, cost_table, index_table);
+    else
+        hipLaunchKernelGGL(k_dp_unary<false>, grid, dim3(nwaves * 64), lds, stream, *P, ncols, recs,
+                           lutT, pwinv, vhor, cost_table, index_table);
+    return hipGetLastError();
+}
+
+hipError_t isk_launch_dp_pairwise(const DevParams* P, int ncols, int nwaves, const RowRec* recs,
+                                  const float* lutT, const PriorRec* priors, const float* odr,
+                                  const int* vhor, float* cost_table, int32_t* index_table,
+                                  hipStream_t stream) {
+    const size_t lds = isk_pairwise_lds_bytes(P, nwaves);
+    if (P->invalid >= 0)
+        hipLaunchKernelGGL(k_dp_pairwise<true>, dim3(ncols), dim3(nwaves * 64), lds, stream, *P,
+                           ncols, recs, lutT, priors, odr, vhor, cost_table, index_table);
+    else
+        hipLaunchKernelGGL(k_dp_pairwise<false>, dim3(ncols), dim3(nwaves * 64), lds, stream, *P,
+                           ncols, recs, lutT, priors, odr, vhor, cost_table, index_table);
+    return hipGetLastError();
+}
+
+hipError_t isk_launch_backtrace(const DevParams* P, int ncols, int pairwise, const RowRec* recs,
+                                const float* cost_table, const int32_t* index_table,
+                                is_section* sections, hipStream_t stream) {
+    hipLaunchKernelGGL(k_backtrace, dim3((ncols + 63) / 64), dim3(64), 0, stream, *P, ncols,
+                       pairwise, recs, cost_table, index_table, sections);
+    return hipGetLastError();
+}
+
+hipError_t isk_launch_compact(const DevParams* P, const is_section* sections_img, float* com,
+                              int32_t* indices, uint8_t* core, int32_t* per_class,
+                              hipStream_t stream) {
+    const size_t lds = sizeof(int) * (size_t)P->C * IS_INSTANCE_CLASSES + 16;
+    hipLaunchKernelGGL(k_compact_instances, dim3(1), dim3(256), lds, stream, *P, sections_img, com,
+                       indices, core, per_class);
+    return hipGetLastError();
+}
+
+hipError_t isk_set_lds_limits(const DevParams* P, int nwaves_pair) {
+    hipError_t e;
+    const int a = (int)isk_prepare_lds_bytes(P);
+    e = hipFuncSetAttribute((const void*)k_prepare_columns, hipFuncAttributeMaxDynamicSharedMemorySize, a);
+    if (e != hipSuccess) return e;
+    const int b = (int)isk_unary_lds_bytes(P);
+    e = hipFuncSetAttribute((const void*)k_dp_unary<true>, hipFuncAttributeMaxDynamicSharedMemorySize, b);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void*)k_dp_unary<false>, hipFuncAttributeMaxDynamicSharedMemorySize, b);
+    if (e != hipSuccess) return e;
+    const int c = (int)isk_pairwise_lds_bytes(P, nwaves_pair);
+    e = hipFuncSetAttribute((const void*)k_dp_pairwise<true>, hipFuncAttributeMaxDynamicSharedMemorySize, c);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void*)k_dp_pairwise<false>, hipFuncAttributeMaxDynamicSharedMemorySize, c);
+    return e;
+}
+
+} /* extern "C" */
