@@ -39,6 +39,14 @@ def lib():
             raise CoreError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
                 "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        # PyTorch-ROCm wheels bundle their own libamdhip64.so (SONAME libamdhip64.so.7).  Two HIP
+        # runtimes in one process do not work ("No HIP GPUs are available"), so when torch is
+        # importable it must be loaded FIRST; the dynamic linker then resolves this library's
+        # libamdhip64.so.7 dependency to the already loaded copy.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = ctypes.CDLL(LIB_PATH)
         vp, ci, cf = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
         L.is_ctx_create.argtypes = [ctypes.POINTER(StixelParams), vp, vp, ci, ci,
