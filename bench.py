@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""Column-DP throughput bench (BASELINE.json metric: images/s on 1024x2048x128-disparity frames).
+
+One "step" = one pass of the hot path (JoinColumns + per-column preparation + DP + back-trace)
+over a batch of synthetic frames that is already resident in HBM; outputs (Section arrays) stay
+on the device.  With N > 1 (launched by torch.distributed.run, one rank per GPU) every rank
+processes its own shard of the batch -- the path has no data-path collective -- and the only
+communication is the final gather of the stixel outputs to rank 0 over RCCL, inside the timed
+region.  Rank 0 prints ONE JSON line.
+
+    python bench.py [--gpus N --steps K --warmup W] [--batch B] [--preset drn_d_22_unary]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
+VALU_PEAK_LANEOPS = 78.6e12    # 157.3 TFLOP/s fp32 vector = 78.6 T lane-FMA/s
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=64, help="frames per GPU per step")
+    ap.add_argument("--preset", default="drn_d_22_unary")
+    ap.add_argument("--rows", type=int, default=1024)
+    ap.add_argument("--cols", type=int, default=2048)
+    ap.add_argument("--max-dis", type=int, default=128)
+    ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic frames per rank")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-cols", type=int, default=48)
+    ap.add_argument("--no-gather", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(cfg, frame, ncols_sample):
+    """The oracle (kind "port": the reference has no CPU path) on a bounded sample: the first
+    `ncols_sample` stixel columns of one frame, all host cores."""
+    from oracle import oracle
+    params, lut, odr = oracle.host_initialize(cfg)
+    gf, ng, ig, vhor = oracle.host_ground(cfg, frame.vhor_image, frame.camera_tilt,
+                                          frame.camera_height, frame.alpha_ground)
+    joined = oracle.join_columns(cfg, frame.disparity)
+    cores = os.cpu_count() or 1
+    ncols_sample = min(ncols_sample, cfg.realcols)
+    oracle.compute(params, lut, odr, joined, frame.segmentation, gf, ng, ig, vhor, cfg.pairwise,
+                   col_range=(0, min(cores, ncols_sample)), nthreads=cores, want_tables=False)
+    t0 = time.perf_counter()
+    oracle.compute(params, lut, odr, joined, frame.segmentation, gf, ng, ig, vhor, cfg.pairwise,
+                   col_range=(0, ncols_sample), nthreads=cores, want_tables=False)
+    dt = time.perf_counter() - t0
+    return dict(value=(ncols_sample / cfg.realcols) / dt, unit="images/s", cores=cores,
+                kind="port",
+                sample=f"{ncols_sample} of {cfg.realcols} stixel columns of one "
+                       f"{cfg.rows}x{cfg.cols}x{cfg.max_dis} frame in {dt:.2f} s, "
+                       f"OpenMP over columns")
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+    import torch
+    import torch.distributed as dist
+    from instance_stixels_amd import make_config, synthetic, host
+    from instance_stixels_amd.core import Core, InstanceBuffers
+    from instance_stixels_amd.parallel import gather_sections
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    cfg = make_config(args.preset, args.rows, args.cols, args.max_dis)
+    B = args.batch
+    H, W, C, D = int(cfg.rows), int(cfg.cols), cfg.realcols, int(cfg.max_dis)
+
+    # ---- host side: the C++ Stixels class computes the parameter block, LUTs, ground model
+    st = host.Stixels()
+    st.SetConfig(cfg)
+    st.PrecomputeHost()
+    params = st.GetParameters()
+    lut, odr = st.GetLUTs()
+    frames = [synthetic.make_frame(cfg, seed=17 + 101 * rank + i) for i in range(args.distinct)]
+    gfs, ngs, igs, vhs = [], [], [], []
+    for f in frames:
+        st.SetRoadParameters(f.vhor_image, f.camera_tilt, f.camera_height, f.alpha_ground)
+        gf, ng, ig, vh = st.GetGroundModel()
+        gfs.append(gf); ngs.append(ng); igs.append(ig); vhs.append(vh)
+    pick = [i % args.distinct for i in range(B)]
+    gf = np.stack([gfs[i] for i in pick]); ng = np.stack([ngs[i] for i in pick])
+    ig = np.stack([igs[i] for i in pick]); vh = np.array([vhs[i] for i in pick], np.int32)
+
+    # ---- inputs resident in HBM before the timed region
+    d_frames = torch.from_numpy(np.stack([f.disparity for f in frames])).to(dev)
+    s_frames = torch.from_numpy(np.stack([f.segmentation for f in frames])).to(dev)
+    idx = torch.tensor(pick, device=dev)
+    d_big = d_frames[idx].contiguous()                    # [B][H][W] f32
+    d_seg = s_frames[idx].contiguous()                    # [B][C][21][P2S] i32
+    d_joined = torch.empty((B, C, H), dtype=torch.float32, device=dev)
+    S = params.max_sections
+    d_sections = torch.empty((B, C, S, 8), dtype=torch.int32, device=dev)
+    del d_frames, s_frames
+
+    core = Core(params, lut, odr, max_batch=B, device=local_rank)
+    core.set_kernel_timing(True)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    gathered = None
+    if world > 1 and rank == 0 and not args.no_gather:
+        gathered = [torch.empty_like(d_sections) for _ in range(world)]
+
+    def step():
+        core.join_columns_ptr(d_big.data_ptr(), W, cfg.median_join, d_joined.data_ptr(), B, stream)
+        core.compute_ptr(d_joined.data_ptr(), d_seg.data_ptr(), gf, ng, ig, vh, cfg.pairwise, B,
+                         d_sections.data_ptr(), None, None, None, stream)
+        if world > 1 and not args.no_gather:
+            gather_sections(d_sections, gathered, dst=0)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    # per-kernel durations of the LAST timed step, measured with HIP events on the launch stream
+    kt = core.kernel_times_ms()
+
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        images = B * world * args.steps
+        value = images / dt
+        alg_bytes_img = synthetic.algorithmic_bytes_per_image(cfg)
+        pairs_img = synthetic.pair_evaluations_per_image(cfg)
+        dp_s = kt["dp_ms"] * 1e-3
+        achieved = alg_bytes_img * B / dp_s / 1e9
+        out = {
+            "metric": "images/s on 1024x2048x128-disp column DP",
+            "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32+i32", "data": "synthetic",
+            "config": {"workload": f"C2/C3: {B} frames/GPU of {H}x{W}, {D} disparity bins, "
+                                   f"19 classes + 2 offset channels, preset {args.preset} "
+                                   f"({'pairwise' if cfg.pairwise else 'unary'}), JoinColumns + "
+                                   "prepare + DP + back-trace, device-resident in/out",
+                       "batch_per_gpu": B, "rows": H, "cols": W, "max_dis": D,
+                       "preset": args.preset,
+                       "parallelism": f"batch shards x{world}, RCCL gather of sections to rank 0"
+                                      if world > 1 else "single GPU"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "k_dp_pairwise" if cfg.pairwise else "k_dp_unary",
+                         "kernel_ms": kt["dp_ms"],
+                         "algorithmic_bytes_per_image": alg_bytes_img,
+                         "note": "the column DP is VALU-bound, not HBM-bound (SURVEY.md H1): "
+                                 "see valu_* fields"},
+            "valu": {"pair_evals_per_s": pairs_img * B / dp_s,
+                     "pair_evals_per_image": pairs_img,
+                     "lane_ops_peak_per_s": VALU_PEAK_LANEOPS},
+            "kernel_ms": kt,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(cfg, frames[0], args.cpu_sample_cols)
+        print(json.dumps(out), flush=True)
+
+    core.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,157 @@
+/*
+ * Stixels.hpp -- host class of the MI355X-native stixel library.
+ *
+ * Public surface = the reference's `class Stixels`
+ * (/root/reference/InstanceStixels/include/InstanceStixels/Stixels.hpp:40-96): same method
+ * names, argument meaning and error behaviour, so run_cityscapes / StixelsWrapper / the ROS node
+ * compile against it unchanged.  Differences, all behind the same API:
+ *   - plain C++ header (no CUDA/HIP types): callers need not be device translation units;
+ *   - the device side is the C ABI of include/instance_stixels_core.h (HIP, gfx950);
+ *   - Compute() does not modify the segmentation buffer it is given;
+ *   - ComputeBatch() / InitializeBatch() are additions for batched, multi-GPU use.
+ */
+#ifndef INSTANCESTIXELS_AMD_STIXELS_HPP_
+#define INSTANCESTIXELS_AMD_STIXELS_HPP_
+
+#include <stdint.h>
+
+#include <cmath>
+#include <map>
+#include <utility>
+#include <vector>
+
+#include "configuration.h"
+#include "types.h"
+#include "util.h"
+
+constexpr float PIFLOAT = 3.1416f;
+
+class Stixels {
+public:
+    Stixels();
+    ~Stixels();
+
+    void Initialize();
+    void Finish();
+
+    float Compute(bool pairwise, StixelsData& stixels, int32_t* d_segmentation_local = nullptr);
+    float ClusterInstances();
+    std::map<std::pair<int, int>, int> GetInstanceStixels();
+    int GetRealCols();
+    int GetMaxSections();
+    void SetConfig(const StixelConfig& config);
+    void SetSegmentation(const std::vector<int32_t>& segmentation);
+    void SetSegmentationParameters(const int classes, const int instance_channels);
+    void SetClusteringParameters(const float eps, const int min_pts, const int size_filter);
+    void SetWeightParameters(const float prior_weight, const float disparity_weight,
+                             const float segmentation_weight, const float instance_weight);
+    void SetDisparityImage(const std::vector<pixel_t>& disp_im);
+    pixel_t* GetInputDisparityImageOnDevice();
+    void SetProbabilities(float pout, float pout_sky, float pground_given_nexist,
+                          float pobject_given_nexist, float psky_given_nexist, float pnexist_dis,
+                          float pground, float pobject, float psky, float pord, float pgrav,
+                          float pblg);
+    void SetRoadParameters(int vhor, float camera_tilt, float camera_height, float alpha_ground);
+    void SetCameraParameters(float focal, float baseline, float sigma_camera_tilt,
+                             float sigma_camera_height, float camera_center_x = -1,
+                             float camera_center_y = -1);
+    void SetDisparityParameters(const int rows, const int cols, const int max_dis,
+                                const float invalid_disparity, const float sigma_disparity_object,
+                                const float sigma_disparity_ground, float sigma_sky);
+    void SetModelParameters(const int column_step, const bool median_join, float epsilon,
+                            float range_objects_z, int width_margin);
+    std::vector<float> Get3DVertices(const StixelsData& stixels_data);
+    static void SaveStixels(Section* stixels, std::map<std::pair<int, int>, int> instance_stixels,
+                            const float alpha_ground, const int vhor, const int real_cols,
+                            const int max_segments, const char* fname);
+    bool IsInitialized() { return m_is_initialized; }
+
+    /* ---- additions (not in the reference) ---- */
+    /* Road parameters of one frame of a batch, image-convention vhor as in SetRoadParameters. */
+    struct RoadParameters {
+        int vhor;
+        float camera_tilt, camera_height, alpha_ground;
+    };
+    /* Host half of Initialize() (tables + parameter block); needs no device. */
+    void PrecomputeHost();
+    /* Like Initialize(), with device scratch for up to max_batch frames per ComputeBatch(). */
+    void InitializeBatch(int max_batch);
+    /* Batched Compute on device-resident inputs:
+     *   d_disparity_big [n][rows][cols] float, d_segmentation [n][realcols][channels][P2S] int32.
+     * Fills `out[i]` like Compute() fills its StixelsData.  `stream` is a hipStream_t. */
+    void ComputeBatch(bool pairwise, int n_images, const pixel_t* d_disparity_big,
+                      const int32_t* d_segmentation, const RoadParameters* road,
+                      std::vector<StixelsData>& out, void* stream = nullptr);
+    /* Introspection for tests / bench. */
+    const StixelParameters& GetParameters() const { return m_params; }
+    const std::vector<float>& GetObjectCostLUT() const { return m_obj_cost_lut; }
+    const std::vector<float>& GetObjectDisparityRange() const { return m_object_disparity_range; }
+    void GetGroundModel(std::vector<float>& ground_function,
+                        std::vector<float>& normalization_ground,
+                        std::vector<float>& inv_sigma2_ground, int& vhor_lib);
+    is_ctx* GetCoreContext() { return m_ctx; }
+
+private:
+    struct GroundModel {
+        std::vector<float> function, normalization, inv_sigma2;
+    };
+    void PrecomputeSky();
+    void PrecomputeObject();
+    void PrecomputeGround(int vhor_lib, float camera_tilt, float camera_height, float alpha_ground,
+                          GroundModel& out) const;
+    float GetDataCostObject(const int fn, const int dis) const;
+    float ComputeObjectDisparityRange(const float previous_mean) const;
+    float FastLog(float v) const;
+    void FillHeader(StixelsData& d, float alpha_ground, int vhor_lib) const;
+
+    /* device (owned between Initialize and Finish, Stixels.cu:53-74, 136-163) */
+    is_ctx* m_ctx = nullptr;
+    pixel_t* d_disparity = nullptr;
+    pixel_t* d_disparity_big = nullptr;
+    int32_t* d_segmentation = nullptr;
+    Section* d_stixels = nullptr;
+    float* d_instance_centerofmass = nullptr;
+    int32_t* d_instance_indices = nullptr;
+    uint8_t* d_instance_core_candidates = nullptr;
+    int32_t* d_instances_per_class = nullptr;
+    int m_max_batch = 1;
+
+    StixelParameters m_params{};
+    int m_max_sections = MAX_STIXELS_PER_COLUMN;
+    bool m_is_initialized = false;
+
+    /* probabilities */
+    float m_pout = 0, m_pout_sky = 0;
+    float m_pnexists_given_ground = 0, m_pnexists_given_object = 0, m_pnexists_given_sky = 0;
+    float m_pord = 0, m_pgrav = 0, m_pblg = 0;
+    /* camera */
+    float m_focal = 0, m_baseline = 0, m_camera_tilt = 0, m_sigma_camera_tilt = 0;
+    float m_camera_height = 0, m_sigma_camera_height = 0;
+    float m_camera_center_x = -1, m_camera_center_y = -1;
+    int m_vhor = 0;
+    /* segmentation / weights */
+    int m_segmentation_classes = 0, m_segmentation_channels = 0;
+    float m_prior_weight = 0, m_disparity_weight = 0, m_segmentation_weight = 0,
+          m_instance_weight = 0;
+    /* disparity */
+    int m_max_dis = 0;
+    float m_max_disf = 0, m_invalid_disparity = -1;
+    int m_rows = 0, m_cols = 0, m_realcols = 0;
+    float m_sigma_disparity_object = 0, m_sigma_disparity_ground = 0, m_sigma_sky = 0;
+    /* model */
+    int m_column_step = 0;
+    bool m_median_join = false;
+    float m_alpha_ground = 0, m_range_objects_z = 0, m_epsilon = 0;
+    int m_width_margin = 0;
+    /* tables */
+    std::vector<float> m_log_lut, m_obj_cost_lut, m_object_disparity_range;
+    std::vector<float> m_normalization_object, m_inv_sigma2_object;
+    float m_max_dis_log = 0, m_rows_log = 0;
+    float m_puniform = 0, m_puniform_sky = 0, m_normalization_sky = 0, m_inv_sigma2_sky = 0;
+    /* instances (host mirrors) */
+    std::vector<int32_t> m_instance_labels, m_instance_indices;
+    std::vector<int> m_instances_per_class;
+    int m_instance_classes = IS_INSTANCE_CLASSES;
+};
+
+#endif

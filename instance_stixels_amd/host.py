@@ -1,0 +1,215 @@
+"""Python view of the C++ `Stixels` host class (instance_stixels_amd/host/Stixels.cpp).
+
+Method names, argument meaning and call order are those of the reference's class
+(/root/reference/InstanceStixels/include/InstanceStixels/Stixels.hpp:40-96) so that tests read
+like its callers (apps/run_cityscapes.cu:328-449).  Everything executes in the C++ library; this
+module only marshals numpy arrays.
+"""
+import ctypes
+import dataclasses
+import os
+
+import numpy as np
+
+from . import core as _core
+from .config import StixelConfig, StixelParams, SECTION_DTYPE
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libInstanceStixels.so")
+_LIB = None
+
+EXPORTS = [
+    "ish_last_error", "ish_create", "ish_destroy", "ish_set_config", "ish_initialize",
+    "ish_precompute_host",
+    "ish_finish", "ish_is_initialized", "ish_real_cols", "ish_max_sections",
+    "ish_get_parameters", "ish_get_luts", "ish_core_context", "ish_set_disparity_image",
+    "ish_set_segmentation", "ish_set_road_parameters", "ish_get_ground_model", "ish_compute",
+    "ish_get_instance_stixels", "ish_get_3d_vertices", "ish_save_stixels",
+]
+
+
+class _IshConfig(ctypes.Structure):
+    _f, _i = ctypes.c_float, ctypes.c_int
+    _fields_ = [
+        ("rows", _f), ("cols", _f), ("max_dis", _i), ("invalid_disparity", _f), ("eps", _f),
+        ("min_pts", _i), ("size_filter", _i), ("n_semantic_classes", _i),
+        ("n_offset_channels", _i), ("prior_weight", _f), ("segmentation_weight", _f),
+        ("instance_weight", _f), ("disparity_weight", _f), ("pairwise", _i), ("column_step", _i),
+        ("focal", _f), ("baseline", _f), ("camera_center_x", _f), ("camera_center_y", _f),
+        ("sigma_disparity_object", _f), ("sigma_disparity_ground", _f), ("sigma_sky", _f),
+        ("pout", _f), ("pout_sky", _f), ("pord", _f), ("pgrav", _f), ("pblg", _f),
+        ("pground_given_nexist", _f), ("pobject_given_nexist", _f), ("psky_given_nexist", _f),
+        ("pnexist_dis", _f), ("pground", _f), ("pobject", _f), ("psky", _f), ("width_margin", _i),
+        ("sigma_camera_tilt", _f), ("sigma_camera_height", _f), ("median_join", _i),
+        ("epsilon", _f), ("range_objects_z", _f), ("road_vdisparity_threshold", _f),
+    ]
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _core.lib()  # loads torch's HIP runtime first (if any) and libis_core.so
+        if not os.path.exists(LIB_PATH):
+            raise _core.CoreError(f"{LIB_PATH} is missing: run __graft_entry__.build()")
+        L = ctypes.CDLL(LIB_PATH)
+        vp, ci, cf = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
+        L.ish_last_error.restype = ctypes.c_char_p
+        L.ish_create.restype = vp
+        L.ish_destroy.argtypes = [vp]
+        L.ish_set_config.argtypes = [vp, ctypes.POINTER(_IshConfig)]
+        L.ish_initialize.argtypes = [vp, ci]
+        L.ish_finish.argtypes = [vp]
+        L.ish_precompute_host.argtypes = [vp]
+        L.ish_is_initialized.argtypes = [vp]
+        L.ish_real_cols.argtypes = [vp]
+        L.ish_max_sections.argtypes = [vp]
+        L.ish_get_parameters.argtypes = [vp, ctypes.POINTER(StixelParams)]
+        L.ish_get_luts.argtypes = [vp, vp, vp]
+        L.ish_core_context.argtypes = [vp]
+        L.ish_core_context.restype = vp
+        L.ish_set_disparity_image.argtypes = [vp, vp, ctypes.c_size_t]
+        L.ish_set_segmentation.argtypes = [vp, vp, ctypes.c_size_t]
+        L.ish_set_road_parameters.argtypes = [vp, ci, cf, cf, cf]
+        L.ish_get_ground_model.argtypes = [vp, vp, vp, vp, ctypes.POINTER(ci)]
+        L.ish_compute.argtypes = [vp, ci, vp, vp, ctypes.POINTER(cf), ctypes.POINTER(cf)]
+        L.ish_get_instance_stixels.argtypes = [vp, vp, ci]
+        L.ish_get_3d_vertices.argtypes = [vp, vp, cf, ci, vp, ci]
+        L.ish_save_stixels.argtypes = [vp, vp, vp, ci, cf, ci, ctypes.c_char_p]
+        _LIB = L
+    return _LIB
+
+
+@dataclasses.dataclass
+class StixelsData:               # types.h:196-205
+    sections: np.ndarray         # [realcols][max_sections] SECTION_DTYPE
+    rows: int
+    cols: int
+    realcols: int
+    max_sections: int
+    max_dis: int
+    column_step: int
+    semantic_classes: int
+    alpha_ground: float
+    vhor: int
+
+
+class Stixels:
+    def __init__(self):
+        self._h = ctypes.c_void_p(lib().ish_create())
+        self._cfg = None
+
+    def _check(self, rc, what):
+        if rc == -1:
+            raise ValueError(lib().ish_last_error().decode())   # std::invalid_argument
+        if rc < 0:
+            raise RuntimeError(f"{what}: {lib().ish_last_error().decode()}")
+        return rc
+
+    def close(self):
+        if self._h:
+            lib().ish_finish(self._h)
+            lib().ish_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- reference API ---------------------------------------------------------------
+    def SetConfig(self, cfg: StixelConfig):
+        c = _IshConfig()
+        for name, _ in _IshConfig._fields_:
+            v = getattr(cfg, name)
+            setattr(c, name, int(v) if isinstance(v, (bool, np.bool_)) else v)
+        self._check(lib().ish_set_config(self._h, ctypes.byref(c)), "SetConfig")
+        self._cfg = cfg
+
+    def Initialize(self, max_batch=1):
+        self._check(lib().ish_initialize(self._h, int(max_batch)), "Initialize")
+
+    def PrecomputeHost(self):
+        """Host half of Initialize (tables + StixelParameters); needs no GPU."""
+        self._check(lib().ish_precompute_host(self._h), "PrecomputeHost")
+
+    def Finish(self):
+        self._check(lib().ish_finish(self._h), "Finish")
+
+    def IsInitialized(self):
+        return bool(lib().ish_is_initialized(self._h))
+
+    def GetRealCols(self):
+        return lib().ish_real_cols(self._h)
+
+    def GetMaxSections(self):
+        return lib().ish_max_sections(self._h)
+
+    def SetDisparityImage(self, disp):
+        a = np.ascontiguousarray(disp, np.float32)
+        self._check(lib().ish_set_disparity_image(self._h, a.ctypes.data, a.size),
+                    "SetDisparityImage")
+
+    def SetSegmentation(self, seg):
+        a = np.ascontiguousarray(seg, np.int32)
+        self._check(lib().ish_set_segmentation(self._h, a.ctypes.data, a.size), "SetSegmentation")
+
+    def SetRoadParameters(self, vhor, camera_tilt, camera_height, alpha_ground):
+        self._check(lib().ish_set_road_parameters(self._h, int(vhor), camera_tilt, camera_height,
+                                                  alpha_ground), "SetRoadParameters")
+
+    def Compute(self, pairwise) -> StixelsData:
+        C, S = self.GetRealCols(), self.GetMaxSections()
+        sec = np.zeros((C, S), SECTION_DTYPE)
+        hdr = np.zeros(9, np.int32)
+        alpha, ret = ctypes.c_float(), ctypes.c_float()
+        self._check(lib().ish_compute(self._h, int(bool(pairwise)), sec.ctypes.data,
+                                      hdr.ctypes.data, ctypes.byref(alpha), ctypes.byref(ret)),
+                    "Compute")
+        return StixelsData(sec, *[int(x) for x in hdr[:7]], float(alpha.value), int(hdr[7]))
+
+    def GetInstanceStixels(self):
+        cap = self.GetRealCols() * self.GetMaxSections()
+        t = np.zeros((cap, 3), np.int32)
+        n = self._check(lib().ish_get_instance_stixels(self._h, t.ctypes.data, cap),
+                        "GetInstanceStixels")
+        return {(int(u), int(v)): int(l) for u, v, l in t[:n]}
+
+    def Get3DVertices(self, data: StixelsData):
+        cap = data.sections.size * 12
+        out = np.zeros(cap, np.float32)
+        sec = np.ascontiguousarray(data.sections)
+        n = self._check(lib().ish_get_3d_vertices(self._h, sec.ctypes.data, data.alpha_ground,
+                                                  data.vhor, out.ctypes.data, cap),
+                        "Get3DVertices")
+        return out[:n].copy()
+
+    def SaveStixels(self, data: StixelsData, instance_stixels, alpha_ground, vhor, fname):
+        t = np.array([[u, v, l] for (u, v), l in instance_stixels.items()],
+                     np.int32).reshape(-1, 3)
+        sec = np.ascontiguousarray(data.sections)
+        self._check(lib().ish_save_stixels(self._h, sec.ctypes.data, t.ctypes.data, len(t),
+                                           alpha_ground, int(vhor), fname.encode()),
+                    "SaveStixels")
+
+    # ---- introspection ---------------------------------------------------------------
+    def GetParameters(self) -> StixelParams:
+        p = StixelParams()
+        lib().ish_get_parameters(self._h, ctypes.byref(p))
+        return p
+
+    def GetLUTs(self):
+        D = self.GetParameters().max_dis
+        lut = np.zeros((D, D), np.float32)
+        odr = np.zeros(D, np.float32)
+        lib().ish_get_luts(self._h, lut.ctypes.data, odr.ctypes.data)
+        return lut, odr
+
+    def GetGroundModel(self):
+        H = self.GetParameters().rows
+        gf, ng, ig = (np.zeros(H, np.float32) for _ in range(3))
+        vh = ctypes.c_int()
+        self._check(lib().ish_get_ground_model(self._h, gf.ctypes.data, ng.ctypes.data,
+                                               ig.ctypes.data, ctypes.byref(vh)),
+                    "GetGroundModel")
+        return gf, ng, ig, vh.value

@@ -1,0 +1,616 @@
+/*
+ * Stixels.cpp -- host class of the MI355X-native stixel library (plain C++, no HIP headers).
+ *
+ * Mirrors the behaviour of the reference's host driver
+ * (/root/reference/InstanceStixels/src/Stixels.cu:33-926) on top of the C ABI in
+ * include/instance_stixels_core.h: same setters, same frame-independent precompute
+ * (Initialize), same per-frame ground model (PrecomputeGround), same Compute() call sequence
+ * and error conventions (std::invalid_argument for unset configuration, message + exit(1) for
+ * device runtime failures).  Citations `Stixels.cu:N` refer to that file.
+ */
+#include "InstanceStixels/Stixels.hpp"
+
+#include <algorithm>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <stdexcept>
+
+Stixels::Stixels() {}
+Stixels::~Stixels() {} /* like the reference, buffers are released by Finish(), Stixels.cu:36-37 */
+
+/* ---------------------------------------------------------------- configuration setters */
+
+void Stixels::SetConfig(const StixelConfig& config) { /* Stixels.cu:292-338 */
+    if (config.rows == -1 || config.cols == -1)
+        throw std::invalid_argument("Number of rows or columns are not set.");
+    if (config.max_dis == -1) throw std::invalid_argument("Maximum disparity value is not set.");
+    if (config.eps == -1 || config.min_pts == -1 || config.size_filter == -1)
+        throw std::invalid_argument("Clustering parameters are not set.");
+    if (config.prior_weight == -1 || config.segmentation_weight == -1 ||
+        config.instance_weight == -1 || config.disparity_weight == -1)
+        throw std::invalid_argument("Energy term weights are not set.");
+    if (config.column_step == -1) throw std::invalid_argument("Stixel width is not set.");
+    if (config.focal == -1 || config.baseline == -1)
+        throw std::invalid_argument("Camera parameters are not set.");
+
+    SetDisparityParameters(config.rows, config.cols, config.max_dis, config.invalid_disparity,
+                           config.sigma_disparity_object, config.sigma_disparity_ground,
+                           config.sigma_sky);
+    SetSegmentationParameters(config.n_semantic_classes, config.n_offset_channels);
+    SetClusteringParameters(config.eps, config.min_pts, config.size_filter);
+    SetWeightParameters(config.prior_weight, config.disparity_weight, config.segmentation_weight,
+                        config.instance_weight);
+    SetProbabilities(config.pout, config.pout_sky, config.pground_given_nexist,
+                     config.pobject_given_nexist, config.psky_given_nexist, config.pnexist_dis,
+                     config.pground, config.pobject, config.psky, config.pord, config.pgrav,
+                     config.pblg);
+    SetModelParameters(config.column_step, config.median_join, config.epsilon,
+                       config.range_objects_z, config.width_margin);
+    SetCameraParameters(config.focal, config.baseline, config.sigma_camera_tilt,
+                        config.sigma_camera_height, config.camera_center_x,
+                        config.camera_center_y);
+}
+
+void Stixels::SetProbabilities(float pout, float pout_sky, float pground_given_nexist,
+                               float pobject_given_nexist, float psky_given_nexist,
+                               float pnexist_dis, float pground, float pobject, float psky,
+                               float pord, float pgrav, float pblg) { /* Stixels.cu:361-373 */
+    m_pout = pout;
+    m_pout_sky = pout_sky;
+    m_pnexists_given_ground = (pground_given_nexist * pnexist_dis) / pground;
+    m_pnexists_given_object = (pobject_given_nexist * pnexist_dis) / pobject;
+    m_pnexists_given_sky = (psky_given_nexist * pnexist_dis) / psky;
+    m_pord = pord;
+    m_pgrav = pgrav;
+    m_pblg = pblg;
+}
+
+void Stixels::SetRoadParameters(int vhor, float camera_tilt, float camera_height,
+                                float alpha_ground) { /* Stixels.cu:375-381 */
+    m_vhor = m_rows - vhor - 1;
+    m_camera_tilt = camera_tilt;
+    m_camera_height = camera_height;
+    m_alpha_ground = alpha_ground;
+}
+
+void Stixels::SetCameraParameters(float focal, float baseline, float sigma_camera_tilt,
+                                  float sigma_camera_height, float camera_center_x,
+                                  float camera_center_y) { /* Stixels.cu:383-393 */
+    m_focal = focal;
+    m_baseline = baseline;
+    m_sigma_camera_tilt = sigma_camera_tilt * (PIFLOAT) / 180.0f; /* degrees -> radians */
+    m_sigma_camera_height = sigma_camera_height;
+    m_camera_center_x = camera_center_x;
+    m_camera_center_y = camera_center_y;
+}
+
+void Stixels::SetClusteringParameters(const float eps, const int min_pts,
+                                      const int size_filter) { /* Stixels.cu:395-400 */
+    m_params.clustering_eps = eps;
+    m_params.clustering_min_pts = min_pts;
+    m_params.clustering_size_filter = size_filter;
+}
+
+void Stixels::SetSegmentationParameters(const int classes,
+                                        const int instance_channels) { /* Stixels.cu:402-406 */
+    m_segmentation_classes = classes;
+    m_segmentation_channels = classes + instance_channels;
+}
+
+void Stixels::SetWeightParameters(const float prior_weight, const float disparity_weight,
+                                  const float segmentation_weight,
+                                  const float instance_weight) { /* Stixels.cu:408-423 */
+    m_prior_weight = prior_weight;
+    m_disparity_weight = disparity_weight;
+    m_segmentation_weight = segmentation_weight;
+    /* the instance weight is expressed relative to the segmentation weight */
+    m_instance_weight = 0.0;
+    if (segmentation_weight > 1e-5) {
+        m_instance_weight = instance_weight / segmentation_weight;
+        if (instance_weight < 1e-8) m_instance_weight = 0.0;
+    }
+}
+
+void Stixels::SetDisparityParameters(const int rows, const int cols, const int max_dis,
+                                     const float invalid_disparity,
+                                     const float sigma_disparity_object,
+                                     const float sigma_disparity_ground,
+                                     const float sigma_sky) { /* Stixels.cu:425-437 */
+    m_rows = rows;
+    m_cols = cols;
+    m_max_dis = max_dis;
+    m_max_disf = (float)m_max_dis;
+    m_sigma_disparity_object = sigma_disparity_object;
+    m_sigma_disparity_ground = sigma_disparity_ground;
+    m_sigma_sky = sigma_sky;
+    m_invalid_disparity = invalid_disparity;
+}
+
+void Stixels::SetModelParameters(const int column_step, const bool median_join, float epsilon,
+                                 float range_objects_z, int width_margin) { /* Stixels.cu:439-446 */
+    m_column_step = column_step;
+    m_median_join = median_join;
+    m_epsilon = epsilon;
+    m_range_objects_z = range_objects_z;
+    m_width_margin = width_margin;
+}
+
+/* ---------------------------------------------------------------- precompute */
+
+float Stixels::FastLog(float v) const { /* Stixels.cu:786-788 */
+    return m_log_lut[(int)((v)*LOG_LUT_SIZE + 0.5f)];
+}
+
+float Stixels::ComputeObjectDisparityRange(const float previous_mean) const { /* :879-887 */
+    float range_disp = 0.0f;
+    if (previous_mean != 0) {
+        const float pmean_plus_z = (m_baseline * m_focal / previous_mean) + m_range_objects_z;
+        range_disp = previous_mean - (m_baseline * m_focal / pmean_plus_z);
+    }
+    return range_disp;
+}
+
+void Stixels::PrecomputeSky() { /* Stixels.cu:856-865 */
+    const float sigma = m_sigma_sky;
+    const float pout = m_pout_sky;
+    const float a_range =
+        0.5f * (std::erf(m_max_disf / (sigma * sqrtf(2.0f))) - std::erf(0.0f));
+    m_normalization_sky =
+        FastLog(a_range) - logf((1.0f - pout) / (sigma * sqrtf(2.0f * PIFLOAT)));
+    m_inv_sigma2_sky = 1.0f / (2.0f * sigma * sigma);
+}
+
+void Stixels::PrecomputeObject() { /* Stixels.cu:819-840 */
+    const float pout = m_pout;
+    m_normalization_object.assign(m_max_dis, 0.0f);
+    m_inv_sigma2_object.assign(m_max_dis, 0.0f);
+    for (int dis = 0; dis < m_max_dis; dis++) {
+        const float fn = (float)dis;
+        const float sigma_object = fn * fn * m_range_objects_z / (m_focal * m_baseline);
+        const float sigma = sqrtf(m_sigma_disparity_object * m_sigma_disparity_object +
+                                  sigma_object * sigma_object);
+        const float a_range = 0.5f * (std::erf((m_max_disf - fn) / (sigma * sqrtf(2.0f))) -
+                                      std::erf((-fn) / (sigma * sqrtf(2.0f))));
+        m_normalization_object[dis] =
+            FastLog(a_range) - FastLog((1.0f - pout) / (sigma * sqrtf(2.0f * PIFLOAT)));
+        m_inv_sigma2_object[dis] = 1.0f / (2.0f * sigma * sigma);
+    }
+}
+
+float Stixels::GetDataCostObject(const int fn, const int dis) const { /* Stixels.cu:842-854 */
+    float data_cost = m_params.pnexists_given_object_log;
+    if (dis != (int)m_invalid_disparity) {
+        const float model_diff = (float)(dis - fn);
+        const float pgaussian =
+            m_normalization_object[fn] + model_diff * model_diff * m_inv_sigma2_object[fn];
+        const float p_data = fminf(m_puniform, pgaussian);
+        data_cost = p_data + m_params.nopnexists_given_object_log;
+    }
+    return data_cost;
+}
+
+void Stixels::PrecomputeGround(int vhor_lib, float camera_tilt, float camera_height,
+                               float alpha_ground, GroundModel& out) const { /* :790-817 */
+    const float fb = (m_focal * m_baseline) / camera_height;
+    const float pout = m_pout;
+    out.function.resize(m_rows);
+    out.normalization.resize(m_rows);
+    out.inv_sigma2.resize(m_rows);
+    for (int v = 0; v < m_rows; v++) {
+        const float fn = alpha_ground * (float)(vhor_lib - v); /* GroundFunction, :867-877 */
+        out.function[v] = fn;
+        const float x = camera_tilt + (float)(vhor_lib - v) / m_focal;
+        const float sigma2_road =
+            fb * fb *
+            (m_sigma_camera_height * m_sigma_camera_height * x * x /
+                 (camera_height * camera_height) +
+             m_sigma_camera_tilt * m_sigma_camera_tilt);
+        const float sigma =
+            sqrtf(m_sigma_disparity_ground * m_sigma_disparity_ground + sigma2_road);
+        const float a_range = 0.5f * (std::erf((m_max_disf - fn) / (sigma * sqrtf(2.0f))) -
+                                      std::erf((-fn) / (sigma * sqrtf(2.0f))));
+        out.normalization[v] =
+            FastLog(a_range) - FastLog((1.0f - pout) / (sigma * sqrtf(2.0f * PIFLOAT)));
+        out.inv_sigma2[v] = 1.0f / (2.0f * sigma * sigma);
+    }
+}
+
+void Stixels::GetGroundModel(std::vector<float>& ground_function,
+                             std::vector<float>& normalization_ground,
+                             std::vector<float>& inv_sigma2_ground, int& vhor_lib) {
+    GroundModel g;
+    PrecomputeGround(m_vhor, m_camera_tilt, m_camera_height, m_alpha_ground, g);
+    ground_function = g.function;
+    normalization_ground = g.normalization;
+    inv_sigma2_ground = g.inv_sigma2;
+    vhor_lib = m_vhor;
+}
+
+/* ---------------------------------------------------------------- Initialize / Finish */
+
+void Stixels::Initialize() { InitializeBatch(1); }
+
+/* Host half of Initialize: every frame-independent table and the kernel parameter block
+ * (Stixels.cu:44-47, 79-133, 212-245).  Needs no device. */
+void Stixels::PrecomputeHost() {
+    m_realcols = (m_cols - m_width_margin) / m_column_step;
+    m_max_sections = MAX_STIXELS_PER_COLUMN;
+    m_instance_classes = IS_INSTANCE_CLASSES;
+
+    const size_t inst_n = (size_t)m_instance_classes * m_realcols * m_max_sections;
+    m_instance_labels.assign(inst_n, -1);
+    m_instance_indices.assign(inst_n * 2, 0);
+    m_instances_per_class.assign(m_instance_classes, 0);
+
+    /* log LUT over [0, 1], Stixels.cu:79-84 */
+    m_log_lut.resize(LOG_LUT_SIZE + 1);
+    for (int i = 0; i < LOG_LUT_SIZE; i++) {
+        const float log_res = (float)i / ((float)LOG_LUT_SIZE);
+        m_log_lut[i] = logf(log_res);
+    }
+    m_log_lut[LOG_LUT_SIZE] = 0.0f;
+
+    /* frequently used values, Stixels.cu:93-102 */
+    m_max_dis_log = logf(m_max_disf);
+    m_rows_log = logf((float)m_rows);
+    m_puniform_sky = m_max_dis_log - logf(m_pout_sky);
+    m_puniform = m_max_dis_log - logf(m_pout);
+    m_params.pnexists_given_sky_log = -logf(m_pnexists_given_sky);
+    m_params.nopnexists_given_sky_log = -logf(1.0f - m_pnexists_given_sky);
+    m_params.pnexists_given_ground_log = -logf(m_pnexists_given_ground);
+    m_params.nopnexists_given_ground_log = -logf(1.0f - m_pnexists_given_ground);
+    m_params.pnexists_given_object_log = -logf(m_pnexists_given_object);
+    m_params.nopnexists_given_object_log = -logf(1.0f - m_pnexists_given_object);
+
+    m_object_disparity_range.resize(m_max_dis);
+    for (int i = 0; i < m_max_dis; i++)
+        m_object_disparity_range[i] = ComputeObjectDisparityRange((float)i); /* :111-115 */
+
+    PrecomputeSky();
+    PrecomputeObject();
+
+    m_obj_cost_lut.resize((size_t)m_max_dis * m_max_dis); /* :122-129 */
+    for (int fn = 0; fn < m_max_dis; fn++)
+        for (int dis = 0; dis < m_max_dis; dis++)
+            m_obj_cost_lut[(size_t)fn * m_max_dis + dis] = GetDataCostObject(fn, dis);
+
+    const int rows_power2 = (int)powf(2, ceilf(log2f(m_rows + 1))); /* :131-133 */
+    const int rows_power2_segmentation = (int)powf(2, ceilf(log2f(m_rows / 8 + 1)));
+
+    /* kernel parameter block, Stixels.cu:212-245 */
+    m_params.vhor = 0;
+    m_params.rows = m_rows;
+    m_params.cols = m_realcols;
+    m_params.max_dis = m_max_dis;
+    m_params.invalid_disparity = m_invalid_disparity;
+    m_params.rows_log = m_rows_log;
+    m_params.normalization_sky = m_normalization_sky;
+    m_params.inv_sigma2_sky = m_inv_sigma2_sky;
+    m_params.puniform_sky = m_puniform_sky;
+    m_params.puniform = m_puniform;
+    m_params.baseline = m_baseline;
+    m_params.focal = m_focal;
+    m_params.range_objects_z = m_range_objects_z;
+    m_params.pord = m_pord;
+    m_params.epsilon = m_epsilon;
+    m_params.pgrav = m_pgrav;
+    m_params.pblg = m_pblg;
+    m_params.rows_power2 = rows_power2;
+    m_params.rows_power2_segmentation = rows_power2_segmentation;
+    m_params.max_sections = m_max_sections;
+    m_params.max_dis_log = m_max_dis_log;
+    m_params.width_margin = m_width_margin;
+    m_params.segmentation_classes = m_segmentation_classes;
+    m_params.segmentation_channels = m_segmentation_channels;
+    m_params.prior_weight = m_prior_weight;
+    m_params.disparity_weight = m_disparity_weight;
+    m_params.segmentation_weight = m_segmentation_weight;
+    m_params.instance_weight = m_instance_weight;
+    m_params.column_step = m_column_step;
+}
+
+void Stixels::InitializeBatch(int max_batch) { /* Stixels.cu:43-248 */
+    m_max_batch = std::max(1, max_batch);
+    PrecomputeHost();
+    const size_t inst_n = (size_t)m_instance_classes * m_realcols * m_max_sections;
+    const int rows_power2_segmentation = m_params.rows_power2_segmentation;
+
+    /* device side: LUT upload + all buffers (Stixels.cu:53-74, 136-210) */
+    IS_CHECK_RETURN(is_ctx_create(&m_params, m_obj_cost_lut.data(),
+                                  m_object_disparity_range.data(), m_max_batch, 0, &m_ctx));
+    const size_t B = m_max_batch;
+    IS_CHECK_RETURN(is_device_malloc((void**)&d_stixels,
+                                     B * m_realcols * m_max_sections * sizeof(Section)));
+    IS_CHECK_RETURN(is_device_malloc((void**)&d_instance_centerofmass,
+                                     B * inst_n * 2 * sizeof(float)));
+    IS_CHECK_RETURN(is_device_malloc((void**)&d_instance_indices,
+                                     B * inst_n * 2 * sizeof(int32_t)));
+    IS_CHECK_RETURN(is_device_malloc((void**)&d_instance_core_candidates, B * inst_n));
+    IS_CHECK_RETURN(is_device_malloc((void**)&d_instances_per_class,
+                                     B * m_instance_classes * sizeof(int32_t)));
+    IS_CHECK_RETURN(is_device_malloc(
+        (void**)&d_segmentation,
+        (size_t)rows_power2_segmentation * m_realcols * m_segmentation_channels * sizeof(int32_t)));
+    IS_CHECK_RETURN(is_device_malloc((void**)&d_disparity_big,
+                                     (size_t)m_rows * m_cols * sizeof(float)));
+    IS_CHECK_RETURN(is_device_malloc((void**)&d_disparity,
+                                     B * m_rows * m_realcols * sizeof(float)));
+    m_is_initialized = true;
+}
+
+void Stixels::Finish() { /* Stixels.cu:250-283 */
+    IS_CHECK_RETURN(is_device_free(d_segmentation));
+    IS_CHECK_RETURN(is_device_free(d_disparity_big));
+    IS_CHECK_RETURN(is_device_free(d_disparity));
+    IS_CHECK_RETURN(is_device_free(d_stixels));
+    IS_CHECK_RETURN(is_device_free(d_instance_centerofmass));
+    IS_CHECK_RETURN(is_device_free(d_instance_indices));
+    IS_CHECK_RETURN(is_device_free(d_instance_core_candidates));
+    IS_CHECK_RETURN(is_device_free(d_instances_per_class));
+    IS_CHECK_RETURN(is_ctx_destroy(m_ctx));
+    m_ctx = nullptr;
+    d_segmentation = nullptr; d_disparity_big = nullptr; d_disparity = nullptr;
+    d_stixels = nullptr; d_instance_centerofmass = nullptr; d_instance_indices = nullptr;
+    d_instance_core_candidates = nullptr; d_instances_per_class = nullptr;
+    m_log_lut.clear(); m_obj_cost_lut.clear(); m_object_disparity_range.clear();
+    m_normalization_object.clear(); m_inv_sigma2_object.clear();
+    m_is_initialized = false;
+}
+
+/* ---------------------------------------------------------------- per-frame inputs */
+
+void Stixels::SetSegmentation(const std::vector<int32_t>& segmentation) { /* :340-346 */
+    IS_CHECK_RETURN(is_memcpy_h2d(d_segmentation, segmentation.data(),
+                                  sizeof(int32_t) * segmentation.size(), nullptr));
+    IS_CHECK_RETURN(is_stream_synchronize(nullptr));
+}
+
+void Stixels::SetDisparityImage(const std::vector<pixel_t>& disp_im) { /* :348-355 */
+    IS_CHECK_RETURN(is_memcpy_h2d(d_disparity_big, disp_im.data(),
+                                  sizeof(pixel_t) * disp_im.size(), nullptr));
+}
+
+pixel_t* Stixels::GetInputDisparityImageOnDevice() { return d_disparity_big; } /* :357-359 */
+int Stixels::GetRealCols() { return m_realcols; }
+int Stixels::GetMaxSections() { return m_max_sections; }
+
+/* ---------------------------------------------------------------- Compute */
+
+void Stixels::FillHeader(StixelsData& d, float alpha_ground, int vhor_lib) const { /* :615-627 */
+    d.sections.resize((size_t)m_realcols * m_max_sections);
+    d.rows = m_rows;
+    d.cols = m_cols;
+    d.realcols = m_realcols;
+    d.max_sections = m_max_sections;
+    d.max_dis = m_max_dis;
+    d.column_step = m_column_step;
+    d.semantic_classes = m_segmentation_classes;
+    d.alpha_ground = alpha_ground;
+    d.vhor = vhor_lib;
+}
+
+float Stixels::Compute(const bool pairwise, StixelsData& stixels_data,
+                       int32_t* d_segmentation_local) { /* Stixels.cu:449-637 */
+    if (d_segmentation_local == nullptr) d_segmentation_local = d_segmentation;
+
+    GroundModel g;
+    PrecomputeGround(m_vhor, m_camera_tilt, m_camera_height, m_alpha_ground, g); /* :463 */
+    m_params.vhor = m_vhor;                                                       /* :532 */
+
+    IS_CHECK_RETURN(is_join_columns(m_ctx, d_disparity_big, m_cols, m_median_join ? 1 : 0,
+                                    d_disparity, 1, nullptr)); /* :509-511 */
+    is_instance_buffers ib;
+    ib.d_centerofmass = d_instance_centerofmass;
+    ib.d_indices = d_instance_indices;
+    ib.d_core_candidates = d_instance_core_candidates;
+    ib.d_instances_per_class = d_instances_per_class;
+    IS_CHECK_RETURN(is_compute(m_ctx, d_disparity, d_segmentation_local, g.function.data(),
+                               g.normalization.data(), g.inv_sigma2.data(), &m_vhor,
+                               pairwise ? 1 : 0, 1, d_stixels, &ib, nullptr, nullptr,
+                               nullptr)); /* :535-590 */
+    IS_CHECK_RETURN(is_device_synchronize()); /* :600 */
+
+    ClusterInstances(); /* :613 */
+
+    FillHeader(stixels_data, m_alpha_ground, m_vhor);
+    IS_CHECK_RETURN(is_memcpy_d2h(stixels_data.sections.data(), d_stixels,
+                                  (size_t)m_realcols * m_max_sections * sizeof(Section), nullptr));
+    IS_CHECK_RETURN(is_stream_synchronize(nullptr));
+    return -1; /* the reference's timers are commented out, Stixels.cu:636 */
+}
+
+void Stixels::ComputeBatch(bool pairwise, int n_images, const pixel_t* d_big,
+                           const int32_t* d_seg, const RoadParameters* road,
+                           std::vector<StixelsData>& out, void* stream) {
+    if (n_images < 1 || n_images > m_max_batch)
+        throw std::invalid_argument("n_images outside [1, max_batch] of InitializeBatch().");
+    std::vector<float> gf((size_t)n_images * m_rows), ng(gf.size()), ig(gf.size());
+    std::vector<int> vh(n_images);
+    for (int i = 0; i < n_images; i++) {
+        GroundModel g;
+        vh[i] = m_rows - road[i].vhor - 1;
+        PrecomputeGround(vh[i], road[i].camera_tilt, road[i].camera_height, road[i].alpha_ground,
+                         g);
+        std::copy(g.function.begin(), g.function.end(), gf.begin() + (size_t)i * m_rows);
+        std::copy(g.normalization.begin(), g.normalization.end(), ng.begin() + (size_t)i * m_rows);
+        std::copy(g.inv_sigma2.begin(), g.inv_sigma2.end(), ig.begin() + (size_t)i * m_rows);
+    }
+    IS_CHECK_RETURN(is_join_columns(m_ctx, d_big, m_cols, m_median_join ? 1 : 0, d_disparity,
+                                    n_images, stream));
+    IS_CHECK_RETURN(is_compute(m_ctx, d_disparity, d_seg, gf.data(), ng.data(), ig.data(),
+                               vh.data(), pairwise ? 1 : 0, n_images, d_stixels, nullptr, nullptr,
+                               nullptr, stream));
+    out.resize(n_images);
+    const size_t per = (size_t)m_realcols * m_max_sections;
+    for (int i = 0; i < n_images; i++) {
+        FillHeader(out[i], road[i].alpha_ground, vh[i]);
+        IS_CHECK_RETURN(is_memcpy_d2h(out[i].sections.data(), d_stixels + per * i,
+                                      per * sizeof(Section), stream));
+    }
+    IS_CHECK_RETURN(is_stream_synchronize(stream));
+}
+
+/* ---------------------------------------------------------------- instances */
+
+/* Size-filtered DBSCAN over the predicted instance centres of each instance class.
+ * The reference calls a cuML fork whose source is not in its tree (Stixels.cu:639-681,
+ * SURVEY.md §8f f1); the semantics implemented here are those of its Python twin
+ * (/root/reference/tools/visualization/clustering_visualization.py:894-960): only stixels with
+ * height >= size_filter ("core candidates") are clustered (eps, min_pts counted among
+ * candidates, self included); every other stixel takes the label of its nearest core point if
+ * that is within eps, else -1.  Labels are 0.. per class in order of discovery. */
+float Stixels::ClusterInstances() {
+    const float eps2 = m_params.clustering_eps * m_params.clustering_eps;
+    const int min_pts = m_params.clustering_min_pts;
+    const size_t per_class = (size_t)m_realcols * m_max_sections;
+
+    IS_CHECK_RETURN(is_memcpy_d2h(m_instances_per_class.data(), d_instances_per_class,
+                                  m_instance_classes * sizeof(int), nullptr));
+    IS_CHECK_RETURN(is_stream_synchronize(nullptr));
+    std::vector<float> com;
+    std::vector<uint8_t> cand;
+    for (int cls = 0; cls < m_instance_classes; cls++) {
+        const int n = m_instances_per_class[cls];
+        if (n <= 0) continue;
+        com.resize((size_t)n * 2);
+        cand.resize(n);
+        IS_CHECK_RETURN(is_memcpy_d2h(com.data(), d_instance_centerofmass + per_class * cls * 2,
+                                      sizeof(float) * 2 * n, nullptr));
+        IS_CHECK_RETURN(is_memcpy_d2h(cand.data(), d_instance_core_candidates + per_class * cls, n,
+                                      nullptr));
+        IS_CHECK_RETURN(is_stream_synchronize(nullptr));
+        int32_t* labels = m_instance_labels.data() + per_class * cls;
+        std::fill(labels, labels + n, -1);
+
+        auto dist2 = [&](int a, int b) {
+            const float dx = com[2 * a] - com[2 * b], dy = com[2 * a + 1] - com[2 * b + 1];
+            return dx * dx + dy * dy;
+        };
+        std::vector<int> large;
+        for (int i = 0; i < n; i++)
+            if (cand[i]) large.push_back(i);
+        if ((int)large.size() <= min_pts) continue; /* twin: X_large.shape[1] > min_samples */
+
+        std::vector<uint8_t> is_core(n, 0);
+        for (int a : large) {
+            int cnt = 0;
+            for (int b : large)
+                if (dist2(a, b) <= eps2) cnt++;
+            is_core[a] = cnt >= min_pts;
+        }
+        int next_label = 0;
+        std::vector<int> stack;
+        for (int seed : large) {
+            if (!is_core[seed] || labels[seed] != -1) continue;
+            labels[seed] = next_label;
+            stack.assign(1, seed);
+            while (!stack.empty()) {
+                const int a = stack.back();
+                stack.pop_back();
+                for (int b : large) {
+                    if (labels[b] != -1 || dist2(a, b) > eps2) continue;
+                    labels[b] = next_label;
+                    if (is_core[b]) stack.push_back(b);
+                }
+            }
+            next_label++;
+        }
+        for (int i = 0; i < n; i++) {
+            if (cand[i]) continue;
+            float best = eps2;
+            int best_core = -1;
+            for (int a : large) {
+                if (!is_core[a]) continue;
+                const float d = dist2(i, a);
+                if (d <= best && (best_core == -1 || d < best)) { best = d; best_core = a; }
+            }
+            if (best_core >= 0) labels[i] = labels[best_core];
+        }
+    }
+    return -1;
+}
+
+std::map<std::pair<int, int>, int> Stixels::GetInstanceStixels() { /* Stixels.cu:744-776 */
+    const size_t per_class = (size_t)m_realcols * m_max_sections;
+    IS_CHECK_RETURN(is_memcpy_d2h(m_instance_indices.data(), d_instance_indices,
+                                  m_instance_classes * per_class * 2 * sizeof(int32_t), nullptr));
+    IS_CHECK_RETURN(is_stream_synchronize(nullptr));
+    std::map<std::pair<int, int>, int> mapping;
+    for (int cls = 0; cls < m_instance_classes; cls++) {
+        const int instances = m_instances_per_class[cls];
+        const size_t class_offset = per_class * cls;
+        for (int i = 0; i < instances; i++) {
+            const int u = m_instance_indices[class_offset * 2 + i * 2];
+            const int v = m_instance_indices[class_offset * 2 + i * 2 + 1];
+            mapping[std::make_pair(u, v)] = m_instance_labels[class_offset + i];
+        }
+    }
+    return mapping;
+}
+
+/* ---------------------------------------------------------------- outputs */
+
+std::vector<float> Stixels::Get3DVertices(const StixelsData& stixels_data) { /* :683-742 */
+    if (m_camera_center_x == -1 || m_camera_center_y == -1)
+        throw std::invalid_argument("Camera parameters are not set.");
+    std::vector<float> vertices;
+    for (size_t i = 0; i < (size_t)m_realcols; i++) {
+        for (size_t j = 0; j < (size_t)m_max_sections; j++) {
+            const Section& section = stixels_data.sections[i * m_max_sections + j];
+            if (section.type == -1) break;
+            const float x_l = i * m_column_step;
+            const float x_r = x_l + m_column_step;
+            const float y_t = m_rows - section.vT - 1;
+            const float y_b = m_rows - section.vB;
+            float top_depth = 0.0, bottom_depth = 0.0; /* sky stays at depth 0 */
+            if (section.type == OBJECT) {
+                top_depth = m_baseline * m_focal / section.disparity;
+                bottom_depth = top_depth;
+            } else if (section.type == GROUND) {
+                const float top_disparity =
+                    stixels_data.alpha_ground * (stixels_data.vhor - section.vT);
+                const float bottom_disparity =
+                    stixels_data.alpha_ground * (stixels_data.vhor - section.vB);
+                top_depth = m_baseline * m_focal / top_disparity;
+                bottom_depth = m_baseline * m_focal / bottom_disparity;
+            }
+            const float corner[4][3] = {
+                {x_l, y_t, top_depth}, {x_r, y_t, top_depth},
+                {x_r, y_b, bottom_depth}, {x_l, y_b, bottom_depth}}; /* clockwise from top left */
+            for (const auto& c : corner) {
+                vertices.push_back(-c[2] / m_focal * (m_camera_center_x - c[0]));
+                vertices.push_back(-c[2] / m_focal * (m_camera_center_y - c[1]));
+                vertices.push_back(c[2]);
+            }
+        }
+    }
+    return vertices;
+}
+
+void Stixels::SaveStixels(Section* stixels,
+                          std::map<std::pair<int, int>, int> instance_stixels_mapping,
+                          const float alpha_ground, const int vhor, const int real_cols,
+                          const int max_segments, const char* fname) { /* Stixels.cu:889-926 */
+    std::ofstream fp;
+    fp.open(fname, std::ofstream::out | std::ofstream::trunc);
+    if (!fp.is_open()) {
+        std::cerr << "Counldn't write file: " << fname << std::endl;
+        return;
+    }
+    for (size_t i = 0; i < (size_t)real_cols; i++) {
+        for (size_t j = 0; j < (size_t)max_segments; j++) {
+            const Section& section = stixels[i * max_segments + j];
+            if (section.type == -1) break;
+            fp << section.type << "," << section.vB << "," << section.vT << ","
+               << section.disparity << "," << section.semantic_class << "," << section.cost << ","
+               << section.instance_meanx << "," << section.instance_meany;
+            const auto it = instance_stixels_mapping.find(std::make_pair((int)i, (int)j));
+            if (it != instance_stixels_mapping.end()) fp << "," << (*it).second;
+            fp << ";";
+        }
+        fp << std::endl;
+    }
+    fp << "groundplane" << alpha_ground << "," << vhor << "\n";
+    fp.close();
+}

@@ -1,0 +1,190 @@
+/*
+ * stixels_capi.cpp -- flat C view of the C++ `Stixels` host class, so that Python tests and
+ * bench.py drive the SAME host code a C++ caller (run_cityscapes, StixelsWrapper) would:
+ * SetConfig -> Initialize -> [SetDisparityImage, SetSegmentation, SetRoadParameters, Compute,
+ * GetInstanceStixels] -> Finish  (call sequence of apps/run_cityscapes.cu:328-449).
+ * C++ exceptions are turned into a negative return code + message.
+ */
+#include <cstring>
+#include <exception>
+#include <string>
+
+#include "InstanceStixels/Stixels.hpp"
+
+namespace {
+thread_local std::string g_host_err;
+template <class F>
+int guard(F&& f) {
+    try {
+        f();
+        return 0;
+    } catch (const std::invalid_argument& e) {
+        g_host_err = e.what();
+        return -1;
+    } catch (const std::exception& e) {
+        g_host_err = e.what();
+        return -2;
+    }
+}
+}  // namespace
+
+extern "C" {
+
+/* C mirror of StixelConfig (types.h), field for field. */
+struct ish_config {
+    float rows, cols;
+    int max_dis;
+    float invalid_disparity, eps;
+    int min_pts, size_filter, n_semantic_classes, n_offset_channels;
+    float prior_weight, segmentation_weight, instance_weight, disparity_weight;
+    int pairwise, column_step;
+    float focal, baseline, camera_center_x, camera_center_y;
+    float sigma_disparity_object, sigma_disparity_ground, sigma_sky;
+    float pout, pout_sky, pord, pgrav, pblg;
+    float pground_given_nexist, pobject_given_nexist, psky_given_nexist, pnexist_dis;
+    float pground, pobject, psky;
+    int width_margin;
+    float sigma_camera_tilt, sigma_camera_height;
+    int median_join;
+    float epsilon, range_objects_z, road_vdisparity_threshold;
+};
+
+static StixelConfig to_cpp(const ish_config* c) {
+    StixelConfig s;
+    s.rows = c->rows; s.cols = c->cols; s.max_dis = c->max_dis;
+    s.invalid_disparity = c->invalid_disparity; s.eps = c->eps; s.min_pts = c->min_pts;
+    s.size_filter = c->size_filter; s.n_semantic_classes = c->n_semantic_classes;
+    s.n_offset_channels = c->n_offset_channels; s.prior_weight = c->prior_weight;
+    s.segmentation_weight = c->segmentation_weight; s.instance_weight = c->instance_weight;
+    s.disparity_weight = c->disparity_weight; s.pairwise = c->pairwise != 0;
+    s.column_step = c->column_step; s.focal = c->focal; s.baseline = c->baseline;
+    s.camera_center_x = c->camera_center_x; s.camera_center_y = c->camera_center_y;
+    s.sigma_disparity_object = c->sigma_disparity_object;
+    s.sigma_disparity_ground = c->sigma_disparity_ground; s.sigma_sky = c->sigma_sky;
+    s.pout = c->pout; s.pout_sky = c->pout_sky; s.pord = c->pord; s.pgrav = c->pgrav;
+    s.pblg = c->pblg; s.pground_given_nexist = c->pground_given_nexist;
+    s.pobject_given_nexist = c->pobject_given_nexist;
+    s.psky_given_nexist = c->psky_given_nexist; s.pnexist_dis = c->pnexist_dis;
+    s.pground = c->pground; s.pobject = c->pobject; s.psky = c->psky;
+    s.width_margin = c->width_margin; s.sigma_camera_tilt = c->sigma_camera_tilt;
+    s.sigma_camera_height = c->sigma_camera_height; s.median_join = c->median_join != 0;
+    s.epsilon = c->epsilon; s.range_objects_z = c->range_objects_z;
+    s.road_vdisparity_threshold = c->road_vdisparity_threshold;
+    return s;
+}
+
+const char* ish_last_error(void) { return g_host_err.c_str(); }
+
+void* ish_create(void) { return new Stixels(); }
+void ish_destroy(void* h) { delete (Stixels*)h; }
+
+int ish_set_config(void* h, const ish_config* c) {
+    return guard([&] { ((Stixels*)h)->SetConfig(to_cpp(c)); });
+}
+int ish_initialize(void* h, int max_batch) {
+    return guard([&] { ((Stixels*)h)->InitializeBatch(max_batch); });
+}
+int ish_precompute_host(void* h) {
+    return guard([&] { ((Stixels*)h)->PrecomputeHost(); });
+}
+int ish_finish(void* h) {
+    return guard([&] {
+        if (((Stixels*)h)->IsInitialized()) ((Stixels*)h)->Finish();
+    });
+}
+int ish_is_initialized(void* h) { return ((Stixels*)h)->IsInitialized() ? 1 : 0; }
+int ish_real_cols(void* h) { return ((Stixels*)h)->GetRealCols(); }
+int ish_max_sections(void* h) { return ((Stixels*)h)->GetMaxSections(); }
+
+int ish_get_parameters(void* h, StixelParameters* out) {
+    *out = ((Stixels*)h)->GetParameters();
+    return 0;
+}
+int ish_get_luts(void* h, float* obj_cost_lut, float* obj_disparity_range) {
+    Stixels* s = (Stixels*)h;
+    std::memcpy(obj_cost_lut, s->GetObjectCostLUT().data(),
+                s->GetObjectCostLUT().size() * sizeof(float));
+    std::memcpy(obj_disparity_range, s->GetObjectDisparityRange().data(),
+                s->GetObjectDisparityRange().size() * sizeof(float));
+    return 0;
+}
+void* ish_core_context(void* h) { return ((Stixels*)h)->GetCoreContext(); }
+
+int ish_set_disparity_image(void* h, const float* data, size_t n) {
+    return guard([&] { ((Stixels*)h)->SetDisparityImage(std::vector<pixel_t>(data, data + n)); });
+}
+int ish_set_segmentation(void* h, const int32_t* data, size_t n) {
+    return guard([&] { ((Stixels*)h)->SetSegmentation(std::vector<int32_t>(data, data + n)); });
+}
+int ish_set_road_parameters(void* h, int vhor, float tilt, float height, float alpha) {
+    return guard([&] { ((Stixels*)h)->SetRoadParameters(vhor, tilt, height, alpha); });
+}
+int ish_get_ground_model(void* h, float* gf, float* ng, float* ig, int* vhor_lib) {
+    return guard([&] {
+        std::vector<float> a, b, c;
+        ((Stixels*)h)->GetGroundModel(a, b, c, *vhor_lib);
+        std::memcpy(gf, a.data(), a.size() * sizeof(float));
+        std::memcpy(ng, b.data(), b.size() * sizeof(float));
+        std::memcpy(ig, c.data(), c.size() * sizeof(float));
+    });
+}
+
+/* Compute(): sections [realcols*max_sections]; header fields through `hdr[9]` =
+ * rows, cols, realcols, max_sections, max_dis, column_step, semantic_classes, vhor, (unused). */
+int ish_compute(void* h, int pairwise, Section* sections, int* hdr, float* alpha_ground,
+                float* ret) {
+    return guard([&] {
+        StixelsData d;
+        *ret = ((Stixels*)h)->Compute(pairwise != 0, d);
+        std::memcpy(sections, d.sections.data(), d.sections.size() * sizeof(Section));
+        hdr[0] = d.rows; hdr[1] = d.cols; hdr[2] = d.realcols; hdr[3] = d.max_sections;
+        hdr[4] = d.max_dis; hdr[5] = d.column_step; hdr[6] = d.semantic_classes; hdr[7] = d.vhor;
+        *alpha_ground = d.alpha_ground;
+    });
+}
+
+/* GetInstanceStixels(): triples (column, section, label); returns the count (<= cap) or <0. */
+int ish_get_instance_stixels(void* h, int* triples, int cap) {
+    int n = 0;
+    const int rc = guard([&] {
+        const auto m = ((Stixels*)h)->GetInstanceStixels();
+        for (const auto& kv : m) {
+            if (n >= cap) break;
+            triples[3 * n] = kv.first.first;
+            triples[3 * n + 1] = kv.first.second;
+            triples[3 * n + 2] = kv.second;
+            n++;
+        }
+    });
+    return rc ? rc : n;
+}
+
+int ish_get_3d_vertices(void* h, const Section* sections, float alpha_ground, int vhor,
+                        float* out, int cap) {
+    int n = 0;
+    const int rc = guard([&] {
+        Stixels* s = (Stixels*)h;
+        StixelsData d;
+        d.sections.assign(sections, sections + (size_t)s->GetRealCols() * s->GetMaxSections());
+        d.alpha_ground = alpha_ground;
+        d.vhor = vhor;
+        const std::vector<float> v = s->Get3DVertices(d);
+        n = (int)std::min<size_t>(v.size(), (size_t)cap);
+        std::memcpy(out, v.data(), (size_t)n * sizeof(float));
+    });
+    return rc ? rc : n;
+}
+
+int ish_save_stixels(void* h, Section* sections, const int* triples, int n_triples,
+                     float alpha_ground, int vhor, const char* fname) {
+    return guard([&] {
+        Stixels* s = (Stixels*)h;
+        std::map<std::pair<int, int>, int> m;
+        for (int i = 0; i < n_triples; i++)
+            m[std::make_pair(triples[3 * i], triples[3 * i + 1])] = triples[3 * i + 2];
+        Stixels::SaveStixels(sections, m, alpha_ground, vhor, s->GetRealCols(),
+                             s->GetMaxSections(), fname);
+    });
+}
+
+} /* extern "C" */

@@ -1,0 +1,99 @@
+"""CPU tests of the host logic and of the C-ABI surface (no compute call: there is no GPU here)."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from instance_stixels_amd import core, host, make_config, PRESETS
+from oracle import oracle
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_core_library_exports_every_declared_symbol():
+    text = open(os.path.join(ROOT, "include", "instance_stixels_core.h")).read()
+    declared = set(re.findall(r"\b(is_[a-z0-9_]+)\s*\(", text))
+    assert {"is_ctx_create", "is_ctx_destroy", "is_join_columns", "is_compute"} <= declared
+    L = core.lib()
+    for name in sorted(declared):
+        assert hasattr(L, name), f"libis_core.so does not export {name}"
+    assert set(core.EXPORTS) <= declared
+    assert b"gfx950" in L.is_version()
+
+
+def test_host_library_exports():
+    L = host.lib()
+    for name in host.EXPORTS:
+        assert hasattr(L, name)
+
+
+def test_struct_layouts_match_reference_types():
+    from instance_stixels_amd.config import StixelParams, SECTION_DTYPE
+    import ctypes
+    assert ctypes.sizeof(StixelParams) == 152           # 38 x 4 bytes, types.h:145-184
+    assert StixelParams.vhor.offset == 0 and StixelParams.invalid_disparity.offset == 148
+    assert SECTION_DTYPE.itemsize == 32                  # types.h:186-194
+    assert SECTION_DTYPE.fields["cost"][1] == 20
+
+
+@pytest.mark.parametrize("preset", sorted(PRESETS))
+@pytest.mark.parametrize("shape", [(128, 256, 32), (512, 1024, 64), (1024, 2048, 128)])
+def test_host_precompute_matches_oracle(preset, shape):
+    cfg = make_config(preset, *shape)
+    st = host.Stixels()
+    st.SetConfig(cfg)
+    st.PrecomputeHost()
+    p, (lut, odr) = st.GetParameters(), st.GetLUTs()
+    po, luto, odro = oracle.host_initialize(cfg)
+    assert bytes(p) == bytes(po)
+    assert np.array_equal(lut.view(np.uint32), luto.view(np.uint32))
+    assert np.array_equal(odr.view(np.uint32), odro.view(np.uint32))
+    for vhor_img in (0, shape[0] // 3, shape[0] - 1):
+        st.SetRoadParameters(vhor_img, 0.05, 1.2, 0.11)
+        gf, ng, ig, vh = st.GetGroundModel()
+        g2 = oracle.host_ground(cfg, vhor_img, 0.05, 1.2, 0.11)
+        assert vh == g2[3] == shape[0] - vhor_img - 1     # Stixels.cu:377
+        for a, b in zip((gf, ng, ig), g2[:3]):
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    st.close()
+
+
+def test_instance_weight_rule():
+    # Stixels.cu:408-423: divided by the segmentation weight, zeroed for tiny weights
+    cfg = make_config("drn_d_22_unary", 64, 64, 32)
+    p, _, _ = oracle.host_initialize(cfg)
+    assert p.instance_weight == np.float32(np.float32(0.001731) / np.float32(11.241965))
+    cfg.segmentation_weight = 0.0
+    assert oracle.host_initialize(cfg)[0].instance_weight == 0.0
+    cfg.segmentation_weight, cfg.instance_weight = 1.0, 1e-9
+    assert oracle.host_initialize(cfg)[0].instance_weight == 0.0
+
+
+@pytest.mark.parametrize("field,msg", [
+    ("rows", "Number of rows or columns are not set."),
+    ("max_dis", "Maximum disparity value is not set."),
+    ("eps", "Clustering parameters are not set."),
+    ("prior_weight", "Energy term weights are not set."),
+    ("column_step", "Stixel width is not set."),
+    ("focal", "Camera parameters are not set."),
+])
+def test_set_config_rejects_unset_fields(field, msg):
+    # std::invalid_argument messages of Stixels.cu:292-313
+    cfg = make_config("drn_d_22_unary", 64, 64, 32)
+    setattr(cfg, field, -1)
+    st = host.Stixels()
+    with pytest.raises(ValueError, match=re.escape(msg)):
+        st.SetConfig(cfg)
+    with pytest.raises(ValueError):
+        oracle.host_initialize(cfg)
+    st.close()
+
+
+def test_bench_byte_formula():
+    from instance_stixels_amd import synthetic
+    # C1 4 292 608 B, C2 15 532 032 B, C5 31 064 064 B
+    assert synthetic.algorithmic_bytes_per_image(make_config("drn_d_22_unary", 512, 1024, 64)) == 4292608
+    assert synthetic.algorithmic_bytes_per_image(make_config("drn_d_22_unary", 1024, 2048, 128)) == 15532032
+    assert synthetic.algorithmic_bytes_per_image(make_config("drn_d_22_unary", 1024, 4096, 256)) == 31064064
+    assert synthetic.pair_evaluations_per_image(make_config("drn_d_22_unary", 1024, 2048, 128)) == 134348800

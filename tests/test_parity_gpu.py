@@ -1,0 +1,243 @@
+"""Parity tests proper: the HIP path (through the C ABI / the C++ host class) against the CPU
+oracle on the same seeded inputs.  Bar: bit-exact for every integer field (cuts, types, classes,
+indices) AND, because the fp32 association of the reference is replicated, bit-exact for every
+fp32 field (costs, mean disparity, instance centres, the full DP cost table); the contract's
+tolerance (cost within 1e-4 relative) is asserted as well for documentation."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import helpers
+from test_oracle_properties import load_golden, check_column_structure, GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+def _assert_parity(case, got, images=None, cols=None):
+    cfg = case["cfg"]
+    for img in (range(len(case["frames"])) if images is None else images):
+        ref = helpers.run_oracle(case, image=img,
+                                 col_range=None if cols is None else (min(cols), max(cols) + 1))
+        errs = helpers.compare(ref, got, img, cfg, cols=cols)
+        assert not errs, "\n".join(errs[:10])
+        # the contract's stated tolerance (north_star): costs within 1e-4 relative
+        for c in (range(cfg.realcols) if cols is None else cols):
+            n = helpers.n_sections(ref["sections"][c])
+            a, b = ref["sections"][c][:n]["cost"], got["sections"][img][c][:n]["cost"]
+            assert np.all(np.abs(a - b) <= 1e-4 * np.maximum(np.abs(a), 1e-30))
+
+
+SMALL = [
+    ("drn_d_22_unary", 64, 64, 32, {}),
+    ("drn_d_38_unary", 128, 256, 32, {}),
+    ("drn_d_22_pairwise", 64, 64, 32, {}),
+    ("drn_d_38_pairwise", 128, 256, 32, {}),
+    ("drn_d_22_unary", 128, 256, 32, dict(invalid_disparity=0.0)),
+    ("drn_d_38_pairwise", 128, 256, 32, dict(invalid_disparity=0.0)),
+    ("drn_d_22_unary", 136, 128, 48, dict(median_join=True)),              # H % 64 != 0, D not 2^k
+    ("drn_d_38_pairwise", 136, 128, 48, dict(median_join=True, invalid_disparity=0.0)),
+    ("disparity_only_unary", 128, 128, 64, {}),                             # BASELINE configs[0] model
+    ("disparity_only_pairwise", 128, 128, 64, {}),
+    ("drn_d_22_unary", 8, 64, 8, {}),                                       # smallest legal shape
+    ("drn_d_38_pairwise", 8, 64, 8, {}),
+    ("drn_d_22_unary", 64, 72, 32, dict(width_margin=8)),
+]
+
+
+@pytest.mark.parametrize("preset,rows,cols,D,ov", SMALL)
+def test_small_cases_bit_exact(preset, rows, cols, D, ov):
+    case = helpers.build_case(preset, rows, cols, D, seed=7, n_images=2, **ov)
+    got = helpers.run_core(case)
+    _assert_parity(case, got)
+
+
+@pytest.mark.parametrize("preset", ["drn_d_38_unary", "drn_d_22_pairwise"])
+def test_config1_shape_512x1024x64(preset):
+    case = helpers.build_case(preset, 512, 1024, 64, seed=11)
+    got = helpers.run_core(case)
+    _assert_parity(case, got)
+
+
+def test_config1_disparity_only_512x1024x64():
+    for preset in ("disparity_only_unary", "disparity_only_pairwise"):
+        case = helpers.build_case(preset, 512, 1024, 64, seed=12)
+        got = helpers.run_core(case)
+        _assert_parity(case, got)
+
+
+@pytest.mark.parametrize("preset", ["drn_d_22_unary", "drn_d_38_pairwise"])
+def test_config2_full_frame_1024x2048x128(preset):
+    """BASELINE configs[1]: the whole 256-column frame against the oracle (a few CPU-seconds)."""
+    case = helpers.build_case(preset, 1024, 2048, 128, seed=13)
+    got = helpers.run_core(case)
+    _assert_parity(case, got)
+
+
+def test_config5_ultrawide_1024x4096x256_column_subset():
+    """BASELINE configs[4] (LDS-pressure shape): every 16th column against the oracle, structure
+    checks on all 512 columns."""
+    case = helpers.build_case("drn_d_22_unary", 1024, 4096, 256, seed=14)
+    got = helpers.run_core(case, want_tables=True)
+    cfg = case["cfg"]
+    joined = got["joined"][0]
+    from oracle import oracle
+    assert np.array_equal(joined.view(np.uint32),
+                          oracle.join_columns(cfg, case["disparity"][0]).view(np.uint32))
+    cols = list(range(0, cfg.realcols, 16))
+    for c in cols:
+        ref = helpers.run_oracle(case, col_range=(c, c + 1), joined=joined)
+        errs = helpers.compare(ref, got, 0, cfg, cols=[c])
+        assert not errs, "\n".join(errs[:5])
+    for c in range(cfg.realcols):
+        check_column_structure(got["sections"][0][c], 1024)
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p) for p in GOLDEN])
+def test_golden_vectors(path):
+    from instance_stixels_amd.core import Core
+    g = load_golden(path)
+    core = Core(g["params"], g["lut"], g["odr"], max_batch=1)
+    out = core.run(disparity_big=g["disparity"][None], segmentation=g["segmentation"][None],
+                   ground_function=g["gf"], normalization_ground=g["ng"],
+                   inv_sigma2_ground=g["ig"], vhor=[int(g["vhor"])], pairwise=bool(g["pairwise"]),
+                   median_join=bool(g["median_join"]), want_tables=True)
+    core.close()
+    assert np.array_equal(out["joined"][0].view(np.uint32), g["joined"].view(np.uint32))
+    C = g["params"].cols
+    for c in range(C):
+        n = helpers.n_sections(g["sections"][c])
+        assert helpers.n_sections(out["sections"][0][c]) == n
+        assert np.array_equal(out["sections"][0][c][:n].view(np.uint8), g["sections"][c][:n].view(np.uint8))
+    assert np.array_equal(out["cost_table"][0].view(np.uint32), g["cost_table"].view(np.uint32))
+    assert np.array_equal(out["inst_per_class"][0], g["inst_per_class"])
+
+
+@pytest.mark.parametrize("vhor_image", [-5, 0, 1, 63, 126, 127, 140])
+@pytest.mark.parametrize("preset", ["drn_d_22_unary", "drn_d_38_pairwise"])
+def test_horizon_edge_cases(preset, vhor_image):
+    """Horizon at / beyond the image borders: ground-only, sky-only and mixed columns."""
+    case = helpers.build_case(preset, 128, 64, 32, seed=31)
+    from oracle import oracle
+    f = case["frames"][0]
+    g = oracle.host_ground(case["cfg"], vhor_image, f.camera_tilt, f.camera_height, f.alpha_ground)
+    case["gf"][0], case["ng"][0], case["ig"][0], case["vhor"][0] = g
+    got = helpers.run_core(case)
+    _assert_parity(case, got)
+
+
+@pytest.mark.parametrize("preset", ["drn_d_22_unary", "drn_d_38_pairwise"])
+def test_degenerate_inputs(preset):
+    """All-invalid columns, constant disparity, zero segmentation, extreme offsets."""
+    case = helpers.build_case(preset, 128, 128, 32, seed=33, invalid_disparity=0.0)
+    d = case["disparity"][0]
+    d[:, 0:8] = 0.0                       # column 0 entirely invalid
+    d[:, 8:16] = 5.0                      # column 1 constant
+    d[:, 16:24] = 30.98                   # column 2 at the top of the input domain (D - 1.01)
+    d[64:, 24:32] = 0.0                   # column 3 invalid lower half
+    s = case["segmentation"][0]
+    s[4] = 0                              # column 4: zero segmentation
+    s[5, 19:21, :16] = 8 * 4000           # column 5: huge offsets (int64 sums of squares)
+    s[6, 19:21, :16] = -8 * 4000
+    s[7, :19, :16] = 0                    # column 7: all classes tie
+    got = helpers.run_core(case)
+    _assert_parity(case, got)
+
+
+def test_batch_consistency_and_input_immutability():
+    """Images of a batch are independent: a frame gives the same result at any batch position,
+    and (unlike the reference) the segmentation input is left intact."""
+    import torch
+    from instance_stixels_amd.core import Core
+    case = helpers.build_case("drn_d_38_pairwise", 128, 256, 32, seed=41, n_images=3)
+    order = [2, 0, 1, 0, 2]
+    core = Core(case["params"], case["lut"], case["odr"], max_batch=len(order))
+    dev = torch.device("cuda", 0)
+    seg = torch.from_numpy(case["segmentation"][order]).to(dev)
+    seg_before = seg.clone()
+    big = torch.from_numpy(case["disparity"][order]).to(dev)
+    p = case["params"]
+    joined = torch.empty((len(order), p.cols, p.rows), dtype=torch.float32, device=dev)
+    sec = torch.empty((len(order), p.cols, p.max_sections, 8), dtype=torch.int32, device=dev)
+    core.join_columns_ptr(big.data_ptr(), big.shape[2], False, joined.data_ptr(), len(order))
+    core.compute_ptr(joined.data_ptr(), seg.data_ptr(), case["gf"][order], case["ng"][order],
+                     case["ig"][order], case["vhor"][order], True, len(order), sec.data_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(seg, seg_before)
+    out = sec.cpu().numpy()
+    single = helpers.run_core(case)["sections"].view(np.int32).reshape(3, p.cols, p.max_sections, 8)
+    for k, img in enumerate(order):
+        for c in range(p.cols):
+            n = helpers.n_sections(single[img][c].view(helpers.np.dtype(
+                [("type", np.int32), ("r", np.int32, 7)])).reshape(-1))
+            assert np.array_equal(out[k][c][:n + 1, 0], single[img][c][:n + 1, 0])
+            assert np.array_equal(out[k][c][:n], single[img][c][:n])
+    core.close()
+
+
+@pytest.mark.parametrize("preset", ["drn_d_22_unary", "drn_d_38_pairwise"])
+def test_host_class_call_sequence(preset, tmp_path):
+    """The reference's caller sequence (apps/run_cityscapes.cu:328-449) through the C++ class."""
+    from instance_stixels_amd import host
+    case = helpers.build_case(preset, 128, 256, 32, seed=51)
+    cfg, f = case["cfg"], case["frames"][0]
+    st = host.Stixels()
+    st.SetConfig(cfg)
+    assert not st.IsInitialized()
+    st.Initialize()
+    assert st.IsInitialized() and st.GetRealCols() == 32 and st.GetMaxSections() == 200
+    for _ in range(2):                     # two frames on one initialised object
+        st.SetDisparityImage(f.disparity)
+        st.SetSegmentation(f.segmentation)
+        st.SetRoadParameters(f.vhor_image, f.camera_tilt, f.camera_height, f.alpha_ground)
+        data = st.Compute(cfg.pairwise)
+    mapping = st.GetInstanceStixels()
+    ref = helpers.run_oracle(case)
+    got = dict(joined=ref["joined"][None], sections=data.sections[None])
+    assert not helpers.compare(ref, got, 0, cfg, check_tables=False)
+    assert (data.rows, data.cols, data.realcols, data.max_sections) == (128, 256, 32, 200)
+    assert data.vhor == 128 - f.vhor_image - 1 and data.max_dis == 32
+    # every instance-class stixel has a mapping entry; labels are -1 or a cluster id
+    want_keys = {(int(c), int(i)) for cls in range(8)
+                 for c, i in ref["inst_indices"][cls][:ref["inst_per_class"][cls]]}
+    assert set(mapping) == want_keys
+    # output formats (SaveStixels text, Stixels.cu:889-926)
+    path = str(tmp_path / "frame.stixels")
+    st.SaveStixels(data, mapping, f.alpha_ground, data.vhor, path)
+    lines = open(path).read().splitlines()
+    assert len(lines) == 33 and lines[-1].startswith("groundplane")
+    first = lines[0].split(";")[0].split(",")
+    s0 = data.sections[0][0]
+    assert [int(first[0]), int(first[1]), int(first[2]), int(first[4])] == \
+        [s0["type"], s0["vB"], s0["vT"], s0["semantic_class"]]
+    verts = st.Get3DVertices(data)
+    assert len(verts) == 12 * int((data.sections["type"] >= 0).sum())
+    st.Finish()
+    assert not st.IsInitialized()
+    st.close()
+
+
+def test_core_rejects_bad_shapes():
+    from instance_stixels_amd.core import Core, CoreError
+    case = helpers.build_case("drn_d_22_unary", 64, 64, 32, seed=1)
+    p = case["params"]
+    bad = type(p).from_buffer_copy(p); bad.column_step = 4
+    with pytest.raises(CoreError, match="column_step"):
+        Core(bad, case["lut"], case["odr"])
+    bad = type(p).from_buffer_copy(p); bad.rows_power2 = 64
+    with pytest.raises(CoreError, match="rows_power2"):
+        Core(bad, case["lut"], case["odr"])
+    core = Core(p, case["lut"], case["odr"], max_batch=1)
+    with pytest.raises(CoreError, match="n_images"):
+        core.compute_ptr(1, 1, np.zeros((2, 64)), np.zeros((2, 64)), np.zeros((2, 64)), [0, 0],
+                         False, 2, 1)
+    core.close()
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from instance_stixels_amd import core
+    monkeypatch.setattr(core, "_LIB", None)
+    monkeypatch.setattr(core, "LIB_PATH", "/nonexistent/libis_core.so")
+    with pytest.raises(core.CoreError, match="no CPU fallback"):
+        core.lib()
