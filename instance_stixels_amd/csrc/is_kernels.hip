@@ -470,7 +470,7 @@ __device__ __forceinline__ RowRec load_rec(const RowRec* p) {
  * order that matters is the strict-< tie rule (smallest vB wins).  index_table holds the winning
  * vB (or -1); the predecessor TYPE is resolved in k_backtrace from the final cost_table. */
 template <bool HAS_INVALID>
-__global__ __launch_bounds__(256) void k_dp_unary(const DevParams P, int ncols,
+__global__ __launch_bounds__(512) void k_dp_unary(const DevParams P, int ncols,
                                                   const RowRec* __restrict__ recs,
                                                   const float* __restrict__ lutT,
                                                   const float* __restrict__ pwinv,
@@ -673,7 +673,7 @@ __device__ __forceinline__ void pairwise_step(const DevParams& P, const RowRec& 
 }
 
 template <bool HAS_INVALID>
-__global__ __launch_bounds__(256) void k_dp_pairwise(
+__global__ __launch_bounds__(512) void k_dp_pairwise(
     const DevParams P, int ncols, const RowRec* __restrict__ recs, const float* __restrict__ lutT,
     const PriorRec* __restrict__ priors, const float* __restrict__ odr,
     const int* __restrict__ vhor_arr, float* __restrict__ cost_table,

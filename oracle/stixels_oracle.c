@@ -392,7 +392,10 @@ void orc_object_lut_column(const float* disp_col, const float* obj_cost_lut, flo
                 for (int lane = 0; lane < WARP; lane++)
                     if (lane >= j) cost[lane] += n[lane];
             }
-            for (int lane = 0; lane < WARP; lane++) arr[i + lane + 1] = cost[lane]; /* :266 */
+            /* :266.  The reference stores all 32 lanes, which overruns its (rows_power2+1)-float
+             * row when rows < 31; such shapes are outside its domain, we just do not overrun. */
+            for (int lane = 0; lane < WARP; lane++)
+                if (i + lane + 1 <= p->rows_power2) arr[i + lane + 1] = cost[lane];
             add = cost[WARP - 1]; /* :268-272 */
         }
     }
