@@ -12,7 +12,7 @@ import numpy as np
 from .config import StixelParams, SECTION_DTYPE, INSTANCE_CLASSES
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libis_core.so")
+LIB_PATH = os.environ.get("IS_CORE_LIB", os.path.join(_HERE, "lib", "libis_core.so"))
 _LIB = None
 
 EXPORTS = [

@@ -23,15 +23,15 @@ size_t isk_unary_lds_bytes(const DevParams* P);
 size_t isk_pairwise_lds_bytes(const DevParams* P, int nwaves);
 hipError_t isk_launch_join(const float*, float*, int, int, int, int, int, int, float, int, hipStream_t);
 hipError_t isk_launch_prepare(const DevParams*, int, const float*, const int32_t*, const float*,
-                              const int*, const float*, RowRec*, float*, hipStream_t);
+                              const int*, const float*, RowRec*, float*, int*, hipStream_t);
 hipError_t isk_launch_priors(const DevParams*, const float*, PriorRec*, int, hipStream_t);
 hipError_t isk_launch_dp_unary(const DevParams*, int, int, const RowRec*, const float*, const float*,
-                               const int*, float*, int32_t*, hipStream_t);
+                               const int*, const int*, float*, int32_t*, hipStream_t);
 hipError_t isk_launch_dp_pairwise(const DevParams*, int, int, const RowRec*, const float*,
-                                  const PriorRec*, const float*, const int*, float*, int32_t*,
-                                  hipStream_t);
+                                  const PriorRec*, const float*, const float*, const int*,
+                                  const int*, float*, int32_t*, hipStream_t);
 hipError_t isk_launch_backtrace(const DevParams*, int, int, const RowRec*, const float*,
-                                const int32_t*, is_section*, hipStream_t);
+                                const int32_t*, const int*, is_section*, hipStream_t);
 hipError_t isk_launch_compact(const DevParams*, const is_section*, float*, int32_t*, uint8_t*,
                               int32_t*, hipStream_t);
 hipError_t isk_set_lds_limits(const DevParams*, int);
@@ -63,7 +63,8 @@ struct is_ctx {
     /* frame-independent device tables */
     float* d_obj_cost_lut;   /* [D][D]  */
     float* d_odr;            /* [D]     object_disparity_range */
-    float* d_pwinv;          /* [H+1]   prior_weight * (float)(1.0/h) */
+    float* d_rcp;            /* [H+1]   RN(1/h) = (float)(1./h), the reference's inverse_height */
+    int* d_col_flags;        /* [max_batch*C] 0 = FAST column, see RowRec */
     /* per-call device inputs */
     float* d_ground;         /* [max_batch][3][H] */
     int* d_vhor;             /* [max_batch] */
@@ -162,7 +163,7 @@ int is_ctx_create(const is_stixel_params* p, const float* obj_cost_lut,
     d.column_step = p->column_step;
 
     /* waves per DP workgroup: the LUT tile is 64*(D+1) floats; keep >= 16 waves per CU */
-    c->nwaves_unary = (d.D <= 128) ? 4 : 8;
+    c->nwaves_unary = IS_UNARY_WAVES;
     c->nwaves_pairwise = 4;
     if (isk_unary_lds_bytes(&d) > 160 * 1024 || isk_pairwise_lds_bytes(&d, c->nwaves_pairwise) > 160 * 1024 ||
         isk_prepare_lds_bytes(&d) > 160 * 1024) {
@@ -179,7 +180,8 @@ int is_ctx_create(const is_stixel_params* p, const float* obj_cost_lut,
     } while (0)
     ALLOC(c->d_obj_cost_lut, sizeof(float) * D * D);
     ALLOC(c->d_odr, sizeof(float) * D);
-    ALLOC(c->d_pwinv, sizeof(float) * (H + 1));
+    ALLOC(c->d_rcp, sizeof(float) * (H + 1));
+    ALLOC(c->d_col_flags, sizeof(int) * B * C);
     ALLOC(c->d_ground, sizeof(float) * B * 3 * H);
     ALLOC(c->d_vhor, sizeof(int) * B);
     ALLOC(c->d_recs, sizeof(RowRec) * B * C * (H + 1));
@@ -197,17 +199,20 @@ int is_ctx_create(const is_stixel_params* p, const float* obj_cost_lut,
     HIP_TRY(hipMemcpy(c->d_obj_cost_lut, obj_cost_lut, sizeof(float) * D * D, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->d_odr, obj_disparity_range, sizeof(float) * D, hipMemcpyHostToDevice));
     {
-        /* prior_weight * inverse_height with inverse_height = (float)(1./(vT+1-vB)),
-         * StixelsKernels.cu:485, 608, 716-719 */
+        /* inverse_height = (float)(1./(vT+1-vB)) (StixelsKernels.cu:485, 608) doubles as the
+         * reciprocal of the exact-division trick; both definitions must agree bit for bit */
         float* t = (float*)malloc(sizeof(float) * (H + 1));
         t[0] = 0.0f;
+        bool same = true;
         for (size_t h = 1; h <= H; h++) {
             const float inverse_height = (float)(1. / (double)h);
-            t[h] = p->prior_weight * inverse_height;
+            t[h] = 1.0f / (float)h;
+            same = same && (t[h] == inverse_height);
         }
-        hipError_t e = hipMemcpy(c->d_pwinv, t, sizeof(float) * (H + 1), hipMemcpyHostToDevice);
+        hipError_t e = hipMemcpy(c->d_rcp, t, sizeof(float) * (H + 1), hipMemcpyHostToDevice);
         free(t);
         HIP_TRY(e);
+        if (!same) return fail_arg("internal: (float)(1./h) != 1.0f/h for some h <= rows");
     }
     HIP_TRY(isk_set_lds_limits(&d, c->nwaves_pairwise));
     *out_ctx = c;
@@ -218,7 +223,7 @@ int is_ctx_destroy(is_ctx* c) {
     if (!c) return IS_OK;
     hipSetDevice(c->device);
     hipDeviceSynchronize();
-    hipFree(c->d_obj_cost_lut); hipFree(c->d_odr); hipFree(c->d_pwinv); hipFree(c->d_ground);
+    hipFree(c->d_obj_cost_lut); hipFree(c->d_odr); hipFree(c->d_rcp); hipFree(c->d_col_flags); hipFree(c->d_ground);
     hipFree(c->d_vhor); hipFree(c->d_recs); hipFree(c->d_lutT); hipFree(c->d_priors);
     hipFree(c->d_cost_table); hipFree(c->d_index_table);
     hipHostFree(c->h_ground_pinned); hipHostFree(c->h_vhor_pinned);
@@ -297,17 +302,19 @@ int is_compute(is_ctx* c, const float* d_joined, const int32_t* d_seg, const flo
 
     if (c->timing) HIP_TRY(hipEventRecord(c->ev[0], stream));
     HIP_TRY(isk_launch_prepare(&P, ncols, d_joined, d_seg, c->d_ground, c->d_vhor,
-                               c->d_obj_cost_lut, c->d_recs, c->d_lutT, stream));
+                               c->d_obj_cost_lut, c->d_recs, c->d_lutT, c->d_col_flags, stream));
     if (pairwise) HIP_TRY(isk_launch_priors(&P, c->d_ground, c->d_priors, n_images, stream));
     if (c->timing) HIP_TRY(hipEventRecord(c->ev[1], stream));
     if (pairwise)
         HIP_TRY(isk_launch_dp_pairwise(&P, ncols, c->nwaves_pairwise, c->d_recs, c->d_lutT,
-                                       c->d_priors, c->d_odr, c->d_vhor, ct, it, stream));
+                                       c->d_priors, c->d_odr, c->d_rcp, c->d_vhor, c->d_col_flags,
+                                       ct, it, stream));
     else
-        HIP_TRY(isk_launch_dp_unary(&P, ncols, c->nwaves_unary, c->d_recs, c->d_lutT, c->d_pwinv,
-                                    c->d_vhor, ct, it, stream));
+        HIP_TRY(isk_launch_dp_unary(&P, ncols, c->nwaves_unary, c->d_recs, c->d_lutT, c->d_rcp,
+                                    c->d_vhor, c->d_col_flags, ct, it, stream));
     if (c->timing) HIP_TRY(hipEventRecord(c->ev[2], stream));
-    HIP_TRY(isk_launch_backtrace(&P, ncols, pairwise ? 1 : 0, c->d_recs, ct, it, d_sections, stream));
+    HIP_TRY(isk_launch_backtrace(&P, ncols, pairwise ? 1 : 0, c->d_recs, ct, it, c->d_col_flags,
+                                 d_sections, stream));
     if (instances) {
         for (int i = 0; i < n_images; i++) {
             const is_instance_buffers& ib = instances[i];

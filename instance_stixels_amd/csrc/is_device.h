@@ -15,26 +15,55 @@
 
 #include <stdint.h>
 
+#ifndef IS_UNARY_WAVES
+#define IS_UNARY_WAVES 8   /* waves per unary-DP workgroup; x4 workgroups/CU (LDS) = waves/SIMD */
+#endif
 #define IS_TILE 64          /* rows (vT values) per DP tile = one wavefront */
 #define IS_N_ON 8           /* non-instance object classes 2..9   (Cityscapes.h:69) */
 #define IS_N_OI 8           /* instance object classes     11..18 (Cityscapes.h:75) */
 
 /* Full-resolution exclusive prefix values at row index v (v = 0..rows).
  * F_c[v] = sum_{j<v} x_c[j/8] in wrapping int32: DownsampledSum(c, vB, vT) of
- * Cityscapes.h:28-42 equals F_c[vT+1] - F_c[vB] exactly (ring arithmetic mod 2^32). */
+ * Cityscapes.h:28-42 equals F_c[vT+1] - F_c[vB] exactly (ring arithmetic mod 2^32).
+ *
+ * Two encodings of the same 128 bytes, chosen per column by k_prepare_columns (col_flags):
+ *  - FAST (flag 0): the 19 class prefixes are stored as fp32 -- exact, because FAST requires
+ *    every class value >= 0 and every column total < 2^24, so each prefix and each difference is
+ *    an integer in [0, 2^24) -- and the four instance prefixes as binary64 -- exact, because
+ *    FAST requires |mx|, |my| < 2^18, so every prefix / difference is an integer below 2^52.
+ *    float(int difference) then costs one v_sub_f32 (a 2-cycle op on gfx950, where integer
+ *    subtraction with an SGPR operand, conversions and min/max all cost 4) or one v_add_f64 +
+ *    v_cvt_f32_f64.
+ *  - generic (flag != 0): int32 / int64 bit patterns, see RowRecWide. */
 struct __attribute__((aligned(128))) RowRec {
-    int32_t Fg0, Fg1;        /* classes 0 (road), 1 (sidewalk)            */
-    int32_t Fon[IS_N_ON];    /* classes 2..9                                */
-    int32_t Foi[IS_N_OI];    /* classes 11..18                              */
-    int32_t Fsky;            /* class 10                                    */
+    float Fg0, Fg1;          /* classes 0 (road), 1 (sidewalk)            */
+    float Fon[IS_N_ON];      /* classes 2..9                                */
+    float Foi[IS_N_OI];      /* classes 11..18                              */
+    float Fsky;              /* class 10                                    */
     int32_t Fnic;            /* squared offset channels, x + y (StixelsKernels.cu:62-70) */
     float G;                 /* ground data-cost prefix (Blelloch association)  */
     float K;                 /* sky data-cost prefix    (Blelloch association)  */
     float S;                 /* disparity prefix        (Blelloch association)  */
     float V;                 /* valid-pixel count prefix (exact)                */
-    int64_t MX, MY, MX2, MY2; /* instance-centre prefix sums (StixelsKernels.cu:401-409) */
+    double MX, MY, MX2, MY2; /* instance-centre prefix sums (StixelsKernels.cu:401-409) */
 };
 static_assert(sizeof(RowRec) == 128, "RowRec must be one 128-byte line");
+
+struct __attribute__((aligned(128))) RowRecWide { /* generic encoding of the same bytes */
+    int32_t Fg0, Fg1;
+    int32_t Fon[IS_N_ON];
+    int32_t Foi[IS_N_OI];
+    int32_t Fsky;
+    int32_t Fnic;
+    float G, K, S, V;
+    int64_t MX, MY, MX2, MY2;
+};
+static_assert(sizeof(RowRecWide) == 128, "RowRecWide must alias RowRec");
+
+#define IS_FAST_CLASS_LIMIT (1 << 24)      /* column total of every class channel          */
+#define IS_FAST_INSTANCE_LIMIT (1 << 18)   /* |mx|, |my| bound of FAST columns            */
+#define IS_FAST_DISP_MIN 0x1p-60f          /* nonzero |d| range of FAST columns: then every */
+#define IS_FAST_DISP_MAX 0x1p60f           /* prefix difference is 0 or in [2^-84, 2^75]    */
 
 /* Per-vB transition priors of the pairwise model that do not depend on the DP state
  * (StixelsKernels.cu:88-199); one 32-byte record per vB, read with scalar loads. */

@@ -186,10 +186,21 @@ __device__ __forceinline__ int32_t full_prefix(const int32_t* ps, int v) {
     return r;
 }
 
+__device__ __forceinline__ void store_instance_prefix(RowRec* o, int slow, int64_t mx, int64_t my,
+                                                      int64_t mx2, int64_t my2) {
+    if (slow) {
+        RowRecWide* w = reinterpret_cast<RowRecWide*>(o);
+        w->MX = mx; w->MY = my; w->MX2 = mx2; w->MY2 = my2;
+    } else { /* exact: all four are integers below 2^52 in magnitude */
+        o->MX = (double)mx; o->MY = (double)my; o->MX2 = (double)mx2; o->MY2 = (double)my2;
+    }
+}
+
 __global__ __launch_bounds__(PREP_THREADS) void k_prepare_columns(
     const DevParams P, const float* __restrict__ joined, const int32_t* __restrict__ seg,
     const float* __restrict__ ground /*[img][3][H]*/, const int* __restrict__ vhor_arr,
-    const float* __restrict__ obj_cost_lut, RowRec* __restrict__ recs, float* __restrict__ lutT) {
+    const float* __restrict__ obj_cost_lut, RowRec* __restrict__ recs, float* __restrict__ lutT,
+    int* __restrict__ col_flags) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int H = P.H, D = P.D, P2 = P.P2, P2S = P.P2S, CH = P.CH, K = P.K;
     float* s_d = (float*)smem;                          /* [P2]   disparity column        */
@@ -221,17 +232,34 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_columns(
     const int32_t* offy = s_seg + K * P2S;
     const int32_t* offx = s_seg + (K + 1) * P2S;
     int64_t sum_mx = 0, sum_my = 0, sum_mx2 = 0, sum_my2 = 0;
+    int slow = 0; /* column needs the generic (int64 / IEEE-division) DP path, see RowRec */
     for (int r = r_lo; r < r_lo + R && r < H; r++) {
         const double fx = ((double)(P.column_step * col) + 0.5 * ((double)P.column_step - 1.0)) +
                           (double)offx[r >> 3] + 0.5;
         const int64_t mx = (int64_t)fx;
         const int32_t n32 = (int32_t)((uint32_t)r - (uint32_t)offy[r >> 3]);
         const int64_t my = (int64_t)((double)n32 + 0.5);
+        slow |= (mx >= IS_FAST_INSTANCE_LIMIT) | (mx <= -IS_FAST_INSTANCE_LIMIT) |
+                (my >= IS_FAST_INSTANCE_LIMIT) | (my <= -IS_FAST_INSTANCE_LIMIT);
+        const float ad = __builtin_fabsf(s_d[r]);
+        slow |= !((ad == 0.0f) || (ad >= IS_FAST_DISP_MIN && ad <= IS_FAST_DISP_MAX));
         sum_mx += mx;
         sum_my += my;
         sum_mx2 = (int64_t)((uint64_t)sum_mx2 + (uint64_t)mx * (uint64_t)mx);
         sum_my2 = (int64_t)((uint64_t)sum_my2 + (uint64_t)my * (uint64_t)my);
     }
+    if (tid < K) { /* class channels of a FAST column: values >= 0, full-resolution total < 2^24 */
+        const int32_t* ch = s_seg + tid * P2S;
+        uint64_t total = 0;
+        int negative = 0;
+        for (int k = 0; k < P2S; k++) {
+            negative |= (ch[k] < 0);
+            total += (uint64_t)(uint32_t)ch[k];
+        }
+        slow |= negative | (total * IS_DOWNSAMPLE_FACTOR >= (uint64_t)IS_FAST_CLASS_LIMIT);
+    }
+    slow = __syncthreads_or(slow);
+    if (tid == 0) col_flags[colg] = slow;
     int64_t base_mx = block_excl_scan_i64(sum_mx, s_wave);
     int64_t base_my = block_excl_scan_i64(sum_my, s_wave);
     int64_t base_mx2 = block_excl_scan_i64(sum_mx2, s_wave);
@@ -239,8 +267,7 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_columns(
     /* the owner of rows [r_lo, r_lo+R) writes the exclusive prefix at those indices; the owner
      * of row H-1 also writes index H (the total) */
     for (int r = r_lo; r < r_lo + R && r < H; r++) {
-        RowRec* o = rcol + r;
-        o->MX = base_mx; o->MY = base_my; o->MX2 = base_mx2; o->MY2 = base_my2;
+        store_instance_prefix(rcol + r, slow, base_mx, base_my, base_mx2, base_my2);
         const double fx = ((double)(P.column_step * col) + 0.5 * ((double)P.column_step - 1.0)) +
                           (double)offx[r >> 3] + 0.5;
         const int64_t mx = (int64_t)fx;
@@ -251,10 +278,8 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_columns(
         base_mx2 = (int64_t)((uint64_t)base_mx2 + (uint64_t)mx * (uint64_t)mx);
         base_my2 = (int64_t)((uint64_t)base_my2 + (uint64_t)my * (uint64_t)my);
     }
-    if (r_lo <= H - 1 && H - 1 < r_lo + R) {
-        RowRec* o = rcol + H;
-        o->MX = base_mx; o->MY = base_my; o->MX2 = base_mx2; o->MY2 = base_my2;
-    }
+    if (r_lo <= H - 1 && H - 1 < r_lo + R)
+        store_instance_prefix(rcol + H, slow, base_mx, base_my, base_mx2, base_my2);
     __syncthreads();
 
     /* ---- square the offset channels in place (StixelsKernels.cu:411-416), then exclusive
@@ -275,16 +300,31 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_columns(
     }
     __syncthreads();
     for (int v = tid; v <= H; v += PREP_THREADS) {
-        RowRec* o = rcol + v;
-        o->Fg0 = full_prefix(s_seg + 0 * P2S, v);
-        o->Fg1 = full_prefix(s_seg + 1 * P2S, v);
+        RowRecWide* o = (RowRecWide*)(rcol + v);
+        const int32_t f_g0 = full_prefix(s_seg + 0 * P2S, v);
+        const int32_t f_g1 = full_prefix(s_seg + 1 * P2S, v);
+        int32_t f_on[IS_N_ON], f_oi[IS_N_OI];
 #pragma unroll
-        for (int c = 0; c < IS_N_ON; c++) o->Fon[c] = full_prefix(s_seg + (2 + c) * P2S, v);
+        for (int c = 0; c < IS_N_ON; c++) f_on[c] = full_prefix(s_seg + (2 + c) * P2S, v);
 #pragma unroll
-        for (int c = 0; c < IS_N_OI; c++) o->Foi[c] = full_prefix(s_seg + (11 + c) * P2S, v);
-        o->Fsky = full_prefix(s_seg + 10 * P2S, v);
+        for (int c = 0; c < IS_N_OI; c++) f_oi[c] = full_prefix(s_seg + (11 + c) * P2S, v);
+        const int32_t f_sky = full_prefix(s_seg + 10 * P2S, v);
         o->Fnic = (int32_t)((uint32_t)full_prefix(s_seg + (K + 1) * P2S, v) +
                             (uint32_t)full_prefix(s_seg + K * P2S, v));
+        if (slow) {
+            o->Fg0 = f_g0; o->Fg1 = f_g1; o->Fsky = f_sky;
+#pragma unroll
+            for (int c = 0; c < IS_N_ON; c++) o->Fon[c] = f_on[c];
+#pragma unroll
+            for (int c = 0; c < IS_N_OI; c++) o->Foi[c] = f_oi[c];
+        } else {
+            RowRec* f = rcol + v;
+            f->Fg0 = (float)f_g0; f->Fg1 = (float)f_g1; f->Fsky = (float)f_sky;
+#pragma unroll
+            for (int c = 0; c < IS_N_ON; c++) f->Fon[c] = (float)f_on[c];
+#pragma unroll
+            for (int c = 0; c < IS_N_OI; c++) f->Foi[c] = (float)f_oi[c];
+        }
     }
 
     /* ---- fp32 prefixes with the reference's block-scan association (:452-461) */
@@ -403,53 +443,108 @@ struct SegTerms {
     int fni;                   /* floor(mean), clamped to [0, D-1]                          */
 };
 
-/* `my` = record at vT+1 (per lane), `rb` = record at vB (wave-uniform, scalar loads).
+/* a / h for an integer-valued h in [1, 11000] with r = RN(1/h): one multiplication and two
+ * FMAs give the correctly rounded IEEE quotient for every fp32 a in [2^-100, 2^100] and a = 0
+ * (exhaustively verified over all 2^23 mantissas x all h by tools/verify_exact_division.c). */
+__device__ __forceinline__ float fast_div(float a, float h, float r) {
+    const float q0 = a * r;
+    const float e0 = __builtin_fmaf(-q0, h, a);
+    return __builtin_fmaf(e0, r, q0);
+}
+
+/* wave-uniform record through the constant address space: scalar loads, values live in SGPRs */
+__device__ __forceinline__ RowRec sload_rec(const RowRec* p) {
+    crec_t q = (crec_t)p;
+    RowRec r;
+    r.Fg0 = q->Fg0; r.Fg1 = q->Fg1;
+#pragma unroll
+    for (int c = 0; c < IS_N_ON; c++) r.Fon[c] = q->Fon[c];
+#pragma unroll
+    for (int c = 0; c < IS_N_OI; c++) r.Foi[c] = q->Foi[c];
+    r.Fsky = q->Fsky; r.Fnic = q->Fnic;
+    r.G = q->G; r.K = q->K; r.S = q->S; r.V = q->V;
+    r.MX = q->MX; r.MY = q->MY; r.MX2 = q->MX2; r.MY2 = q->MY2;
+    return r;
+}
+
+/* `my` = record at vT+1 (per lane), `rb` = record at vB (wave-uniform copy in SGPRs), r = RN(1/h).
  * Exact rewrites w.r.t. Cityscapes.h:44-118 / StixelsKernels.cu:62-86:
  *   DownsampledSum(c) = my.F_c - rb.F_c;
  *   min_c (k + float(S_c)) = k + float(min_c S_c) for classes sharing the additive term k
- *   (int -> float conversion and fp32 addition are monotone). */
-template <bool HAS_INVALID>
-__device__ __forceinline__ SegTerms eval_segment(const RowRec& my, crec_t rb, int h, int D,
-                                                 float iw) {
+ *   (int -> float conversion and fp32 addition are monotone);
+ *   (0.0f + k) + float(S) = k + float(S): float(int) is never -0, so the leading `0.0f +` of
+ *   Cityscapes.h:67-79 cannot change the sum;
+ *   FAST columns only: float(int64 difference) via exact binary64, x / h via fast_div, and
+ *   (int)floorf(max(mean,0)) = (int)fmaxf(mean,0) because the mean is finite there. */
+template <bool FAST, bool HAS_INVALID>
+__device__ __forceinline__ SegTerms eval_segment(const RowRec& my, const RowRec& rb, float height,
+                                                 float r, int D, float iw) {
     SegTerms t;
-    const int32_t s_g = min(my.Fg0 - rb->Fg0, my.Fg1 - rb->Fg1);
-    int32_t s_on = my.Fon[0] - rb->Fon[0];
+    const float nic = iw * (float)(my.Fnic - rb.Fnic); /* ComputeNonInstanceOffsetCost, :62-70, :496-499 */
+    float ic; /* ComputeInstanceOffsetCost, :72-86 */
+    float f_g, f_on, f_oi, f_sky; /* float(min_c DownsampledSum_c) per class group */
+    if (FAST) {
+        f_g = __builtin_fminf(my.Fg0 - rb.Fg0, my.Fg1 - rb.Fg1);
+        f_on = my.Fon[0] - rb.Fon[0];
 #pragma unroll
-    for (int c = 1; c < IS_N_ON; c++) s_on = min(s_on, my.Fon[c] - rb->Fon[c]);
-    int32_t s_oi = my.Foi[0] - rb->Foi[0];
+        for (int c = 1; c < IS_N_ON; c++) f_on = __builtin_fminf(f_on, my.Fon[c] - rb.Fon[c]);
+        f_oi = my.Foi[0] - rb.Foi[0];
 #pragma unroll
-    for (int c = 1; c < IS_N_OI; c++) s_oi = min(s_oi, my.Foi[c] - rb->Foi[c]);
-    const int32_t s_sky = my.Fsky - rb->Fsky;
-    const int32_t s_nic = my.Fnic - rb->Fnic;
+        for (int c = 1; c < IS_N_OI; c++) f_oi = __builtin_fminf(f_oi, my.Foi[c] - rb.Foi[c]);
+        f_sky = my.Fsky - rb.Fsky;
+        const float meanx = (float)(my.MX - rb.MX);
+        const float meany = (float)(my.MY - rb.MY);
+        const float meanx2 = (float)(my.MX2 - rb.MX2);
+        const float meany2 = (float)(my.MY2 - rb.MY2);
+        ic = iw * (meanx2 - fast_div(meanx * meanx, height, r) + meany2 -
+                   fast_div(meany * meany, height, r));
+    } else {
+        const RowRecWide& mw = reinterpret_cast<const RowRecWide&>(my);
+        const RowRecWide& bw = reinterpret_cast<const RowRecWide&>(rb);
+        f_g = (float)min(mw.Fg0 - bw.Fg0, mw.Fg1 - bw.Fg1);
+        int32_t s_on = mw.Fon[0] - bw.Fon[0];
+#pragma unroll
+        for (int c = 1; c < IS_N_ON; c++) s_on = min(s_on, mw.Fon[c] - bw.Fon[c]);
+        int32_t s_oi = mw.Foi[0] - bw.Foi[0];
+#pragma unroll
+        for (int c = 1; c < IS_N_OI; c++) s_oi = min(s_oi, mw.Foi[c] - bw.Foi[c]);
+        f_on = (float)s_on;
+        f_oi = (float)s_oi;
+        f_sky = (float)(mw.Fsky - bw.Fsky);
+        const float meanx = (float)(mw.MX - bw.MX);
+        const float meany = (float)(mw.MY - bw.MY);
+        const float meanx2 = (float)(mw.MX2 - bw.MX2);
+        const float meany2 = (float)(mw.MY2 - bw.MY2);
+        ic = iw * (meanx2 - meanx * meanx / height + meany2 - meany * meany / height);
+    }
 
-    const float nic = iw * (float)s_nic; /* ComputeNonInstanceOffsetCost, :62-70, :496-499 */
-    /* ComputeInstanceOffsetCost, :72-86 */
-    const float meanx = (float)(my.MX - rb->MX);
-    const float meany = (float)(my.MY - rb->MY);
-    const float meanx2 = (float)(my.MX2 - rb->MX2);
-    const float meany2 = (float)(my.MY2 - rb->MY2);
-    const float height = (float)h;
-    const float ic = iw * (meanx2 - meanx * meanx / height + meany2 - meany * meany / height);
+    t.seg_g = f_g + nic;
+    const float on = nic + f_on;
+    const float oi = ic + f_oi;
+    t.seg_o = FAST ? __builtin_fminf(oi, on) : ((oi < on) ? oi : on); /* both finite when FAST */
+    t.seg_s = f_sky + nic;
 
-    t.seg_g = (float)s_g + nic;
-    const float on = (0.0f + nic) + (float)s_on;
-    const float oi = (0.0f + ic) + (float)s_oi;
-    t.seg_o = (oi < on) ? oi : on;
-    t.seg_s = (float)s_sky + nic;
-
-    t.gd = my.G - rb->G;
-    t.sd = my.K - rb->K;
+    t.gd = my.G - rb.G;
+    t.sd = my.K - rb.K;
     float mean; /* ComputeMean, :47-60 */
     if (HAS_INVALID) {
-        const float valid_dif = my.V - rb->V;
-        mean = (valid_dif == 0) ? 0 : (my.S - rb->S) / valid_dif;
+        const float valid_dif = my.V - rb.V;
+        mean = (valid_dif == 0) ? 0 : (my.S - rb.S) / valid_dif;
+    } else if (FAST) {
+        mean = fast_div(my.S - rb.S, height, r);
     } else {
-        mean = (my.S - rb->S) / (float)h;
+        mean = (my.S - rb.S) / height;
     }
-    if (mean < 0) mean = 0; /* :525-527 */
-    t.mean = mean;
-    int fni = (int)__builtin_floorf(mean);
-    t.fni = min(max(fni, 0), D - 1); /* memory safety outside the input domain (Q8) */
+    if (FAST) {
+        mean = __builtin_fmaxf(mean, 0.0f); /* :525-527; the mean is finite in FAST columns */
+        t.mean = mean;
+        t.fni = min((int)mean, D - 1);
+    } else {
+        if (mean < 0) mean = 0; /* :525-527 */
+        t.mean = mean;
+        const int fni = (int)__builtin_floorf(mean);
+        t.fni = min(max(fni, 0), D - 1); /* memory safety outside the input domain (Q8) */
+    }
     return t;
 }
 
@@ -469,19 +564,85 @@ __device__ __forceinline__ RowRec load_rec(const RowRec* p) {
  * minimum over vB of a single-segment cost, so all (vB, vT) pairs are independent and the only
  * order that matters is the strict-< tie rule (smallest vB wins).  index_table holds the winning
  * vB (or -1); the predecessor TYPE is resolved in k_backtrace from the final cost_table. */
+struct UnaryBest {
+    float g, o, s;
+    int vg, vo, vs;
+};
+
+/* One (vB, vT) evaluation of the unary model.  DIAG = the segment start may lie above this
+ * lane's vT (diagonal 64x64 block of the tile): such lanes are masked. */
+template <bool FAST, bool HAS_INVALID, bool DIAG>
+__device__ __forceinline__ void unary_step(const DevParams& P, const RowRec& my, const RowRec& rb,
+                                           const float* __restrict__ lrow, const float* my_tile,
+                                           const float* s_rcp, int vT, int vTc, int vhor, int vB,
+                                           bool row_ok, UnaryBest& b) {
+    const int h = vTc + 1 - vB;
+    const bool live = DIAG ? ((h > 0) && row_ok) : row_ok;
+    const int hc = DIAG ? max(h, 1) : h;
+    const float r = s_rcp[hc]; /* RN(1/h) = (float)(1./h) = inverse_height, :485, :608 */
+    const SegTerms t = eval_segment<FAST, HAS_INVALID>(my, rb, (float)hc, r, P.D, P.iw);
+#if defined(ABL_NOGATHER)
+    const float od = my_tile[t.fni] - (float)t.fni;
+#elif defined(ABL_NOLDS)
+    const float od = (float)t.fni - lrow[(unsigned)t.fni];
+#else
+    const float od = my_tile[t.fni] - lrow[(unsigned)t.fni];
+#endif
+    const float pwih = P.pw * r;
+    /* cost = dw*data + pw*(1/h) + sw*seg, left to right (:716-719, 762-765, 820-823) */
+    const float cost_o = P.dw * od + pwih + P.sw * t.seg_o;
+    if (live && cost_o < b.o) { b.o = cost_o; b.vo = vB; }
+    if (vB == 0 || vB <= vhor) { /* ground: vB-1 < vhor (:687); vB = 0 needs vT <= vhor (:542-545) */
+        const float cost_g = P.dw * t.gd + pwih + P.sw * t.seg_g;
+        const bool ok = live && (vB > 0 || vT <= vhor);
+        if (ok && cost_g < b.g) { b.g = cost_g; b.vg = vB; }
+    } else { /* sky: vB-1 >= vhor (:729) */
+        const float cost_s = P.dw * t.sd + pwih + P.sw * t.seg_s;
+        if (live && cost_s < b.s) { b.s = cost_s; b.vs = vB; }
+    }
+}
+
+/* The wave walks vB = w, w+nw, ... <= vB_end: first the part where every lane of the tile has
+ * vT >= vB, then the diagonal block where lanes below vB are masked. */
+template <bool FAST, bool HAS_INVALID>
+__device__ __forceinline__ void unary_loop(const DevParams& P, const RowRec& my,
+                                           const RowRec* __restrict__ rcol,
+                                           const float* __restrict__ lcol, const float* my_tile,
+                                           const float* s_rcp, int vT, int vTc, int vhor, int w,
+                                           int nw, int tile_lo, int vB_end, UnaryBest& b) {
+    const int D = P.D;
+    const bool row_ok = vT < P.H;
+    int vB = w;
+    for (; vB <= tile_lo && vB <= vB_end; vB += nw) {
+#if defined(ABL_SAMEREC)
+        const RowRec cur = sload_rec(rcol + (vB & 7));
+#else
+        const RowRec cur = sload_rec(rcol + vB);
+#endif
+        unary_step<FAST, HAS_INVALID, false>(P, my, cur, lcol + (size_t)vB * D, my_tile, s_rcp, vT,
+                                             vTc, vhor, vB, row_ok, b);
+    }
+    for (; vB <= vB_end; vB += nw) {
+        const RowRec cur = sload_rec(rcol + vB);
+        unary_step<FAST, HAS_INVALID, true>(P, my, cur, lcol + (size_t)vB * D, my_tile, s_rcp, vT,
+                                            vTc, vhor, vB, row_ok, b);
+    }
+}
+
 template <bool HAS_INVALID>
-__global__ __launch_bounds__(512) void k_dp_unary(const DevParams P, int ncols,
+__global__ __launch_bounds__(IS_UNARY_WAVES * 64, IS_UNARY_WAVES) void k_dp_unary(const DevParams P, int ncols,
                                                   const RowRec* __restrict__ recs,
                                                   const float* __restrict__ lutT,
-                                                  const float* __restrict__ pwinv,
+                                                  const float* __restrict__ rcp,
                                                   const int* __restrict__ vhor_arr,
+                                                  const int* __restrict__ col_flags,
                                                   float* __restrict__ cost_table,
                                                   int32_t* __restrict__ index_table) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int H = P.H, D = P.D;
     const int DP = D + 1; /* padded row: conflict-free when lanes share fni */
     float* s_tile = (float*)smem;             /* [64][D+1] lutT rows tile_lo+1 .. tile_lo+64 */
-    float* s_pwinv = s_tile + IS_TILE * DP;   /* [H+1]     prior_weight * (1/h)               */
+    float* s_rcp = s_tile + IS_TILE * DP;     /* [H+1]     RN(1/h)                            */
 
     /* XCD-aware order: blocks b, b+8, ... share an XCD/L2; keep all tiles of a column on one
      * XCD (they gather from the same lutT) and start with the tallest tiles. */
@@ -505,47 +666,32 @@ __global__ __launch_bounds__(512) void k_dp_unary(const DevParams P, int ncols,
         const int v = min(tile_lo + 1 + r, H);
         s_tile[r * DP + f] = lcol[(size_t)v * D + f];
     }
-    for (int i = tid; i <= H; i += blockDim.x) s_pwinv[i] = pwinv[i];
+    for (int i = tid; i <= H; i += blockDim.x) s_rcp[i] = rcp[i];
 
     const int vT = tile_lo + lane;
     const int vTc = min(vT, H - 1);
     const RowRec my = load_rec(rcol + vTc + 1);
     __syncthreads();
 
-    float best_g = IS_INF, best_o = IS_INF, best_s = IS_INF;
-    int vb_g = -1, vb_o = 0 /* index_table[vT*3+OBJECT] = OBJECT at vB = 0, :592 */, vb_s = -1;
+    UnaryBest b;
+    b.g = b.o = b.s = IS_INF;
+    b.vg = b.vs = -1;
+    b.vo = 0; /* index_table[vT*3+OBJECT] = OBJECT at vB = 0, :592 */
     const float* my_tile = s_tile + lane * DP;
     const int vB_end = min(tile_lo + IS_TILE - 1, H - 1);
-
-    for (int vB = w; vB <= vB_end; vB += nw) {
-        crec_t rb = (crec_t)(rcol + vB);
-        const int h = vTc + 1 - vB;
-        const bool live = (h > 0) && (vT < H);
-        const int hc = max(h, 1);
-        const SegTerms t = eval_segment<HAS_INVALID>(my, rb, hc, D, P.iw);
-        const float od = my_tile[t.fni] - lcol[(size_t)vB * D + t.fni];
-        const float pwih = s_pwinv[hc];
-        /* cost = dw*data + pw*(1/h) + sw*seg, left to right (:716-719, 762-765, 820-823) */
-        const float cost_o = P.dw * od + pwih + P.sw * t.seg_o;
-        if (live && cost_o < best_o) { best_o = cost_o; vb_o = vB; }
-        if (vB == 0 || vB <= vhor) { /* ground: vB-1 < vhor (:687); vB = 0 needs vT <= vhor (:542-545) */
-            const float cost_g = P.dw * t.gd + pwih + P.sw * t.seg_g;
-            const bool ok = live && (vB > 0 || vT <= vhor);
-            if (ok && cost_g < best_g) { best_g = cost_g; vb_g = vB; }
-        } else { /* sky: vB-1 >= vhor (:729) */
-            const float cost_s = P.dw * t.sd + pwih + P.sw * t.seg_s;
-            if (live && cost_s < best_s) { best_s = cost_s; vb_s = vB; }
-        }
-    }
+    if (__builtin_amdgcn_readfirstlane(col_flags[colg]) == 0)
+        unary_loop<true, HAS_INVALID>(P, my, rcol, lcol, my_tile, s_rcp, vT, vTc, vhor, w, nw, tile_lo, vB_end, b);
+    else
+        unary_loop<false, HAS_INVALID>(P, my, rcol, lcol, my_tile, s_rcp, vT, vTc, vhor, w, nw, tile_lo, vB_end, b);
 
     /* merge the waves' partial minima: min cost, ties -> smallest vB (= first strict minimum
      * of the reference's ascending-vB loop) */
     __syncthreads();
     float* m_cost = (float*)smem;                  /* [nw][3][64] (aliases the LUT tile) */
     int* m_vb = (int*)(m_cost + nw * 3 * 64);      /* [nw][3][64] */
-    m_cost[(w * 3 + 0) * 64 + lane] = best_g; m_vb[(w * 3 + 0) * 64 + lane] = vb_g;
-    m_cost[(w * 3 + 1) * 64 + lane] = best_o; m_vb[(w * 3 + 1) * 64 + lane] = vb_o;
-    m_cost[(w * 3 + 2) * 64 + lane] = best_s; m_vb[(w * 3 + 2) * 64 + lane] = vb_s;
+    m_cost[(w * 3 + 0) * 64 + lane] = b.g; m_vb[(w * 3 + 0) * 64 + lane] = b.vg;
+    m_cost[(w * 3 + 1) * 64 + lane] = b.o; m_vb[(w * 3 + 1) * 64 + lane] = b.vo;
+    m_cost[(w * 3 + 2) * 64 + lane] = b.s; m_vb[(w * 3 + 2) * 64 + lane] = b.vs;
     __syncthreads();
     if (tid < 3 * 64) {
         const int type = tid >> 6;
@@ -620,8 +766,8 @@ struct PairBest {
 
 /* One (vB >= 1, vT) evaluation of the pairwise model for the lane owning vT. */
 template <bool HAS_INVALID>
-__device__ __forceinline__ void pairwise_step(const DevParams& P, const RowRec& my, crec_t rb,
-                                              cprior_t pr, const PredRec& pd, int vB, int vhor,
+__device__ __forceinline__ void pairwise_step(const DevParams& P, const RowRec& my,
+                                              const RowRec& rb, cprior_t pr, const PredRec& pd, int vB, int vhor,
                                               int h, bool live, float od_hi, float od_lo_base,
                                               const SegTerms& t, PairBest& b) {
     const float pw = P.pw;
@@ -672,13 +818,12 @@ __device__ __forceinline__ void pairwise_step(const DevParams& P, const RowRec& 
     }
 }
 
-template <bool HAS_INVALID>
-__global__ __launch_bounds__(512) void k_dp_pairwise(
-    const DevParams P, int ncols, const RowRec* __restrict__ recs, const float* __restrict__ lutT,
-    const PriorRec* __restrict__ priors, const float* __restrict__ odr,
-    const int* __restrict__ vhor_arr, float* __restrict__ cost_table,
-    int32_t* __restrict__ index_table) {
-    extern __shared__ __attribute__((aligned(32))) char smem[];
+template <bool FAST, bool HAS_INVALID>
+__device__ __forceinline__ void pairwise_column(
+    const DevParams& P, char* smem, int colg, const RowRec* __restrict__ recs,
+    const float* __restrict__ lutT, const PriorRec* __restrict__ priors,
+    const float* __restrict__ odr, const float* __restrict__ rcp, int vhor,
+    float* __restrict__ cost_table, int32_t* __restrict__ index_table) {
     const int H = P.H, D = P.D;
     const int DP = D + 1;
     const int nw = blockDim.x >> 6;
@@ -686,16 +831,15 @@ __global__ __launch_bounds__(512) void k_dp_pairwise(
     float* s_tile = (float*)(s_pred + H);                    /* [64][D+1]                  */
     float* m_cost = s_tile + IS_TILE * DP;                   /* [nw][3][64]                */
     int* m_idx = (int*)(m_cost + nw * 3 * 64);               /* [nw][3][64]                */
+    float* s_rcp = (float*)(m_idx + nw * 3 * 64);            /* [H+1] RN(1/h)              */
 
-    const int colg = blockIdx.x;
-    if (colg >= ncols) return;
     const int img = colg / P.C;
-    const int vhor = vhor_arr[img];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const RowRec* rcol = recs + (size_t)colg * (H + 1);
     const float* lcol = lutT + (size_t)colg * (H + 1) * D;
     const PriorRec* pcol = priors + (size_t)img * H;
+    for (int i = tid; i <= H; i += blockDim.x) s_rcp[i] = rcp[i];
 
     for (int tile = 0; tile < P.ntiles; tile++) {
         const int tile_lo = tile * IS_TILE;
@@ -719,10 +863,10 @@ __global__ __launch_bounds__(512) void k_dp_pairwise(
         /* ---- phase 1: segments starting in earlier tiles (their predecessors are final),
          * vB strided over the waves */
         for (int vB = w; vB <= tile_lo && vB < H; vB += nw) {
-            crec_t rb = (crec_t)(rcol + vB);
+            const RowRec rb = sload_rec(rcol + vB);
             const int h = vTc + 1 - vB;
             const bool live = vT < H;
-            const SegTerms t = eval_segment<HAS_INVALID>(my, rb, h, D, P.iw);
+            const SegTerms t = eval_segment<FAST, HAS_INVALID>(my, rb, (float)h, s_rcp[h], D, P.iw);
             const float od_hi = my_tile[t.fni];
             const float od_lo = lcol[(size_t)vB * D + t.fni];
             if (vB == 0) { /* first segment, :481-594 */
@@ -767,11 +911,11 @@ __global__ __launch_bounds__(512) void k_dp_pairwise(
                 const int r = tile_lo + s; /* row that becomes final now */
                 if (s > 0) {
                     const int vB = r;
-                    crec_t rb = (crec_t)(rcol + vB);
+                    const RowRec rb = sload_rec(rcol + vB);
                     const int h = vTc + 1 - vB;
                     const bool live = (vT < H) && (h > 0);
                     const int hc = max(h, 1);
-                    const SegTerms t = eval_segment<HAS_INVALID>(my, rb, hc, D, P.iw);
+                    const SegTerms t = eval_segment<FAST, HAS_INVALID>(my, rb, (float)hc, s_rcp[hc], D, P.iw);
                     const float od_hi = my_tile[t.fni];
                     const float od_lo = lcol[(size_t)vB * D + t.fni];
                     const PredRec pd = s_pred[vB - 1];
@@ -798,6 +942,25 @@ __global__ __launch_bounds__(512) void k_dp_pairwise(
     }
 }
 
+template <bool HAS_INVALID>
+__global__ __launch_bounds__(512) void k_dp_pairwise(
+    const DevParams P, int ncols, const RowRec* __restrict__ recs, const float* __restrict__ lutT,
+    const PriorRec* __restrict__ priors, const float* __restrict__ odr,
+    const float* __restrict__ rcp, const int* __restrict__ vhor_arr,
+    const int* __restrict__ col_flags, float* __restrict__ cost_table,
+    int32_t* __restrict__ index_table) {
+    extern __shared__ __attribute__((aligned(32))) char smem[];
+    const int colg = blockIdx.x;
+    if (colg >= ncols) return;
+    const int vhor = vhor_arr[colg / P.C];
+    if (__builtin_amdgcn_readfirstlane(col_flags[colg]) == 0)
+        pairwise_column<true, HAS_INVALID>(P, smem, colg, recs, lutT, priors, odr, rcp, vhor,
+                                           cost_table, index_table);
+    else
+        pairwise_column<false, HAS_INVALID>(P, smem, colg, recs, lutT, priors, odr, rcp, vhor,
+                                            cost_table, index_table);
+}
+
 /* ====================================================================================== */
 /* A10  back-tracing, one lane per column                                                  */
 /* ====================================================================================== */
@@ -814,9 +977,11 @@ __global__ __launch_bounds__(64) void k_backtrace(const DevParams P, int ncols, 
                                                   const RowRec* __restrict__ recs,
                                                   const float* __restrict__ cost_table,
                                                   const int32_t* __restrict__ index_table,
+                                                  const int* __restrict__ col_flags,
                                                   is_section* __restrict__ sections) {
     const int colg = blockIdx.x * blockDim.x + threadIdx.x;
     if (colg >= ncols) return;
+    const bool wide = col_flags[colg] != 0; /* int64 bit patterns instead of binary64, see RowRec */
     const int H = P.H;
     const RowRec* rcol = recs + (size_t)colg * (H + 1);
     const float* ct = cost_table + (size_t)colg * H * 3;
@@ -864,20 +1029,22 @@ __global__ __launch_bounds__(64) void k_backtrace(const DevParams P, int ncols, 
         sec.disparity = bt_mean(rcol, vB, vT, P.invalid);
         sec.cost = __builtin_fminf(ct[vT * 3 + type], 1e4f);
         const int hgt = vT + 1 - vB;
-        sec.instance_meanx = (float)(a.MX - bq.MX) / (float)hgt;
-        sec.instance_meany = (float)(a.MY - bq.MY) / (float)hgt;
+        const RowRecWide& aw = reinterpret_cast<const RowRecWide&>(a);
+        const RowRecWide& bw = reinterpret_cast<const RowRecWide&>(bq);
+        const float meanx = wide ? (float)(aw.MX - bw.MX) : (float)(a.MX - bq.MX);
+        const float meany = wide ? (float)(aw.MY - bw.MY) : (float)(a.MY - bq.MY);
+        sec.instance_meanx = meanx / (float)hgt;
+        sec.instance_meany = meany / (float)hgt;
         if (sec.type == IS_GROUND) { /* GetGroundSegmentationClass, Cityscapes.h:52-59 */
-            const float cost_road = (float)(a.Fg0 - bq.Fg0);
-            const float cost_sidewalk = (float)(a.Fg1 - bq.Fg1);
+            const float cost_road = wide ? (float)(aw.Fg0 - bw.Fg0) : (a.Fg0 - bq.Fg0);
+            const float cost_sidewalk = wide ? (float)(aw.Fg1 - bw.Fg1) : (a.Fg1 - bq.Fg1);
             sec.semantic_class = (cost_road < cost_sidewalk) ? 0 : 1;
         } else if (sec.type == IS_SKY || sec.disparity < 1.0f) { /* :894-902 */
             sec.type = IS_SKY;
             sec.semantic_class = 10;
         } else { /* GetObjectSegmentationClass, Cityscapes.h:85-111 */
-            const float meanx = (float)(a.MX - bq.MX);
-            const float meany = (float)(a.MY - bq.MY);
-            const float meanx2 = (float)(a.MX2 - bq.MX2);
-            const float meany2 = (float)(a.MY2 - bq.MY2);
+            const float meanx2 = wide ? (float)(aw.MX2 - bw.MX2) : (float)(a.MX2 - bq.MX2);
+            const float meany2 = wide ? (float)(aw.MY2 - bw.MY2) : (float)(a.MY2 - bq.MY2);
             const float height = (float)hgt;
             const float ic = P.iw * (meanx2 - meanx * meanx / height + meany2 - meany * meany / height);
             const float nic = P.iw * (float)(a.Fnic - bq.Fnic);
@@ -887,14 +1054,14 @@ __global__ __launch_bounds__(64) void k_backtrace(const DevParams P, int ncols, 
             for (int c = 0; c < IS_N_ON; c++) {
                 float cs = 0.0f;
                 cs += nic;
-                cs += (float)(a.Fon[c] - bq.Fon[c]);
+                cs += wide ? (float)(aw.Fon[c] - bw.Fon[c]) : (a.Fon[c] - bq.Fon[c]);
                 if (min_cost > cs) { min_cost = cs; min_class = 2 + c; }
             }
 #pragma unroll
             for (int c = 0; c < IS_N_OI; c++) {
                 float cs = 0.0f;
                 cs += ic;
-                cs += (float)(a.Foi[c] - bq.Foi[c]);
+                cs += wide ? (float)(aw.Foi[c] - bw.Foi[c]) : (a.Foi[c] - bq.Foi[c]);
                 if (min_cost > cs) { min_cost = cs; min_class = 11 + c; }
             }
             sec.semantic_class = min_class;
@@ -986,7 +1153,7 @@ size_t isk_unary_lds_bytes(const DevParams* P) {
 }
 size_t isk_pairwise_lds_bytes(const DevParams* P, int nwaves) {
     return sizeof(PredRec) * (size_t)P->H + sizeof(float) * (size_t)IS_TILE * (P->D + 1) +
-           (size_t)nwaves * 3 * 64 * 8 + 32;
+           (size_t)nwaves * 3 * 64 * 8 + sizeof(float) * ((size_t)P->H + 1) + 32;
 }
 
 hipError_t isk_launch_join(const float* big, float* joined, int H, int W, int C, int step,
@@ -1001,10 +1168,10 @@ hipError_t isk_launch_join(const float* big, float* joined, int H, int W, int C,
 hipError_t isk_launch_prepare(const DevParams* P, int ncols, const float* joined,
                               const int32_t* seg, const float* ground, const int* vhor,
                               const float* obj_cost_lut, RowRec* recs, float* lutT,
-                              hipStream_t stream) {
+                              int* col_flags, hipStream_t stream) {
     hipLaunchKernelGGL(k_prepare_columns, dim3(ncols), dim3(PREP_THREADS),
                        isk_prepare_lds_bytes(P), stream, *P, joined, seg, ground, vhor,
-                       obj_cost_lut, recs, lutT);
+                       obj_cost_lut, recs, lutT, col_flags);
     return hipGetLastError();
 }
 
@@ -1017,39 +1184,42 @@ hipError_t isk_launch_priors(const DevParams* P, const float* ground, PriorRec* 
 }
 
 hipError_t isk_launch_dp_unary(const DevParams* P, int ncols, int nwaves, const RowRec* recs,
-                               const float* lutT, const float* pwinv, const int* vhor,
-                               float* cost_table, int32_t* index_table, hipStream_t stream) {
+                               const float* lutT, const float* rcp, const int* vhor,
+                               const int* col_flags, float* cost_table, int32_t* index_table,
+                               hipStream_t stream) {
     const int groups = (ncols + 7) / 8;
     const dim3 grid(groups * 8 * P->ntiles);
     const size_t lds = isk_unary_lds_bytes(P);
     if (P->invalid >= 0)
         hipLaunchKernelGGL(k_dp_unary<true>, grid, dim3(nwaves * 64), lds, stream, *P, ncols, recs,
-                           lutT, pwinv, vhor, cost_table, index_table);
+                           lutT, rcp, vhor, col_flags, cost_table, index_table);
     else
         hipLaunchKernelGGL(k_dp_unary<false>, grid, dim3(nwaves * 64), lds, stream, *P, ncols, recs,
-                           lutT, pwinv, vhor, cost_table, index_table);
+                           lutT, rcp, vhor, col_flags, cost_table, index_table);
     return hipGetLastError();
 }
 
 hipError_t isk_launch_dp_pairwise(const DevParams* P, int ncols, int nwaves, const RowRec* recs,
                                   const float* lutT, const PriorRec* priors, const float* odr,
-                                  const int* vhor, float* cost_table, int32_t* index_table,
-                                  hipStream_t stream) {
+                                  const float* rcp, const int* vhor, const int* col_flags,
+                                  float* cost_table, int32_t* index_table, hipStream_t stream) {
     const size_t lds = isk_pairwise_lds_bytes(P, nwaves);
     if (P->invalid >= 0)
         hipLaunchKernelGGL(k_dp_pairwise<true>, dim3(ncols), dim3(nwaves * 64), lds, stream, *P,
-                           ncols, recs, lutT, priors, odr, vhor, cost_table, index_table);
+                           ncols, recs, lutT, priors, odr, rcp, vhor, col_flags, cost_table,
+                           index_table);
     else
         hipLaunchKernelGGL(k_dp_pairwise<false>, dim3(ncols), dim3(nwaves * 64), lds, stream, *P,
-                           ncols, recs, lutT, priors, odr, vhor, cost_table, index_table);
+                           ncols, recs, lutT, priors, odr, rcp, vhor, col_flags, cost_table,
+                           index_table);
     return hipGetLastError();
 }
 
 hipError_t isk_launch_backtrace(const DevParams* P, int ncols, int pairwise, const RowRec* recs,
                                 const float* cost_table, const int32_t* index_table,
-                                is_section* sections, hipStream_t stream) {
+                                const int* col_flags, is_section* sections, hipStream_t stream) {
     hipLaunchKernelGGL(k_backtrace, dim3((ncols + 63) / 64), dim3(64), 0, stream, *P, ncols,
-                       pairwise, recs, cost_table, index_table, sections);
+                       pairwise, recs, cost_table, index_table, col_flags, sections);
     return hipGetLastError();
 }
 

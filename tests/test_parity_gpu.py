@@ -140,9 +140,18 @@ def test_degenerate_inputs(preset):
     d[64:, 24:32] = 0.0                   # column 3 invalid lower half
     s = case["segmentation"][0]
     s[4] = 0                              # column 4: zero segmentation
-    s[5, 19:21, :16] = 8 * 4000           # column 5: huge offsets (int64 sums of squares)
+    s[5, 19:21, :16] = 8 * 4000           # column 5: large offsets, still a FAST column
     s[6, 19:21, :16] = -8 * 4000
     s[7, :19, :16] = 0                    # column 7: all classes tie
+    s[8, 19:21, :16] = 8 * 50000          # columns 8-10: |centre| >= 2^18 -> generic int64 path
+    s[9, 19:21, :16] = -8 * 50000
+    s[10, 19, 3] = 2 ** 30
+    s[13, 3, :16] = 200000                # column 13: class total >= 2^24 -> generic int32 sums
+    s[14, 12, 5] = -7                     # column 14: negative class value -> generic path
+    s[15, :19, :16] = 130000              # column 15: every class just below the fp32-exact limit
+    d[:, 88:96] = 1e-30                   # column 11: tiny disparities -> generic division path
+    d[40:50, 96:104] = 1e-30              # column 12: mixed
+    d[10, 96:104] = 3.0e-39               # subnormal
     got = helpers.run_core(case)
     _assert_parity(case, got)
 
