@@ -61,7 +61,7 @@ struct is_ctx {
     int max_batch;
     int nwaves_unary, nwaves_pairwise;
     /* frame-independent device tables */
-    float* d_obj_cost_lut;   /* [D][D]  */
+    float* d_obj_cost_lut;   /* [D dis][D fn], transposed w.r.t. Stixels.cu:122-129 */
     float* d_odr;            /* [D]     object_disparity_range */
     float* d_rcp;            /* [H+1]   RN(1/h) = (float)(1./h), the reference's inverse_height */
     int* d_col_flags;        /* [max_batch*C] 0 = FAST column, see RowRec */
@@ -196,7 +196,15 @@ int is_ctx_create(const is_stixel_params* p, const float* obj_cost_lut,
     HIP_TRY(hipEventCreateWithFlags(&c->staging_free, hipEventDisableTiming));
     for (int i = 0; i < 4; i++) HIP_TRY(hipEventCreate(&c->ev[i]));
 
-    HIP_TRY(hipMemcpy(c->d_obj_cost_lut, obj_cost_lut, sizeof(float) * D * D, hipMemcpyHostToDevice));
+    {
+        /* device copy is TRANSPOSED ([dis][fn]): a wave of 64 consecutive fn reads one row */
+        float* t = (float*)malloc(sizeof(float) * D * D);
+        for (size_t fn = 0; fn < D; fn++)
+            for (size_t dis = 0; dis < D; dis++) t[dis * D + fn] = obj_cost_lut[fn * D + dis];
+        hipError_t e = hipMemcpy(c->d_obj_cost_lut, t, sizeof(float) * D * D, hipMemcpyHostToDevice);
+        free(t);
+        HIP_TRY(e);
+    }
     HIP_TRY(hipMemcpy(c->d_odr, obj_disparity_range, sizeof(float) * D, hipMemcpyHostToDevice));
     {
         /* inverse_height = (float)(1./(vT+1-vB)) (StixelsKernels.cu:485, 608) doubles as the

@@ -199,10 +199,9 @@ __device__ __forceinline__ void store_instance_prefix(RowRec* o, int slow, int64
 __global__ __launch_bounds__(PREP_THREADS) void k_prepare_columns(
     const DevParams P, const float* __restrict__ joined, const int32_t* __restrict__ seg,
     const float* __restrict__ ground /*[img][3][H]*/, const int* __restrict__ vhor_arr,
-    const float* __restrict__ obj_cost_lut, RowRec* __restrict__ recs, float* __restrict__ lutT,
-    int* __restrict__ col_flags) {
+    RowRec* __restrict__ recs, int* __restrict__ col_flags) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int H = P.H, D = P.D, P2 = P.P2, P2S = P.P2S, CH = P.CH, K = P.K;
+    const int H = P.H, P2 = P.P2, P2S = P.P2S, CH = P.CH, K = P.K;
     float* s_d = (float*)smem;                          /* [P2]   disparity column        */
     float* s_pyr = s_d + P2;                            /* [2*P2] scan tree                */
     int32_t* s_seg = (int32_t*)(s_pyr + 2 * P2);        /* [CH][P2S]                       */
@@ -217,7 +216,6 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_columns(
     const float* dcol = joined + (size_t)colg * H;
     const int32_t* scol = seg + (size_t)colg * CH * P2S;
     RowRec* rcol = recs + (size_t)colg * (H + 1);
-    float* lcol = lutT + (size_t)colg * (H + 1) * D;
     const int tid = threadIdx.x;
 
     for (int i = tid; i < P2; i += PREP_THREADS) s_d[i] = (i < H) ? dcol[i] : 0.0f;
@@ -373,35 +371,58 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_columns(
     __syncthreads();
     blelloch_build(s_pyr, P2, P.log2P2);
     for (int v = tid; v <= H; v += PREP_THREADS) rcol[v].K = blelloch_prefix(s_pyr, P2, P.log2P2, v);
+}
 
-    /* ---- object data-cost prefix table (ComputeObjectLUT, :236-296, 959-978).  Association:
-     * 32-lane Kogge-Stone with the running carry added into lane 0 first, 32-row blocks chained
-     * serially.  One half-wavefront plays the reference's warp; the two halves of a wavefront
-     * work on two different fn. */
-    const int l32 = tid & 31;
-    const int hw = tid >> 5;
-    const int nhw = PREP_THREADS / 32;
-    for (int fn0 = 0; fn0 < D; fn0 += nhw) {
-        const int fn = fn0 + hw;
-        const bool fn_ok = fn < D;
-        const int fnc = fn_ok ? fn : D - 1;
-        float add = 0.0f;
-        if (fn_ok && l32 == 0) lcol[fn] = 0.0f; /* arr[0] = 0, :283-285 */
-        for (int i = 0; i < H; i += 32) {
-            const int row = i + l32;
-            int dis = 0;
-            if (row < H) dis = (int)s_d[row];
-            dis = min(max(dis, 0), D - 1); /* memory safety outside the input domain (Q8) */
-            float cost = obj_cost_lut[fnc * D + dis];
-            if (l32 == 0) cost += add;
+/* ====================================================================================== */
+/* A4  object data-cost prefix table (ComputeObjectLUT, StixelsKernels.cu:236-296, 959-978) */
+/* ====================================================================================== */
+/* lutT[v][fn] = prefix over rows of obj_cost_lut[fn][(int)d[row]] with the reference's
+ * association: per 32-row block a 32-lane Kogge-Stone network (shuffle distances 1,2,4,8,16)
+ * whose lane 0 first receives the running carry; blocks chained serially.
+ *
+ * The reference gives a warp one fn and lets lanes be rows (5 shuffles per block).  Here a LANE
+ * owns one fn and evaluates the same 32-input network on registers (129 fp32 adds per block, no
+ * cross-lane traffic); the 64 lanes of a wave are 64 consecutive fn, so every load of the
+ * transposed cost table and every store of a lutT row is one fully coalesced 256-byte access. */
+#define LUT_BLOCK 32
+__global__ __launch_bounds__(64) void k_object_lut(const DevParams P,
+                                                   const float* __restrict__ joined,
+                                                   const float* __restrict__ cost_T /*[dis][fn]*/,
+                                                   float* __restrict__ lutT) {
+    const int H = P.H, D = P.D;
+    const int colg = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int fn = blockIdx.y * 64 + lane;
+    const bool fn_ok = fn < D;
+    const int fnc = fn_ok ? fn : D - 1;
+    const float* dcol = joined + (size_t)colg * H;
+    float* lcol = lutT + (size_t)colg * (H + 1) * D;
+    if (fn_ok) lcol[fn] = 0.0f; /* arr[0] = 0, :283-285 */
+    float add = 0.0f;
+    for (int i = 0; i < H; i += LUT_BLOCK) {
+        /* (int)d of the block's 32 rows: one coalesced load, then wave-uniform broadcasts */
+        const int rl = i + (lane & (LUT_BLOCK - 1));
+        int dis_l = 0; /* rows beyond the image use dis = 0, :244-247 */
+        if (rl < H) dis_l = (int)dcol[rl];
+        dis_l = min(max(dis_l, 0), D - 1); /* memory safety outside the input domain (Q8) */
+        float c[LUT_BLOCK];
 #pragma unroll
-            for (int j = 1; j < 32; j <<= 1) {
-                const float n = __shfl_up(cost, j, 32);
-                if (l32 >= j) cost += n;
-            }
-            if (fn_ok && row < H) lcol[(size_t)(row + 1) * D + fn] = cost;
-            add = __shfl(cost, 31, 32);
+        for (int l = 0; l < LUT_BLOCK; l++) {
+            const int dis = __builtin_amdgcn_readlane(dis_l, l);
+            c[l] = cost_T[(size_t)dis * D + fnc];
         }
+        c[0] += add; /* :249-251 */
+#pragma unroll
+        for (int j = 1; j < LUT_BLOCK; j <<= 1) { /* :255-263; descending l reads pre-step values */
+#pragma unroll
+            for (int l = LUT_BLOCK - 1; l >= j; l--) c[l] += c[l - j];
+        }
+        if (fn_ok) {
+#pragma unroll
+            for (int l = 0; l < LUT_BLOCK; l++)
+                if (i + l < H) lcol[(size_t)(i + l + 1) * D + fn] = c[l]; /* :266 */
+        }
+        add = c[LUT_BLOCK - 1]; /* :268-272 */
     }
 }
 
@@ -1167,11 +1188,13 @@ hipError_t isk_launch_join(const float* big, float* joined, int H, int W, int C,
 
 hipError_t isk_launch_prepare(const DevParams* P, int ncols, const float* joined,
                               const int32_t* seg, const float* ground, const int* vhor,
-                              const float* obj_cost_lut, RowRec* recs, float* lutT,
+                              const float* cost_T, RowRec* recs, float* lutT,
                               int* col_flags, hipStream_t stream) {
     hipLaunchKernelGGL(k_prepare_columns, dim3(ncols), dim3(PREP_THREADS),
-                       isk_prepare_lds_bytes(P), stream, *P, joined, seg, ground, vhor,
-                       obj_cost_lut, recs, lutT, col_flags);
+                       isk_prepare_lds_bytes(P), stream, *P, joined, seg, ground, vhor, recs,
+                       col_flags);
+    hipLaunchKernelGGL(k_object_lut, dim3(ncols, (P->D + 63) / 64), dim3(64), 0, stream, *P, joined,
+                       cost_T, lutT);
     return hipGetLastError();
 }
 
