@@ -23,13 +23,15 @@ size_t isk_unary_lds_bytes(const DevParams* P);
 size_t isk_pairwise_lds_bytes(const DevParams* P, int nwaves);
 hipError_t isk_launch_join(const float*, float*, int, int, int, int, int, int, float, int, hipStream_t);
 hipError_t isk_launch_prepare(const DevParams*, int, const float*, const int32_t*, const float*,
-                              const int*, const float*, RowRec*, float*, int*, hipStream_t);
+                              const int*, const float*, RowRec*, float*, int*, float*, hipStream_t);
+struct PredRec;
 hipError_t isk_launch_priors(const DevParams*, const float*, PriorRec*, int, hipStream_t);
 hipError_t isk_launch_dp_unary(const DevParams*, int, int, const RowRec*, const float*, const float*,
                                const int*, const int*, float*, int32_t*, hipStream_t);
 hipError_t isk_launch_dp_pairwise(const DevParams*, int, int, const RowRec*, const float*,
-                                  const PriorRec*, const float*, const float*, const int*,
-                                  const int*, float*, int32_t*, hipStream_t);
+                                  const PriorRec*, const float*, const float*, const float*,
+                                  const int*, const int*, PredRec*, float*, int*, float*, int32_t*,
+                                  hipStream_t);
 hipError_t isk_launch_backtrace(const DevParams*, int, int, const RowRec*, const float*,
                                 const int32_t*, const int*, is_section*, hipStream_t);
 hipError_t isk_launch_compact(const DevParams*, const is_section*, float*, int32_t*, uint8_t*,
@@ -76,6 +78,10 @@ struct is_ctx {
     RowRec* d_recs;          /* [max_batch*C][H+1] */
     float* d_lutT;           /* [max_batch*C][H+1][D] */
     PriorRec* d_priors;      /* [max_batch][H] */
+    PredRec* d_pred;         /* [max_batch*C][H]   finished-row records of the pairwise DP (32 B) */
+    float* d_part_cost;      /* [max_batch*C][3][64] merged partial minima of the current tile */
+    int* d_part_idx;         /* [max_batch*C][3][64] */
+    float* d_sv;             /* [max_batch*C][2][H+1] compact S / V prefixes */
     float* d_cost_table;     /* [max_batch*C][H][3] */
     int32_t* d_index_table;  /* [max_batch*C][H][3] */
     size_t scratch_bytes;
@@ -164,7 +170,7 @@ int is_ctx_create(const is_stixel_params* p, const float* obj_cost_lut,
 
     /* waves per DP workgroup: the LUT tile is 64*(D+1) floats; keep >= 16 waves per CU */
     c->nwaves_unary = IS_UNARY_WAVES;
-    c->nwaves_pairwise = 4;
+    c->nwaves_pairwise = IS_UNARY_WAVES;
     if (isk_unary_lds_bytes(&d) > 160 * 1024 || isk_pairwise_lds_bytes(&d, c->nwaves_pairwise) > 160 * 1024 ||
         isk_prepare_lds_bytes(&d) > 160 * 1024) {
         free(c);
@@ -187,6 +193,10 @@ int is_ctx_create(const is_stixel_params* p, const float* obj_cost_lut,
     ALLOC(c->d_recs, sizeof(RowRec) * B * C * (H + 1));
     ALLOC(c->d_lutT, sizeof(float) * B * C * (H + 1) * D);
     ALLOC(c->d_priors, sizeof(PriorRec) * B * H);
+    ALLOC(c->d_pred, (size_t)32 * B * C * H);
+    ALLOC(c->d_part_cost, sizeof(float) * B * C * 3 * 64);
+    ALLOC(c->d_part_idx, sizeof(int) * B * C * 3 * 64);
+    ALLOC(c->d_sv, sizeof(float) * B * C * 2 * (H + 1));
     ALLOC(c->d_cost_table, sizeof(float) * B * C * H * 3);
     ALLOC(c->d_index_table, sizeof(int32_t) * B * C * H * 3);
 #undef ALLOC
@@ -232,7 +242,7 @@ int is_ctx_destroy(is_ctx* c) {
     hipSetDevice(c->device);
     hipDeviceSynchronize();
     hipFree(c->d_obj_cost_lut); hipFree(c->d_odr); hipFree(c->d_rcp); hipFree(c->d_col_flags); hipFree(c->d_ground);
-    hipFree(c->d_vhor); hipFree(c->d_recs); hipFree(c->d_lutT); hipFree(c->d_priors);
+    hipFree(c->d_vhor); hipFree(c->d_recs); hipFree(c->d_lutT); hipFree(c->d_priors); hipFree(c->d_pred); hipFree(c->d_part_cost); hipFree(c->d_part_idx); hipFree(c->d_sv);
     hipFree(c->d_cost_table); hipFree(c->d_index_table);
     hipHostFree(c->h_ground_pinned); hipHostFree(c->h_vhor_pinned);
     hipEventDestroy(c->staging_free);
@@ -310,13 +320,14 @@ int is_compute(is_ctx* c, const float* d_joined, const int32_t* d_seg, const flo
 
     if (c->timing) HIP_TRY(hipEventRecord(c->ev[0], stream));
     HIP_TRY(isk_launch_prepare(&P, ncols, d_joined, d_seg, c->d_ground, c->d_vhor,
-                               c->d_obj_cost_lut, c->d_recs, c->d_lutT, c->d_col_flags, stream));
+                               c->d_obj_cost_lut, c->d_recs, c->d_lutT, c->d_col_flags, c->d_sv, stream));
     if (pairwise) HIP_TRY(isk_launch_priors(&P, c->d_ground, c->d_priors, n_images, stream));
     if (c->timing) HIP_TRY(hipEventRecord(c->ev[1], stream));
     if (pairwise)
         HIP_TRY(isk_launch_dp_pairwise(&P, ncols, c->nwaves_pairwise, c->d_recs, c->d_lutT,
-                                       c->d_priors, c->d_odr, c->d_rcp, c->d_vhor, c->d_col_flags,
-                                       ct, it, stream));
+                                       c->d_priors, c->d_odr, c->d_rcp, c->d_sv, c->d_vhor,
+                                       c->d_col_flags, c->d_pred, c->d_part_cost, c->d_part_idx, ct, it,
+                                       stream));
     else
         HIP_TRY(isk_launch_dp_unary(&P, ncols, c->nwaves_unary, c->d_recs, c->d_lutT, c->d_rcp,
                                     c->d_vhor, c->d_col_flags, ct, it, stream));

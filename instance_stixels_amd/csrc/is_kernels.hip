@@ -12,7 +12,8 @@
  *   k_dp_unary          A7-A9 StixelsKernels.cu:477-839, PAIRWISE=false: independent
  *                            (column, 64-row tile) work items, one lane per vT, vB-side
  *                            operands in SGPRs via scalar loads, vT-side LUT rows in LDS
- *   k_dp_pairwise       A7-A9 PAIRWISE=true: one workgroup per column walking the tiles
+ *   k_pw_phase1/2       A7-A9 PAIRWISE=true: per 64-row tile, a parallel launch for segments
+ *                            starting in earlier tiles + a one-wave-per-column diagonal walk
  *   k_backtrace         A10  StixelsKernels.cu:843-955
  *   k_compact_instances A10  StixelsKernels.cu:926-942 in canonical order
  *
@@ -199,7 +200,7 @@ __device__ __forceinline__ void store_instance_prefix(RowRec* o, int slow, int64
 __global__ __launch_bounds__(PREP_THREADS) void k_prepare_columns(
     const DevParams P, const float* __restrict__ joined, const int32_t* __restrict__ seg,
     const float* __restrict__ ground /*[img][3][H]*/, const int* __restrict__ vhor_arr,
-    RowRec* __restrict__ recs, int* __restrict__ col_flags) {
+    RowRec* __restrict__ recs, int* __restrict__ col_flags, float* __restrict__ sv_arr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int H = P.H, P2 = P.P2, P2S = P.P2S, CH = P.CH, K = P.K;
     float* s_d = (float*)smem;                          /* [P2]   disparity column        */
@@ -342,14 +343,23 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_columns(
     }
     __syncthreads();
     blelloch_build(s_pyr, P2, P.log2P2);
-    for (int v = tid; v <= H; v += PREP_THREADS) rcol[v].S = blelloch_prefix(s_pyr, P2, P.log2P2, v);
+    float* svcol = sv_arr + (size_t)colg * 2 * (H + 1); /* compact copies for the pairwise phase 2 */
+    for (int v = tid; v <= H; v += PREP_THREADS) {
+        const float x = blelloch_prefix(s_pyr, P2, P.log2P2, v);
+        rcol[v].S = x;
+        svcol[v] = x;
+    }
     __syncthreads();
     /* V: valid count */
     for (int i = tid; i < P2; i += PREP_THREADS)
         s_pyr[i] = (i < H && P.invalid >= 0) ? (float)(s_d[i] != P.invalid) : 0.0f;
     __syncthreads();
     blelloch_build(s_pyr, P2, P.log2P2);
-    for (int v = tid; v <= H; v += PREP_THREADS) rcol[v].V = blelloch_prefix(s_pyr, P2, P.log2P2, v);
+    for (int v = tid; v <= H; v += PREP_THREADS) {
+        const float x = blelloch_prefix(s_pyr, P2, P.log2P2, v);
+        rcol[v].V = x;
+        svcol[H + 1 + v] = x;
+    }
     __syncthreads();
     /* G: ground data cost, +inf at / above the horizon (:435-446) */
     for (int i = tid; i < P2; i += PREP_THREADS) {
@@ -745,25 +755,32 @@ struct __attribute__((aligned(32))) PredRec {
     float pm_hi, pm_lo; /* pm + dif, pm - dif                                               */
 };
 
-template <bool HAS_INVALID>
-__device__ __forceinline__ float mean_between(const RowRec* rcol, int vB, int vT) {
-    /* ComputeMean(vB, vT) from the boundary records, :47-60 */
-    const float s1 = rcol[vT + 1].S, s0 = rcol[vB].S;
-    if (HAS_INVALID) {
-        const float valid_dif = rcol[vT + 1].V - rcol[vB].V;
-        return (valid_dif == 0) ? 0 : (s1 - s0) / valid_dif;
-    }
-    return (s1 - s0) / (float)(vT + 1 - vB);
+typedef const __attribute__((address_space(4))) PredRec* cpred_t;
+
+__device__ __forceinline__ PredRec sload_pred(const PredRec* p) {
+    cpred_t q = (cpred_t)p;
+    PredRec r;
+    r.cG = q->cG; r.cO = q->cO; r.cS = q->cS; r.pm = q->pm;
+    r.oo_hi = q->oo_hi; r.oo_lo = q->oo_lo; r.pm_hi = q->pm_hi; r.pm_lo = q->pm_lo;
+    return r;
 }
 
-/* Builds the PredRec of finished row r from its final costs and winning object start. */
+/* Builds the PredRec of finished row r from its final costs and winning object start.
+ * s_S / s_V: the column's disparity / valid-count prefixes (Blelloch association) in LDS. */
 template <bool HAS_INVALID>
-__device__ __forceinline__ PredRec make_pred(const DevParams& P, const RowRec* rcol,
+__device__ __forceinline__ PredRec make_pred(const DevParams& P, const float* s_S, const float* s_V,
                                              const float* __restrict__ odr, int vhor, int r,
                                              float cG, float cO, float cS, int obj_vB, float pc_next) {
     PredRec p;
     p.cG = cG; p.cO = cO; p.cS = cS;
-    float pm = mean_between<HAS_INVALID>(rcol, obj_vB, r);
+    /* previous_mean = ComputeMean(previous_object_vB, previous_vT), :47-60, :675-685 */
+    float pm;
+    if (HAS_INVALID) {
+        const float valid_dif = s_V[r + 1] - s_V[obj_vB];
+        pm = (valid_dif == 0) ? 0 : (s_S[r + 1] - s_S[obj_vB]) / valid_dif;
+    } else {
+        pm = (s_S[r + 1] - s_S[obj_vB]) / (float)(r + 1 - obj_vB);
+    }
     if (pm < 0) pm = 0;
     p.pm = pm;
     /* GetPriorCostObjectFromObject(vB = r+1, ...), :146-171 */
@@ -839,147 +856,211 @@ __device__ __forceinline__ void pairwise_step(const DevParams& P, const RowRec& 
     }
 }
 
+/* The pairwise DP of one 64-row tile is split over two launches (per tile, bottom-up):
+ *
+ *  phase 1  k_pw_phase1: segments that START in earlier tiles (vB <= tile_lo).  Their
+ *           predecessor rows are final (PredRec written by earlier launches, read with scalar
+ *           loads), so all (vB, vT) pairs are independent: same structure, occupancy and issue
+ *           bound as the unary kernel.  Writes the merged partial minima of the tile.
+ *  phase 2  k_pw_phase2: the 64x64 diagonal block, where step vB needs the final row vB-1 of
+ *           the same tile: one wavefront per column walks the 63 steps; the finished row is
+ *           broadcast with v_readlane, its PredRec is computed uniformly and published.
+ *
+ * The serial chain of the reference (rows x __syncthreads, StixelsKernels.cu:600-603) is thus
+ * confined to phase 2, 1/16 of the pair evaluations at 1024 rows. */
 template <bool FAST, bool HAS_INVALID>
-__device__ __forceinline__ void pairwise_column(
-    const DevParams& P, char* smem, int colg, const RowRec* __restrict__ recs,
-    const float* __restrict__ lutT, const PriorRec* __restrict__ priors,
-    const float* __restrict__ odr, const float* __restrict__ rcp, int vhor,
-    float* __restrict__ cost_table, int32_t* __restrict__ index_table) {
+__device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, int colg, int tile,
+                                               const RowRec* __restrict__ recs,
+                                               const float* __restrict__ lutT,
+                                               const PriorRec* __restrict__ priors,
+                                               const PredRec* __restrict__ pred,
+                                               const float* __restrict__ rcp, int vhor,
+                                               float* __restrict__ part_cost,
+                                               int* __restrict__ part_idx) {
     const int H = P.H, D = P.D;
     const int DP = D + 1;
-    const int nw = blockDim.x >> 6;
-    PredRec* s_pred = (PredRec*)smem;                        /* [H] finished rows          */
-    float* s_tile = (float*)(s_pred + H);                    /* [64][D+1]                  */
-    float* m_cost = s_tile + IS_TILE * DP;                   /* [nw][3][64]                */
-    int* m_idx = (int*)(m_cost + nw * 3 * 64);               /* [nw][3][64]                */
-    float* s_rcp = (float*)(m_idx + nw * 3 * 64);            /* [H+1] RN(1/h)              */
-
-    const int img = colg / P.C;
+    float* s_tile = (float*)smem;             /* [64][D+1] */
+    float* s_rcp = s_tile + IS_TILE * DP;     /* [H+1]     */
     const int tid = threadIdx.x, lane = tid & 63;
+    const int nw = blockDim.x >> 6;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile_lo = tile * IS_TILE;
     const RowRec* rcol = recs + (size_t)colg * (H + 1);
     const float* lcol = lutT + (size_t)colg * (H + 1) * D;
-    const PriorRec* pcol = priors + (size_t)img * H;
+    const PriorRec* pcol = priors + (size_t)(colg / P.C) * H;
+    const PredRec* dcol = pred + (size_t)colg * H;
+
+    for (int i = tid; i < IS_TILE * D; i += blockDim.x) {
+        const int r = i / D, f = i - r * D;
+        const int v = min(tile_lo + 1 + r, H);
+        s_tile[r * DP + f] = lcol[(size_t)v * D + f];
+    }
     for (int i = tid; i <= H; i += blockDim.x) s_rcp[i] = rcp[i];
+    const int vT = tile_lo + lane;
+    const int vTc = min(vT, H - 1);
+    const RowRec my = load_rec(rcol + vTc + 1);
+    const float* my_tile = s_tile + lane * DP;
+    const bool live = vT < H;
+    __syncthreads();
 
-    for (int tile = 0; tile < P.ntiles; tile++) {
-        const int tile_lo = tile * IS_TILE;
-        __syncthreads(); /* previous tile fully consumed */
-        for (int i = tid; i < IS_TILE * D; i += blockDim.x) {
-            const int r = i / D, f = i - r * D;
-            const int v = min(tile_lo + 1 + r, H);
-            s_tile[r * DP + f] = lcol[(size_t)v * D + f];
+    PairBest b;
+    b.g = b.o = b.s = IS_INF;
+    b.ig = b.is = -1;
+    b.io = IS_OBJECT; /* :592 */
+    for (int vB = w; vB <= tile_lo && vB < H; vB += nw) {
+        const RowRec rb = sload_rec(rcol + vB);
+        const int h = vTc + 1 - vB;
+        const SegTerms t = eval_segment<FAST, HAS_INVALID>(my, rb, (float)h, s_rcp[h], D, P.iw);
+        const float od_hi = my_tile[t.fni];
+        const float od_lo = (lcol + (size_t)vB * D)[(unsigned)t.fni];
+        if (vB == 0) { /* first segment, :481-594 */
+            const bool below = vT <= vhor;
+            if (below) {
+                const float cost = P.dw * t.gd + P.pw * P.first_g + P.sw * t.seg_g;
+                if (live && cost < b.g) { b.g = cost; b.ig = IS_GROUND; }
+            }
+            const float prior = below ? P.first_o_below : P.first_o_above;
+            const float cost = P.dw * (od_hi - od_lo) + P.pw * prior + P.sw * t.seg_o;
+            if (live && cost < b.o) b.o = cost;
+        } else {
+            const PredRec pd = sload_pred(dcol + vB - 1);
+            pairwise_step<HAS_INVALID>(P, my, rb, (cprior_t)(pcol + vB), pd, vB, vhor, h, live, od_hi,
+                                       od_lo, t, b);
         }
-        const int vT = tile_lo + lane;
-        const int vTc = min(vT, H - 1);
-        const RowRec my = load_rec(rcol + vTc + 1);
-        const float* my_tile = s_tile + lane * DP;
-        __syncthreads();
-
-        PairBest b;
-        b.g = b.o = b.s = IS_INF;
-        b.ig = b.is = -1;
-        b.io = IS_OBJECT; /* :592 */
-
-        /* ---- phase 1: segments starting in earlier tiles (their predecessors are final),
-         * vB strided over the waves */
-        for (int vB = w; vB <= tile_lo && vB < H; vB += nw) {
-            const RowRec rb = sload_rec(rcol + vB);
-            const int h = vTc + 1 - vB;
-            const bool live = vT < H;
-            const SegTerms t = eval_segment<FAST, HAS_INVALID>(my, rb, (float)h, s_rcp[h], D, P.iw);
-            const float od_hi = my_tile[t.fni];
-            const float od_lo = lcol[(size_t)vB * D + t.fni];
-            if (vB == 0) { /* first segment, :481-594 */
-                const bool below = vT <= vhor;
-                if (below) {
-                    const float cost = P.dw * t.gd + P.pw * P.first_g + P.sw * t.seg_g;
-                    if (live && cost < b.g) { b.g = cost; b.ig = IS_GROUND; }
-                }
-                const float prior = below ? P.first_o_below : P.first_o_above;
-                const float cost = P.dw * (od_hi - od_lo) + P.pw * prior + P.sw * t.seg_o;
-                if (live && cost < b.o) b.o = cost;
-            } else {
-                const PredRec pd = s_pred[vB - 1];
-                pairwise_step<HAS_INVALID>(P, my, rb, (cprior_t)(pcol + vB), pd, vB, vhor, h, live,
-                                           od_hi, od_lo, t, b);
-            }
+    }
+    /* merge the waves: min cost, ties -> smallest vB (a finite cost always has a real index) */
+    __syncthreads();
+    float* m_cost = (float*)smem;              /* [nw][3][64] (aliases the tile) */
+    int* m_idx = (int*)(m_cost + nw * 3 * 64); /* [nw][3][64] */
+    m_cost[(w * 3 + 0) * 64 + lane] = b.g; m_idx[(w * 3 + 0) * 64 + lane] = b.ig;
+    m_cost[(w * 3 + 1) * 64 + lane] = b.o; m_idx[(w * 3 + 1) * 64 + lane] = b.io;
+    m_cost[(w * 3 + 2) * 64 + lane] = b.s; m_idx[(w * 3 + 2) * 64 + lane] = b.is;
+    __syncthreads();
+    if (tid < 3 * 64) {
+        const int type = tid >> 6;
+        float c = m_cost[(0 * 3 + type) * 64 + lane];
+        int ix = m_idx[(0 * 3 + type) * 64 + lane];
+        for (int ww = 1; ww < nw; ww++) {
+            const float c2 = m_cost[(ww * 3 + type) * 64 + lane];
+            const int ix2 = m_idx[(ww * 3 + type) * 64 + lane];
+            const bool take = (c2 < c) || (c2 == c && c2 < IS_INF && (ix2 / 3) < (ix / 3));
+            if (take) { c = c2; ix = ix2; }
         }
-        m_cost[(w * 3 + 0) * 64 + lane] = b.g; m_idx[(w * 3 + 0) * 64 + lane] = b.ig;
-        m_cost[(w * 3 + 1) * 64 + lane] = b.o; m_idx[(w * 3 + 1) * 64 + lane] = b.io;
-        m_cost[(w * 3 + 2) * 64 + lane] = b.s; m_idx[(w * 3 + 2) * 64 + lane] = b.is;
-        __syncthreads();
-
-        /* ---- phase 2: wave 0 merges (min cost, ties -> smallest vB) and walks the diagonal
-         * block sequentially: step vB needs the final row vB-1 of this same tile */
-        if (w == 0) {
-            for (int type = 0; type < 3; type++) {
-                float c = m_cost[(0 * 3 + type) * 64 + lane];
-                int ix = m_idx[(0 * 3 + type) * 64 + lane];
-                for (int ww = 1; ww < nw; ww++) {
-                    const float c2 = m_cost[(ww * 3 + type) * 64 + lane];
-                    const int ix2 = m_idx[(ww * 3 + type) * 64 + lane];
-                    /* a finite cost always comes with an index whose vB part orders ties */
-                    const bool take = (c2 < c) || (c2 == c && c2 < IS_INF && (ix2 / 3) < (ix / 3));
-                    if (take) { c = c2; ix = ix2; }
-                }
-                if (type == 0) { b.g = c; b.ig = ix; }
-                else if (type == 1) { b.o = c; b.io = ix; }
-                else { b.s = c; b.is = ix; }
-            }
-            const int n_rows = min(IS_TILE, H - tile_lo);
-            for (int s = 0; s < n_rows; s++) {
-                const int r = tile_lo + s; /* row that becomes final now */
-                if (s > 0) {
-                    const int vB = r;
-                    const RowRec rb = sload_rec(rcol + vB);
-                    const int h = vTc + 1 - vB;
-                    const bool live = (vT < H) && (h > 0);
-                    const int hc = max(h, 1);
-                    const SegTerms t = eval_segment<FAST, HAS_INVALID>(my, rb, (float)hc, s_rcp[hc], D, P.iw);
-                    const float od_hi = my_tile[t.fni];
-                    const float od_lo = lcol[(size_t)vB * D + t.fni];
-                    const PredRec pd = s_pred[vB - 1];
-                    pairwise_step<HAS_INVALID>(P, my, rb, (cprior_t)(pcol + vB), pd, vB, vhor, hc, live,
-                                               od_hi, od_lo, t, b);
-                }
-                /* lane s now holds the final values of row r: publish its PredRec */
-                const float cG = __shfl(b.g, s, 64), cO = __shfl(b.o, s, 64), cS = __shfl(b.s, s, 64);
-                const int io = __shfl(b.io, s, 64);
-                if (lane == 0) {
-                    const float pc_next = (r + 1 < H) ? ((cprior_t)(pcol + r + 1))->pc : 0.0f;
-                    s_pred[r] = make_pred<HAS_INVALID>(P, rcol, odr, vhor, r, cG, cO, cS, io / 3, pc_next);
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            }
-            if (vT < H) {
-                const size_t o = ((size_t)colg * H + vT) * 3;
-                cost_table[o + 0] = b.g; cost_table[o + 1] = b.o; cost_table[o + 2] = b.s;
-                index_table[o + 0] = b.ig; index_table[o + 1] = b.io; index_table[o + 2] = b.is;
-            }
-        }
+        part_cost[((size_t)colg * 3 + type) * 64 + lane] = c;
+        part_idx[((size_t)colg * 3 + type) * 64 + lane] = ix;
     }
 }
 
 template <bool HAS_INVALID>
-__global__ __launch_bounds__(512) void k_dp_pairwise(
-    const DevParams P, int ncols, const RowRec* __restrict__ recs, const float* __restrict__ lutT,
-    const PriorRec* __restrict__ priors, const float* __restrict__ odr,
-    const float* __restrict__ rcp, const int* __restrict__ vhor_arr,
-    const int* __restrict__ col_flags, float* __restrict__ cost_table,
-    int32_t* __restrict__ index_table) {
-    extern __shared__ __attribute__((aligned(32))) char smem[];
+__global__ __launch_bounds__(IS_UNARY_WAVES * 64) void k_pw_phase1(
+    const DevParams P, int ncols, int tile, const RowRec* __restrict__ recs,
+    const float* __restrict__ lutT, const PriorRec* __restrict__ priors,
+    const PredRec* __restrict__ pred, const float* __restrict__ rcp,
+    const int* __restrict__ vhor_arr, const int* __restrict__ col_flags,
+    float* __restrict__ part_cost, int* __restrict__ part_idx) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int colg = blockIdx.x;
     if (colg >= ncols) return;
     const int vhor = vhor_arr[colg / P.C];
     if (__builtin_amdgcn_readfirstlane(col_flags[colg]) == 0)
-        pairwise_column<true, HAS_INVALID>(P, smem, colg, recs, lutT, priors, odr, rcp, vhor,
-                                           cost_table, index_table);
+        pw_phase1_body<true, HAS_INVALID>(P, smem, colg, tile, recs, lutT, priors, pred, rcp, vhor,
+                                          part_cost, part_idx);
     else
-        pairwise_column<false, HAS_INVALID>(P, smem, colg, recs, lutT, priors, odr, rcp, vhor,
-                                            cost_table, index_table);
+        pw_phase1_body<false, HAS_INVALID>(P, smem, colg, tile, recs, lutT, priors, pred, rcp, vhor,
+                                           part_cost, part_idx);
+}
+
+__device__ __forceinline__ float readlane_f(float x, int l) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), l));
+}
+
+template <bool FAST, bool HAS_INVALID>
+__device__ __forceinline__ void pw_phase2_body(const DevParams& P, char* smem, int colg, int tile,
+                                               const RowRec* __restrict__ recs,
+                                               const float* __restrict__ lutT,
+                                               const PriorRec* __restrict__ priors,
+                                               const float* __restrict__ odr,
+                                               const float* __restrict__ rcp,
+                                               const float* __restrict__ sv_arr, int vhor,
+                                               const float* __restrict__ part_cost,
+                                               const int* __restrict__ part_idx,
+                                               PredRec* __restrict__ pred,
+                                               float* __restrict__ cost_table,
+                                               int32_t* __restrict__ index_table) {
+    const int H = P.H, D = P.D;
+    const int lane = threadIdx.x;
+    float* s_S = (float*)smem;    /* [H+1] */
+    float* s_V = s_S + (H + 1);   /* [H+1] */
+    const int tile_lo = tile * IS_TILE;
+    const RowRec* rcol = recs + (size_t)colg * (H + 1);
+    const float* lcol = lutT + (size_t)colg * (H + 1) * D;
+    const PriorRec* pcol = priors + (size_t)(colg / P.C) * H;
+    PredRec* dcol = pred + (size_t)colg * H;
+    const float* sv = sv_arr + (size_t)colg * 2 * (H + 1);
+    for (int i = lane; i <= H; i += 64) {
+        s_S[i] = sv[i];
+        if (HAS_INVALID) s_V[i] = sv[H + 1 + i];
+    }
+    const int vT = tile_lo + lane;
+    const int vTc = min(vT, H - 1);
+    const RowRec my = load_rec(rcol + vTc + 1);
+    const float* my_row = lcol + (size_t)(vTc + 1) * D;
+    PairBest b;
+    b.g = part_cost[((size_t)colg * 3 + 0) * 64 + lane]; b.ig = part_idx[((size_t)colg * 3 + 0) * 64 + lane];
+    b.o = part_cost[((size_t)colg * 3 + 1) * 64 + lane]; b.io = part_idx[((size_t)colg * 3 + 1) * 64 + lane];
+    b.s = part_cost[((size_t)colg * 3 + 2) * 64 + lane]; b.is = part_idx[((size_t)colg * 3 + 2) * 64 + lane];
+    __syncthreads();
+
+    PredRec pd;
+    pd.cG = pd.cO = pd.cS = IS_INF; pd.pm = 0.0f; pd.oo_hi = pd.oo_lo = IS_INF; pd.pm_hi = pd.pm_lo = 0.0f;
+    const int n_rows = min(IS_TILE, H - tile_lo);
+    for (int s = 0; s < n_rows; s++) {
+        const int r = tile_lo + s; /* row that becomes final in this step */
+        if (s > 0) {
+            const int vB = r;
+            const RowRec rb = sload_rec(rcol + vB);
+            const int h = vTc + 1 - vB;
+            const bool live = (vT < H) && (h > 0);
+            const int hc = max(h, 1);
+            const SegTerms t = eval_segment<FAST, HAS_INVALID>(my, rb, (float)hc, rcp[hc], D, P.iw);
+            const float od_hi = my_row[(unsigned)t.fni];
+            const float od_lo = (lcol + (size_t)vB * D)[(unsigned)t.fni];
+            pairwise_step<HAS_INVALID>(P, my, rb, (cprior_t)(pcol + vB), pd, vB, vhor, hc, live, od_hi,
+                                       od_lo, t, b);
+        }
+        /* lane s holds the final values of row r: broadcast, derive its PredRec (uniform) */
+        const float cG = readlane_f(b.g, s), cO = readlane_f(b.o, s), cS = readlane_f(b.s, s);
+        const int io = __builtin_amdgcn_readlane(b.io, s);
+        const float pc_next = (r + 1 < H) ? ((cprior_t)(pcol + r + 1))->pc : 0.0f;
+        pd = make_pred<HAS_INVALID>(P, s_S, s_V, odr, vhor, r, cG, cO, cS, io / 3, pc_next);
+        if (lane == 0) dcol[r] = pd;
+    }
+    if (vT < H) {
+        const size_t o = ((size_t)colg * H + vT) * 3;
+        cost_table[o + 0] = b.g; cost_table[o + 1] = b.o; cost_table[o + 2] = b.s;
+        index_table[o + 0] = b.ig; index_table[o + 1] = b.io; index_table[o + 2] = b.is;
+    }
+}
+
+template <bool HAS_INVALID>
+__global__ __launch_bounds__(64) void k_pw_phase2(
+    const DevParams P, int ncols, int tile, const RowRec* __restrict__ recs,
+    const float* __restrict__ lutT, const PriorRec* __restrict__ priors,
+    const float* __restrict__ odr, const float* __restrict__ rcp,
+    const float* __restrict__ sv_arr, const int* __restrict__ vhor_arr,
+    const int* __restrict__ col_flags, const float* __restrict__ part_cost,
+    const int* __restrict__ part_idx, PredRec* __restrict__ pred, float* __restrict__ cost_table,
+    int32_t* __restrict__ index_table) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int colg = blockIdx.x;
+    if (colg >= ncols) return;
+    const int vhor = vhor_arr[colg / P.C];
+    if (__builtin_amdgcn_readfirstlane(col_flags[colg]) == 0)
+        pw_phase2_body<true, HAS_INVALID>(P, smem, colg, tile, recs, lutT, priors, odr, rcp, sv_arr, vhor,
+                                          part_cost, part_idx, pred, cost_table, index_table);
+    else
+        pw_phase2_body<false, HAS_INVALID>(P, smem, colg, tile, recs, lutT, priors, odr, rcp, sv_arr, vhor,
+                                           part_cost, part_idx, pred, cost_table, index_table);
 }
 
 /* ====================================================================================== */
@@ -1172,10 +1253,8 @@ size_t isk_unary_lds_bytes(const DevParams* P) {
     const size_t b = (size_t)8 * 3 * 64 * 8; /* merge area for up to 8 waves */
     return (a > b ? a : b) + 16;
 }
-size_t isk_pairwise_lds_bytes(const DevParams* P, int nwaves) {
-    return sizeof(PredRec) * (size_t)P->H + sizeof(float) * (size_t)IS_TILE * (P->D + 1) +
-           (size_t)nwaves * 3 * 64 * 8 + sizeof(float) * ((size_t)P->H + 1) + 32;
-}
+size_t isk_pairwise_lds_bytes(const DevParams* P, int nwaves) { return isk_unary_lds_bytes(P); }
+size_t isk_phase2_lds_bytes(const DevParams* P) { return sizeof(float) * 2 * ((size_t)P->H + 1) + 16; }
 
 hipError_t isk_launch_join(const float* big, float* joined, int H, int W, int C, int step,
                            int margin, int median, float invalid, int n_images,
@@ -1189,10 +1268,10 @@ hipError_t isk_launch_join(const float* big, float* joined, int H, int W, int C,
 hipError_t isk_launch_prepare(const DevParams* P, int ncols, const float* joined,
                               const int32_t* seg, const float* ground, const int* vhor,
                               const float* cost_T, RowRec* recs, float* lutT,
-                              int* col_flags, hipStream_t stream) {
+                              int* col_flags, float* sv_arr, hipStream_t stream) {
     hipLaunchKernelGGL(k_prepare_columns, dim3(ncols), dim3(PREP_THREADS),
                        isk_prepare_lds_bytes(P), stream, *P, joined, seg, ground, vhor, recs,
-                       col_flags);
+                       col_flags, sv_arr);
     hipLaunchKernelGGL(k_object_lut, dim3(ncols, (P->D + 63) / 64), dim3(64), 0, stream, *P, joined,
                        cost_T, lutT);
     return hipGetLastError();
@@ -1224,17 +1303,29 @@ hipError_t isk_launch_dp_unary(const DevParams* P, int ncols, int nwaves, const 
 
 hipError_t isk_launch_dp_pairwise(const DevParams* P, int ncols, int nwaves, const RowRec* recs,
                                   const float* lutT, const PriorRec* priors, const float* odr,
-                                  const float* rcp, const int* vhor, const int* col_flags,
-                                  float* cost_table, int32_t* index_table, hipStream_t stream) {
-    const size_t lds = isk_pairwise_lds_bytes(P, nwaves);
-    if (P->invalid >= 0)
-        hipLaunchKernelGGL(k_dp_pairwise<true>, dim3(ncols), dim3(nwaves * 64), lds, stream, *P,
-                           ncols, recs, lutT, priors, odr, rcp, vhor, col_flags, cost_table,
-                           index_table);
-    else
-        hipLaunchKernelGGL(k_dp_pairwise<false>, dim3(ncols), dim3(nwaves * 64), lds, stream, *P,
-                           ncols, recs, lutT, priors, odr, rcp, vhor, col_flags, cost_table,
-                           index_table);
+                                  const float* rcp, const float* sv_arr, const int* vhor,
+                                  const int* col_flags, PredRec* pred, float* part_cost,
+                                  int* part_idx, float* cost_table, int32_t* index_table,
+                                  hipStream_t stream) {
+    const size_t lds1 = isk_pairwise_lds_bytes(P, nwaves);
+    const size_t lds2 = isk_phase2_lds_bytes(P);
+    for (int tile = 0; tile < P->ntiles; tile++) {
+        if (P->invalid >= 0) {
+            hipLaunchKernelGGL(k_pw_phase1<true>, dim3(ncols), dim3(nwaves * 64), lds1, stream, *P,
+                               ncols, tile, recs, lutT, priors, pred, rcp, vhor, col_flags, part_cost,
+                               part_idx);
+            hipLaunchKernelGGL(k_pw_phase2<true>, dim3(ncols), dim3(64), lds2, stream, *P, ncols, tile,
+                               recs, lutT, priors, odr, rcp, sv_arr, vhor, col_flags, part_cost,
+                               part_idx, pred, cost_table, index_table);
+        } else {
+            hipLaunchKernelGGL(k_pw_phase1<false>, dim3(ncols), dim3(nwaves * 64), lds1, stream, *P,
+                               ncols, tile, recs, lutT, priors, pred, rcp, vhor, col_flags, part_cost,
+                               part_idx);
+            hipLaunchKernelGGL(k_pw_phase2<false>, dim3(ncols), dim3(64), lds2, stream, *P, ncols, tile,
+                               recs, lutT, priors, odr, rcp, sv_arr, vhor, col_flags, part_cost,
+                               part_idx, pred, cost_table, index_table);
+        }
+    }
     return hipGetLastError();
 }
 
@@ -1266,9 +1357,9 @@ hipError_t isk_set_lds_limits(const DevParams* P, int nwaves_pair) {
     e = hipFuncSetAttribute((const void*)k_dp_unary<false>, hipFuncAttributeMaxDynamicSharedMemorySize, b);
     if (e != hipSuccess) return e;
     const int c = (int)isk_pairwise_lds_bytes(P, nwaves_pair);
-    e = hipFuncSetAttribute((const void*)k_dp_pairwise<true>, hipFuncAttributeMaxDynamicSharedMemorySize, c);
+    e = hipFuncSetAttribute((const void*)k_pw_phase1<true>, hipFuncAttributeMaxDynamicSharedMemorySize, c);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute((const void*)k_dp_pairwise<false>, hipFuncAttributeMaxDynamicSharedMemorySize, c);
+    e = hipFuncSetAttribute((const void*)k_pw_phase1<false>, hipFuncAttributeMaxDynamicSharedMemorySize, c);
     return e;
 }
 
