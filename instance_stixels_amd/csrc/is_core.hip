@@ -24,13 +24,13 @@ size_t isk_pairwise_lds_bytes(const DevParams* P, int nwaves);
 hipError_t isk_launch_join(const float*, float*, int, int, int, int, int, int, float, int, hipStream_t);
 hipError_t isk_launch_prepare(const DevParams*, int, const float*, const int32_t*, const float*,
                               const int*, const float*, RowRec*, float*, int*, float*, hipStream_t);
-struct PredRec;
+struct StepRec;
 hipError_t isk_launch_priors(const DevParams*, const float*, PriorRec*, int, hipStream_t);
 hipError_t isk_launch_dp_unary(const DevParams*, int, int, const RowRec*, const float*, const float*,
                                const int*, const int*, float*, int32_t*, hipStream_t);
 hipError_t isk_launch_dp_pairwise(const DevParams*, int, int, const RowRec*, const float*,
                                   const PriorRec*, const float*, const float*, const float*,
-                                  const int*, const int*, PredRec*, float*, int*, float*, int32_t*,
+                                  const int*, const int*, StepRec*, float*, int*, float*, int32_t*,
                                   hipStream_t);
 hipError_t isk_launch_backtrace(const DevParams*, int, int, const RowRec*, const float*,
                                 const int32_t*, const int*, is_section*, hipStream_t);
@@ -78,7 +78,7 @@ struct is_ctx {
     RowRec* d_recs;          /* [max_batch*C][H+1] */
     float* d_lutT;           /* [max_batch*C][H+1][D] */
     PriorRec* d_priors;      /* [max_batch][H] */
-    PredRec* d_pred;         /* [max_batch*C][H]   finished-row records of the pairwise DP (32 B) */
+    StepRec* d_steps;        /* [max_batch*C][H]   per-vB transition records of the pairwise DP (64 B) */
     float* d_part_cost;      /* [max_batch*C][3][64] merged partial minima of the current tile */
     int* d_part_idx;         /* [max_batch*C][3][64] */
     float* d_sv;             /* [max_batch*C][2][H+1] compact S / V prefixes */
@@ -162,6 +162,8 @@ int is_ctx_create(const is_stixel_params* p, const float* obj_cost_lut,
     d.log2c = is_logf(2.0f);
     d.nlog07 = -is_logf(0.7f);
     d.nlog03 = -is_logf(0.3f);
+    d.nlog_pord = -is_logf(p->pord);
+    d.nlog_1mpord = -is_logf(1.0f - p->pord);
     d.first_g = d.log2c + d.rows_log;                       /* StixelsKernels.cu:196-199 */
     d.first_o_below = d.rows_log + d.log2c + d.max_dis_log; /* :189-194 */
     d.first_o_above = d.rows_log + 0.0f + d.max_dis_log;
@@ -193,7 +195,7 @@ int is_ctx_create(const is_stixel_params* p, const float* obj_cost_lut,
     ALLOC(c->d_recs, sizeof(RowRec) * B * C * (H + 1));
     ALLOC(c->d_lutT, sizeof(float) * B * C * (H + 1) * D);
     ALLOC(c->d_priors, sizeof(PriorRec) * B * H);
-    ALLOC(c->d_pred, (size_t)32 * B * C * H);
+    ALLOC(c->d_steps, (size_t)64 * B * C * H);
     ALLOC(c->d_part_cost, sizeof(float) * B * C * 3 * 64);
     ALLOC(c->d_part_idx, sizeof(int) * B * C * 3 * 64);
     ALLOC(c->d_sv, sizeof(float) * B * C * 2 * (H + 1));
@@ -242,7 +244,7 @@ int is_ctx_destroy(is_ctx* c) {
     hipSetDevice(c->device);
     hipDeviceSynchronize();
     hipFree(c->d_obj_cost_lut); hipFree(c->d_odr); hipFree(c->d_rcp); hipFree(c->d_col_flags); hipFree(c->d_ground);
-    hipFree(c->d_vhor); hipFree(c->d_recs); hipFree(c->d_lutT); hipFree(c->d_priors); hipFree(c->d_pred); hipFree(c->d_part_cost); hipFree(c->d_part_idx); hipFree(c->d_sv);
+    hipFree(c->d_vhor); hipFree(c->d_recs); hipFree(c->d_lutT); hipFree(c->d_priors); hipFree(c->d_steps); hipFree(c->d_part_cost); hipFree(c->d_part_idx); hipFree(c->d_sv);
     hipFree(c->d_cost_table); hipFree(c->d_index_table);
     hipHostFree(c->h_ground_pinned); hipHostFree(c->h_vhor_pinned);
     hipEventDestroy(c->staging_free);
@@ -326,7 +328,7 @@ int is_compute(is_ctx* c, const float* d_joined, const int32_t* d_seg, const flo
     if (pairwise)
         HIP_TRY(isk_launch_dp_pairwise(&P, ncols, c->nwaves_pairwise, c->d_recs, c->d_lutT,
                                        c->d_priors, c->d_odr, c->d_rcp, c->d_sv, c->d_vhor,
-                                       c->d_col_flags, c->d_pred, c->d_part_cost, c->d_part_idx, ct, it,
+                                       c->d_col_flags, c->d_steps, c->d_part_cost, c->d_part_idx, ct, it,
                                        stream));
     else
         HIP_TRY(isk_launch_dp_unary(&P, ncols, c->nwaves_unary, c->d_recs, c->d_lutT, c->d_rcp,

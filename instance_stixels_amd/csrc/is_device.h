@@ -92,6 +92,7 @@ struct DevParams {
     /* pairwise model */
     float rows_log, max_dis_log, epsilon, pgrav, pblg, pord, max_disf;
     float log2c, nlog07, nlog03; /* is_logf(2), -is_logf(0.7), -is_logf(0.3) */
+    float nlog_pord, nlog_1mpord; /* -is_logf(pord), -is_logf(1 - pord) (NegFastLogDiv, :162, :166) */
     float first_g;  /* GetPriorCostGroundFirst  :196-199 */
     float first_o_below, first_o_above; /* GetPriorCostObjectFirst :189-194 */
     int size_filter;

@@ -600,9 +600,13 @@ struct UnaryBest {
     int vg, vo, vs;
 };
 
-/* One (vB, vT) evaluation of the unary model.  DIAG = the segment start may lie above this
- * lane's vT (diagonal 64x64 block of the tile): such lanes are masked. */
-template <bool FAST, bool HAS_INVALID, bool DIAG>
+/* One (vB, vT) evaluation of the unary model.
+ *   SKY   the segment's lower neighbour is at / above the horizon (vB-1 >= vhor, :729): the
+ *         non-object candidate is SKY, otherwise GROUND (:687); wave-uniform, so the caller runs
+ *         separate loops and each loop has ONE accumulator pair live in its body;
+ *   DIAG  the segment start may lie above this lane's vT (diagonal 64x64 block): masked lanes;
+ *   FIRST vB = 0: ground additionally needs vT <= vhor (:542-545). */
+template <bool FAST, bool HAS_INVALID, bool SKY, bool DIAG, bool FIRST>
 __device__ __forceinline__ void unary_step(const DevParams& P, const RowRec& my, const RowRec& rb,
                                            const float* __restrict__ lrow, const float* my_tile,
                                            const float* s_rcp, int vT, int vTc, int vhor, int vB,
@@ -612,52 +616,70 @@ __device__ __forceinline__ void unary_step(const DevParams& P, const RowRec& my,
     const int hc = DIAG ? max(h, 1) : h;
     const float r = s_rcp[hc]; /* RN(1/h) = (float)(1./h) = inverse_height, :485, :608 */
     const SegTerms t = eval_segment<FAST, HAS_INVALID>(my, rb, (float)hc, r, P.D, P.iw);
-#if defined(ABL_NOGATHER)
-    const float od = my_tile[t.fni] - (float)t.fni;
-#elif defined(ABL_NOLDS)
-    const float od = (float)t.fni - lrow[(unsigned)t.fni];
-#else
     const float od = my_tile[t.fni] - lrow[(unsigned)t.fni];
-#endif
     const float pwih = P.pw * r;
     /* cost = dw*data + pw*(1/h) + sw*seg, left to right (:716-719, 762-765, 820-823) */
     const float cost_o = P.dw * od + pwih + P.sw * t.seg_o;
-    if (live && cost_o < b.o) { b.o = cost_o; b.vo = vB; }
-    if (vB == 0 || vB <= vhor) { /* ground: vB-1 < vhor (:687); vB = 0 needs vT <= vhor (:542-545) */
-        const float cost_g = P.dw * t.gd + pwih + P.sw * t.seg_g;
-        const bool ok = live && (vB > 0 || vT <= vhor);
-        if (ok && cost_g < b.g) { b.g = cost_g; b.vg = vB; }
-    } else { /* sky: vB-1 >= vhor (:729) */
+    const bool uo = live && (cost_o < b.o);
+    b.o = uo ? cost_o : b.o;
+    b.vo = uo ? vB : b.vo;
+    if (SKY) {
         const float cost_s = P.dw * t.sd + pwih + P.sw * t.seg_s;
-        if (live && cost_s < b.s) { b.s = cost_s; b.vs = vB; }
+        const bool us = live && (cost_s < b.s);
+        b.s = us ? cost_s : b.s;
+        b.vs = us ? vB : b.vs;
+    } else {
+        const float cost_g = P.dw * t.gd + pwih + P.sw * t.seg_g;
+        const bool ug = (FIRST ? (live && (vT <= vhor)) : live) && (cost_g < b.g);
+        b.g = ug ? cost_g : b.g;
+        b.vg = ug ? vB : b.vg;
     }
 }
 
-/* The wave walks vB = w, w+nw, ... <= vB_end: first the part where every lane of the tile has
- * vT >= vB, then the diagonal block where lanes below vB are masked. */
+template <bool FAST, bool HAS_INVALID, bool SKY, bool DIAG>
+__device__ __forceinline__ int unary_range(const DevParams& P, const RowRec& my,
+                                           const RowRec* __restrict__ rcol,
+                                           const float* __restrict__ lcol, const float* my_tile,
+                                           const float* s_rcp, int vT, int vTc, int vhor, int vB,
+                                           int nw, int bound, bool row_ok, UnaryBest& b) {
+    for (; vB <= bound; vB += nw) {
+        const RowRec cur = sload_rec(rcol + vB);
+        unary_step<FAST, HAS_INVALID, SKY, DIAG, false>(P, my, cur, lcol + (size_t)vB * P.D, my_tile,
+                                                        s_rcp, vT, vTc, vhor, vB, row_ok, b);
+    }
+    return vB;
+}
+
+/* The wave walks vB = w, w+nw, ... <= vB_end in ascending order through (at most) four ranges:
+ * ground/full, ground/diagonal, sky/full, sky/diagonal (ground while vB <= vhor; "full" while
+ * every lane of the tile has vT >= vB, i.e. vB <= tile_lo). */
 template <bool FAST, bool HAS_INVALID>
 __device__ __forceinline__ void unary_loop(const DevParams& P, const RowRec& my,
                                            const RowRec* __restrict__ rcol,
                                            const float* __restrict__ lcol, const float* my_tile,
                                            const float* s_rcp, int vT, int vTc, int vhor, int w,
                                            int nw, int tile_lo, int vB_end, UnaryBest& b) {
-    const int D = P.D;
     const bool row_ok = vT < P.H;
     int vB = w;
-    for (; vB <= tile_lo && vB <= vB_end; vB += nw) {
-#if defined(ABL_SAMEREC)
-        const RowRec cur = sload_rec(rcol + (vB & 7));
-#else
-        const RowRec cur = sload_rec(rcol + vB);
-#endif
-        unary_step<FAST, HAS_INVALID, false>(P, my, cur, lcol + (size_t)vB * D, my_tile, s_rcp, vT,
-                                             vTc, vhor, vB, row_ok, b);
+    if (vB > vB_end) return;
+    if (vB == 0) { /* first segment (:481-594): ground + object, always "full" for tile 0? no: */
+        const RowRec cur = sload_rec(rcol);
+        if (tile_lo == 0)
+            unary_step<FAST, HAS_INVALID, false, true, true>(P, my, cur, lcol, my_tile, s_rcp, vT, vTc,
+                                                             vhor, 0, row_ok, b);
+        else
+            unary_step<FAST, HAS_INVALID, false, false, true>(P, my, cur, lcol, my_tile, s_rcp, vT, vTc,
+                                                              vhor, 0, row_ok, b);
+        vB += nw;
     }
-    for (; vB <= vB_end; vB += nw) {
-        const RowRec cur = sload_rec(rcol + vB);
-        unary_step<FAST, HAS_INVALID, true>(P, my, cur, lcol + (size_t)vB * D, my_tile, s_rcp, vT,
-                                            vTc, vhor, vB, row_ok, b);
-    }
+    vB = unary_range<FAST, HAS_INVALID, false, false>(P, my, rcol, lcol, my_tile, s_rcp, vT, vTc, vhor,
+                                                      vB, nw, min(min(vhor, tile_lo), vB_end), row_ok, b);
+    vB = unary_range<FAST, HAS_INVALID, false, true>(P, my, rcol, lcol, my_tile, s_rcp, vT, vTc, vhor,
+                                                     vB, nw, min(vhor, vB_end), row_ok, b);
+    vB = unary_range<FAST, HAS_INVALID, true, false>(P, my, rcol, lcol, my_tile, s_rcp, vT, vTc, vhor,
+                                                     vB, nw, min(tile_lo, vB_end), row_ok, b);
+    unary_range<FAST, HAS_INVALID, true, true>(P, my, rcol, lcol, my_tile, s_rcp, vT, vTc, vhor, vB, nw,
+                                               vB_end, row_ok, b);
 }
 
 template <bool HAS_INVALID>
@@ -743,36 +765,89 @@ __global__ __launch_bounds__(IS_UNARY_WAVES * 64, IS_UNARY_WAVES) void k_dp_unar
 }
 
 /* ====================================================================================== */
-/* A7-A9  pairwise DP: one workgroup per column walks the tiles bottom-up                  */
+/* A7-A9  pairwise DP                                                                      */
 /* ====================================================================================== */
-/* Per finished row r (= vB-1 of later segments): final costs and the object-chain terms that
- * depend on the DP state (previous_mean of the best OBJECT segment ending at r). */
-struct __attribute__((aligned(32))) PredRec {
-    float cG, cO, cS;  /* cost_table[r*3 + {G,O,S}]                                        */
-    float pm;          /* previous_mean, clamped >= 0 (:675-685)                           */
-    float oo_hi;       /* GetPriorCostObjectFromObject, fn > pm + dif (:159-162)           */
-    float oo_lo;       /*                                fn < pm - dif (:163-166)          */
-    float pm_hi, pm_lo; /* pm + dif, pm - dif                                               */
+/* Everything of a transition INTO a segment starting at vB that does not depend on the lane:
+ * the final costs of row vB-1 combined with the transition priors (StixelsKernels.cu:88-199,
+ * 687-837).  Built once, when row vB-1 becomes final, from the row's costs, the winning
+ * object chain (previous_mean) and the frame's PriorRec; read by every later segment through
+ * scalar loads.  64 bytes. */
+struct __attribute__((aligned(64))) StepRec {
+    float pwmp;      /* pw * fminf(p1, p2) of the ground (vB-1 < vhor) or sky transition       */
+    int idx_gs;      /* vB*3 + (p1 < p2 ? GROUND : OBJECT)                    :723-727, 769-773 */
+    float g_hi_thr, g_lo_thr;   /* g_prev + epsilon, g_prev - epsilon                 :132, 136 */
+    float p1_hi, p1_lo, p1_mid; /* cG + pw * GetPriorCostObjectFromGround, three cases :120-144 */
+    float o_hi_thr, o_lo_thr;   /* pm + dif, pm - dif                                 :159, 163 */
+    float p2_hi, p2_lo, p2_mid; /* cO + pw * GetPriorCostObjectFromObject, three cases :146-171 */
+    float p3_yes, p3_no;        /* cS + pw * GetPriorCostObjectFromSky, fn > eps or not :173-183 */
+    float pad0, pad1;
+};
+static_assert(sizeof(StepRec) == 64, "StepRec must be 64 bytes");
+typedef const __attribute__((address_space(4))) StepRec* cstep_t;
+
+struct StepVals { /* register copy of a StepRec, always passed by value */
+    float pwmp;
+    int idx_gs;
+    float g_hi_thr, g_lo_thr, p1_hi, p1_lo, p1_mid, o_hi_thr, o_lo_thr, p2_hi, p2_lo, p2_mid, p3_yes,
+        p3_no;
 };
 
-typedef const __attribute__((address_space(4))) PredRec* cpred_t;
+__device__ __forceinline__ void store_step(StepRec* dst, const StepVals v) {
+    float4* d = reinterpret_cast<float4*>(dst);
+    d[0] = make_float4(v.pwmp, __builtin_bit_cast(float, v.idx_gs), v.g_hi_thr, v.g_lo_thr);
+    d[1] = make_float4(v.p1_hi, v.p1_lo, v.p1_mid, v.o_hi_thr);
+    d[2] = make_float4(v.o_lo_thr, v.p2_hi, v.p2_lo, v.p2_mid);
+    d[3] = make_float4(v.p3_yes, v.p3_no, 0.0f, 0.0f);
+}
 
-__device__ __forceinline__ PredRec sload_pred(const PredRec* p) {
-    cpred_t q = (cpred_t)p;
-    PredRec r;
-    r.cG = q->cG; r.cO = q->cO; r.cS = q->cS; r.pm = q->pm;
-    r.oo_hi = q->oo_hi; r.oo_lo = q->oo_lo; r.pm_hi = q->pm_hi; r.pm_lo = q->pm_lo;
+/* A scalar-loaded value made opaque to the optimiser: without this, LLVM rewrites the selects
+ * between neighbouring record fields (p1_hi / p1_lo / p1_mid ...) into a per-lane indexed load
+ * from a scratch copy of the record. */
+__device__ __forceinline__ float opaque_s(float x) {
+    asm volatile("" : "+s"(x));
+    return x;
+}
+
+__device__ __forceinline__ StepVals sload_step(const StepRec* p) {
+    cstep_t q = (cstep_t)p;
+    StepVals r;
+    r.pwmp = q->pwmp; r.idx_gs = q->idx_gs;
+    r.g_hi_thr = q->g_hi_thr; r.g_lo_thr = q->g_lo_thr;
+    r.p1_hi = opaque_s(q->p1_hi); r.p1_lo = opaque_s(q->p1_lo); r.p1_mid = opaque_s(q->p1_mid);
+    r.o_hi_thr = q->o_hi_thr; r.o_lo_thr = q->o_lo_thr;
+    r.p2_hi = opaque_s(q->p2_hi); r.p2_lo = opaque_s(q->p2_lo); r.p2_mid = opaque_s(q->p2_mid);
+    r.p3_yes = opaque_s(q->p3_yes); r.p3_no = opaque_s(q->p3_no);
     return r;
 }
 
-/* Builds the PredRec of finished row r from its final costs and winning object start.
- * s_S / s_V: the column's disparity / valid-count prefixes (Blelloch association) in LDS. */
+__device__ __forceinline__ float readlane_f(float x, int l) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), l));
+}
+
+/* -is_logf(v) + is_logf(v2) (NegFastLogDiv, :35-38) for TWO argument pairs at once: the lower
+ * half of the wave evaluates pair A, the upper half pair B, so the serial chain pays for one
+ * logarithm instead of two.  v is a compile-time-like constant whose log is passed in. */
+__device__ __forceinline__ void neg_fastlog_div2(float neg_log_va, float v2a, float neg_log_vb,
+                                                 float v2b, const double* s_invc,
+                                                 const double* s_logc, float* outa, float* outb) {
+    const bool upper = threadIdx.x >= 32;
+    const float arg = upper ? v2b : v2a;
+    const float l = is_logf_t(arg, s_invc, s_logc);
+    const float la = readlane_f(l, 0), lb = readlane_f(l, 32);
+    *outa = neg_log_va + la;
+    *outb = neg_log_vb + lb;
+}
+
+/* StepRec of vB = r + 1 from the final row r.  All inputs are wave-uniform; every lane computes
+ * the same values.  s_S / s_V: the column's disparity / valid-count prefixes in LDS. */
 template <bool HAS_INVALID>
-__device__ __forceinline__ PredRec make_pred(const DevParams& P, const float* s_S, const float* s_V,
-                                             const float* __restrict__ odr, int vhor, int r,
-                                             float cG, float cO, float cS, int obj_vB, float pc_next) {
-    PredRec p;
-    p.cG = cG; p.cO = cO; p.cS = cS;
+__device__ __forceinline__ StepVals make_step(const DevParams& P, const float* s_S, const float* s_V,
+                                             const float* s_odr, const double* s_invc,
+                                             const double* s_logc, cprior_t pr, int vhor, int r,
+                                             float cG, float cO, float cS, int obj_vB) {
+    const int vB = r + 1;
+    const float pw = P.pw;
+    StepVals st;
     /* previous_mean = ComputeMean(previous_object_vB, previous_vT), :47-60, :675-685 */
     float pm;
     if (HAS_INVALID) {
@@ -782,19 +857,46 @@ __device__ __forceinline__ PredRec make_pred(const DevParams& P, const float* s_
         pm = (s_S[r + 1] - s_S[obj_vB]) / (float)(r + 1 - obj_vB);
     }
     if (pm < 0) pm = 0;
-    p.pm = pm;
-    /* GetPriorCostObjectFromObject(vB = r+1, ...), :146-171 */
+    const float pc = pr->pc;
+
+    if (r < vhor) { /* ground, :687-728 */
+        const float prev_cost = pr->g_from;
+        const float p1 = cG + pw * prev_cost;
+        const float p2 = cO + pw * prev_cost;
+        st.pwmp = pw * __builtin_fminf(p1, p2);
+        st.idx_gs = vB * 3 + ((p1 < p2) ? IS_GROUND : IS_OBJECT);
+    } else { /* sky, :729-775 */
+        const float p1 = cG + pw * pr->s_from_g;
+        const float so = (pm < P.epsilon) ? IS_INF : (P.log2c + pc); /* :88-96 */
+        const float p2 = cO + pw * so;
+        st.pwmp = pw * __builtin_fminf(p1, p2);
+        st.idx_gs = vB * 3 + ((p1 < p2) ? IS_GROUND : IS_OBJECT);
+    }
+    /* object from ground, :120-144 */
+    st.g_hi_thr = pr->g_prev + P.epsilon;
+    st.g_lo_thr = pr->g_prev - P.epsilon;
+    st.p1_hi = cG + pw * pr->og_hi;
+    st.p1_lo = cG + pw * pr->og_lo;
+    st.p1_mid = cG + pw * pr->og_mid;
+    /* object from object, :146-171 */
     float base = (r < vhor) ? P.nlog07 : P.log2c;
-    base += pc_next;
+    base += pc;
     int k = (int)pm;
     k = min(max(k, 0), P.D - 1);
-    float dif = odr[k];
+    float dif = s_odr[k];
     if (dif < 0.0f) dif = 0.0f;
-    p.pm_hi = pm + dif;
-    p.pm_lo = pm - dif;
-    p.oo_hi = base + neg_fastlog_div(P.pord, P.max_disf - pm - dif);
-    p.oo_lo = base + neg_fastlog_div(1.0f - P.pord, p.pm_lo);
-    return p;
+    st.o_hi_thr = pm + dif;
+    st.o_lo_thr = pm - dif;
+    float nl_hi, nl_lo;
+    neg_fastlog_div2(P.nlog_pord, P.max_disf - pm - dif, P.nlog_1mpord, st.o_lo_thr, s_invc, s_logc,
+                     &nl_hi, &nl_lo);
+    st.p2_hi = cO + pw * (base + nl_hi);
+    st.p2_lo = cO + pw * (base + nl_lo);
+    st.p2_mid = cO + pw * IS_INF;
+    /* object from sky, :173-183 */
+    st.p3_yes = cS + pw * pr->o_from_s;
+    st.p3_no = cS + pw * IS_INF;
+    return st;
 }
 
 struct PairBest {
@@ -802,69 +904,48 @@ struct PairBest {
     int ig, io, is; /* vB*3 + prev type */
 };
 
-/* One (vB >= 1, vT) evaluation of the pairwise model for the lane owning vT. */
-template <bool HAS_INVALID>
-__device__ __forceinline__ void pairwise_step(const DevParams& P, const RowRec& my,
-                                              const RowRec& rb, cprior_t pr, const PredRec& pd, int vB, int vhor,
-                                              int h, bool live, float od_hi, float od_lo_base,
-                                              const SegTerms& t, PairBest& b) {
-    const float pw = P.pw;
-    if (vB - 1 < vhor) { /* ground, :687-728 */
-        const float prev_cost = pr->g_from;
-        const float p1 = pd.cG + pw * prev_cost;
-        const float p2 = pd.cO + pw * prev_cost;
-        const float mp = __builtin_fminf(p1, p2);
-        const float cost = P.dw * t.gd + pw * mp + P.sw * t.seg_g;
-        if (live && cost < b.g) {
-            b.g = cost;
-            b.ig = vB * 3 + ((p1 < p2) ? IS_GROUND : IS_OBJECT);
-        }
-    } else { /* sky, :729-775 */
-        const float p1 = pd.cG + pw * pr->s_from_g;
-        const float so = (pd.pm < P.epsilon) ? IS_INF : (P.log2c + pr->pc); /* :88-96 */
-        const float p2 = pd.cO + pw * so;
-        const float mp = __builtin_fminf(p1, p2);
-        const float cost = P.dw * t.sd + pw * mp + P.sw * t.seg_s;
-        if (live && cost < b.s) {
-            b.s = cost;
-            b.is = vB * 3 + ((p1 < p2) ? IS_GROUND : IS_OBJECT);
-        }
+/* One (vB >= 1, vT) evaluation of the pairwise model for the lane owning vT; `st` is the
+ * wave-uniform StepRec of vB.  SKY: vB-1 >= vhor (:729), else ground (:687). */
+template <bool SKY>
+__device__ __forceinline__ void pairwise_step(const DevParams& P, const StepVals st, int vB,
+                                              bool live, float od, const SegTerms& t, PairBest& b) {
+    if (SKY) { /* :729-775 */
+        const float cost = P.dw * t.sd + st.pwmp + P.sw * t.seg_s;
+        const bool u = live && (cost < b.s);
+        b.s = u ? cost : b.s;
+        b.is = u ? st.idx_gs : b.is;
+    } else { /* :687-728 */
+        const float cost = P.dw * t.gd + st.pwmp + P.sw * t.seg_g;
+        const bool u = live && (cost < b.g);
+        b.g = u ? cost : b.g;
+        b.ig = u ? st.idx_gs : b.ig;
     }
     /* object, :777-837 */
     const float fn = t.mean;
-    float og; /* GetPriorCostObjectFromGround, :120-144 */
-    if (fn > (pr->g_prev + P.epsilon)) og = pr->og_hi;
-    else if (fn < (pr->g_prev - P.epsilon)) og = pr->og_lo;
-    else og = pr->og_mid;
-    float oo; /* GetPriorCostObjectFromObject, :146-171 */
-    if (fn > pd.pm_hi) oo = pd.oo_hi;
-    else if (fn < pd.pm_lo) oo = pd.oo_lo;
-    else oo = IS_INF;
-    const float os = (fn > P.epsilon) ? pr->o_from_s : IS_INF; /* :173-183 */
-    const float p1 = pd.cG + pw * og;
-    const float p2 = pd.cO + pw * oo;
-    const float p3 = pd.cS + pw * os;
-    const float mp = __builtin_fminf(__builtin_fminf(p1, p2), p3);
-    const float od = od_hi - od_lo_base;
-    const float cost = P.dw * od + pw * mp + P.sw * t.seg_o;
-    if (live && cost < b.o) {
-        b.o = cost;
-        int min_prev = IS_OBJECT;
-        if (p1 < p2) min_prev = IS_GROUND;
-        if (p3 < __builtin_fminf(p1, p2)) min_prev = IS_SKY;
-        b.io = vB * 3 + min_prev;
-    }
+    const float p1 = (fn > st.g_hi_thr) ? st.p1_hi : ((fn < st.g_lo_thr) ? st.p1_lo : st.p1_mid);
+    const float p2 = (fn > st.o_hi_thr) ? st.p2_hi : ((fn < st.o_lo_thr) ? st.p2_lo : st.p2_mid);
+    const float p3 = (fn > P.epsilon) ? st.p3_yes : st.p3_no;
+    const float m12 = __builtin_fminf(p1, p2);
+    const float mp = __builtin_fminf(m12, p3);
+    const float cost = P.dw * od + P.pw * mp + P.sw * t.seg_o;
+    /* min_prev: OBJECT (1), GROUND (0) if p1 < p2, SKY (2) if p3 < fminf(p1, p2), :828-835 */
+    const int base_o = vB * 3 + IS_OBJECT;
+    int idx = (p1 < p2) ? (base_o - 1) : base_o;
+    idx = (p3 < m12) ? (base_o + 1) : idx;
+    const bool u = live && (cost < b.o);
+    b.o = u ? cost : b.o;
+    b.io = u ? idx : b.io;
 }
 
 /* The pairwise DP of one 64-row tile is split over two launches (per tile, bottom-up):
  *
  *  phase 1  k_pw_phase1: segments that START in earlier tiles (vB <= tile_lo).  Their
- *           predecessor rows are final (PredRec written by earlier launches, read with scalar
+ *           predecessor rows are final (StepRec written by earlier launches, read with scalar
  *           loads), so all (vB, vT) pairs are independent: same structure, occupancy and issue
  *           bound as the unary kernel.  Writes the merged partial minima of the tile.
  *  phase 2  k_pw_phase2: the 64x64 diagonal block, where step vB needs the final row vB-1 of
  *           the same tile: one wavefront per column walks the 63 steps; the finished row is
- *           broadcast with v_readlane, its PredRec is computed uniformly and published.
+ *           broadcast with v_readlane, its StepRec is computed uniformly and published.
  *
  * The serial chain of the reference (rows x __syncthreads, StixelsKernels.cu:600-603) is thus
  * confined to phase 2, 1/16 of the pair evaluations at 1024 rows. */
@@ -872,8 +953,7 @@ template <bool FAST, bool HAS_INVALID>
 __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, int colg, int tile,
                                                const RowRec* __restrict__ recs,
                                                const float* __restrict__ lutT,
-                                               const PriorRec* __restrict__ priors,
-                                               const PredRec* __restrict__ pred,
+                                               const StepRec* __restrict__ steps,
                                                const float* __restrict__ rcp, int vhor,
                                                float* __restrict__ part_cost,
                                                int* __restrict__ part_idx) {
@@ -887,8 +967,7 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
     const int tile_lo = tile * IS_TILE;
     const RowRec* rcol = recs + (size_t)colg * (H + 1);
     const float* lcol = lutT + (size_t)colg * (H + 1) * D;
-    const PriorRec* pcol = priors + (size_t)(colg / P.C) * H;
-    const PredRec* dcol = pred + (size_t)colg * H;
+    const StepRec* scol = steps + (size_t)colg * H;
 
     for (int i = tid; i < IS_TILE * D; i += blockDim.x) {
         const int r = i / D, f = i - r * D;
@@ -907,26 +986,38 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
     b.g = b.o = b.s = IS_INF;
     b.ig = b.is = -1;
     b.io = IS_OBJECT; /* :592 */
-    for (int vB = w; vB <= tile_lo && vB < H; vB += nw) {
+    const int vB_last = min(tile_lo, H - 1);
+    int vB = w;
+    if (vB == 0) { /* first segment, :481-594 */
+        const RowRec rb = sload_rec(rcol);
+        const int h = vTc + 1;
+        const SegTerms t = eval_segment<FAST, HAS_INVALID>(my, rb, (float)h, s_rcp[h], D, P.iw);
+        const float od = my_tile[t.fni] - lcol[(unsigned)t.fni];
+        const bool below = vT <= vhor;
+        const float cost_g = P.dw * t.gd + P.pw * P.first_g + P.sw * t.seg_g;
+        const bool ug = live && below && (cost_g < b.g);
+        b.g = ug ? cost_g : b.g;
+        b.ig = ug ? IS_GROUND : b.ig;
+        const float prior = below ? P.first_o_below : P.first_o_above;
+        const float cost = P.dw * od + P.pw * prior + P.sw * t.seg_o;
+        b.o = (live && cost < b.o) ? cost : b.o;
+        vB += nw;
+    }
+    for (; vB <= min(vhor, vB_last); vB += nw) { /* ground range: vB-1 < vhor */
         const RowRec rb = sload_rec(rcol + vB);
+        const StepVals st = sload_step(scol + vB);
         const int h = vTc + 1 - vB;
         const SegTerms t = eval_segment<FAST, HAS_INVALID>(my, rb, (float)h, s_rcp[h], D, P.iw);
-        const float od_hi = my_tile[t.fni];
-        const float od_lo = (lcol + (size_t)vB * D)[(unsigned)t.fni];
-        if (vB == 0) { /* first segment, :481-594 */
-            const bool below = vT <= vhor;
-            if (below) {
-                const float cost = P.dw * t.gd + P.pw * P.first_g + P.sw * t.seg_g;
-                if (live && cost < b.g) { b.g = cost; b.ig = IS_GROUND; }
-            }
-            const float prior = below ? P.first_o_below : P.first_o_above;
-            const float cost = P.dw * (od_hi - od_lo) + P.pw * prior + P.sw * t.seg_o;
-            if (live && cost < b.o) b.o = cost;
-        } else {
-            const PredRec pd = sload_pred(dcol + vB - 1);
-            pairwise_step<HAS_INVALID>(P, my, rb, (cprior_t)(pcol + vB), pd, vB, vhor, h, live, od_hi,
-                                       od_lo, t, b);
-        }
+        const float od = my_tile[t.fni] - (lcol + (size_t)vB * D)[(unsigned)t.fni];
+        pairwise_step<false>(P, st, vB, live, od, t, b);
+    }
+    for (; vB <= vB_last; vB += nw) { /* sky range */
+        const RowRec rb = sload_rec(rcol + vB);
+        const StepVals st = sload_step(scol + vB);
+        const int h = vTc + 1 - vB;
+        const SegTerms t = eval_segment<FAST, HAS_INVALID>(my, rb, (float)h, s_rcp[h], D, P.iw);
+        const float od = my_tile[t.fni] - (lcol + (size_t)vB * D)[(unsigned)t.fni];
+        pairwise_step<true>(P, st, vB, live, od, t, b);
     }
     /* merge the waves: min cost, ties -> smallest vB (a finite cost always has a real index) */
     __syncthreads();
@@ -952,26 +1043,52 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
 }
 
 template <bool HAS_INVALID>
-__global__ __launch_bounds__(IS_UNARY_WAVES * 64) void k_pw_phase1(
+__global__ __launch_bounds__(IS_UNARY_WAVES * 64, IS_UNARY_WAVES) void k_pw_phase1(
     const DevParams P, int ncols, int tile, const RowRec* __restrict__ recs,
-    const float* __restrict__ lutT, const PriorRec* __restrict__ priors,
-    const PredRec* __restrict__ pred, const float* __restrict__ rcp,
-    const int* __restrict__ vhor_arr, const int* __restrict__ col_flags,
-    float* __restrict__ part_cost, int* __restrict__ part_idx) {
+    const float* __restrict__ lutT, const StepRec* __restrict__ steps,
+    const float* __restrict__ rcp, const int* __restrict__ vhor_arr,
+    const int* __restrict__ col_flags, float* __restrict__ part_cost, int* __restrict__ part_idx) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int colg = blockIdx.x;
     if (colg >= ncols) return;
     const int vhor = vhor_arr[colg / P.C];
     if (__builtin_amdgcn_readfirstlane(col_flags[colg]) == 0)
-        pw_phase1_body<true, HAS_INVALID>(P, smem, colg, tile, recs, lutT, priors, pred, rcp, vhor,
-                                          part_cost, part_idx);
+        pw_phase1_body<true, HAS_INVALID>(P, smem, colg, tile, recs, lutT, steps, rcp, vhor, part_cost,
+                                          part_idx);
     else
-        pw_phase1_body<false, HAS_INVALID>(P, smem, colg, tile, recs, lutT, priors, pred, rcp, vhor,
-                                           part_cost, part_idx);
+        pw_phase1_body<false, HAS_INVALID>(P, smem, colg, tile, recs, lutT, steps, rcp, vhor, part_cost,
+                                           part_idx);
 }
 
-__device__ __forceinline__ float readlane_f(float x, int l) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), l));
+/* wave-uniform copy of lane `l`'s record (the record at vB = tile_lo + s IS lane s-1's vT+1
+ * record, so the diagonal walk needs no memory access for its vB side) */
+__device__ __forceinline__ RowRec bcast_rec(const RowRec& my, int l) {
+    RowRec r;
+    const int* src = reinterpret_cast<const int*>(&my);
+    int* dst = reinterpret_cast<int*>(&r);
+#pragma unroll
+    for (int i = 0; i < 32; i++) dst[i] = __builtin_amdgcn_readlane(src[i], l);
+    return r;
+}
+
+struct DiagPre { /* lane-dependent, DP-state independent part of one diagonal step */
+    SegTerms t;
+    float od_hi, od_lo;
+};
+
+template <bool FAST, bool HAS_INVALID>
+__device__ __forceinline__ DiagPre diag_prefetch(const DevParams& P, const RowRec& my, int s,
+                                                 int vTc, int tile_lo, const float* __restrict__ rcp,
+                                                 const float* __restrict__ my_row,
+                                                 const float* __restrict__ lcol) {
+    DiagPre d;
+    const int vB = tile_lo + s;
+    const RowRec rb = bcast_rec(my, s - 1);
+    const int hc = max(vTc + 1 - vB, 1);
+    d.t = eval_segment<FAST, HAS_INVALID>(my, rb, (float)hc, rcp[hc], P.D, P.iw);
+    d.od_hi = my_row[(unsigned)d.t.fni];
+    d.od_lo = (lcol + (size_t)vB * P.D)[(unsigned)d.t.fni];
+    return d;
 }
 
 template <bool FAST, bool HAS_INVALID>
@@ -984,23 +1101,28 @@ __device__ __forceinline__ void pw_phase2_body(const DevParams& P, char* smem, i
                                                const float* __restrict__ sv_arr, int vhor,
                                                const float* __restrict__ part_cost,
                                                const int* __restrict__ part_idx,
-                                               PredRec* __restrict__ pred,
+                                               StepRec* __restrict__ steps,
                                                float* __restrict__ cost_table,
                                                int32_t* __restrict__ index_table) {
     const int H = P.H, D = P.D;
     const int lane = threadIdx.x;
-    float* s_S = (float*)smem;    /* [H+1] */
-    float* s_V = s_S + (H + 1);   /* [H+1] */
+    double* s_invc = (double*)smem;                    /* [32] */
+    double* s_logc = s_invc + IS_LOG_TABLE_SIZE;       /* [32] */
+    float* s_S = (float*)(s_logc + IS_LOG_TABLE_SIZE); /* [H+1] */
+    float* s_V = s_S + (H + 1);                        /* [H+1] */
+    float* s_odr = s_V + (H + 1);                      /* [D]   */
     const int tile_lo = tile * IS_TILE;
     const RowRec* rcol = recs + (size_t)colg * (H + 1);
     const float* lcol = lutT + (size_t)colg * (H + 1) * D;
     const PriorRec* pcol = priors + (size_t)(colg / P.C) * H;
-    PredRec* dcol = pred + (size_t)colg * H;
+    StepRec* scol = steps + (size_t)colg * H;
     const float* sv = sv_arr + (size_t)colg * 2 * (H + 1);
+    if (lane == 0) is_log_tables(s_invc, s_logc);
     for (int i = lane; i <= H; i += 64) {
         s_S[i] = sv[i];
         if (HAS_INVALID) s_V[i] = sv[H + 1 + i];
     }
+    for (int i = lane; i < D; i += 64) s_odr[i] = odr[i];
     const int vT = tile_lo + lane;
     const int vTc = min(vT, H - 1);
     const RowRec my = load_rec(rcol + vTc + 1);
@@ -1011,29 +1133,35 @@ __device__ __forceinline__ void pw_phase2_body(const DevParams& P, char* smem, i
     b.s = part_cost[((size_t)colg * 3 + 2) * 64 + lane]; b.is = part_idx[((size_t)colg * 3 + 2) * 64 + lane];
     __syncthreads();
 
-    PredRec pd;
-    pd.cG = pd.cO = pd.cS = IS_INF; pd.pm = 0.0f; pd.oo_hi = pd.oo_lo = IS_INF; pd.pm_hi = pd.pm_lo = 0.0f;
     const int n_rows = min(IS_TILE, H - tile_lo);
+    StepVals st;
+    st.pwmp = IS_INF; st.idx_gs = -1;
+    st.g_hi_thr = st.g_lo_thr = st.p1_hi = st.p1_lo = st.p1_mid = st.o_hi_thr = st.o_lo_thr = 0.0f;
+    st.p2_hi = st.p2_lo = st.p2_mid = st.p3_yes = st.p3_no = 0.0f;
+    DiagPre cur;
+    if (n_rows > 1) cur = diag_prefetch<FAST, HAS_INVALID>(P, my, 1, vTc, tile_lo, rcp, my_row, lcol);
     for (int s = 0; s < n_rows; s++) {
         const int r = tile_lo + s; /* row that becomes final in this step */
+        /* independent of the DP state: everything of the NEXT step that is lane-dependent */
+        DiagPre nxt = cur;
+        if (s >= 1 && s + 1 < n_rows)
+            nxt = diag_prefetch<FAST, HAS_INVALID>(P, my, s + 1, vTc, tile_lo, rcp, my_row, lcol);
         if (s > 0) {
-            const int vB = r;
-            const RowRec rb = sload_rec(rcol + vB);
-            const int h = vTc + 1 - vB;
-            const bool live = (vT < H) && (h > 0);
-            const int hc = max(h, 1);
-            const SegTerms t = eval_segment<FAST, HAS_INVALID>(my, rb, (float)hc, rcp[hc], D, P.iw);
-            const float od_hi = my_row[(unsigned)t.fni];
-            const float od_lo = (lcol + (size_t)vB * D)[(unsigned)t.fni];
-            pairwise_step<HAS_INVALID>(P, my, rb, (cprior_t)(pcol + vB), pd, vB, vhor, hc, live, od_hi,
-                                       od_lo, t, b);
+            const bool live = (vT < H) && (vT >= r);
+            if (r - 1 < vhor)
+                pairwise_step<false>(P, st, r, live, cur.od_hi - cur.od_lo, cur.t, b);
+            else
+                pairwise_step<true>(P, st, r, live, cur.od_hi - cur.od_lo, cur.t, b);
+            cur = nxt;
         }
-        /* lane s holds the final values of row r: broadcast, derive its PredRec (uniform) */
-        const float cG = readlane_f(b.g, s), cO = readlane_f(b.o, s), cS = readlane_f(b.s, s);
-        const int io = __builtin_amdgcn_readlane(b.io, s);
-        const float pc_next = (r + 1 < H) ? ((cprior_t)(pcol + r + 1))->pc : 0.0f;
-        pd = make_pred<HAS_INVALID>(P, s_S, s_V, odr, vhor, r, cG, cO, cS, io / 3, pc_next);
-        if (lane == 0) dcol[r] = pd;
+        /* lane s holds the final values of row r: broadcast, derive the StepRec of vB = r+1 */
+        if (r + 1 < H) {
+            const float cG = readlane_f(b.g, s), cO = readlane_f(b.o, s), cS = readlane_f(b.s, s);
+            const int io = __builtin_amdgcn_readlane(b.io, s);
+            st = make_step<HAS_INVALID>(P, s_S, s_V, s_odr, s_invc, s_logc, (cprior_t)(pcol + r + 1), vhor,
+                                        r, cG, cO, cS, io / 3);
+            if (lane == 0) store_step(scol + r + 1, st);
+        }
     }
     if (vT < H) {
         const size_t o = ((size_t)colg * H + vT) * 3;
@@ -1049,7 +1177,7 @@ __global__ __launch_bounds__(64) void k_pw_phase2(
     const float* __restrict__ odr, const float* __restrict__ rcp,
     const float* __restrict__ sv_arr, const int* __restrict__ vhor_arr,
     const int* __restrict__ col_flags, const float* __restrict__ part_cost,
-    const int* __restrict__ part_idx, PredRec* __restrict__ pred, float* __restrict__ cost_table,
+    const int* __restrict__ part_idx, StepRec* __restrict__ steps, float* __restrict__ cost_table,
     int32_t* __restrict__ index_table) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int colg = blockIdx.x;
@@ -1057,10 +1185,10 @@ __global__ __launch_bounds__(64) void k_pw_phase2(
     const int vhor = vhor_arr[colg / P.C];
     if (__builtin_amdgcn_readfirstlane(col_flags[colg]) == 0)
         pw_phase2_body<true, HAS_INVALID>(P, smem, colg, tile, recs, lutT, priors, odr, rcp, sv_arr, vhor,
-                                          part_cost, part_idx, pred, cost_table, index_table);
+                                          part_cost, part_idx, steps, cost_table, index_table);
     else
         pw_phase2_body<false, HAS_INVALID>(P, smem, colg, tile, recs, lutT, priors, odr, rcp, sv_arr, vhor,
-                                           part_cost, part_idx, pred, cost_table, index_table);
+                                           part_cost, part_idx, steps, cost_table, index_table);
 }
 
 /* ====================================================================================== */
@@ -1254,7 +1382,9 @@ size_t isk_unary_lds_bytes(const DevParams* P) {
     return (a > b ? a : b) + 16;
 }
 size_t isk_pairwise_lds_bytes(const DevParams* P, int nwaves) { return isk_unary_lds_bytes(P); }
-size_t isk_phase2_lds_bytes(const DevParams* P) { return sizeof(float) * 2 * ((size_t)P->H + 1) + 16; }
+size_t isk_phase2_lds_bytes(const DevParams* P) {
+    return sizeof(double) * 2 * IS_LOG_TABLE_SIZE + sizeof(float) * (2 * ((size_t)P->H + 1) + P->D) + 16;
+}
 
 hipError_t isk_launch_join(const float* big, float* joined, int H, int W, int C, int step,
                            int margin, int median, float invalid, int n_images,
@@ -1304,7 +1434,7 @@ hipError_t isk_launch_dp_unary(const DevParams* P, int ncols, int nwaves, const 
 hipError_t isk_launch_dp_pairwise(const DevParams* P, int ncols, int nwaves, const RowRec* recs,
                                   const float* lutT, const PriorRec* priors, const float* odr,
                                   const float* rcp, const float* sv_arr, const int* vhor,
-                                  const int* col_flags, PredRec* pred, float* part_cost,
+                                  const int* col_flags, StepRec* steps, float* part_cost,
                                   int* part_idx, float* cost_table, int32_t* index_table,
                                   hipStream_t stream) {
     const size_t lds1 = isk_pairwise_lds_bytes(P, nwaves);
@@ -1312,18 +1442,16 @@ hipError_t isk_launch_dp_pairwise(const DevParams* P, int ncols, int nwaves, con
     for (int tile = 0; tile < P->ntiles; tile++) {
         if (P->invalid >= 0) {
             hipLaunchKernelGGL(k_pw_phase1<true>, dim3(ncols), dim3(nwaves * 64), lds1, stream, *P,
-                               ncols, tile, recs, lutT, priors, pred, rcp, vhor, col_flags, part_cost,
-                               part_idx);
+                               ncols, tile, recs, lutT, steps, rcp, vhor, col_flags, part_cost, part_idx);
             hipLaunchKernelGGL(k_pw_phase2<true>, dim3(ncols), dim3(64), lds2, stream, *P, ncols, tile,
                                recs, lutT, priors, odr, rcp, sv_arr, vhor, col_flags, part_cost,
-                               part_idx, pred, cost_table, index_table);
+                               part_idx, steps, cost_table, index_table);
         } else {
             hipLaunchKernelGGL(k_pw_phase1<false>, dim3(ncols), dim3(nwaves * 64), lds1, stream, *P,
-                               ncols, tile, recs, lutT, priors, pred, rcp, vhor, col_flags, part_cost,
-                               part_idx);
+                               ncols, tile, recs, lutT, steps, rcp, vhor, col_flags, part_cost, part_idx);
             hipLaunchKernelGGL(k_pw_phase2<false>, dim3(ncols), dim3(64), lds2, stream, *P, ncols, tile,
                                recs, lutT, priors, odr, rcp, sv_arr, vhor, col_flags, part_cost,
-                               part_idx, pred, cost_table, index_table);
+                               part_idx, steps, cost_table, index_table);
         }
     }
     return hipGetLastError();
