@@ -27,13 +27,16 @@
  * Cityscapes.h:28-42 equals F_c[vT+1] - F_c[vB] exactly (ring arithmetic mod 2^32).
  *
  * Two encodings of the same 128 bytes, chosen per column by k_prepare_columns (col_flags):
- *  - FAST (flag 0): the 19 class prefixes are stored as fp32 -- exact, because FAST requires
- *    every class value >= 0 and every column total < 2^24, so each prefix and each difference is
- *    an integer in [0, 2^24) -- and the four instance prefixes as binary64 -- exact, because
- *    FAST requires |mx|, |my| < 2^18, so every prefix / difference is an integer below 2^52.
- *    float(int difference) then costs one v_sub_f32 (a 2-cycle op on gfx950, where integer
- *    subtraction with an SGPR operand, conversions and min/max all cost 4) or one v_add_f64 +
- *    v_cvt_f32_f64.
+ *  - FAST (flag 0): everything is fp32 and every float(integer difference) is one or three
+ *    2-cycle fp32 subtractions/additions (on gfx950 integer subtraction with an SGPR operand,
+ *    conversions, min/max and f64 all cost 4 cycles per wave):
+ *      * the 19 class prefixes as fp32 -- exact, because FAST requires every class value >= 0
+ *        and every column total < 2^24, so each prefix and difference is an integer in [0, 2^24);
+ *      * sum(mx), sum(my) as fp32 -- exact, because FAST requires sum|mx|, sum|my| < 2^23, so
+ *        every prefix is below 2^23 and every difference below 2^24 in magnitude;
+ *      * sum(mx^2), sum(my^2) split as P = Ph + Pl with Pl = P mod 2^22: the same bound gives
+ *        P <= max|mx| * sum|mx| < 2^46, so Ph (a multiple of 2^22 below 2^46), Pl (< 2^22) and
+ *        both differences are exact in fp32, and RN((Ah-Bh) + (Al-Bl)) = RN(A-B) = float(A-B).
  *  - generic (flag != 0): int32 / int64 bit patterns, see RowRecWide. */
 struct __attribute__((aligned(128))) RowRec {
     float Fg0, Fg1;          /* classes 0 (road), 1 (sidewalk)            */
@@ -45,7 +48,11 @@ struct __attribute__((aligned(128))) RowRec {
     float K;                 /* sky data-cost prefix    (Blelloch association)  */
     float S;                 /* disparity prefix        (Blelloch association)  */
     float V;                 /* valid-pixel count prefix (exact)                */
-    double MX, MY, MX2, MY2; /* instance-centre prefix sums (StixelsKernels.cu:401-409) */
+    /* instance-centre prefix sums (StixelsKernels.cu:401-409), FAST encoding */
+    float MX, MY;            /* sum(mx), sum(my)                                 */
+    float MX2h, MX2l;        /* sum(mx^2) = MX2h + MX2l, MX2l = sum mod 2^22    */
+    float MY2h, MY2l;        /* sum(my^2) likewise                               */
+    float pad[2];
 };
 static_assert(sizeof(RowRec) == 128, "RowRec must be one 128-byte line");
 
@@ -61,7 +68,8 @@ struct __attribute__((aligned(128))) RowRecWide { /* generic encoding of the sam
 static_assert(sizeof(RowRecWide) == 128, "RowRecWide must alias RowRec");
 
 #define IS_FAST_CLASS_LIMIT (1 << 24)      /* column total of every class channel          */
-#define IS_FAST_INSTANCE_LIMIT (1 << 18)   /* |mx|, |my| bound of FAST columns            */
+#define IS_FAST_INSTANCE_LIMIT (1 << 23)   /* sum|mx|, sum|my| bound of FAST columns       */
+#define IS_FAST_SPLIT_BITS 22              /* low part of the squared-sum split            */
 #define IS_FAST_DISP_MIN 0x1p-60f          /* nonzero |d| range of FAST columns: then every */
 #define IS_FAST_DISP_MAX 0x1p60f           /* prefix difference is 0 or in [2^-84, 2^75]    */
 

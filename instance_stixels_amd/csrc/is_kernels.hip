@@ -192,8 +192,12 @@ __device__ __forceinline__ void store_instance_prefix(RowRec* o, int slow, int64
     if (slow) {
         RowRecWide* w = reinterpret_cast<RowRecWide*>(o);
         w->MX = mx; w->MY = my; w->MX2 = mx2; w->MY2 = my2;
-    } else { /* exact: all four are integers below 2^52 in magnitude */
-        o->MX = (double)mx; o->MY = (double)my; o->MX2 = (double)mx2; o->MY2 = (double)my2;
+    } else { /* exact fp32 encodings, see RowRec */
+        o->MX = (float)mx; o->MY = (float)my;
+        const int64_t lo_mask = ((int64_t)1 << IS_FAST_SPLIT_BITS) - 1;
+        o->MX2l = (float)(mx2 & lo_mask); o->MX2h = (float)(mx2 - (mx2 & lo_mask));
+        o->MY2l = (float)(my2 & lo_mask); o->MY2h = (float)(my2 - (my2 & lo_mask));
+        o->pad[0] = 0.0f; o->pad[1] = 0.0f;
     }
 }
 
@@ -231,6 +235,7 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_columns(
     const int32_t* offy = s_seg + K * P2S;
     const int32_t* offx = s_seg + (K + 1) * P2S;
     int64_t sum_mx = 0, sum_my = 0, sum_mx2 = 0, sum_my2 = 0;
+    uint64_t abs_mx = 0, abs_my = 0;
     int slow = 0; /* column needs the generic (int64 / IEEE-division) DP path, see RowRec */
     for (int r = r_lo; r < r_lo + R && r < H; r++) {
         const double fx = ((double)(P.column_step * col) + 0.5 * ((double)P.column_step - 1.0)) +
@@ -238,14 +243,25 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_columns(
         const int64_t mx = (int64_t)fx;
         const int32_t n32 = (int32_t)((uint32_t)r - (uint32_t)offy[r >> 3]);
         const int64_t my = (int64_t)((double)n32 + 0.5);
-        slow |= (mx >= IS_FAST_INSTANCE_LIMIT) | (mx <= -IS_FAST_INSTANCE_LIMIT) |
-                (my >= IS_FAST_INSTANCE_LIMIT) | (my <= -IS_FAST_INSTANCE_LIMIT);
+        abs_mx += (uint64_t)(mx < 0 ? -mx : mx);
+        abs_my += (uint64_t)(my < 0 ? -my : my);
         const float ad = __builtin_fabsf(s_d[r]);
         slow |= !((ad == 0.0f) || (ad >= IS_FAST_DISP_MIN && ad <= IS_FAST_DISP_MAX));
         sum_mx += mx;
         sum_my += my;
         sum_mx2 = (int64_t)((uint64_t)sum_mx2 + (uint64_t)mx * (uint64_t)mx);
         sum_my2 = (int64_t)((uint64_t)sum_my2 + (uint64_t)my * (uint64_t)my);
+    }
+    { /* instance centres of a FAST column: sum|mx|, sum|my| < 2^23 (block totals through LDS) */
+        unsigned long long* s_abs = (unsigned long long*)s_wave;
+        if (tid < 2) s_abs[tid] = 0ull;
+        __syncthreads();
+        atomicAdd(&s_abs[0], (unsigned long long)abs_mx);
+        atomicAdd(&s_abs[1], (unsigned long long)abs_my);
+        __syncthreads();
+        slow |= (s_abs[0] >= (unsigned long long)IS_FAST_INSTANCE_LIMIT) |
+                (s_abs[1] >= (unsigned long long)IS_FAST_INSTANCE_LIMIT);
+        __syncthreads(); /* s_wave is reused by the scans below */
     }
     if (tid < K) { /* class channels of a FAST column: values >= 0, full-resolution total < 2^24 */
         const int32_t* ch = s_seg + tid * P2S;
@@ -494,7 +510,8 @@ __device__ __forceinline__ RowRec sload_rec(const RowRec* p) {
     for (int c = 0; c < IS_N_OI; c++) r.Foi[c] = q->Foi[c];
     r.Fsky = q->Fsky; r.Fnic = q->Fnic;
     r.G = q->G; r.K = q->K; r.S = q->S; r.V = q->V;
-    r.MX = q->MX; r.MY = q->MY; r.MX2 = q->MX2; r.MY2 = q->MY2;
+    r.MX = q->MX; r.MY = q->MY; r.MX2h = q->MX2h; r.MX2l = q->MX2l;
+    r.MY2h = q->MY2h; r.MY2l = q->MY2l; r.pad[0] = q->pad[0]; r.pad[1] = q->pad[1];
     return r;
 }
 
@@ -523,10 +540,10 @@ __device__ __forceinline__ SegTerms eval_segment(const RowRec& my, const RowRec&
 #pragma unroll
         for (int c = 1; c < IS_N_OI; c++) f_oi = __builtin_fminf(f_oi, my.Foi[c] - rb.Foi[c]);
         f_sky = my.Fsky - rb.Fsky;
-        const float meanx = (float)(my.MX - rb.MX);
-        const float meany = (float)(my.MY - rb.MY);
-        const float meanx2 = (float)(my.MX2 - rb.MX2);
-        const float meany2 = (float)(my.MY2 - rb.MY2);
+        const float meanx = my.MX - rb.MX;
+        const float meany = my.MY - rb.MY;
+        const float meanx2 = (my.MX2h - rb.MX2h) + (my.MX2l - rb.MX2l);
+        const float meany2 = (my.MY2h - rb.MY2h) + (my.MY2l - rb.MY2l);
         ic = iw * (meanx2 - fast_div(meanx * meanx, height, r) + meany2 -
                    fast_div(meany * meany, height, r));
     } else {
@@ -569,7 +586,7 @@ __device__ __forceinline__ SegTerms eval_segment(const RowRec& my, const RowRec&
     if (FAST) {
         mean = __builtin_fmaxf(mean, 0.0f); /* :525-527; the mean is finite in FAST columns */
         t.mean = mean;
-        t.fni = min((int)mean, D - 1);
+        t.fni = (int)min((unsigned)mean, (unsigned)(D - 1)); /* = floorf for a finite mean >= 0 */
     } else {
         if (mean < 0) mean = 0; /* :525-527 */
         t.mean = mean;
@@ -1261,8 +1278,8 @@ __global__ __launch_bounds__(64) void k_backtrace(const DevParams P, int ncols, 
         const int hgt = vT + 1 - vB;
         const RowRecWide& aw = reinterpret_cast<const RowRecWide&>(a);
         const RowRecWide& bw = reinterpret_cast<const RowRecWide&>(bq);
-        const float meanx = wide ? (float)(aw.MX - bw.MX) : (float)(a.MX - bq.MX);
-        const float meany = wide ? (float)(aw.MY - bw.MY) : (float)(a.MY - bq.MY);
+        const float meanx = wide ? (float)(aw.MX - bw.MX) : (a.MX - bq.MX);
+        const float meany = wide ? (float)(aw.MY - bw.MY) : (a.MY - bq.MY);
         sec.instance_meanx = meanx / (float)hgt;
         sec.instance_meany = meany / (float)hgt;
         if (sec.type == IS_GROUND) { /* GetGroundSegmentationClass, Cityscapes.h:52-59 */
@@ -1273,8 +1290,10 @@ __global__ __launch_bounds__(64) void k_backtrace(const DevParams P, int ncols, 
             sec.type = IS_SKY;
             sec.semantic_class = 10;
         } else { /* GetObjectSegmentationClass, Cityscapes.h:85-111 */
-            const float meanx2 = wide ? (float)(aw.MX2 - bw.MX2) : (float)(a.MX2 - bq.MX2);
-            const float meany2 = wide ? (float)(aw.MY2 - bw.MY2) : (float)(a.MY2 - bq.MY2);
+            const float meanx2 = wide ? (float)(aw.MX2 - bw.MX2)
+                                      : ((a.MX2h - bq.MX2h) + (a.MX2l - bq.MX2l));
+            const float meany2 = wide ? (float)(aw.MY2 - bw.MY2)
+                                      : ((a.MY2h - bq.MY2h) + (a.MY2l - bq.MY2l));
             const float height = (float)hgt;
             const float ic = P.iw * (meanx2 - meanx * meanx / height + meany2 - meany * meany / height);
             const float nic = P.iw * (float)(a.Fnic - bq.Fnic);
