@@ -79,7 +79,7 @@ def main():
     import torch.distributed as dist
     from instance_stixels_amd import make_config, synthetic, host
     from instance_stixels_amd.core import Core, InstanceBuffers
-    from instance_stixels_amd.parallel import gather_sections
+    from instance_stixels_amd.parallel import PipelinedGather
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
@@ -122,18 +122,22 @@ def main():
     core = Core(params, lut, odr, max_batch=B, device=local_rank)
     core.set_kernel_timing(True)
     stream = torch.cuda.current_stream(dev).cuda_stream
-    gathered = None
-    if world > 1 and rank == 0 and not args.no_gather:
-        gathered = [torch.empty_like(d_sections) for _ in range(world)]
+    # N > 1: the stixel outputs of every step are gathered on rank 0 (RCCL over xGMI); the gather
+    # of step k overlaps the compute of step k+1 (double-buffered outputs)
+    pipe = PipelinedGather(d_sections, depth=2, dst=0) if (world > 1 and not args.no_gather) else None
 
     def step():
+        out = pipe.next_buffer() if pipe is not None else d_sections
         core.join_columns_ptr(d_big.data_ptr(), W, cfg.median_join, d_joined.data_ptr(), B, stream)
         core.compute_ptr(d_joined.data_ptr(), d_seg.data_ptr(), gf, ng, ig, vh, cfg.pairwise, B,
-                         d_sections.data_ptr(), None, None, None, stream)
-        if world > 1 and not args.no_gather:
-            gather_sections(d_sections, gathered, dst=0)
+                         out.data_ptr(), None, None, None, stream)
+        if pipe is not None:
+            pipe.submit()
 
     def barrier():
+        if pipe is not None:
+            pipe.flush()
+        torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
@@ -173,7 +177,8 @@ def main():
                                    "prepare + DP + back-trace, device-resident in/out",
                        "batch_per_gpu": B, "rows": H, "cols": W, "max_dis": D,
                        "preset": args.preset,
-                       "parallelism": f"batch shards x{world}, RCCL gather of sections to rank 0"
+                       "parallelism": f"batch shards x{world}, RCCL gather of sections to rank 0 "
+                                      "(overlapped with the next step)"
                                       if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,

@@ -41,3 +41,47 @@ def gather_variable(local: torch.Tensor, dst: int = 0, group=None):
     if rank != dst:
         return None
     return torch.cat([o[:s] for o, s in zip(out, sizes)], dim=0)
+
+
+class PipelinedGather:
+    """Final gather of per-step outputs to `dst`, overlapped with the next step's compute.
+
+    The column DP has no data-path collective; only its outputs travel.  Step k writes its
+    Section tensor into buffer k % depth, the gather of that buffer is issued asynchronously (on
+    the communication stream of the backend) and step k+1 computes into the other buffer meanwhile.
+    `flush()` waits for everything that is still in flight."""
+
+    def __init__(self, like: torch.Tensor, depth: int = 2, dst: int = 0, group=None):
+        self.dst, self.group, self.depth = dst, group, depth
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        self.buffers = [torch.empty_like(like) for _ in range(depth)]
+        self.gathered = None
+        if self.rank == dst:
+            self.gathered = [[torch.empty_like(like) for _ in range(self.world)]
+                             for _ in range(depth)]
+        self.inflight = [None] * depth
+        self.step = 0
+
+    def next_buffer(self) -> torch.Tensor:
+        """Output buffer of the coming step; blocks (stream-wise) until its last gather is done."""
+        slot = self.step % self.depth
+        if self.inflight[slot] is not None:
+            self.inflight[slot].wait()
+            self.inflight[slot] = None
+        return self.buffers[slot]
+
+    def submit(self):
+        """Issues the gather of the buffer handed out by the last next_buffer() call."""
+        slot = self.step % self.depth
+        self.inflight[slot] = dist.gather(
+            self.buffers[slot], gather_list=self.gathered[slot] if self.rank == self.dst else None,
+            dst=self.dst, group=self.group, async_op=True)
+        self.step += 1
+        return slot
+
+    def flush(self):
+        for i, w in enumerate(self.inflight):
+            if w is not None:
+                w.wait()
+                self.inflight[i] = None

@@ -28,7 +28,8 @@ def _worker(rank, world, port, n_images, out_path):
             sys.path.insert(0, p)
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from instance_stixels_amd.parallel import shard_range, gather_variable, gather_sections
+    from instance_stixels_amd.parallel import (shard_range, gather_variable, gather_sections,
+                                               PipelinedGather)
     case = helpers.build_case("drn_d_22_unary", 64, 64, 32, seed=21, n_images=n_images)
     lo, hi = shard_range(n_images, rank, world)
     local = np.stack([helpers.run_oracle(case, image=i)["sections"] for i in range(lo, hi)])
@@ -38,6 +39,21 @@ def _worker(rank, world, port, n_images, out_path):
     fixed = t[:1].contiguous()
     lst = [torch.empty_like(fixed) for _ in range(world)] if rank == 0 else None
     gather_sections(fixed, lst, dst=0)
+    # pipelined (double-buffered, asynchronous) gather of 3 consecutive "steps": step k sends
+    # `fixed + k`; slots alternate 0, 1, 0, so slot 0 ends with step 2 and slot 1 with step 1
+    pipe = PipelinedGather(fixed, depth=2, dst=0)
+    slots = []
+    for k in range(3):
+        buf = pipe.next_buffer()
+        buf.copy_(fixed + k)
+        slots.append(pipe.submit())
+    pipe.flush()
+    assert slots == [0, 1, 0]
+    if rank == 0:
+        firsts = [shard_range(n_images, r, world)[0] for r in range(world)]
+        for r, f in enumerate(firsts):
+            assert torch.equal(pipe.gathered[0][r][0], full[f] + 2)
+            assert torch.equal(pipe.gathered[1][r][0], full[f] + 1)
     if rank == 0:
         np.save(out_path, full.numpy())
         firsts = [shard_range(n_images, r, world)[0] for r in range(world)]
