@@ -173,7 +173,8 @@ int is_ctx_create(const is_stixel_params* p, const float* obj_cost_lut,
     /* waves per DP workgroup: the LUT tile is 64*(D+1) floats; keep >= 16 waves per CU */
     c->nwaves_unary = IS_UNARY_WAVES;
     c->nwaves_pairwise = IS_UNARY_WAVES;
-    if (isk_unary_lds_bytes(&d) > 160 * 1024 || isk_pairwise_lds_bytes(&d, c->nwaves_pairwise) > 160 * 1024 ||
+    if (sizeof(int) * (6 * (size_t)d.H + 3 * (size_t)d.S + 4) > 160 * 1024 ||
+        isk_unary_lds_bytes(&d) > 160 * 1024 || isk_pairwise_lds_bytes(&d, c->nwaves_pairwise) > 160 * 1024 ||
         isk_prepare_lds_bytes(&d) > 160 * 1024) {
         free(c);
         return fail_arg("shape needs more than 160 KiB of LDS per workgroup");

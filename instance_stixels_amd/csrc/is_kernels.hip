@@ -1209,121 +1209,151 @@ __global__ __launch_bounds__(64) void k_pw_phase2(
 }
 
 /* ====================================================================================== */
-/* A10  back-tracing, one lane per column                                                  */
+/* A10  back-tracing, one wavefront per column                                             */
 /* ====================================================================================== */
-__device__ __forceinline__ float bt_mean(const RowRec* rcol, int vB, int vT, float invalid) {
-    const float s1 = rcol[vT + 1].S, s0 = rcol[vB].S;
-    if (invalid >= 0) {
-        const float valid_dif = rcol[vT + 1].V - rcol[vB].V;
-        return (valid_dif == 0) ? 0 : (s1 - s0) / valid_dif;
+/* Everything of one Section that depends only on (vT, vB, type): StixelsKernels.cu:868-944. */
+__device__ __forceinline__ is_section make_section(const DevParams& P, const RowRec* rcol, bool wide,
+                                                   int vT, int vB, int type, float cost) {
+    const RowRec a = load_rec(rcol + vT + 1);
+    const RowRec bq = load_rec(rcol + vB);
+    const RowRecWide& aw = reinterpret_cast<const RowRecWide&>(a);
+    const RowRecWide& bw = reinterpret_cast<const RowRecWide&>(bq);
+    is_section sec;
+    sec.vT = vT;
+    sec.type = type;
+    sec.vB = vB;
+    { /* ComputeMean, :47-60 */
+        const float sd = a.S - bq.S;
+        if (P.invalid >= 0) {
+            const float valid_dif = a.V - bq.V;
+            sec.disparity = (valid_dif == 0) ? 0 : sd / valid_dif;
+        } else {
+            sec.disparity = sd / (float)(vT + 1 - vB);
+        }
     }
-    return (s1 - s0) / (float)(vT + 1 - vB);
+    sec.cost = __builtin_fminf(cost, 1e4f);
+    const int hgt = vT + 1 - vB;
+    const float meanx = wide ? (float)(aw.MX - bw.MX) : (a.MX - bq.MX);
+    const float meany = wide ? (float)(aw.MY - bw.MY) : (a.MY - bq.MY);
+    sec.instance_meanx = meanx / (float)hgt;
+    sec.instance_meany = meany / (float)hgt;
+    if (sec.type == IS_GROUND) { /* GetGroundSegmentationClass, Cityscapes.h:52-59 */
+        const float cost_road = wide ? (float)(aw.Fg0 - bw.Fg0) : (a.Fg0 - bq.Fg0);
+        const float cost_sidewalk = wide ? (float)(aw.Fg1 - bw.Fg1) : (a.Fg1 - bq.Fg1);
+        sec.semantic_class = (cost_road < cost_sidewalk) ? 0 : 1;
+    } else if (sec.type == IS_SKY || sec.disparity < 1.0f) { /* :894-902 */
+        sec.type = IS_SKY;
+        sec.semantic_class = 10;
+    } else { /* GetObjectSegmentationClass, Cityscapes.h:85-111 */
+        const float meanx2 = wide ? (float)(aw.MX2 - bw.MX2)
+                                  : ((a.MX2h - bq.MX2h) + (a.MX2l - bq.MX2l));
+        const float meany2 = wide ? (float)(aw.MY2 - bw.MY2)
+                                  : ((a.MY2h - bq.MY2h) + (a.MY2l - bq.MY2l));
+        const float height = (float)hgt;
+        const float ic = P.iw * (meanx2 - meanx * meanx / height + meany2 - meany * meany / height);
+        const float nic = P.iw * (float)(a.Fnic - bq.Fnic);
+        float min_cost = IS_INF;
+        int min_class = 2;
+#pragma unroll
+        for (int c = 0; c < IS_N_ON; c++) {
+            float cs = 0.0f;
+            cs += nic;
+            cs += wide ? (float)(aw.Fon[c] - bw.Fon[c]) : (a.Fon[c] - bq.Fon[c]);
+            if (min_cost > cs) { min_cost = cs; min_class = 2 + c; }
+        }
+#pragma unroll
+        for (int c = 0; c < IS_N_OI; c++) {
+            float cs = 0.0f;
+            cs += ic;
+            cs += wide ? (float)(aw.Foi[c] - bw.Foi[c]) : (a.Foi[c] - bq.Foi[c]);
+            if (min_cost > cs) { min_cost = cs; min_class = 11 + c; }
+        }
+        sec.semantic_class = min_class;
+    }
+    return sec;
 }
 
+/* One wavefront per column.  The reference lets thread 0 do everything serially
+ * (StixelsKernels.cu:843-955); only the index chase is inherently serial, so: the column's
+ * tables are staged in LDS (coalesced), lane 0 walks the chain in LDS and records the cuts,
+ * then the lanes build the Sections in parallel (one per lane). */
 __global__ __launch_bounds__(64) void k_backtrace(const DevParams P, int ncols, int pairwise,
                                                   const RowRec* __restrict__ recs,
                                                   const float* __restrict__ cost_table,
                                                   const int32_t* __restrict__ index_table,
                                                   const int* __restrict__ col_flags,
                                                   is_section* __restrict__ sections) {
-    const int colg = blockIdx.x * blockDim.x + threadIdx.x;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int colg = blockIdx.x;
     if (colg >= ncols) return;
-    const bool wide = col_flags[colg] != 0; /* int64 bit patterns instead of binary64, see RowRec */
-    const int H = P.H;
+    const int lane = threadIdx.x;
+    const int H = P.H, S = P.S;
+    float* s_cost = (float*)smem;           /* [3H] */
+    int* s_idx = (int*)(s_cost + 3 * H);    /* [3H] */
+    int* s_cut = s_idx + 3 * H;             /* [S][3]: vT, vB, type */
+    int* s_n = s_cut + 3 * S;               /* [1] */
+    const bool wide = col_flags[colg] != 0; /* generic record encoding, see RowRec */
     const RowRec* rcol = recs + (size_t)colg * (H + 1);
     const float* ct = cost_table + (size_t)colg * H * 3;
     const int32_t* it = index_table + (size_t)colg * H * 3;
-    is_section* out = sections + (size_t)colg * P.S;
-
-    int vT = H - 1;
-    const float last_ground = ct[vT * 3 + IS_GROUND];
-    const float last_object = ct[vT * 3 + IS_OBJECT];
-    const float last_sky = ct[vT * 3 + IS_SKY];
-    int type = IS_OBJECT; /* :854-861 */
-    if (last_ground < last_object) type = IS_GROUND;
-    if (last_sky < __builtin_fminf(last_ground, last_object)) type = IS_SKY;
-
-    int i = 0;
-    int prev_vT;
-    do {
-        const int raw = it[vT * 3 + type];
-        int vB, prev_type;
-        if (pairwise) {
-            vB = raw / 3;
-            prev_type = raw % 3;
-        } else {
-            /* unary: index_table holds the winning vB; the predecessor type is the arg-min of
-             * the FINAL cost_table[vB-1] with the tie rules of :723-727, 769-773, 828-835 */
-            vB = raw;
-            prev_type = IS_OBJECT;
-            if (vB > 0) {
-                const float cG = ct[(vB - 1) * 3 + IS_GROUND];
-                const float cO = ct[(vB - 1) * 3 + IS_OBJECT];
-                if (cG < cO) prev_type = IS_GROUND;
-                if (type == IS_OBJECT) {
-                    const float cS = ct[(vB - 1) * 3 + IS_SKY];
-                    if (cS < __builtin_fminf(cG, cO)) prev_type = IS_SKY;
+    is_section* out = sections + (size_t)colg * S;
+    for (int i = lane; i < 3 * H; i += 64) {
+        s_cost[i] = ct[i];
+        s_idx[i] = it[i];
+    }
+    __syncthreads();
+    if (lane == 0) {
+        int vT = H - 1;
+        const float last_ground = s_cost[vT * 3 + IS_GROUND];
+        const float last_object = s_cost[vT * 3 + IS_OBJECT];
+        const float last_sky = s_cost[vT * 3 + IS_SKY];
+        int type = IS_OBJECT; /* :854-861 */
+        if (last_ground < last_object) type = IS_GROUND;
+        if (last_sky < __builtin_fminf(last_ground, last_object)) type = IS_SKY;
+        int n = 0;
+        int prev_vT;
+        do {
+            const int raw = s_idx[vT * 3 + type];
+            int vB, prev_type;
+            if (pairwise) {
+                vB = raw / 3;
+                prev_type = raw % 3;
+            } else {
+                /* unary: index_table holds the winning vB; the predecessor type is the arg-min
+                 * of the FINAL cost_table[vB-1], tie rules of :723-727, 769-773, 828-835 */
+                vB = raw;
+                prev_type = IS_OBJECT;
+                if (vB > 0) {
+                    const float cG = s_cost[(vB - 1) * 3 + IS_GROUND];
+                    const float cO = s_cost[(vB - 1) * 3 + IS_OBJECT];
+                    if (cG < cO) prev_type = IS_GROUND;
+                    if (type == IS_OBJECT) {
+                        const float cS = s_cost[(vB - 1) * 3 + IS_SKY];
+                        if (cS < __builtin_fminf(cG, cO)) prev_type = IS_SKY;
+                    }
                 }
             }
-        }
-        prev_vT = vB - 1;
-        const RowRec a = load_rec(rcol + vT + 1);
-        const RowRec bq = load_rec(rcol + vB);
+            s_cut[n * 3 + 0] = vT; s_cut[n * 3 + 1] = vB; s_cut[n * 3 + 2] = type;
+            prev_vT = vB - 1;
+            type = prev_type;
+            vT = prev_vT;
+            n++;
+        } while (prev_vT != -1 && n < S - 1); /* the reference asserts i < max_sections (:950) */
+        *s_n = n;
+    }
+    __syncthreads();
+    const int n = *s_n;
+    for (int i = lane; i <= n; i += 64) {
         is_section sec;
-        sec.vT = vT;
-        sec.type = type;
-        sec.vB = vB;
-        sec.disparity = bt_mean(rcol, vB, vT, P.invalid);
-        sec.cost = __builtin_fminf(ct[vT * 3 + type], 1e4f);
-        const int hgt = vT + 1 - vB;
-        const RowRecWide& aw = reinterpret_cast<const RowRecWide&>(a);
-        const RowRecWide& bw = reinterpret_cast<const RowRecWide&>(bq);
-        const float meanx = wide ? (float)(aw.MX - bw.MX) : (a.MX - bq.MX);
-        const float meany = wide ? (float)(aw.MY - bw.MY) : (a.MY - bq.MY);
-        sec.instance_meanx = meanx / (float)hgt;
-        sec.instance_meany = meany / (float)hgt;
-        if (sec.type == IS_GROUND) { /* GetGroundSegmentationClass, Cityscapes.h:52-59 */
-            const float cost_road = wide ? (float)(aw.Fg0 - bw.Fg0) : (a.Fg0 - bq.Fg0);
-            const float cost_sidewalk = wide ? (float)(aw.Fg1 - bw.Fg1) : (a.Fg1 - bq.Fg1);
-            sec.semantic_class = (cost_road < cost_sidewalk) ? 0 : 1;
-        } else if (sec.type == IS_SKY || sec.disparity < 1.0f) { /* :894-902 */
-            sec.type = IS_SKY;
-            sec.semantic_class = 10;
-        } else { /* GetObjectSegmentationClass, Cityscapes.h:85-111 */
-            const float meanx2 = wide ? (float)(aw.MX2 - bw.MX2)
-                                      : ((a.MX2h - bq.MX2h) + (a.MX2l - bq.MX2l));
-            const float meany2 = wide ? (float)(aw.MY2 - bw.MY2)
-                                      : ((a.MY2h - bq.MY2h) + (a.MY2l - bq.MY2l));
-            const float height = (float)hgt;
-            const float ic = P.iw * (meanx2 - meanx * meanx / height + meany2 - meany * meany / height);
-            const float nic = P.iw * (float)(a.Fnic - bq.Fnic);
-            float min_cost = IS_INF;
-            int min_class = 2;
-#pragma unroll
-            for (int c = 0; c < IS_N_ON; c++) {
-                float cs = 0.0f;
-                cs += nic;
-                cs += wide ? (float)(aw.Fon[c] - bw.Fon[c]) : (a.Fon[c] - bq.Fon[c]);
-                if (min_cost > cs) { min_cost = cs; min_class = 2 + c; }
-            }
-#pragma unroll
-            for (int c = 0; c < IS_N_OI; c++) {
-                float cs = 0.0f;
-                cs += ic;
-                cs += wide ? (float)(aw.Foi[c] - bw.Foi[c]) : (a.Foi[c] - bq.Foi[c]);
-                if (min_cost > cs) { min_cost = cs; min_class = 11 + c; }
-            }
-            sec.semantic_class = min_class;
+        if (i < n) {
+            const int vT = s_cut[i * 3 + 0], vB = s_cut[i * 3 + 1], type = s_cut[i * 3 + 2];
+            sec = make_section(P, rcol, wide, vT, vB, type, s_cost[vT * 3 + type]);
+        } else { /* terminator, :952-954 */
+            sec.type = -1; sec.vB = 0; sec.vT = 0; sec.disparity = 0.0f;
+            sec.semantic_class = 0; sec.cost = 0.0f; sec.instance_meanx = 0.0f; sec.instance_meany = 0.0f;
         }
         out[i] = sec;
-        type = prev_type;
-        vT = prev_vT;
-        i++;
-    } while (prev_vT != -1 && i < P.S - 1); /* the reference asserts i < max_sections (:950) */
-    is_section term;
-    term.type = -1; term.vB = 0; term.vT = 0; term.disparity = 0.0f;
-    term.semantic_class = 0; term.cost = 0.0f; term.instance_meanx = 0.0f; term.instance_meany = 0.0f;
-    out[i] = term;
+    }
 }
 
 /* ====================================================================================== */
@@ -1479,8 +1509,9 @@ hipError_t isk_launch_dp_pairwise(const DevParams* P, int ncols, int nwaves, con
 hipError_t isk_launch_backtrace(const DevParams* P, int ncols, int pairwise, const RowRec* recs,
                                 const float* cost_table, const int32_t* index_table,
                                 const int* col_flags, is_section* sections, hipStream_t stream) {
-    hipLaunchKernelGGL(k_backtrace, dim3((ncols + 63) / 64), dim3(64), 0, stream, *P, ncols,
-                       pairwise, recs, cost_table, index_table, col_flags, sections);
+    const size_t lds = sizeof(int) * (6 * (size_t)P->H + 3 * (size_t)P->S + 4);
+    hipLaunchKernelGGL(k_backtrace, dim3(ncols), dim3(64), lds, stream, *P, ncols, pairwise, recs,
+                       cost_table, index_table, col_flags, sections);
     return hipGetLastError();
 }
 
@@ -1502,6 +1533,9 @@ hipError_t isk_set_lds_limits(const DevParams* P, int nwaves_pair) {
     e = hipFuncSetAttribute((const void*)k_dp_unary<true>, hipFuncAttributeMaxDynamicSharedMemorySize, b);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void*)k_dp_unary<false>, hipFuncAttributeMaxDynamicSharedMemorySize, b);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void*)k_backtrace, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(sizeof(int) * (6 * (size_t)P->H + 3 * (size_t)P->S + 4)));
     if (e != hipSuccess) return e;
     const int c = (int)isk_pairwise_lds_bytes(P, nwaves_pair);
     e = hipFuncSetAttribute((const void*)k_pw_phase1<true>, hipFuncAttributeMaxDynamicSharedMemorySize, c);
