@@ -144,6 +144,23 @@ int is_compute(is_ctx* ctx, const float* d_joined, const int32_t* d_segmentation
                int n_images, is_section* d_sections, const is_instance_buffers* instances,
                float* d_cost_table, int32_t* d_index_table, void* stream);
 
+/* Replaces the output wrapper of the reference's CNN export ("FlipAndPad",
+ * tools/CNN_training/models/wrappers.py:35-61), i.e. the producer of d_segmentation:
+ *   d_cnn_out       device, [n_images][channels][rows8][cols8] float (NCHW network output)
+ *   d_segmentation  device, [n_images][cols8][channels][rows_power2_segmentation] int32:
+ *                   permuted, rows flipped (index 0 = image bottom), zero padded, (int)(8*x). */
+int is_flip_and_pad(const float* d_cnn_out, int32_t* d_segmentation, int n_images, int channels,
+                    int rows8, int cols8, int rows_power2_segmentation, void* stream);
+
+/* Replaces the three launches of RoadEstimation::Compute (RoadEstimation.cu:103-118, kernels
+ * RoadEstimationKernels.cu:25-60): v-disparity histogram of the full-resolution disparity image
+ * (pixels equal to 0 are skipped), its maximum, and the binarised image
+ * (count > maximum * threshold ? 255 : 0).
+ *   d_disparity [rows][cols] float;  d_vdisp [rows][max_dis] int;  d_maximum [1] int;
+ *   d_binary [rows][max_dis] uint8. */
+int is_road_vdisparity(const float* d_disparity, int rows, int cols, int max_dis, float threshold,
+                       int* d_vdisp, int* d_maximum, uint8_t* d_binary, void* stream);
+
 /* Thin wrappers over the HIP runtime so that the plain-C++ host class needs no HIP headers
  * (the reference's callers are all .cu files; ours may be plain C++). */
 int is_device_malloc(void** ptr, size_t bytes);

@@ -19,7 +19,7 @@ EXPORTS = [
     "is_ctx_create", "is_ctx_destroy", "is_join_columns", "is_compute", "is_device_malloc",
     "is_device_free", "is_memcpy_h2d", "is_memcpy_d2h", "is_memset", "is_stream_synchronize",
     "is_device_synchronize", "is_last_error", "is_version", "is_set_kernel_timing",
-    "is_get_kernel_times_ms", "is_scratch_bytes",
+    "is_get_kernel_times_ms", "is_scratch_bytes", "is_flip_and_pad", "is_road_vdisparity",
 ]
 
 
@@ -65,6 +65,8 @@ def lib():
         L.is_set_kernel_timing.argtypes = [vp, ci]
         L.is_get_kernel_times_ms.argtypes = [vp, ctypes.POINTER(cf), ctypes.POINTER(cf),
                                              ctypes.POINTER(cf)]
+        L.is_flip_and_pad.argtypes = [vp, vp, ci, ci, ci, ci, ci, vp]
+        L.is_road_vdisparity.argtypes = [vp, ci, ci, ci, cf, vp, vp, vp, vp]
         L.is_scratch_bytes.argtypes = [vp]
         L.is_scratch_bytes.restype = ctypes.c_size_t
         _LIB = L
@@ -192,3 +194,17 @@ class Core:
             out["inst_core"] = inst_t[2].cpu().numpy()
             out["inst_per_class"] = inst_t[3].cpu().numpy()
         return out
+
+
+def flip_and_pad(cnn_out, rows_power2_segmentation, device=0):
+    """CNN output [n][CH][Hs][Ws] float32 (numpy) -> DP input [n][Ws][CH][P2S] int32 (numpy)."""
+    import torch
+    dev = torch.device("cuda", device)
+    x = torch.from_numpy(np.ascontiguousarray(cnn_out, np.float32)).to(dev)
+    n, CH, Hs, Ws = x.shape
+    out = torch.empty((n, Ws, CH, int(rows_power2_segmentation)), dtype=torch.int32, device=dev)
+    _check(lib().is_flip_and_pad(x.data_ptr(), out.data_ptr(), n, CH, Hs, Ws,
+                                 int(rows_power2_segmentation),
+                                 torch.cuda.current_stream(dev).cuda_stream), "is_flip_and_pad")
+    torch.cuda.synchronize(dev)
+    return out.cpu().numpy()

@@ -37,6 +37,8 @@ hipError_t isk_launch_backtrace(const DevParams*, int, int, const RowRec*, const
 hipError_t isk_launch_compact(const DevParams*, const is_section*, float*, int32_t*, uint8_t*,
                               int32_t*, hipStream_t);
 hipError_t isk_set_lds_limits(const DevParams*, int);
+hipError_t isk_launch_flip_and_pad(const float*, int32_t*, int, int, int, int, int, hipStream_t);
+hipError_t isk_launch_vdisparity(const float*, int*, int*, uint8_t*, int, int, int, float, hipStream_t);
 }
 
 static thread_local char g_err[512] = "";
@@ -265,6 +267,27 @@ int is_join_columns(is_ctx* c, const float* d_big, int full_cols, int median_joi
     HIP_TRY(isk_launch_join(d_big, d_joined, p.rows, full_cols, p.cols, p.column_step,
                             p.width_margin, median_join, p.invalid_disparity, n_images,
                             (hipStream_t)stream));
+    return IS_OK;
+}
+
+int is_flip_and_pad(const float* d_cnn_out, int32_t* d_segmentation, int n_images, int channels,
+                    int rows8, int cols8, int rows_power2_segmentation, void* stream) {
+    if (!d_cnn_out || !d_segmentation) return fail_arg("null pointer");
+    if (n_images < 1 || channels < 1 || rows8 < 1 || cols8 < 1) return fail_arg("empty shape");
+    if (rows_power2_segmentation < rows8 + 1 ||
+        (rows_power2_segmentation & (rows_power2_segmentation - 1)) != 0)
+        return fail_arg("rows_power2_segmentation must be a power of two > rows/8 (Stixels.cu:132-133)");
+    HIP_TRY(isk_launch_flip_and_pad(d_cnn_out, d_segmentation, n_images, channels, rows8, cols8,
+                                    rows_power2_segmentation, (hipStream_t)stream));
+    return IS_OK;
+}
+
+int is_road_vdisparity(const float* d_disparity, int rows, int cols, int max_dis, float threshold,
+                       int* d_vdisp, int* d_maximum, uint8_t* d_binary, void* stream) {
+    if (!d_disparity || !d_vdisp || !d_maximum || !d_binary) return fail_arg("null pointer");
+    if (rows < 1 || cols < 1 || max_dis < 1 || max_dis > 16384) return fail_arg("bad shape");
+    HIP_TRY(isk_launch_vdisparity(d_disparity, d_vdisp, d_maximum, d_binary, rows, cols, max_dis,
+                                  threshold, (hipStream_t)stream));
     return IS_OK;
 }
 

@@ -1418,6 +1418,84 @@ __global__ __launch_bounds__(256) void k_compact_instances(
 }
 
 /* ====================================================================================== */
+/* f4  CNN output -> DP input layout ("FlipAndPad", tools/CNN_training/models/wrappers.py:35-61) */
+/* ====================================================================================== */
+/* in  [n][CH][Hs][Ws] float (NCHW network output: 19 x -log-softmax, 2 offset channels)
+ * out [n][Ws][CH][P2S] int32: permute(0,3,1,2), rows flipped (index 0 = image bottom), zero
+ * padded to P2S, value = (int)(8 * x) (truncation toward zero, as torch's .int()).
+ * A 64x64 (w, k) tile per channel is transposed through LDS so that reads run along w and
+ * writes along k: both sides are coalesced. */
+__global__ __launch_bounds__(256) void k_flip_and_pad(const float* __restrict__ in,
+                                                      int32_t* __restrict__ out, int CH, int Hs,
+                                                      int Ws, int P2S) {
+    __shared__ int32_t tile[64][65];
+    const int n = blockIdx.z / CH, c = blockIdx.z % CH;
+    const int w0 = blockIdx.x * 64, k0 = blockIdx.y * 64;
+    const float* src = in + ((size_t)n * CH + c) * Hs * Ws;
+    int32_t* dst = out + (size_t)n * Ws * CH * P2S + (size_t)c * P2S;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int kk = ty; kk < 64; kk += 4) { /* read: lanes along w */
+        const int k = k0 + kk, w = w0 + tx;
+        int32_t v = 0;
+        if (k < Hs && w < Ws) v = (int32_t)(src[(size_t)(Hs - 1 - k) * Ws + w] * 8.0f);
+        tile[kk][tx] = v;
+    }
+    __syncthreads();
+    for (int ww = ty; ww < 64; ww += 4) { /* write: lanes along k */
+        const int w = w0 + ww, k = k0 + tx;
+        if (w < Ws && k < P2S) dst[(size_t)w * CH * P2S + k] = tile[tx][ww];
+    }
+}
+
+/* ====================================================================================== */
+/* f3  road estimation: v-disparity histogram, maximum, binarisation                       */
+/*     (RoadEstimationKernels.cu:25-60)                                                     */
+/* ====================================================================================== */
+/* The reference does one global atomicAdd per pixel and a second kernel of global atomicMax.
+ * Here one workgroup owns one image row: the row is read coalesced, binned with LDS atomics,
+ * written once, and its maximum goes to a single global atomicMax.  Integer counts and maxima
+ * do not depend on the order, so the result is identical. */
+__global__ __launch_bounds__(256) void k_vdisp_histogram(const float* __restrict__ disparity,
+                                                         int* __restrict__ vdisp,
+                                                         int* __restrict__ maximum, int cols,
+                                                         int max_dis) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int* bins = (int*)smem; /* [max_dis] */
+    const int row = blockIdx.x;
+    for (int i = threadIdx.x; i < max_dis; i += blockDim.x) bins[i] = 0;
+    __syncthreads();
+    const float* src = disparity + (size_t)row * cols;
+    for (int j = threadIdx.x; j < cols; j += blockDim.x) {
+        const float d = src[j];
+        if (d != 0) { /* RoadEstimationKernels.cu:33-37 */
+            const int col = (int)d;
+            if (col >= 0 && col < max_dis) atomicAdd(&bins[col], 1); /* guard: reference is unchecked */
+        }
+    }
+    __syncthreads();
+    int m = 0;
+    for (int i = threadIdx.x; i < max_dis; i += blockDim.x) {
+        const int v = bins[i];
+        vdisp[(size_t)row * max_dis + i] = v;
+        m = max(m, v);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(maximum, m);
+}
+
+__global__ __launch_bounds__(256) void k_vdisp_binarize(const int* __restrict__ vdisp,
+                                                        uint8_t* __restrict__ out,
+                                                        const int* __restrict__ maximum,
+                                                        float threshold, int n) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < n) {
+        const float p = (float)vdisp[idx]; /* RoadEstimationKernels.cu:55-58 */
+        out[idx] = (p > (*maximum) * threshold) ? 255 : 0;
+    }
+}
+
+/* ====================================================================================== */
 /* launch helpers (called from is_core.hip)                                                */
 /* ====================================================================================== */
 extern "C" {
@@ -1512,6 +1590,26 @@ hipError_t isk_launch_backtrace(const DevParams* P, int ncols, int pairwise, con
     const size_t lds = sizeof(int) * (6 * (size_t)P->H + 3 * (size_t)P->S + 4);
     hipLaunchKernelGGL(k_backtrace, dim3(ncols), dim3(64), lds, stream, *P, ncols, pairwise, recs,
                        cost_table, index_table, col_flags, sections);
+    return hipGetLastError();
+}
+
+hipError_t isk_launch_flip_and_pad(const float* in, int32_t* out, int n, int CH, int Hs, int Ws,
+                                   int P2S, hipStream_t stream) {
+    dim3 grid((Ws + 63) / 64, (P2S + 63) / 64, n * CH);
+    hipLaunchKernelGGL(k_flip_and_pad, grid, dim3(256), 0, stream, in, out, CH, Hs, Ws, P2S);
+    return hipGetLastError();
+}
+
+hipError_t isk_launch_vdisparity(const float* disparity, int* vdisp, int* maximum, uint8_t* binary,
+                                 int rows, int cols, int max_dis, float threshold,
+                                 hipStream_t stream) {
+    hipError_t e = hipMemsetAsync(maximum, 0, sizeof(int), stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_vdisp_histogram, dim3(rows), dim3(256), sizeof(int) * max_dis, stream,
+                       disparity, vdisp, maximum, cols, max_dis);
+    const int n = rows * max_dis;
+    hipLaunchKernelGGL(k_vdisp_binarize, dim3((n + 255) / 256), dim3(256), 0, stream, vdisp, binary,
+                       maximum, threshold, n);
     return hipGetLastError();
 }
 

@@ -25,6 +25,8 @@ EXPORTS = [
     "ish_get_parameters", "ish_get_luts", "ish_core_context", "ish_set_disparity_image",
     "ish_set_segmentation", "ish_set_road_parameters", "ish_get_ground_model", "ish_compute",
     "ish_get_instance_stixels", "ish_get_3d_vertices", "ish_save_stixels",
+    "ire_create", "ire_destroy", "ire_initialize", "ire_finish", "ire_compute", "ire_get_binary",
+    "ire_hough_lines",
 ]
 
 
@@ -75,6 +77,13 @@ def lib():
         L.ish_get_instance_stixels.argtypes = [vp, vp, ci]
         L.ish_get_3d_vertices.argtypes = [vp, vp, cf, ci, vp, ci]
         L.ish_save_stixels.argtypes = [vp, vp, vp, ci, cf, ci, ctypes.c_char_p]
+        L.ire_create.restype = vp
+        L.ire_destroy.argtypes = [vp]
+        L.ire_initialize.argtypes = [vp, cf, cf, cf, ci, ci, ci, cf]
+        L.ire_finish.argtypes = [vp]
+        L.ire_compute.argtypes = [vp, vp, ctypes.c_size_t, vp]
+        L.ire_get_binary.argtypes = [vp, vp, ctypes.c_size_t]
+        L.ire_hough_lines.argtypes = [vp, ci, ci, cf, cf, ci, vp, ci]
         _LIB = L
     return _LIB
 
@@ -213,3 +222,52 @@ class Stixels:
                                                ig.ctypes.data, ctypes.byref(vh)),
                     "GetGroundModel")
         return gf, ng, ig, vh.value
+
+
+def hough_lines(image, rho=1.0, theta=float(np.pi / 180), threshold=25, cap=4096):
+    """Standard Hough transform of the host library (RoadEstimation::HoughLines)."""
+    img = np.ascontiguousarray(image, np.uint8)
+    out = np.zeros((cap, 2), np.float32)
+    n = lib().ire_hough_lines(img.ctypes.data, img.shape[0], img.shape[1], rho, theta, threshold,
+                              out.ctypes.data, cap)
+    return out[:min(n, cap)].copy()
+
+
+class RoadEstimation:
+    """Python view of the C++ RoadEstimation class (RoadEstimation.h of the reference)."""
+
+    def __init__(self):
+        self._h = ctypes.c_void_p(lib().ire_create())
+        self._shape = None
+
+    def Initialize(self, camera_center_y, baseline, focal, rows, cols, max_dis,
+                   road_vdisparity_threshold=0.2):
+        rc = lib().ire_initialize(self._h, camera_center_y, baseline, focal, rows, cols, max_dis,
+                                  road_vdisparity_threshold)
+        if rc < 0:
+            raise RuntimeError(lib().ish_last_error().decode())
+        self._shape = (rows, max_dis)
+
+    def Compute(self, disparity):
+        a = np.ascontiguousarray(disparity, np.float32)
+        out = np.zeros(4, np.float32)
+        rc = lib().ire_compute(self._h, a.ctypes.data, a.size, out.ctypes.data)
+        if rc < 0:
+            raise RuntimeError(lib().ish_last_error().decode())
+        self.pitch, self.camera_height, self.slope = float(out[0]), float(out[1]), float(out[2])
+        self.horizon_point = int(out[3])
+        return bool(rc)
+
+    def GetBinaryVDisparity(self):
+        out = np.zeros(self._shape, np.uint8)
+        lib().ire_get_binary(self._h, out.ctypes.data, out.size)
+        return out
+
+    def Finish(self):
+        lib().ire_finish(self._h)
+
+    def close(self):
+        if self._h:
+            lib().ire_finish(self._h)
+            lib().ire_destroy(self._h)
+            self._h = ctypes.c_void_p()

@@ -9,6 +9,7 @@
 #include <exception>
 #include <string>
 
+#include "InstanceStixels/RoadEstimation.h"
 #include "InstanceStixels/Stixels.hpp"
 
 namespace {
@@ -185,6 +186,42 @@ int ish_save_stixels(void* h, Section* sections, const int* triples, int n_tripl
         Stixels::SaveStixels(sections, m, alpha_ground, vhor, s->GetRealCols(),
                              s->GetMaxSections(), fname);
     });
+}
+
+/* ---- RoadEstimation (f3) ---- */
+void* ire_create(void) { return new RoadEstimation(); }
+void ire_destroy(void* h) { delete (RoadEstimation*)h; }
+int ire_initialize(void* h, float cy, float baseline, float focal, int rows, int cols, int max_dis,
+                   float threshold) {
+    return guard([&] { ((RoadEstimation*)h)->Initialize(cy, baseline, focal, rows, cols, max_dis, threshold); });
+}
+int ire_finish(void* h) {
+    return guard([&] {
+        if (((RoadEstimation*)h)->IsInitialized()) ((RoadEstimation*)h)->Finish();
+    });
+}
+/* returns 1 if a road line was found; out = pitch, camera height, slope, horizon point */
+int ire_compute(void* h, const float* image, size_t n, float* out4) {
+    int ok = 0;
+    const int rc = guard([&] {
+        RoadEstimation* r = (RoadEstimation*)h;
+        ok = r->Compute(std::vector<pixel_t>(image, image + n)) ? 1 : 0;
+        out4[0] = r->GetPitch(); out4[1] = r->GetCameraHeight(); out4[2] = r->GetSlope();
+        out4[3] = (float)r->GetHorizonPoint();
+    });
+    return rc ? rc : ok;
+}
+int ire_get_binary(void* h, uint8_t* out, size_t n) {
+    const auto& v = ((RoadEstimation*)h)->GetBinaryVDisparity();
+    std::memcpy(out, v.data(), std::min(n, v.size()));
+    return 0;
+}
+int ire_hough_lines(const uint8_t* image, int rows, int cols, float rho, float theta, int threshold,
+                    float* out, int cap) {
+    const auto lines = RoadEstimation::HoughLines(image, rows, cols, rho, theta, threshold);
+    const int n = (int)std::min<size_t>(lines.size(), (size_t)cap);
+    for (int i = 0; i < n; i++) { out[2 * i] = lines[i].first; out[2 * i + 1] = lines[i].second; }
+    return (int)lines.size();
 }
 
 } /* extern "C" */

@@ -170,5 +170,24 @@ def compute(params: StixelParams, obj_cost_lut, obj_disparity_range, disp_joined
                 inst_indices=idx, inst_core=core, inst_per_class=per_class)
 
 
+def road_vdisparity(disparity: np.ndarray, max_dis: int, threshold: float):
+    d = np.ascontiguousarray(disparity, np.float32)
+    rows, cols = d.shape
+    vdisp = np.zeros((rows, max_dis), np.int32)
+    binary = np.zeros((rows, max_dis), np.uint8)
+    m = lib().orc_road_vdisparity(_p(d, ctypes.c_float), rows, cols, int(max_dis),
+                                  ctypes.c_float(threshold), _p(vdisp, ctypes.c_int32),
+                                  _p(binary, ctypes.c_uint8))
+    return vdisp, binary, int(m)
+
+
+def flip_and_pad(cnn_out: np.ndarray, p2s: int) -> np.ndarray:
+    x = np.ascontiguousarray(cnn_out, np.float32)
+    CH, Hs, Ws = x.shape
+    out = np.zeros((Ws, CH, p2s), np.int32)
+    lib().orc_flip_and_pad(_p(x, ctypes.c_float), _p(out, ctypes.c_int32), CH, Hs, Ws, int(p2s))
+    return out
+
+
 def logf(x: float) -> float:
     return float(lib().orc_logf(ctypes.c_float(x)))

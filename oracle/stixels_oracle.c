@@ -33,6 +33,43 @@
 
 float orc_logf(float x) { return is_logf(x); }
 
+/* RoadEstimationKernels.cu:25-60, one loop iteration per CUDA thread */
+int orc_road_vdisparity(const float* d_disparity, int rows, int cols, int max_dis, float threshold,
+                        int* d_vDisp, uint8_t* d_out) {
+    memset(d_vDisp, 0, sizeof(int) * (size_t)rows * max_dis);
+    for (int idx = 0; idx < cols * rows; idx++) { /* ComputeHistogram, :25-39 */
+        const int row = idx / cols;
+        const float d = d_disparity[idx];
+        if (d != 0) {
+            int col = (int)d;
+            d_vDisp[row * max_dis + col] += 1;
+        }
+    }
+    int maximum = 0;
+    for (int idx = 0; idx < max_dis * rows; idx++) /* ComputeMaximum, :42-50 */
+        if (d_vDisp[idx] > maximum) maximum = d_vDisp[idx];
+    for (int idx = 0; idx < max_dis * rows; idx++) { /* ComputeBinaryImage, :52-60 */
+        const float p = (float)d_vDisp[idx];
+        d_out[idx] = (p > maximum * threshold) ? 255 : 0;
+    }
+    return maximum;
+}
+
+/* FlipAndPad.forward, tools/CNN_training/models/wrappers.py:44-61 */
+void orc_flip_and_pad(const float* in, int32_t* out, int CH, int Hs, int Ws, int P2S) {
+    for (int w = 0; w < Ws; w++)            /* x.permute(0,3,1,2): [Ws][CH][Hs] */
+        for (int c = 0; c < CH; c++)
+            for (int k = 0; k < P2S; k++) {
+                int32_t v = 0;              /* F.pad(..., value=0) on the right of the last dim */
+                if (k < Hs) {
+                    float x = in[((size_t)c * Hs + (Hs - 1 - k)) * Ws + w]; /* index_select flip */
+                    x *= 8;                 /* x *= 8 */
+                    v = (int32_t)x;         /* x.int(): truncation toward zero */
+                }
+                out[((size_t)w * CH + c) * P2S + k] = v;
+            }
+}
+
 /* ------------------------------------------------------------------------------------ */
 /* Host side: Stixels::SetConfig / Initialize / PrecomputeGround                         */
 /* ------------------------------------------------------------------------------------ */

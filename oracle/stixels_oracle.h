@@ -87,6 +87,15 @@ int orc_compute(const is_stixel_params* p, const float* obj_cost_lut,
                 float* inst_centerofmass, int32_t* inst_indices, uint8_t* inst_core,
                 int32_t* inst_per_class);
 
+/* FlipAndPad, tools/CNN_training/models/wrappers.py:35-61: in [CH][Hs][Ws] float ->
+ * out [Ws][CH][P2S] int32 (permute, flip rows, zero pad, (int)(8*x)). */
+void orc_flip_and_pad(const float* in, int32_t* out, int CH, int Hs, int Ws, int P2S);
+
+/* ComputeHistogram / ComputeMaximum / ComputeBinaryImage (RoadEstimationKernels.cu:25-60):
+ * vdisp [rows][max_dis] int, binary [rows][max_dis] uint8; returns the maximum. */
+int orc_road_vdisparity(const float* disparity, int rows, int cols, int max_dis, float threshold,
+                        int* vdisp, uint8_t* binary);
+
 float orc_logf(float x); /* = is_logf, exported for tests */
 
 #ifdef __cplusplus

@@ -97,3 +97,40 @@ def test_bench_byte_formula():
     assert synthetic.algorithmic_bytes_per_image(make_config("drn_d_22_unary", 1024, 2048, 128)) == 15532032
     assert synthetic.algorithmic_bytes_per_image(make_config("drn_d_22_unary", 1024, 4096, 256)) == 31064064
     assert synthetic.pair_evaluations_per_image(make_config("drn_d_22_unary", 1024, 2048, 128)) == 134348800
+
+
+def test_hough_lines_on_synthetic_plane():
+    """f3: the host Hough transform that replaces cv::HoughLines (RoadEstimation.cu:153).  A
+    v-disparity line d = alpha * (row - v0) must come back as the strongest line with
+    rho / sin(theta) = v0 (the horizon row, RoadEstimation.cu:181)."""
+    rows, D, v0, alpha = 256, 64, 100, 0.35
+    img = np.zeros((rows, D), np.uint8)
+    for r in range(v0, rows):
+        c = int(round(alpha * (r - v0)))
+        if c < D:
+            img[r, c] = 255
+    lines = host.hough_lines(img, threshold=25)
+    assert len(lines) > 0
+    rho, theta = abs(float(lines[0][0])), float(lines[0][1])
+    assert abs(rho / np.sin(theta) - v0) <= 3.0
+    # slope as computed by ComputeCameraProperties (RoadEstimation.cu:187-189)
+    last = rows - 1
+    down = (rho - last * np.sin(theta)) / np.cos(theta)
+    slope = (0 - down) / (rho / np.sin(theta) - last)
+    assert abs(slope - alpha) < 0.03
+    assert len(host.hough_lines(np.zeros((64, 32), np.uint8))) == 0
+
+
+def test_oracle_vdisparity_kernels():
+    # RoadEstimationKernels.cu:25-60 against numpy
+    rng = np.random.default_rng(2)
+    d = (rng.random((40, 96)) * 31).astype(np.float32)
+    d[rng.random((40, 96)) < 0.2] = 0.0
+    vdisp, binary, m = oracle.road_vdisparity(d, 32, 0.2)
+    want = np.zeros((40, 32), np.int32)
+    for r in range(40):
+        for x in d[r]:
+            if x != 0:
+                want[r, int(x)] += 1
+    assert np.array_equal(vdisp, want) and m == want.max()
+    assert np.array_equal(binary, np.where(want.astype(np.float32) > np.float32(m) * np.float32(0.2), 255, 0))

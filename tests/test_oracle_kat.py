@@ -119,3 +119,13 @@ def test_object_lut_matches_sequential_to_tolerance():
         c = lut[fn, di].astype(np.float64)
         assert tab[fn, 1] == lut[fn, di[0]] + np.float32(0)
         assert np.allclose(tab[fn, 1:65], np.cumsum(c), rtol=1e-5)
+
+
+def test_flip_and_pad_matches_numpy_restatement():
+    # tools/CNN_training/models/wrappers.py:44-61: permute(0,3,1,2), flip rows, pad, *8, .int()
+    rng = np.random.default_rng(8)
+    x = (rng.normal(0, 12, (21, 12, 20))).astype(np.float32)
+    got = oracle.flip_and_pad(x, 16)
+    want = np.zeros((20, 21, 16), np.int32)
+    want[:, :, :12] = np.trunc(np.transpose(x, (2, 0, 1))[:, :, ::-1] * np.float32(8)).astype(np.int32)
+    assert np.array_equal(got, want)

@@ -253,3 +253,50 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(core, "LIB_PATH", "/nonexistent/libis_core.so")
     with pytest.raises(core.CoreError, match="no CPU fallback"):
         core.lib()
+
+
+@pytest.mark.parametrize("shape", [(21, 98, 224, 128), (21, 128, 256, 256), (21, 12, 20, 16), (3, 70, 130, 128)])
+def test_flip_and_pad_kernel(shape):
+    """f4: the CNN-output -> DP-input layout transform (wrappers.py:35-61) against the oracle."""
+    from instance_stixels_amd.core import flip_and_pad
+    from oracle import oracle
+    CH, Hs, Ws, P2S = shape
+    rng = np.random.default_rng(CH * Hs)
+    x = rng.normal(0, 15, (2, CH, Hs, Ws)).astype(np.float32)
+    got = flip_and_pad(x, P2S)
+    for i in range(2):
+        assert np.array_equal(got[i], oracle.flip_and_pad(x[i], P2S))
+
+
+def test_road_vdisparity_kernels_and_estimation():
+    """f3: v-disparity histogram / maximum / binarisation against the oracle (bit-exact), and the
+    whole RoadEstimation::Compute on a synthetic ground plane."""
+    import ctypes
+    import torch
+    from instance_stixels_amd import core, host
+    from oracle import oracle
+    case = helpers.build_case("drn_d_22_unary", 256, 512, 64, seed=61)
+    f = case["frames"][0]
+    disp = f.disparity.copy()
+    disp[::7, ::5] = 0.0                                   # zeros are skipped by the histogram
+    want_v, want_b, want_m = oracle.road_vdisparity(disp, 64, 0.2)
+    dev = torch.device("cuda", 0)
+    d = torch.from_numpy(disp).to(dev)
+    vd = torch.empty((256, 64), dtype=torch.int32, device=dev)
+    mx = torch.zeros(1, dtype=torch.int32, device=dev)
+    bn = torch.empty((256, 64), dtype=torch.uint8, device=dev)
+    rc = core.lib().is_road_vdisparity(d.data_ptr(), 256, 512, 64, ctypes.c_float(0.2), vd.data_ptr(),
+                                       mx.data_ptr(), bn.data_ptr(), None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(vd.cpu().numpy(), want_v) and int(mx.item()) == want_m
+    assert np.array_equal(bn.cpu().numpy(), want_b)
+
+    re = host.RoadEstimation()
+    re.Initialize(case["cfg"].camera_center_y * 256 / 1024, case["cfg"].baseline, case["cfg"].focal,
+                  256, 512, 64)
+    assert re.Compute(disp)
+    assert np.array_equal(re.GetBinaryVDisparity(), want_b)
+    assert abs(re.horizon_point - f.vhor_image) <= 6       # generator: ramp starts at vhor_image
+    assert abs(re.slope - f.alpha_ground) < 0.05 * f.alpha_ground + 0.02
+    re.close()
