@@ -659,6 +659,17 @@ __device__ __forceinline__ int unary_range(const DevParams& P, const RowRec& my,
                                            const float* __restrict__ lcol, const float* my_tile,
                                            const float* s_rcp, int vT, int vTc, int vhor, int vB,
                                            int nw, int bound, bool row_ok, UnaryBest& b) {
+#ifdef IS_UNROLL2
+    for (; vB + nw <= bound; vB += 2 * nw) { /* two segments per trip: one wait for both records */
+        const RowRec cur0 = sload_rec(rcol + vB);
+        const RowRec cur1 = sload_rec(rcol + vB + nw);
+        unary_step<FAST, HAS_INVALID, SKY, DIAG, false>(P, my, cur0, lcol + (size_t)vB * P.D, my_tile,
+                                                        s_rcp, vT, vTc, vhor, vB, row_ok, b);
+        unary_step<FAST, HAS_INVALID, SKY, DIAG, false>(P, my, cur1, lcol + (size_t)(vB + nw) * P.D,
+                                                        my_tile, s_rcp, vT, vTc, vhor, vB + nw, row_ok,
+                                                        b);
+    }
+#endif
     for (; vB <= bound; vB += nw) {
         const RowRec cur = sload_rec(rcol + vB);
         unary_step<FAST, HAS_INVALID, SKY, DIAG, false>(P, my, cur, lcol + (size_t)vB * P.D, my_tile,
@@ -1620,6 +1631,13 @@ hipError_t isk_launch_compact(const DevParams* P, const is_section* sections_img
     hipLaunchKernelGGL(k_compact_instances, dim3(1), dim3(256), lds, stream, *P, sections_img, com,
                        indices, core, per_class);
     return hipGetLastError();
+}
+
+int isk_debug_occupancy(const DevParams* P, int nwaves) {
+    int nb = -1;
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_dp_unary<false>, nwaves * 64,
+                                                 isk_unary_lds_bytes(P));
+    return nb;
 }
 
 hipError_t isk_set_lds_limits(const DevParams* P, int nwaves_pair) {

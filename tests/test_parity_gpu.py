@@ -77,6 +77,15 @@ def test_config2_full_frame_1024x2048x128(preset):
     _assert_parity(case, got)
 
 
+@pytest.mark.parametrize("preset", ["drn_d_22_unary", "drn_d_38_pairwise"])
+def test_tall_frame_2048_rows(preset):
+    """Beyond every structural limit of the reference (one thread per row, rows < 1024): the same
+    formulas at 2048 rows, 32 tiles per column."""
+    case = helpers.build_case(preset, 2048, 128, 64, seed=15)
+    got = helpers.run_core(case)
+    _assert_parity(case, got)
+
+
 def test_config5_ultrawide_1024x4096x256_column_subset():
     """BASELINE configs[4] (LDS-pressure shape): every 16th column against the oracle, structure
     checks on all 512 columns."""
