@@ -722,15 +722,16 @@ __global__ __launch_bounds__(IS_UNARY_WAVES * 64, IS_UNARY_WAVES) void k_dp_unar
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int H = P.H, D = P.D;
     const int DP = D + 1; /* padded row: conflict-free when lanes share fni */
-    float* s_tile = (float*)smem;             /* [64][D+1] lutT rows tile_lo+1 .. tile_lo+64 */
-    float* s_rcp = s_tile + IS_TILE * DP;     /* [H+1]     RN(1/h)                            */
+    float* s_rcp = (float*)smem;              /* [H+1 -> x4] RN(1/h), kept across both tiles   */
+    float* s_tile = s_rcp + ((H + 1 + 3) & ~3); /* [64][D+1] lutT rows tile_lo+1 .. tile_lo+64  */
 
     /* XCD-aware order: blocks b, b+8, ... share an XCD/L2; keep all tiles of a column on one
      * XCD (they gather from the same lutT) and start with the tallest tiles. */
     const int nxcd = 8;
+    const int npairs = (P.ntiles + 1) / 2;
     const int xcd = blockIdx.x % nxcd, q = blockIdx.x / nxcd;
-    const int tile = P.ntiles - 1 - (q % P.ntiles);
-    const int colg = (q / P.ntiles) * nxcd + xcd;
+    const int pair = q % npairs;
+    const int colg = (q / npairs) * nxcd + xcd;
     if (colg >= ncols) return;
     const int img = colg / P.C;
     const int vhor = vhor_arr[img];
@@ -738,16 +739,23 @@ __global__ __launch_bounds__(IS_UNARY_WAVES * 64, IS_UNARY_WAVES) void k_dp_unar
     const int tid = threadIdx.x, lane = tid & 63;
     const int nw = blockDim.x >> 6;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tile_lo = tile * IS_TILE;
     const RowRec* rcol = recs + (size_t)colg * (H + 1);
     const float* lcol = lutT + (size_t)colg * (H + 1) * D;
+    for (int i = tid; i <= H; i += blockDim.x) s_rcp[i] = rcp[i];
+
+    /* a workgroup takes the tile pair (ntiles-1-pair, pair): every workgroup then carries the
+     * same number of (vB, vT) pairs, and the per-workgroup fixed costs are paid half as often */
+    const int n_pass = (P.ntiles - 1 - pair == pair) ? 1 : 2;
+    for (int pass = 0; pass < n_pass; pass++) {
+    const int tile = pass == 0 ? (P.ntiles - 1 - pair) : pair;
+    const int tile_lo = tile * IS_TILE;
+    if (pass) __syncthreads(); /* the merge area of the first tile aliases the LUT tile */
 
     for (int i = tid; i < IS_TILE * D; i += blockDim.x) {
         const int r = i / D, f = i - r * D;
         const int v = min(tile_lo + 1 + r, H);
         s_tile[r * DP + f] = lcol[(size_t)v * D + f];
     }
-    for (int i = tid; i <= H; i += blockDim.x) s_rcp[i] = rcp[i];
 
     const int vT = tile_lo + lane;
     const int vTc = min(vT, H - 1);
@@ -768,7 +776,7 @@ __global__ __launch_bounds__(IS_UNARY_WAVES * 64, IS_UNARY_WAVES) void k_dp_unar
     /* merge the waves' partial minima: min cost, ties -> smallest vB (= first strict minimum
      * of the reference's ascending-vB loop) */
     __syncthreads();
-    float* m_cost = (float*)smem;                  /* [nw][3][64] (aliases the LUT tile) */
+    float* m_cost = s_tile;                        /* [nw][3][64] (aliases the LUT tile) */
     int* m_vb = (int*)(m_cost + nw * 3 * 64);      /* [nw][3][64] */
     m_cost[(w * 3 + 0) * 64 + lane] = b.g; m_vb[(w * 3 + 0) * 64 + lane] = b.vg;
     m_cost[(w * 3 + 1) * 64 + lane] = b.o; m_vb[(w * 3 + 1) * 64 + lane] = b.vo;
@@ -790,6 +798,7 @@ __global__ __launch_bounds__(IS_UNARY_WAVES * 64, IS_UNARY_WAVES) void k_dp_unar
             index_table[o] = vb;
         }
     }
+    } /* pass */
 }
 
 /* ====================================================================================== */
@@ -1515,9 +1524,10 @@ size_t isk_prepare_lds_bytes(const DevParams* P) {
     return sizeof(float) * (size_t)P->P2 * 3 + sizeof(int32_t) * (size_t)P->CH * P->P2S + 64;
 }
 size_t isk_unary_lds_bytes(const DevParams* P) {
-    const size_t a = sizeof(float) * ((size_t)IS_TILE * (P->D + 1) + (size_t)P->H + 1);
-    const size_t b = (size_t)8 * 3 * 64 * 8; /* merge area for up to 8 waves */
-    return (a > b ? a : b) + 16;
+    const size_t rcp = sizeof(float) * (((size_t)P->H + 1 + 3) & ~(size_t)3);
+    const size_t tile = sizeof(float) * (size_t)IS_TILE * (P->D + 1);
+    const size_t merge = (size_t)IS_UNARY_WAVES * 3 * 64 * 8; /* aliases the tile after the loop */
+    return rcp + (tile > merge ? tile : merge) + 16;
 }
 size_t isk_pairwise_lds_bytes(const DevParams* P, int nwaves) { return isk_unary_lds_bytes(P); }
 size_t isk_phase2_lds_bytes(const DevParams* P) {
@@ -1558,7 +1568,7 @@ hipError_t isk_launch_dp_unary(const DevParams* P, int ncols, int nwaves, const 
                                const int* col_flags, float* cost_table, int32_t* index_table,
                                hipStream_t stream) {
     const int groups = (ncols + 7) / 8;
-    const dim3 grid(groups * 8 * P->ntiles);
+    const dim3 grid(groups * 8 * ((P->ntiles + 1) / 2));
     const size_t lds = isk_unary_lds_bytes(P);
     if (P->invalid >= 0)
         hipLaunchKernelGGL(k_dp_unary<true>, grid, dim3(nwaves * 64), lds, stream, *P, ncols, recs,
