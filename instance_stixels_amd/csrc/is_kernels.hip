@@ -1104,37 +1104,6 @@ __global__ __launch_bounds__(IS_UNARY_WAVES * 64, IS_UNARY_WAVES) void k_pw_phas
                                            part_idx);
 }
 
-/* wave-uniform copy of lane `l`'s record (the record at vB = tile_lo + s IS lane s-1's vT+1
- * record, so the diagonal walk needs no memory access for its vB side) */
-__device__ __forceinline__ RowRec bcast_rec(const RowRec& my, int l) {
-    RowRec r;
-    const int* src = reinterpret_cast<const int*>(&my);
-    int* dst = reinterpret_cast<int*>(&r);
-#pragma unroll
-    for (int i = 0; i < 32; i++) dst[i] = __builtin_amdgcn_readlane(src[i], l);
-    return r;
-}
-
-struct DiagPre { /* lane-dependent, DP-state independent part of one diagonal step */
-    SegTerms t;
-    float od_hi, od_lo;
-};
-
-template <bool FAST, bool HAS_INVALID>
-__device__ __forceinline__ DiagPre diag_prefetch(const DevParams& P, const RowRec& my, int s,
-                                                 int vTc, int tile_lo, const float* __restrict__ rcp,
-                                                 const float* __restrict__ my_row,
-                                                 const float* __restrict__ lcol) {
-    DiagPre d;
-    const int vB = tile_lo + s;
-    const RowRec rb = bcast_rec(my, s - 1);
-    const int hc = max(vTc + 1 - vB, 1);
-    d.t = eval_segment<FAST, HAS_INVALID>(my, rb, (float)hc, rcp[hc], P.D, P.iw);
-    d.od_hi = my_row[(unsigned)d.t.fni];
-    d.od_lo = (lcol + (size_t)vB * P.D)[(unsigned)d.t.fni];
-    return d;
-}
-
 template <bool FAST, bool HAS_INVALID>
 __device__ __forceinline__ void pw_phase2_body(const DevParams& P, char* smem, int colg, int tile,
                                                const RowRec* __restrict__ recs,
@@ -1182,21 +1151,18 @@ __device__ __forceinline__ void pw_phase2_body(const DevParams& P, char* smem, i
     st.pwmp = IS_INF; st.idx_gs = -1;
     st.g_hi_thr = st.g_lo_thr = st.p1_hi = st.p1_lo = st.p1_mid = st.o_hi_thr = st.o_lo_thr = 0.0f;
     st.p2_hi = st.p2_lo = st.p2_mid = st.p3_yes = st.p3_no = 0.0f;
-    DiagPre cur;
-    if (n_rows > 1) cur = diag_prefetch<FAST, HAS_INVALID>(P, my, 1, vTc, tile_lo, rcp, my_row, lcol);
     for (int s = 0; s < n_rows; s++) {
         const int r = tile_lo + s; /* row that becomes final in this step */
-        /* independent of the DP state: everything of the NEXT step that is lane-dependent */
-        DiagPre nxt = cur;
-        if (s >= 1 && s + 1 < n_rows)
-            nxt = diag_prefetch<FAST, HAS_INVALID>(P, my, s + 1, vTc, tile_lo, rcp, my_row, lcol);
-        if (s > 0) {
+        if (s > 0) { /* segments starting at vB = r: lanes vT >= r */
+            const RowRec rb = sload_rec(rcol + r);
+            const int hc = max(vTc + 1 - r, 1);
             const bool live = (vT < H) && (vT >= r);
+            const SegTerms t = eval_segment<FAST, HAS_INVALID>(my, rb, (float)hc, rcp[hc], D, P.iw);
+            const float od = my_row[(unsigned)t.fni] - (lcol + (size_t)r * D)[(unsigned)t.fni];
             if (r - 1 < vhor)
-                pairwise_step<false>(P, st, r, live, cur.od_hi - cur.od_lo, cur.t, b);
+                pairwise_step<false>(P, st, r, live, od, t, b);
             else
-                pairwise_step<true>(P, st, r, live, cur.od_hi - cur.od_lo, cur.t, b);
-            cur = nxt;
+                pairwise_step<true>(P, st, r, live, od, t, b);
         }
         /* lane s holds the final values of row r: broadcast, derive the StepRec of vB = r+1 */
         if (r + 1 < H) {

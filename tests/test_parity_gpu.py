@@ -309,3 +309,20 @@ def test_road_vdisparity_kernels_and_estimation():
     assert abs(re.horizon_point - f.vhor_image) <= 6       # generator: ramp starts at vhor_image
     assert abs(re.slope - f.alpha_ground) < 0.05 * f.alpha_ground + 0.02
     re.close()
+
+
+def test_plain_cpp_caller_runs():
+    """examples/run_synthetic.cpp: the reference's run_cityscapes call sequence from a g++-built
+    translation unit (RoadEstimation -> SetRoadParameters -> Compute -> SaveStixels)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "run_synthetic")
+    if not os.path.exists(exe):
+        pytest.skip("examples/run_synthetic not built (run __graft_entry__.build())")
+    for pairwise in ("0", "1"):
+        out = subprocess.run([exe, "256", "512", "64", pairwise, "3"], capture_output=True, text=True,
+                             timeout=120)
+        assert out.returncode == 0, out.stdout + out.stderr
+        assert "stixels" in out.stdout and "horizon row" in out.stdout
+        hor = int(out.stdout.split("horizon row")[1].split()[0])
+        assert abs(hor - int(0.45 * 256)) <= 8
