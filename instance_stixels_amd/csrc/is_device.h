@@ -18,7 +18,10 @@
 #ifndef IS_UNARY_WAVES
 #define IS_UNARY_WAVES 8   /* waves per unary-DP workgroup; x4 workgroups/CU (LDS) = waves/SIMD */
 #endif
-#define IS_TILE 64          /* rows (vT values) per DP tile = one wavefront */
+#ifndef IS_UNARY_OCC
+#define IS_UNARY_OCC IS_UNARY_WAVES /* waves per SIMD the unary DP is compiled for (VGPR budget 512/OCC) */
+#endif
+#define IS_TILE 64
 #define IS_N_ON 8           /* non-instance object classes 2..9   (Cityscapes.h:69) */
 #define IS_N_OI 8           /* instance object classes     11..18 (Cityscapes.h:75) */
 

@@ -491,6 +491,13 @@ struct SegTerms {
     int fni;                   /* floor(mean), clamped to [0, D-1]                          */
 };
 
+/* v_cvt_u32_f32: round toward zero, saturating (negative -> 0, NaN -> 0) */
+__device__ __forceinline__ unsigned cvt_u32_sat(float x) {
+    unsigned u;
+    asm("v_cvt_u32_f32 %0, %1" : "=v"(u) : "v"(x));
+    return u;
+}
+
 /* a / h for an integer-valued h in [1, 11000] with r = RN(1/h): one multiplication and two
  * FMAs give the correctly rounded IEEE quotient for every fp32 a in [2^-100, 2^100] and a = 0
  * (exhaustively verified over all 2^23 mantissas x all h by tools/verify_exact_division.c). */
@@ -585,9 +592,10 @@ __device__ __forceinline__ SegTerms eval_segment(const RowRec& my, const RowRec&
         mean = (my.S - rb.S) / height;
     }
     if (FAST) {
-        mean = __builtin_fmaxf(mean, 0.0f); /* :525-527; the mean is finite in FAST columns */
-        t.mean = mean;
-        t.fni = (int)min((unsigned)mean, (unsigned)(D - 1)); /* = floorf for a finite mean >= 0 */
+        /* :525-527; the mean is finite in FAST columns, and v_cvt_u32_f32 saturates (x < 0 -> 0),
+         * so the clamp at 0 is part of the conversion; = floorf for a finite mean >= 0 */
+        t.fni = (int)min(cvt_u32_sat(mean), (unsigned)(D - 1));
+        t.mean = __builtin_fmaxf(mean, 0.0f); /* (only the pairwise model reads it) */
     } else {
         if (mean < 0) mean = 0; /* :525-527 */
         t.mean = mean;
@@ -624,9 +632,42 @@ struct UnaryBest {
  *         separate loops and each loop has ONE accumulator pair live in its body;
  *   DIAG  the segment start may lie above this lane's vT (diagonal 64x64 block): masked lanes;
  *   FIRST vB = 0: ground additionally needs vT <= vhor (:542-545). */
-template <bool FAST, bool HAS_INVALID, bool SKY, bool DIAG, bool FIRST>
+/* vB-side row of lutT.  NR > 0: the wave holds the whole row in NR registers per lane (element
+ * j*64 + lane), fetched with coalesced loads one step AHEAD of its use -- the address does not
+ * depend on the segment -- and a lane picks its element fni with ds_bpermute (no memory access on
+ * the dependent chain mean -> fni -> LUT value).  NR == 0 (D > 64*NR_MAX): per-lane gather. */
+template <int NR>
+struct LutRow {
+    float r[NR > 0 ? NR : 1];
+    const float* lrow;
+};
+/* Whole-row fetch through a raw buffer resource of the column's lutT: scalar row offset (SALU),
+ * lane offset in a VGPR, no VALU address arithmetic; reads past the column return 0. */
+template <int NR>
+__device__ __forceinline__ void load_lut_row(LutRow<NR>& row, __amdgpu_buffer_rsrc_t lrsrc,
+                                             const float* __restrict__ lcol, int v, int D, int lane4) {
+    row.lrow = lcol + (size_t)v * D;
+#pragma unroll
+    for (int j = 0; j < NR; j++)
+        row.r[j] = __int_as_float(
+            __builtin_amdgcn_raw_buffer_load_b32(lrsrc, lane4, v * D * 4 + j * 256, 0));
+}
+template <int NR>
+__device__ __forceinline__ float pick_lut(const LutRow<NR>& row, int fni) {
+    if (NR == 0) return row.lrow[(unsigned)fni];
+    const int sel = fni << 2; /* ds_bpermute takes the source lane from address bits [7:2] */
+    float v = __int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(row.r[0])));
+#pragma unroll
+    for (int j = 1; j < NR; j++) {
+        const float vj = __int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(row.r[j])));
+        v = (fni >= 64 * j) ? vj : v;
+    }
+    return v;
+}
+
+template <bool FAST, bool HAS_INVALID, bool SKY, bool DIAG, bool FIRST, int NR>
 __device__ __forceinline__ void unary_step(const DevParams& P, const RowRec& my, const RowRec& rb,
-                                           const float* __restrict__ lrow, const float* my_tile,
+                                           const LutRow<NR>& lrow, const float* my_tile,
                                            const float* s_rcp, int vT, int vTc, int vhor, int vB,
                                            bool row_ok, UnaryBest& b) {
     const int h = vTc + 1 - vB;
@@ -634,8 +675,43 @@ __device__ __forceinline__ void unary_step(const DevParams& P, const RowRec& my,
     const int hc = DIAG ? max(h, 1) : h;
     const float r = s_rcp[hc]; /* RN(1/h) = (float)(1./h) = inverse_height, :485, :608 */
     const SegTerms t = eval_segment<FAST, HAS_INVALID>(my, rb, (float)hc, r, P.D, P.iw);
-    const float od = my_tile[t.fni] - lrow[(unsigned)t.fni];
+    const float od = my_tile[t.fni] - pick_lut<NR>(lrow, t.fni);
     const float pwih = P.pw * r;
+#ifdef IS_ABL_FMA /* ablation: IS_ABL_FMA extra independent fp32 FMAs per step */
+    {
+        float x0 = r, x1 = t.gd, x2 = t.sd, x3 = t.mean;
+#pragma unroll
+        for (int i = 0; i < IS_ABL_FMA / 4; i++) {
+            x0 = __builtin_fmaf(x0, P.dw, P.pw); x1 = __builtin_fmaf(x1, P.dw, P.pw);
+            x2 = __builtin_fmaf(x2, P.dw, P.pw); x3 = __builtin_fmaf(x3, P.dw, P.pw);
+        }
+        asm volatile("" ::"v"(x0), "v"(x1), "v"(x2), "v"(x3));
+    }
+#endif
+#ifdef IS_ABL_PK /* ablation: IS_ABL_PK extra independent v_pk_fma_f32 per step */
+    {
+        typedef float abl_f2 __attribute__((ext_vector_type(2)));
+        abl_f2 x0 = {r, t.gd}, x1 = {t.gd, t.sd}, x2 = {t.sd, t.mean}, x3 = {t.mean, r};
+        const abl_f2 ka = {P.dw, P.sw}, kb = {P.pw, P.iw};
+#pragma unroll
+        for (int i = 0; i < IS_ABL_PK / 4; i++) {
+            x0 = __builtin_elementwise_fma(x0, ka, kb); x1 = __builtin_elementwise_fma(x1, ka, kb);
+            x2 = __builtin_elementwise_fma(x2, ka, kb); x3 = __builtin_elementwise_fma(x3, ka, kb);
+        }
+        asm volatile("" ::"v"(x0), "v"(x1), "v"(x2), "v"(x3));
+    }
+#endif
+#ifdef IS_ABL_MIN /* ablation: IS_ABL_MIN extra independent v_min_f32 per step */
+    {
+        float x0 = r, x1 = t.gd, x2 = t.sd, x3 = t.mean;
+#pragma unroll
+        for (int i = 0; i < IS_ABL_MIN / 4; i++) {
+            x0 = __builtin_fminf(x0, P.dw + (float)i); x1 = __builtin_fminf(x1, P.pw + (float)i);
+            x2 = __builtin_fminf(x2, P.sw + (float)i); x3 = __builtin_fminf(x3, P.iw + (float)i);
+            asm volatile("" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3));
+        }
+    }
+#endif
     /* cost = dw*data + pw*(1/h) + sw*seg, left to right (:716-719, 762-765, 820-823) */
     const float cost_o = P.dw * od + pwih + P.sw * t.seg_o;
     const bool uo = live && (cost_o < b.o);
@@ -654,27 +730,20 @@ __device__ __forceinline__ void unary_step(const DevParams& P, const RowRec& my,
     }
 }
 
-template <bool FAST, bool HAS_INVALID, bool SKY, bool DIAG>
+template <bool FAST, bool HAS_INVALID, bool SKY, bool DIAG, int NR>
 __device__ __forceinline__ int unary_range(const DevParams& P, const RowRec& my,
                                            const RowRec* __restrict__ rcol,
                                            const float* __restrict__ lcol, const float* my_tile,
                                            const float* s_rcp, int vT, int vTc, int vhor, int vB,
-                                           int nw, int bound, bool row_ok, UnaryBest& b) {
-#ifdef IS_UNROLL2
-    for (; vB + nw <= bound; vB += 2 * nw) { /* two segments per trip: one wait for both records */
-        const RowRec cur0 = sload_rec(rcol + vB);
-        const RowRec cur1 = sload_rec(rcol + vB + nw);
-        unary_step<FAST, HAS_INVALID, SKY, DIAG, false>(P, my, cur0, lcol + (size_t)vB * P.D, my_tile,
-                                                        s_rcp, vT, vTc, vhor, vB, row_ok, b);
-        unary_step<FAST, HAS_INVALID, SKY, DIAG, false>(P, my, cur1, lcol + (size_t)(vB + nw) * P.D,
-                                                        my_tile, s_rcp, vT, vTc, vhor, vB + nw, row_ok,
-                                                        b);
-    }
-#endif
+                                           int nw, int bound, bool row_ok, int lane4,
+                                           __amdgpu_buffer_rsrc_t lrsrc, LutRow<NR>& next_row,
+                                           UnaryBest& b) {
     for (; vB <= bound; vB += nw) {
         const RowRec cur = sload_rec(rcol + vB);
-        unary_step<FAST, HAS_INVALID, SKY, DIAG, false>(P, my, cur, lcol + (size_t)vB * P.D, my_tile,
-                                                        s_rcp, vT, vTc, vhor, vB, row_ok, b);
+        const LutRow<NR> row = next_row;
+        load_lut_row<NR>(next_row, lrsrc, lcol, min(vB + nw, P.H), P.D, lane4); /* row H exists */
+        unary_step<FAST, HAS_INVALID, SKY, DIAG, false, NR>(P, my, cur, row, my_tile, s_rcp, vT, vTc,
+                                                            vhor, vB, row_ok, b);
     }
     return vB;
 }
@@ -682,37 +751,45 @@ __device__ __forceinline__ int unary_range(const DevParams& P, const RowRec& my,
 /* The wave walks vB = w, w+nw, ... <= vB_end in ascending order through (at most) four ranges:
  * ground/full, ground/diagonal, sky/full, sky/diagonal (ground while vB <= vhor; "full" while
  * every lane of the tile has vT >= vB, i.e. vB <= tile_lo). */
-template <bool FAST, bool HAS_INVALID>
+template <bool FAST, bool HAS_INVALID, int NR>
 __device__ __forceinline__ void unary_loop(const DevParams& P, const RowRec& my,
                                            const RowRec* __restrict__ rcol,
                                            const float* __restrict__ lcol, const float* my_tile,
                                            const float* s_rcp, int vT, int vTc, int vhor, int w,
-                                           int nw, int tile_lo, int vB_end, UnaryBest& b) {
+                                           int nw, int tile_lo, int vB_end, int lane4,
+                                           __amdgpu_buffer_rsrc_t lrsrc, UnaryBest& b) {
     const bool row_ok = vT < P.H;
     int vB = w;
     if (vB > vB_end) return;
-    if (vB == 0) { /* first segment (:481-594): ground + object, always "full" for tile 0? no: */
+    LutRow<NR> next_row; /* lutT row of the step that comes next */
+    load_lut_row<NR>(next_row, lrsrc, lcol, vB, P.D, lane4);
+    if (vB == 0) { /* first segment (:481-594): ground + object */
         const RowRec cur = sload_rec(rcol);
+        const LutRow<NR> row = next_row;
+        load_lut_row<NR>(next_row, lrsrc, lcol, min(nw, P.H), P.D, lane4);
         if (tile_lo == 0)
-            unary_step<FAST, HAS_INVALID, false, true, true>(P, my, cur, lcol, my_tile, s_rcp, vT, vTc,
-                                                             vhor, 0, row_ok, b);
+            unary_step<FAST, HAS_INVALID, false, true, true, NR>(P, my, cur, row, my_tile, s_rcp, vT,
+                                                                 vTc, vhor, 0, row_ok, b);
         else
-            unary_step<FAST, HAS_INVALID, false, false, true>(P, my, cur, lcol, my_tile, s_rcp, vT, vTc,
-                                                              vhor, 0, row_ok, b);
+            unary_step<FAST, HAS_INVALID, false, false, true, NR>(P, my, cur, row, my_tile, s_rcp, vT,
+                                                                  vTc, vhor, 0, row_ok, b);
         vB += nw;
     }
-    vB = unary_range<FAST, HAS_INVALID, false, false>(P, my, rcol, lcol, my_tile, s_rcp, vT, vTc, vhor,
-                                                      vB, nw, min(min(vhor, tile_lo), vB_end), row_ok, b);
-    vB = unary_range<FAST, HAS_INVALID, false, true>(P, my, rcol, lcol, my_tile, s_rcp, vT, vTc, vhor,
-                                                     vB, nw, min(vhor, vB_end), row_ok, b);
-    vB = unary_range<FAST, HAS_INVALID, true, false>(P, my, rcol, lcol, my_tile, s_rcp, vT, vTc, vhor,
-                                                     vB, nw, min(tile_lo, vB_end), row_ok, b);
-    unary_range<FAST, HAS_INVALID, true, true>(P, my, rcol, lcol, my_tile, s_rcp, vT, vTc, vhor, vB, nw,
-                                               vB_end, row_ok, b);
+    vB = unary_range<FAST, HAS_INVALID, false, false, NR>(P, my, rcol, lcol, my_tile, s_rcp, vT, vTc,
+                                                          vhor, vB, nw, min(min(vhor, tile_lo), vB_end),
+                                                          row_ok, lane4, lrsrc, next_row, b);
+    vB = unary_range<FAST, HAS_INVALID, false, true, NR>(P, my, rcol, lcol, my_tile, s_rcp, vT, vTc,
+                                                         vhor, vB, nw, min(vhor, vB_end), row_ok, lane4,
+                                                         lrsrc, next_row, b);
+    vB = unary_range<FAST, HAS_INVALID, true, false, NR>(P, my, rcol, lcol, my_tile, s_rcp, vT, vTc,
+                                                         vhor, vB, nw, min(tile_lo, vB_end), row_ok,
+                                                         lane4, lrsrc, next_row, b);
+    unary_range<FAST, HAS_INVALID, true, true, NR>(P, my, rcol, lcol, my_tile, s_rcp, vT, vTc, vhor, vB,
+                                                   nw, vB_end, row_ok, lane4, lrsrc, next_row, b);
 }
 
-template <bool HAS_INVALID>
-__global__ __launch_bounds__(IS_UNARY_WAVES * 64, IS_UNARY_WAVES) void k_dp_unary(const DevParams P, int ncols,
+template <bool HAS_INVALID, int NR>
+__global__ __launch_bounds__(IS_UNARY_WAVES * 64, IS_UNARY_OCC) void k_dp_unary(const DevParams P, int ncols,
                                                   const RowRec* __restrict__ recs,
                                                   const float* __restrict__ lutT,
                                                   const float* __restrict__ rcp,
@@ -732,12 +809,13 @@ __global__ __launch_bounds__(IS_UNARY_WAVES * 64, IS_UNARY_WAVES) void k_dp_unar
     const int nxcd = 8;
     const int npairs = (P.ntiles + 1) / 2;
     const int wg_per_col = (npairs + pairs_per_wg - 1) / pairs_per_wg;
+    /* (integer division runs on the VALU: pin the uniform results back into SGPRs) */
     const int xcd = blockIdx.x % nxcd, q = blockIdx.x / nxcd;
-    const int wg_in_col = q % wg_per_col;
-    const int colg = (q / wg_per_col) * nxcd + xcd;
+    const int wg_in_col = __builtin_amdgcn_readfirstlane(q % wg_per_col);
+    const int colg = __builtin_amdgcn_readfirstlane((q / wg_per_col) * nxcd + xcd);
     if (colg >= ncols) return;
-    const int img = colg / P.C;
-    const int vhor = vhor_arr[img];
+    const int img = __builtin_amdgcn_readfirstlane(colg / P.C);
+    const int vhor = __builtin_amdgcn_readfirstlane(vhor_arr[img]);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int nw = blockDim.x >> 6;
@@ -745,6 +823,8 @@ __global__ __launch_bounds__(IS_UNARY_WAVES * 64, IS_UNARY_WAVES) void k_dp_unar
     const RowRec* rcol = recs + (size_t)colg * (H + 1);
     const float* lcol = lutT + (size_t)colg * (H + 1) * D;
     for (int i = tid; i <= H; i += blockDim.x) s_rcp[i] = rcp[i];
+    const __amdgpu_buffer_rsrc_t lrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)lcol, 0, (H + 1) * D * (int)sizeof(float), 0x00020000 /* raw, 32-bit data */);
 
     /* a workgroup takes the tile pair (ntiles-1-pair, pair): every workgroup then carries the
      * same number of (vB, vT) pairs, and the per-workgroup fixed costs are paid half as often */
@@ -775,9 +855,11 @@ __global__ __launch_bounds__(IS_UNARY_WAVES * 64, IS_UNARY_WAVES) void k_dp_unar
     const float* my_tile = s_tile + lane * DP;
     const int vB_end = min(tile_lo + IS_TILE - 1, H - 1);
     if (__builtin_amdgcn_readfirstlane(col_flags[colg]) == 0)
-        unary_loop<true, HAS_INVALID>(P, my, rcol, lcol, my_tile, s_rcp, vT, vTc, vhor, w, nw, tile_lo, vB_end, b);
+        unary_loop<true, HAS_INVALID, NR>(P, my, rcol, lcol, my_tile, s_rcp, vT, vTc, vhor, w, nw, tile_lo,
+                                          vB_end, lane * 4, lrsrc, b);
     else
-        unary_loop<false, HAS_INVALID>(P, my, rcol, lcol, my_tile, s_rcp, vT, vTc, vhor, w, nw, tile_lo, vB_end, b);
+        unary_loop<false, HAS_INVALID, NR>(P, my, rcol, lcol, my_tile, s_rcp, vT, vTc, vhor, w, nw, tile_lo,
+                                           vB_end, lane * 4, lrsrc, b);
 
     /* merge the waves' partial minima: min cost, ties -> smallest vB (= first strict minimum
      * of the reference's ascending-vB loop) */
@@ -798,11 +880,19 @@ __global__ __launch_bounds__(IS_UNARY_WAVES * 64, IS_UNARY_WAVES) void k_dp_unar
             const bool take = (c2 < c) || (c2 == c && vb2 >= 0 && (vb < 0 || vb2 < vb));
             if (take) { c = c2; vb = vb2; }
         }
-        if (vT < H) {
-            const size_t o = ((size_t)colg * H + vT) * 3 + type;
-            cost_table[o] = c;
-            index_table[o] = vb;
-        }
+        /* final (cost, vB) of this type back to LDS: one wave then writes the three types of a
+         * row as 12 contiguous bytes (a wave-wide contiguous 768-byte store) instead of three
+         * waves writing every third dword */
+        m_cost[type * 64 + lane] = c;
+        m_vb[type * 64 + lane] = vb;
+    }
+    __syncthreads();
+    if (w == 0 && vT < H) {
+        const size_t o = ((size_t)colg * H + vT) * 3;
+        float* cd = cost_table + o;
+        int32_t* id = index_table + o;
+        cd[0] = m_cost[0 * 64 + lane]; cd[1] = m_cost[1 * 64 + lane]; cd[2] = m_cost[2 * 64 + lane];
+        id[0] = m_vb[0 * 64 + lane]; id[1] = m_vb[1 * 64 + lane]; id[2] = m_vb[2 * 64 + lane];
     }
     } /* pass */
     } /* pair */
@@ -1548,12 +1638,17 @@ hipError_t isk_launch_dp_unary(const DevParams* P, int ncols, int nwaves, const 
     const int wg_per_col = (npairs + pairs_per_wg - 1) / pairs_per_wg;
     const dim3 grid(groups * 8 * wg_per_col);
     const size_t lds = isk_unary_lds_bytes(P);
-    if (P->invalid >= 0)
-        hipLaunchKernelGGL(k_dp_unary<true>, grid, dim3(nwaves * 64), lds, stream, *P, ncols, recs,
-                           lutT, rcp, vhor, col_flags, cost_table, index_table, pairs_per_wg);
-    else
-        hipLaunchKernelGGL(k_dp_unary<false>, grid, dim3(nwaves * 64), lds, stream, *P, ncols, recs,
-                           lutT, rcp, vhor, col_flags, cost_table, index_table, pairs_per_wg);
+    /* D <= 128: the vB-side lutT row travels in two registers per lane (LutRow<2>); wider
+     * tables gather per lane */
+#define IS_LAUNCH_UNARY(INV, NR)                                                                   \
+    hipLaunchKernelGGL((k_dp_unary<INV, NR>), grid, dim3(nwaves * 64), lds, stream, *P, ncols,     \
+                       recs, lutT, rcp, vhor, col_flags, cost_table, index_table, pairs_per_wg)
+    if (P->D <= 128) {
+        if (P->invalid >= 0) IS_LAUNCH_UNARY(true, 2); else IS_LAUNCH_UNARY(false, 2);
+    } else {
+        if (P->invalid >= 0) IS_LAUNCH_UNARY(true, 0); else IS_LAUNCH_UNARY(false, 0);
+    }
+#undef IS_LAUNCH_UNARY
     return hipGetLastError();
 }
 
@@ -1623,8 +1718,8 @@ hipError_t isk_launch_compact(const DevParams* P, const is_section* sections_img
 
 int isk_debug_occupancy(const DevParams* P, int nwaves) {
     int nb = -1;
-    hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_dp_unary<false>, nwaves * 64,
-                                                 isk_unary_lds_bytes(P));
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_dp_unary<false, 2>,
+                                                 nwaves * 64, isk_unary_lds_bytes(P));
     return nb;
 }
 
@@ -1634,9 +1729,13 @@ hipError_t isk_set_lds_limits(const DevParams* P, int nwaves_pair) {
     e = hipFuncSetAttribute((const void*)k_prepare_columns, hipFuncAttributeMaxDynamicSharedMemorySize, a);
     if (e != hipSuccess) return e;
     const int b = (int)isk_unary_lds_bytes(P);
-    e = hipFuncSetAttribute((const void*)k_dp_unary<true>, hipFuncAttributeMaxDynamicSharedMemorySize, b);
+    e = hipFuncSetAttribute((const void*)k_dp_unary<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, b);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute((const void*)k_dp_unary<false>, hipFuncAttributeMaxDynamicSharedMemorySize, b);
+    e = hipFuncSetAttribute((const void*)k_dp_unary<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, b);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void*)k_dp_unary<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, b);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void*)k_dp_unary<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, b);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void*)k_backtrace, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)(sizeof(int) * (6 * (size_t)P->H + 3 * (size_t)P->S + 4)));
