@@ -31,7 +31,7 @@ hipError_t isk_launch_dp_unary(const DevParams*, int, int, const RowRec*, const 
 hipError_t isk_launch_dp_pairwise(const DevParams*, int, int, const RowRec*, const float*,
                                   const PriorRec*, const float*, const float*, const float*,
                                   const int*, const int*, StepRec*, float*, int*, float*, int32_t*,
-                                  hipStream_t);
+                                  hipStream_t, hipStream_t, hipEvent_t, hipEvent_t);
 hipError_t isk_launch_backtrace(const DevParams*, int, int, const RowRec*, const float*,
                                 const int32_t*, const int*, is_section*, hipStream_t);
 hipError_t isk_launch_compact(const DevParams*, const is_section*, float*, int32_t*, uint8_t*,
@@ -76,6 +76,8 @@ struct is_ctx {
     float* h_ground_pinned;
     int* h_vhor_pinned;
     hipEvent_t staging_free; /* recorded after the H2D copies of the last call */
+    hipStream_t aux_stream;  /* second stream of the pairwise DP (two half batches in flight) */
+    hipEvent_t ev_fork, ev_join;
     bool staging_pending;
     /* scratch */
     RowRec* d_recs;          /* [max_batch*C][H+1] */
@@ -210,6 +212,9 @@ int is_ctx_create(const is_stixel_params* p, const float* obj_cost_lut,
     HIP_TRY(hipHostMalloc((void**)&c->h_ground_pinned, sizeof(float) * B * 3 * H));
     HIP_TRY(hipHostMalloc((void**)&c->h_vhor_pinned, sizeof(int) * B));
     HIP_TRY(hipEventCreateWithFlags(&c->staging_free, hipEventDisableTiming));
+    HIP_TRY(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     for (int i = 0; i < 4; i++) HIP_TRY(hipEventCreate(&c->ev[i]));
 
     {
@@ -255,6 +260,9 @@ int is_ctx_destroy(is_ctx* c) {
     hipFree(c->d_cost_table); hipFree(c->d_index_table);
     hipHostFree(c->h_ground_pinned); hipHostFree(c->h_vhor_pinned);
     hipEventDestroy(c->staging_free);
+    if (c->aux_stream) hipStreamDestroy(c->aux_stream);
+    if (c->ev_fork) hipEventDestroy(c->ev_fork);
+    if (c->ev_join) hipEventDestroy(c->ev_join);
     for (int i = 0; i < 4; i++) hipEventDestroy(c->ev[i]);
     free(c);
     return IS_OK;
@@ -357,7 +365,7 @@ int is_compute(is_ctx* c, const float* d_joined, const int32_t* d_seg, const flo
         HIP_TRY(isk_launch_dp_pairwise(&P, ncols, c->nwaves_pairwise, c->d_recs, c->d_lutT,
                                        c->d_priors, c->d_odr, c->d_rcp, c->d_sv, c->d_vhor,
                                        c->d_col_flags, c->d_steps, c->d_part_cost, c->d_part_idx, ct, it,
-                                       stream));
+                                       stream, c->aux_stream, c->ev_fork, c->ev_join));
     else
         HIP_TRY(isk_launch_dp_unary(&P, ncols, c->nwaves_unary, c->d_recs, c->d_lutT, c->d_rcp,
                                     c->d_vhor, c->d_col_flags, ct, it, stream));

@@ -1083,7 +1083,7 @@ __device__ __forceinline__ void pairwise_step(const DevParams& P, const StepVals
  *
  * The serial chain of the reference (rows x __syncthreads, StixelsKernels.cu:600-603) is thus
  * confined to phase 2, 1/16 of the pair evaluations at 1024 rows. */
-template <bool FAST, bool HAS_INVALID>
+template <bool FAST, bool HAS_INVALID, int NR>
 __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, int colg, int tile,
                                                const RowRec* __restrict__ recs,
                                                const float* __restrict__ lutT,
@@ -1122,6 +1122,12 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
     b.io = IS_OBJECT; /* :592 */
     const int vB_last = min(tile_lo, H - 1);
     int vB = w;
+    /* vB-side lutT row: fetched one step ahead, picked with ds_bpermute (see LutRow) */
+    const __amdgpu_buffer_rsrc_t lrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)lcol, 0, (H + 1) * D * (int)sizeof(float), 0x00020000);
+    const int lane4 = lane * 4;
+    LutRow<NR> next_row;
+    if (vB <= vB_last) load_lut_row<NR>(next_row, lrsrc, lcol, vB == 0 ? min(nw, H) : vB, D, lane4);
     if (vB == 0) { /* first segment, :481-594 */
         const RowRec rb = sload_rec(rcol);
         const int h = vTc + 1;
@@ -1140,17 +1146,21 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
     for (; vB <= min(vhor, vB_last); vB += nw) { /* ground range: vB-1 < vhor */
         const RowRec rb = sload_rec(rcol + vB);
         const StepVals st = sload_step(scol + vB);
+        const LutRow<NR> row = next_row;
+        load_lut_row<NR>(next_row, lrsrc, lcol, min(vB + nw, H), D, lane4);
         const int h = vTc + 1 - vB;
         const SegTerms t = eval_segment<FAST, HAS_INVALID>(my, rb, (float)h, s_rcp[h], D, P.iw);
-        const float od = my_tile[t.fni] - (lcol + (size_t)vB * D)[(unsigned)t.fni];
+        const float od = my_tile[t.fni] - pick_lut<NR>(row, t.fni);
         pairwise_step<false>(P, st, vB, live, od, t, b);
     }
     for (; vB <= vB_last; vB += nw) { /* sky range */
         const RowRec rb = sload_rec(rcol + vB);
         const StepVals st = sload_step(scol + vB);
+        const LutRow<NR> row = next_row;
+        load_lut_row<NR>(next_row, lrsrc, lcol, min(vB + nw, H), D, lane4);
         const int h = vTc + 1 - vB;
         const SegTerms t = eval_segment<FAST, HAS_INVALID>(my, rb, (float)h, s_rcp[h], D, P.iw);
-        const float od = my_tile[t.fni] - (lcol + (size_t)vB * D)[(unsigned)t.fni];
+        const float od = my_tile[t.fni] - pick_lut<NR>(row, t.fni);
         pairwise_step<true>(P, st, vB, live, od, t, b);
     }
     /* merge the waves: min cost, ties -> smallest vB (a finite cost always has a real index) */
@@ -1176,22 +1186,22 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
     }
 }
 
-template <bool HAS_INVALID>
+template <bool HAS_INVALID, int NR>
 __global__ __launch_bounds__(IS_UNARY_WAVES * 64, IS_UNARY_WAVES) void k_pw_phase1(
-    const DevParams P, int ncols, int tile, const RowRec* __restrict__ recs,
+    const DevParams P, int col_base, int ncols, int tile, const RowRec* __restrict__ recs,
     const float* __restrict__ lutT, const StepRec* __restrict__ steps,
     const float* __restrict__ rcp, const int* __restrict__ vhor_arr,
     const int* __restrict__ col_flags, float* __restrict__ part_cost, int* __restrict__ part_idx) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int colg = blockIdx.x;
+    const int colg = col_base + blockIdx.x;
     if (colg >= ncols) return;
-    const int vhor = vhor_arr[colg / P.C];
+    const int vhor = __builtin_amdgcn_readfirstlane(vhor_arr[colg / P.C]);
     if (__builtin_amdgcn_readfirstlane(col_flags[colg]) == 0)
-        pw_phase1_body<true, HAS_INVALID>(P, smem, colg, tile, recs, lutT, steps, rcp, vhor, part_cost,
-                                          part_idx);
+        pw_phase1_body<true, HAS_INVALID, NR>(P, smem, colg, tile, recs, lutT, steps, rcp, vhor,
+                                              part_cost, part_idx);
     else
-        pw_phase1_body<false, HAS_INVALID>(P, smem, colg, tile, recs, lutT, steps, rcp, vhor, part_cost,
-                                           part_idx);
+        pw_phase1_body<false, HAS_INVALID, NR>(P, smem, colg, tile, recs, lutT, steps, rcp, vhor,
+                                               part_cost, part_idx);
 }
 
 template <bool FAST, bool HAS_INVALID>
@@ -1272,7 +1282,7 @@ __device__ __forceinline__ void pw_phase2_body(const DevParams& P, char* smem, i
 
 template <bool HAS_INVALID>
 __global__ __launch_bounds__(64) void k_pw_phase2(
-    const DevParams P, int ncols, int tile, const RowRec* __restrict__ recs,
+    const DevParams P, int col_base, int ncols, int tile, const RowRec* __restrict__ recs,
     const float* __restrict__ lutT, const PriorRec* __restrict__ priors,
     const float* __restrict__ odr, const float* __restrict__ rcp,
     const float* __restrict__ sv_arr, const int* __restrict__ vhor_arr,
@@ -1280,9 +1290,9 @@ __global__ __launch_bounds__(64) void k_pw_phase2(
     const int* __restrict__ part_idx, StepRec* __restrict__ steps, float* __restrict__ cost_table,
     int32_t* __restrict__ index_table) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int colg = blockIdx.x;
+    const int colg = col_base + blockIdx.x;
     if (colg >= ncols) return;
-    const int vhor = vhor_arr[colg / P.C];
+    const int vhor = __builtin_amdgcn_readfirstlane(vhor_arr[colg / P.C]);
     if (__builtin_amdgcn_readfirstlane(col_flags[colg]) == 0)
         pw_phase2_body<true, HAS_INVALID>(P, smem, colg, tile, recs, lutT, priors, odr, rcp, sv_arr, vhor,
                                           part_cost, part_idx, steps, cost_table, index_table);
@@ -1657,23 +1667,54 @@ hipError_t isk_launch_dp_pairwise(const DevParams* P, int ncols, int nwaves, con
                                   const float* rcp, const float* sv_arr, const int* vhor,
                                   const int* col_flags, StepRec* steps, float* part_cost,
                                   int* part_idx, float* cost_table, int32_t* index_table,
-                                  hipStream_t stream) {
+                                  hipStream_t stream, hipStream_t aux, hipEvent_t ev_fork,
+                                  hipEvent_t ev_join) {
     const size_t lds1 = isk_pairwise_lds_bytes(P, nwaves);
     const size_t lds2 = isk_phase2_lds_bytes(P);
+    /* Columns are independent: with enough of them the batch is cut in two halves whose
+     * phase-1 / phase-2 chains run on two streams, the second one phase behind the first, so
+     * that the issue-bound phase 1 of one half shares the CUs with the latency-bound serial
+     * phase 2 of the other. */
+    const bool split = aux != nullptr && ncols >= 2 * IS_PAIRWISE_SPLIT_MIN_COLS;
+    const int c_mid = split ? (ncols / 2) : ncols;
+    hipError_t e;
+/* phase 1 with the vB-side lutT row in registers (LutRow<2>) measured SLOWER than the per-lane
+ * gather on MI355X (41.4 vs 38.0 ms per 64 frames): the pick costs more VALU than the gather's
+ * address arithmetic and phase 1 is issue-bound; kept selectable for later rounds */
+#define IS_PW_PHASE1_ROW_REGS 0
+#define IS_LAUNCH_P1(INV, c0, c1, st)                                                              \
+    do {                                                                                           \
+        if (IS_PW_PHASE1_ROW_REGS && P->D <= 128)                                                  \
+            hipLaunchKernelGGL((k_pw_phase1<INV, 2>), dim3((c1) - (c0)), dim3(nwaves * 64), lds1,  \
+                               st, *P, c0, c1, tile, recs, lutT, steps, rcp, vhor, col_flags,      \
+                               part_cost, part_idx);                                               \
+        else                                                                                       \
+            hipLaunchKernelGGL((k_pw_phase1<INV, 0>), dim3((c1) - (c0)), dim3(nwaves * 64), lds1,  \
+                               st, *P, c0, c1, tile, recs, lutT, steps, rcp, vhor, col_flags,      \
+                               part_cost, part_idx);                                               \
+    } while (0)
+#define IS_LAUNCH_P2(INV, c0, c1, st)                                                              \
+    hipLaunchKernelGGL(k_pw_phase2<INV>, dim3((c1) - (c0)), dim3(64), lds2, st, *P, c0, c1, tile,  \
+                       recs, lutT, priors, odr, rcp, sv_arr, vhor, col_flags, part_cost, part_idx, \
+                       steps, cost_table, index_table)
+    const bool inv = P->invalid >= 0;
     for (int tile = 0; tile < P->ntiles; tile++) {
-        if (P->invalid >= 0) {
-            hipLaunchKernelGGL(k_pw_phase1<true>, dim3(ncols), dim3(nwaves * 64), lds1, stream, *P,
-                               ncols, tile, recs, lutT, steps, rcp, vhor, col_flags, part_cost, part_idx);
-            hipLaunchKernelGGL(k_pw_phase2<true>, dim3(ncols), dim3(64), lds2, stream, *P, ncols, tile,
-                               recs, lutT, priors, odr, rcp, sv_arr, vhor, col_flags, part_cost,
-                               part_idx, steps, cost_table, index_table);
-        } else {
-            hipLaunchKernelGGL(k_pw_phase1<false>, dim3(ncols), dim3(nwaves * 64), lds1, stream, *P,
-                               ncols, tile, recs, lutT, steps, rcp, vhor, col_flags, part_cost, part_idx);
-            hipLaunchKernelGGL(k_pw_phase2<false>, dim3(ncols), dim3(64), lds2, stream, *P, ncols, tile,
-                               recs, lutT, priors, odr, rcp, sv_arr, vhor, col_flags, part_cost,
-                               part_idx, steps, cost_table, index_table);
+        if (inv) IS_LAUNCH_P1(true, 0, c_mid, stream); else IS_LAUNCH_P1(false, 0, c_mid, stream);
+        if (split && tile == 0) { /* the second half starts one phase behind the first */
+            if ((e = hipEventRecord(ev_fork, stream)) != hipSuccess) return e;
+            if ((e = hipStreamWaitEvent(aux, ev_fork, 0)) != hipSuccess) return e;
         }
+        if (inv) IS_LAUNCH_P2(true, 0, c_mid, stream); else IS_LAUNCH_P2(false, 0, c_mid, stream);
+        if (split) {
+            if (inv) IS_LAUNCH_P1(true, c_mid, ncols, aux); else IS_LAUNCH_P1(false, c_mid, ncols, aux);
+            if (inv) IS_LAUNCH_P2(true, c_mid, ncols, aux); else IS_LAUNCH_P2(false, c_mid, ncols, aux);
+        }
+    }
+#undef IS_LAUNCH_P1
+#undef IS_LAUNCH_P2
+    if (split) {
+        if ((e = hipEventRecord(ev_join, aux)) != hipSuccess) return e;
+        if ((e = hipStreamWaitEvent(stream, ev_join, 0)) != hipSuccess) return e;
     }
     return hipGetLastError();
 }
@@ -1741,9 +1782,13 @@ hipError_t isk_set_lds_limits(const DevParams* P, int nwaves_pair) {
                             (int)(sizeof(int) * (6 * (size_t)P->H + 3 * (size_t)P->S + 4)));
     if (e != hipSuccess) return e;
     const int c = (int)isk_pairwise_lds_bytes(P, nwaves_pair);
-    e = hipFuncSetAttribute((const void*)k_pw_phase1<true>, hipFuncAttributeMaxDynamicSharedMemorySize, c);
+    e = hipFuncSetAttribute((const void*)k_pw_phase1<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, c);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute((const void*)k_pw_phase1<false>, hipFuncAttributeMaxDynamicSharedMemorySize, c);
+    e = hipFuncSetAttribute((const void*)k_pw_phase1<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, c);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void*)k_pw_phase1<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, c);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void*)k_pw_phase1<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, c);
     return e;
 }
 

@@ -21,6 +21,15 @@ def build_case(preset, rows, cols, max_dis, seed=0, n_images=1, **overrides):
                 segmentation=np.stack([f.segmentation for f in frames]))
 
 
+def sub_case(case, images):
+    """The same case restricted to some of its images."""
+    sub = dict(case)
+    sub["frames"] = [case["frames"][i] for i in images]
+    for k in ("gf", "ng", "ig", "vhor", "disparity", "segmentation"):
+        sub[k] = case[k][list(images)]
+    return sub
+
+
 def run_oracle(case, image=0, col_range=None, joined=None):
     cfg = case["cfg"]
     if joined is None:

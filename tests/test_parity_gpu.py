@@ -165,6 +165,20 @@ def test_degenerate_inputs(preset):
     _assert_parity(case, got)
 
 
+def test_pairwise_two_stream_split_matches_oracle():
+    """With >= 2048 stixel columns in a call the pairwise DP runs its two half batches on two
+    HIP streams (isk_launch_dp_pairwise); a user stream is honoured around the fork / join."""
+    case = helpers.build_case("drn_d_38_pairwise", 64, 2048, 32, seed=53, n_images=9)
+    assert case["cfg"].realcols * 9 >= 2048
+    got = helpers.run_core(case)
+    _assert_parity(case, got, images=[0, 4, 8])   # first half, the image cut by the split, last
+    # every image agrees with the same image computed alone (below the split threshold)
+    for img in (3, 5):
+        alone = helpers.run_core(helpers.sub_case(case, [img]))
+        assert np.array_equal(alone["sections"][0].view(np.int32),
+                              got["sections"][img].view(np.int32))
+
+
 def test_batch_consistency_and_input_immutability():
     """Images of a batch are independent: a frame gives the same result at any batch position,
     and (unlike the reference) the segmentation input is left intact."""
