@@ -67,6 +67,18 @@ def n_sections(sec_col):
     return int(np.argmax(sec_col["type"] == -1))
 
 
+def sections_equal(a, b):
+    """Bitwise equality of two [cols][max_sections] Section arrays up to (and including) each
+    column's terminator; entries behind it are unspecified."""
+    for ca, cb in zip(a, b):
+        n = n_sections(ca)
+        if n != n_sections(cb) or cb["type"][n] != -1:
+            return False
+        if not np.array_equal(ca[:n].view(np.int32), cb[:n].view(np.int32)):
+            return False
+    return True
+
+
 def compare(ref, got, image, cfg, cols=None, check_tables=True):
     """Returns a list of human-readable mismatch strings (empty = parity)."""
     errs = []

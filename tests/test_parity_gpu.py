@@ -175,8 +175,7 @@ def test_pairwise_two_stream_split_matches_oracle():
     # every image agrees with the same image computed alone (below the split threshold)
     for img in (3, 5):
         alone = helpers.run_core(helpers.sub_case(case, [img]))
-        assert np.array_equal(alone["sections"][0].view(np.int32),
-                              got["sections"][img].view(np.int32))
+        assert helpers.sections_equal(alone["sections"][0], got["sections"][img])
 
 
 def test_batch_consistency_and_input_immutability():
