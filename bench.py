@@ -198,11 +198,14 @@ def main():
                                       if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "k_dp_pairwise" if cfg.pairwise else "k_dp_unary",
+                         "kernel": "k_pw_phase1 + k_pw_phase2, all tiles of the step"
+                                   if cfg.pairwise else "k_dp_unary",
                          "kernel_ms": kt["dp_ms"],
                          "algorithmic_bytes_per_image": alg_bytes_img,
-                         "note": "the column DP is VALU-bound, not HBM-bound (SURVEY.md H1): "
-                                 "see valu_* fields"},
+                         "note": "the column DP is bound by VALU issue, not by HBM (SURVEY.md "
+                                 "H1, DESIGN.md section 5): see the valu fields; traffic = "
+                                 "(2*FETCH_SIZE + WRITE_SIZE) per launch from the committed "
+                                 "rocprofv3 PMC passes (profiles/r01_traffic.json)"},
             "valu": {"pair_evals_per_s": pairs_img * B / dp_s,
                      "pair_evals_per_image": pairs_img,
                      "lane_ops_peak_per_s": VALU_PEAK_LANEOPS},
