@@ -788,7 +788,10 @@ __device__ __forceinline__ void unary_loop(const DevParams& P, const RowRec& my,
                                                    nw, vB_end, row_ok, lane4, lrsrc, next_row, b);
 }
 
-template <bool HAS_INVALID, int NR>
+/* FASTCOLS: the launch handles only the columns of that encoding (col_flags), workgroups of the
+ * other kind leave at once.  Two lean kernels instead of one that carries both loop nests: no
+ * register spills, and the generic launch costs ~nothing when every column is FAST. */
+template <bool HAS_INVALID, int NR, bool FASTCOLS>
 __global__ __launch_bounds__(IS_UNARY_WAVES * 64, IS_UNARY_OCC) void k_dp_unary(const DevParams P, int ncols,
                                                   const RowRec* __restrict__ recs,
                                                   const float* __restrict__ lutT,
@@ -814,6 +817,7 @@ __global__ __launch_bounds__(IS_UNARY_WAVES * 64, IS_UNARY_OCC) void k_dp_unary(
     const int wg_in_col = __builtin_amdgcn_readfirstlane(q % wg_per_col);
     const int colg = __builtin_amdgcn_readfirstlane((q / wg_per_col) * nxcd + xcd);
     if (colg >= ncols) return;
+    if ((__builtin_amdgcn_readfirstlane(col_flags[colg]) == 0) != FASTCOLS) return;
     const int img = __builtin_amdgcn_readfirstlane(colg / P.C);
     const int vhor = __builtin_amdgcn_readfirstlane(vhor_arr[img]);
 
@@ -854,12 +858,8 @@ __global__ __launch_bounds__(IS_UNARY_WAVES * 64, IS_UNARY_OCC) void k_dp_unary(
     b.vo = 0; /* index_table[vT*3+OBJECT] = OBJECT at vB = 0, :592 */
     const float* my_tile = s_tile + lane * DP;
     const int vB_end = min(tile_lo + IS_TILE - 1, H - 1);
-    if (__builtin_amdgcn_readfirstlane(col_flags[colg]) == 0)
-        unary_loop<true, HAS_INVALID, NR>(P, my, rcol, lcol, my_tile, s_rcp, vT, vTc, vhor, w, nw, tile_lo,
+    unary_loop<FASTCOLS, HAS_INVALID, NR>(P, my, rcol, lcol, my_tile, s_rcp, vT, vTc, vhor, w, nw, tile_lo,
                                           vB_end, lane * 4, lrsrc, b);
-    else
-        unary_loop<false, HAS_INVALID, NR>(P, my, rcol, lcol, my_tile, s_rcp, vT, vTc, vhor, w, nw, tile_lo,
-                                           vB_end, lane * 4, lrsrc, b);
 
     /* merge the waves' partial minima: min cost, ties -> smallest vB (= first strict minimum
      * of the reference's ascending-vB loop) */
@@ -1651,8 +1651,14 @@ hipError_t isk_launch_dp_unary(const DevParams* P, int ncols, int nwaves, const 
     /* D <= 128: the vB-side lutT row travels in two registers per lane (LutRow<2>); wider
      * tables gather per lane */
 #define IS_LAUNCH_UNARY(INV, NR)                                                                   \
-    hipLaunchKernelGGL((k_dp_unary<INV, NR>), grid, dim3(nwaves * 64), lds, stream, *P, ncols,     \
-                       recs, lutT, rcp, vhor, col_flags, cost_table, index_table, pairs_per_wg)
+    do {                                                                                           \
+        hipLaunchKernelGGL((k_dp_unary<INV, NR, true>), grid, dim3(nwaves * 64), lds, stream, *P,  \
+                           ncols, recs, lutT, rcp, vhor, col_flags, cost_table, index_table,       \
+                           pairs_per_wg);                                                          \
+        hipLaunchKernelGGL((k_dp_unary<INV, NR, false>), grid, dim3(nwaves * 64), lds, stream, *P, \
+                           ncols, recs, lutT, rcp, vhor, col_flags, cost_table, index_table,       \
+                           pairs_per_wg);                                                          \
+    } while (0)
     if (P->D <= 128) {
         if (P->invalid >= 0) IS_LAUNCH_UNARY(true, 2); else IS_LAUNCH_UNARY(false, 2);
     } else {
@@ -1759,7 +1765,7 @@ hipError_t isk_launch_compact(const DevParams* P, const is_section* sections_img
 
 int isk_debug_occupancy(const DevParams* P, int nwaves) {
     int nb = -1;
-    hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_dp_unary<false, 2>,
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_dp_unary<false, 2, true>,
                                                  nwaves * 64, isk_unary_lds_bytes(P));
     return nb;
 }
@@ -1770,14 +1776,15 @@ hipError_t isk_set_lds_limits(const DevParams* P, int nwaves_pair) {
     e = hipFuncSetAttribute((const void*)k_prepare_columns, hipFuncAttributeMaxDynamicSharedMemorySize, a);
     if (e != hipSuccess) return e;
     const int b = (int)isk_unary_lds_bytes(P);
-    e = hipFuncSetAttribute((const void*)k_dp_unary<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, b);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute((const void*)k_dp_unary<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, b);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute((const void*)k_dp_unary<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, b);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute((const void*)k_dp_unary<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, b);
-    if (e != hipSuccess) return e;
+#define IS_SET_UNARY_LDS(INV, NR, FC)                                                             \
+    e = hipFuncSetAttribute((const void*)k_dp_unary<INV, NR, FC>,                                 \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, b);                       \
+    if (e != hipSuccess) return e
+    IS_SET_UNARY_LDS(true, 2, true); IS_SET_UNARY_LDS(true, 2, false);
+    IS_SET_UNARY_LDS(false, 2, true); IS_SET_UNARY_LDS(false, 2, false);
+    IS_SET_UNARY_LDS(true, 0, true); IS_SET_UNARY_LDS(true, 0, false);
+    IS_SET_UNARY_LDS(false, 0, true); IS_SET_UNARY_LDS(false, 0, false);
+#undef IS_SET_UNARY_LDS
     e = hipFuncSetAttribute((const void*)k_backtrace, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)(sizeof(int) * (6 * (size_t)P->H + 3 * (size_t)P->S + 4)));
     if (e != hipSuccess) return e;
