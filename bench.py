@@ -36,10 +36,38 @@ def parse():
     ap.add_argument("--cols", type=int, default=2048)
     ap.add_argument("--max-dis", type=int, default=128)
     ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic frames per rank")
+    ap.add_argument("--no-d2h", action="store_true",
+                    help="skip the extra value_incl_d2h measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=6.0)
     ap.add_argument("--no-gather", action="store_true")
     return ap.parse_args()
+
+
+def usable_cores():
+    """Host threads this process may really run on: the affinity mask, capped by the cgroup CPU
+    quota when the container has one (os.cpu_count() reports the whole machine)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as fh:
+                txt = fh.read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(round(int(txt[0]) / int(txt[1])))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fh:
+                        n = min(n, max(1, int(round(q / int(fh.read())))))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
 
 
 def cpu_baseline(cfg, frame, target_seconds):
@@ -51,7 +79,7 @@ def cpu_baseline(cfg, frame, target_seconds):
     gf, ng, ig, vhor = oracle.host_ground(cfg, frame.vhor_image, frame.camera_tilt,
                                           frame.camera_height, frame.alpha_ground)
     joined = oracle.join_columns(cfg, frame.disparity)
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     run = lambda: oracle.compute(params, lut, odr, joined, frame.segmentation, gf, ng, ig, vhor,
                                  cfg.pairwise, nthreads=cores, want_tables=False)
     run()                                            # warm-up (thread pool, page faults)
@@ -62,10 +90,19 @@ def cpu_baseline(cfg, frame, target_seconds):
         dt = time.perf_counter() - t0
         if dt >= target_seconds or n >= 64:
             break
+    # single-thread figure on a few columns of the same frame, scaled to the frame
+    ncol1 = min(4, cfg.realcols)
+    t1 = time.perf_counter()
+    oracle.compute(params, lut, odr, joined, frame.segmentation, gf, ng, ig, vhor, cfg.pairwise,
+                   nthreads=1, want_tables=False, col_range=(0, ncol1))
+    dt1 = time.perf_counter() - t1
     return dict(value=n / dt, unit="images/s", cores=cores, kind="port",
                 sample=f"{n} x one {cfg.rows}x{cfg.cols}x{cfg.max_dis} frame "
                        f"({cfg.realcols} stixel columns) in {dt:.2f} s wall, OpenMP over columns "
-                       f"on {cores} threads = {dt * cores:.0f} core-seconds")
+                       f"on {cores} threads = {dt * cores:.0f} core-seconds",
+                single_thread_value=ncol1 / dt1 / cfg.realcols,
+                single_thread_sample=f"{ncol1} of {cfg.realcols} columns of that frame on one "
+                                     f"thread in {dt1:.2f} s, scaled to the frame")
 
 
 def committed_traffic(cfg, B, H, W, D):
@@ -173,6 +210,22 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # second figure, N = 1 only and outside the judged `value`: the same step
+    # followed by the D2H copy of the Section output into pinned host memory (what
+    # Stixels::Compute does, Stixels.cu:629-633)
+    d2h_value = None
+    if world == 1 and not args.no_d2h:
+        h_sections = torch.empty(d_sections.shape, dtype=d_sections.dtype, pin_memory=True)
+        for _ in range(2):
+            step(); h_sections.copy_(d_sections, non_blocking=True)
+        torch.cuda.synchronize(dev)
+        k = max(2, min(args.steps, 5))
+        t1 = time.perf_counter()
+        for _ in range(k):
+            step(); h_sections.copy_(d_sections, non_blocking=True)
+        torch.cuda.synchronize(dev)
+        d2h_value = B * k / (time.perf_counter() - t1)
+
     if rank == 0:
         images = B * world * args.steps
         value = images / dt
@@ -211,6 +264,8 @@ def main():
                      "lane_ops_peak_per_s": VALU_PEAK_LANEOPS},
             "kernel_ms": kt,
         }
+        if d2h_value is not None:
+            out["value_incl_d2h"] = d2h_value
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg, frames[0], args.cpu_seconds)
         print(json.dumps(out), flush=True)
