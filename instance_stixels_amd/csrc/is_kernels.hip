@@ -669,49 +669,17 @@ template <bool FAST, bool HAS_INVALID, bool SKY, bool DIAG, bool FIRST, int NR>
 __device__ __forceinline__ void unary_step(const DevParams& P, const RowRec& my, const RowRec& rb,
                                            const LutRow<NR>& lrow, const float* my_tile,
                                            const float* s_rcp, int vT, int vTc, int vhor, int vB,
-                                           bool row_ok, UnaryBest& b) {
+                                           float hf_full, bool row_ok, UnaryBest& b) {
     const int h = vTc + 1 - vB;
     const bool live = DIAG ? ((h > 0) && row_ok) : row_ok;
     const int hc = DIAG ? max(h, 1) : h;
     const float r = s_rcp[hc]; /* RN(1/h) = (float)(1./h) = inverse_height, :485, :608 */
-    const SegTerms t = eval_segment<FAST, HAS_INVALID>(my, rb, (float)hc, r, P.D, P.iw);
+    /* full steps: the caller carries the height as a float (one 2-cycle subtraction per step
+     * instead of an integer update plus a conversion; integers < 2^24 are exact) */
+    const float hf = (DIAG || FIRST) ? (float)hc : hf_full;
+    const SegTerms t = eval_segment<FAST, HAS_INVALID>(my, rb, hf, r, P.D, P.iw);
     const float od = my_tile[t.fni] - pick_lut<NR>(lrow, t.fni);
     const float pwih = P.pw * r;
-#ifdef IS_ABL_FMA /* ablation: IS_ABL_FMA extra independent fp32 FMAs per step */
-    {
-        float x0 = r, x1 = t.gd, x2 = t.sd, x3 = t.mean;
-#pragma unroll
-        for (int i = 0; i < IS_ABL_FMA / 4; i++) {
-            x0 = __builtin_fmaf(x0, P.dw, P.pw); x1 = __builtin_fmaf(x1, P.dw, P.pw);
-            x2 = __builtin_fmaf(x2, P.dw, P.pw); x3 = __builtin_fmaf(x3, P.dw, P.pw);
-        }
-        asm volatile("" ::"v"(x0), "v"(x1), "v"(x2), "v"(x3));
-    }
-#endif
-#ifdef IS_ABL_PK /* ablation: IS_ABL_PK extra independent v_pk_fma_f32 per step */
-    {
-        typedef float abl_f2 __attribute__((ext_vector_type(2)));
-        abl_f2 x0 = {r, t.gd}, x1 = {t.gd, t.sd}, x2 = {t.sd, t.mean}, x3 = {t.mean, r};
-        const abl_f2 ka = {P.dw, P.sw}, kb = {P.pw, P.iw};
-#pragma unroll
-        for (int i = 0; i < IS_ABL_PK / 4; i++) {
-            x0 = __builtin_elementwise_fma(x0, ka, kb); x1 = __builtin_elementwise_fma(x1, ka, kb);
-            x2 = __builtin_elementwise_fma(x2, ka, kb); x3 = __builtin_elementwise_fma(x3, ka, kb);
-        }
-        asm volatile("" ::"v"(x0), "v"(x1), "v"(x2), "v"(x3));
-    }
-#endif
-#ifdef IS_ABL_MIN /* ablation: IS_ABL_MIN extra independent v_min_f32 per step */
-    {
-        float x0 = r, x1 = t.gd, x2 = t.sd, x3 = t.mean;
-#pragma unroll
-        for (int i = 0; i < IS_ABL_MIN / 4; i++) {
-            x0 = __builtin_fminf(x0, P.dw + (float)i); x1 = __builtin_fminf(x1, P.pw + (float)i);
-            x2 = __builtin_fminf(x2, P.sw + (float)i); x3 = __builtin_fminf(x3, P.iw + (float)i);
-            asm volatile("" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3));
-        }
-    }
-#endif
     /* cost = dw*data + pw*(1/h) + sw*seg, left to right (:716-719, 762-765, 820-823) */
     const float cost_o = P.dw * od + pwih + P.sw * t.seg_o;
     const bool uo = live && (cost_o < b.o);
@@ -738,12 +706,15 @@ __device__ __forceinline__ int unary_range(const DevParams& P, const RowRec& my,
                                            int nw, int bound, bool row_ok, int lane4,
                                            __amdgpu_buffer_rsrc_t lrsrc, LutRow<NR>& next_row,
                                            UnaryBest& b) {
+    float hf = (float)(vTc + 1 - vB);
+    const float nwf = (float)nw;
     for (; vB <= bound; vB += nw) {
         const RowRec cur = sload_rec(rcol + vB);
         const LutRow<NR> row = next_row;
         load_lut_row<NR>(next_row, lrsrc, lcol, min(vB + nw, P.H), P.D, lane4); /* row H exists */
         unary_step<FAST, HAS_INVALID, SKY, DIAG, false, NR>(P, my, cur, row, my_tile, s_rcp, vT, vTc,
-                                                            vhor, vB, row_ok, b);
+                                                            vhor, vB, hf, row_ok, b);
+        hf -= nwf;
     }
     return vB;
 }
@@ -769,10 +740,10 @@ __device__ __forceinline__ void unary_loop(const DevParams& P, const RowRec& my,
         load_lut_row<NR>(next_row, lrsrc, lcol, min(nw, P.H), P.D, lane4);
         if (tile_lo == 0)
             unary_step<FAST, HAS_INVALID, false, true, true, NR>(P, my, cur, row, my_tile, s_rcp, vT,
-                                                                 vTc, vhor, 0, row_ok, b);
+                                                                 vTc, vhor, 0, 0.0f, row_ok, b);
         else
             unary_step<FAST, HAS_INVALID, false, false, true, NR>(P, my, cur, row, my_tile, s_rcp, vT,
-                                                                  vTc, vhor, 0, row_ok, b);
+                                                                  vTc, vhor, 0, 0.0f, row_ok, b);
         vB += nw;
     }
     vB = unary_range<FAST, HAS_INVALID, false, false, NR>(P, my, rcol, lcol, my_tile, s_rcp, vT, vTc,
