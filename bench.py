@@ -36,6 +36,8 @@ def parse():
     ap.add_argument("--cols", type=int, default=2048)
     ap.add_argument("--max-dis", type=int, default=128)
     ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic frames per rank")
+    ap.add_argument("--no-single", action="store_true",
+                    help="skip the extra single-frame (batch 1) measurement")
     ap.add_argument("--no-d2h", action="store_true",
                     help="skip the extra value_incl_d2h measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -210,6 +212,24 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # BASELINE.json configs[1] (ONE 1024x2048 frame per call) next to the batched headline value:
+    # the same entry points with n_images = 1, i.e. the latency a per-frame caller sees
+    single = None
+    if world == 1 and not args.no_single:
+        def step1():
+            core.join_columns_ptr(d_big.data_ptr(), W, cfg.median_join, d_joined.data_ptr(), 1, stream)
+            core.compute_ptr(d_joined.data_ptr(), d_seg.data_ptr(), gf[:1], ng[:1], ig[:1], vh[:1],
+                             cfg.pairwise, 1, d_sections.data_ptr(), None, None, None, stream)
+        for _ in range(10):
+            step1()
+        torch.cuda.synchronize(dev)
+        n1 = 100
+        t1 = time.perf_counter()
+        for _ in range(n1):
+            step1()
+        torch.cuda.synchronize(dev)
+        single = (time.perf_counter() - t1) / n1
+
     # second figure, N = 1 only and outside the judged `value`: the same step
     # followed by the D2H copy of the Section output into pinned host memory (what
     # Stixels::Compute does, Stixels.cu:629-633)
@@ -266,6 +286,10 @@ def main():
         }
         if d2h_value is not None:
             out["value_incl_d2h"] = d2h_value
+        if single is not None:
+            out["single_frame"] = {"workload": "BASELINE configs[1]: one frame per call (batch 1), "
+                                               "device-resident in/out",
+                                   "images_per_s": 1.0 / single, "ms_per_frame": single * 1e3}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg, frames[0], args.cpu_seconds)
         print(json.dumps(out), flush=True)
