@@ -23,7 +23,8 @@ size_t isk_unary_lds_bytes(const DevParams* P);
 size_t isk_pairwise_lds_bytes(const DevParams* P, int nwaves);
 hipError_t isk_launch_join(const float*, float*, int, int, int, int, int, int, float, int, hipStream_t);
 hipError_t isk_launch_prepare(const DevParams*, int, const float*, const int32_t*, const float*,
-                              const int*, const float*, RowRec*, float*, int*, float*, hipStream_t);
+                              const int*, const float*, RowRec*, float*, int*, float*, hipStream_t,
+                              hipStream_t, hipEvent_t, hipEvent_t);
 struct StepRec;
 hipError_t isk_launch_priors(const DevParams*, const float*, PriorRec*, int, hipStream_t);
 hipError_t isk_launch_dp_unary(const DevParams*, int, int, const RowRec*, const float*, const float*,
@@ -358,7 +359,8 @@ int is_compute(is_ctx* c, const float* d_joined, const int32_t* d_seg, const flo
 
     if (c->timing) HIP_TRY(hipEventRecord(c->ev[0], stream));
     HIP_TRY(isk_launch_prepare(&P, ncols, d_joined, d_seg, c->d_ground, c->d_vhor,
-                               c->d_obj_cost_lut, c->d_recs, c->d_lutT, c->d_col_flags, c->d_sv, stream));
+                               c->d_obj_cost_lut, c->d_recs, c->d_lutT, c->d_col_flags, c->d_sv, stream,
+                               c->aux_stream, c->ev_fork, c->ev_join));
     if (pairwise) HIP_TRY(isk_launch_priors(&P, c->d_ground, c->d_priors, n_images, stream));
     if (c->timing) HIP_TRY(hipEventRecord(c->ev[1], stream));
     if (pairwise)

@@ -1590,12 +1590,28 @@ hipError_t isk_launch_join(const float* big, float* joined, int H, int W, int C,
 hipError_t isk_launch_prepare(const DevParams* P, int ncols, const float* joined,
                               const int32_t* seg, const float* ground, const int* vhor,
                               const float* cost_T, RowRec* recs, float* lutT,
-                              int* col_flags, float* sv_arr, hipStream_t stream) {
+                              int* col_flags, float* sv_arr, hipStream_t stream, hipStream_t aux,
+                              hipEvent_t ev_fork, hipEvent_t ev_join) {
+    /* The two prepare kernels are independent.  With few columns (a single frame = 256) neither
+     * fills the chip and both are latency chains, so they run side by side on two streams; with
+     * many columns they are throughput-bound (HBM writes) and stay in order on one stream. */
+    const bool side_by_side = aux != nullptr && ncols < IS_PREPARE_OVERLAP_MAX_COLS;
+    hipError_t e;
+    hipStream_t lut_stream = stream;
+    if (side_by_side) {
+        if ((e = hipEventRecord(ev_fork, stream)) != hipSuccess) return e;
+        if ((e = hipStreamWaitEvent(aux, ev_fork, 0)) != hipSuccess) return e;
+        lut_stream = aux;
+    }
+    hipLaunchKernelGGL(k_object_lut, dim3(ncols, (P->D + 63) / 64), dim3(64), 0, lut_stream, *P,
+                       joined, cost_T, lutT);
     hipLaunchKernelGGL(k_prepare_columns, dim3(ncols), dim3(PREP_THREADS),
                        isk_prepare_lds_bytes(P), stream, *P, joined, seg, ground, vhor, recs,
                        col_flags, sv_arr);
-    hipLaunchKernelGGL(k_object_lut, dim3(ncols, (P->D + 63) / 64), dim3(64), 0, stream, *P, joined,
-                       cost_T, lutT);
+    if (side_by_side) {
+        if ((e = hipEventRecord(ev_join, aux)) != hipSuccess) return e;
+        if ((e = hipStreamWaitEvent(stream, ev_join, 0)) != hipSuccess) return e;
+    }
     return hipGetLastError();
 }
 
