@@ -203,8 +203,11 @@ int is_ctx_create(const is_stixel_params* p, const float* obj_cost_lut,
     ALLOC(c->d_lutT, sizeof(float) * B * C * (H + 1) * D);
     ALLOC(c->d_priors, sizeof(PriorRec) * B * H);
     ALLOC(c->d_steps, (size_t)64 * B * C * H);
-    ALLOC(c->d_part_cost, sizeof(float) * B * C * 3 * 64);
-    ALLOC(c->d_part_idx, sizeof(int) * B * C * 3 * 64);
+    /* phase 1 may use up to IS_PW_MAX_SPLIT workgroups per column while columns are few */
+    const size_t part_slots = (B * C > (size_t)IS_PW_SPLIT_TARGET_WGS ? B * C : (size_t)IS_PW_SPLIT_TARGET_WGS) +
+                              (size_t)IS_PW_MAX_SPLIT;
+    ALLOC(c->d_part_cost, sizeof(float) * part_slots * 3 * 64);
+    ALLOC(c->d_part_idx, sizeof(int) * part_slots * 3 * 64);
     ALLOC(c->d_sv, sizeof(float) * B * C * 2 * (H + 1));
     ALLOC(c->d_cost_table, sizeof(float) * B * C * H * 3);
     ALLOC(c->d_index_table, sizeof(int32_t) * B * C * H * 3);

@@ -22,6 +22,8 @@
 #define IS_UNARY_OCC IS_UNARY_WAVES /* waves per SIMD the unary DP is compiled for (VGPR budget 512/OCC) */
 #endif
 #define IS_TILE 64
+#define IS_PW_MAX_SPLIT 4            /* phase-1 workgroups per (column, tile) at small batches */
+#define IS_PW_SPLIT_TARGET_WGS 1024 /* = 4 workgroups per CU */
 #define IS_PREPARE_OVERLAP_MAX_COLS 1024 /* below: the two prepare kernels run on two streams */
 #define IS_PAIRWISE_SPLIT_MIN_COLS 1024 /* columns per half before the pairwise DP uses two streams */
 #define IS_N_ON 8           /* non-instance object classes 2..9   (Cityscapes.h:69) */

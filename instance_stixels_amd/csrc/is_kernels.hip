@@ -1060,6 +1060,7 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
                                                const float* __restrict__ lutT,
                                                const StepRec* __restrict__ steps,
                                                const float* __restrict__ rcp, int vhor,
+                                               int split, int nsplit,
                                                float* __restrict__ part_cost,
                                                int* __restrict__ part_idx) {
     const int H = P.H, D = P.D;
@@ -1067,8 +1068,13 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
     float* s_tile = (float*)smem;             /* [64][D+1] */
     float* s_rcp = s_tile + IS_TILE * DP;     /* [H+1]     */
     const int tid = threadIdx.x, lane = tid & 63;
-    const int nw = blockDim.x >> 6;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    /* `nsplit` workgroups share the vB range of one (column, tile): together they behave like
+     * one workgroup of nsplit * nwl waves (few columns = small batches: more of the chip works
+     * on the latency chain); their partial minima are merged by phase 2 */
+    const int nwl = blockDim.x >> 6;
+    const int wl = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nw = nwl * nsplit;
+    const int w = split * nwl + wl;
     const int tile_lo = tile * IS_TILE;
     const RowRec* rcol = recs + (size_t)colg * (H + 1);
     const float* lcol = lutT + (size_t)colg * (H + 1) * D;
@@ -1136,43 +1142,46 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
     }
     /* merge the waves: min cost, ties -> smallest vB (a finite cost always has a real index) */
     __syncthreads();
-    float* m_cost = (float*)smem;              /* [nw][3][64] (aliases the tile) */
-    int* m_idx = (int*)(m_cost + nw * 3 * 64); /* [nw][3][64] */
-    m_cost[(w * 3 + 0) * 64 + lane] = b.g; m_idx[(w * 3 + 0) * 64 + lane] = b.ig;
-    m_cost[(w * 3 + 1) * 64 + lane] = b.o; m_idx[(w * 3 + 1) * 64 + lane] = b.io;
-    m_cost[(w * 3 + 2) * 64 + lane] = b.s; m_idx[(w * 3 + 2) * 64 + lane] = b.is;
+    float* m_cost = (float*)smem;               /* [nwl][3][64] (aliases the tile) */
+    int* m_idx = (int*)(m_cost + nwl * 3 * 64); /* [nwl][3][64] */
+    m_cost[(wl * 3 + 0) * 64 + lane] = b.g; m_idx[(wl * 3 + 0) * 64 + lane] = b.ig;
+    m_cost[(wl * 3 + 1) * 64 + lane] = b.o; m_idx[(wl * 3 + 1) * 64 + lane] = b.io;
+    m_cost[(wl * 3 + 2) * 64 + lane] = b.s; m_idx[(wl * 3 + 2) * 64 + lane] = b.is;
     __syncthreads();
     if (tid < 3 * 64) {
         const int type = tid >> 6;
         float c = m_cost[(0 * 3 + type) * 64 + lane];
         int ix = m_idx[(0 * 3 + type) * 64 + lane];
-        for (int ww = 1; ww < nw; ww++) {
+        for (int ww = 1; ww < nwl; ww++) {
             const float c2 = m_cost[(ww * 3 + type) * 64 + lane];
             const int ix2 = m_idx[(ww * 3 + type) * 64 + lane];
             const bool take = (c2 < c) || (c2 == c && c2 < IS_INF && (ix2 / 3) < (ix / 3));
             if (take) { c = c2; ix = ix2; }
         }
-        part_cost[((size_t)colg * 3 + type) * 64 + lane] = c;
-        part_idx[((size_t)colg * 3 + type) * 64 + lane] = ix;
+        const size_t o = (((size_t)colg * nsplit + split) * 3 + type) * 64 + lane;
+        part_cost[o] = c;
+        part_idx[o] = ix;
     }
 }
 
 template <bool HAS_INVALID, int NR>
 __global__ __launch_bounds__(IS_UNARY_WAVES * 64, IS_UNARY_WAVES) void k_pw_phase1(
-    const DevParams P, int col_base, int ncols, int tile, const RowRec* __restrict__ recs,
-    const float* __restrict__ lutT, const StepRec* __restrict__ steps,
-    const float* __restrict__ rcp, const int* __restrict__ vhor_arr,
-    const int* __restrict__ col_flags, float* __restrict__ part_cost, int* __restrict__ part_idx) {
+    const DevParams P, int col_base, int ncols, int tile, int nsplit,
+    const RowRec* __restrict__ recs, const float* __restrict__ lutT,
+    const StepRec* __restrict__ steps, const float* __restrict__ rcp,
+    const int* __restrict__ vhor_arr, const int* __restrict__ col_flags,
+    float* __restrict__ part_cost, int* __restrict__ part_idx) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int colg = col_base + blockIdx.x;
+    const int colg = col_base + (int)(blockIdx.x / (unsigned)nsplit);
+    const int split = __builtin_amdgcn_readfirstlane((int)(blockIdx.x % (unsigned)nsplit));
     if (colg >= ncols) return;
     const int vhor = __builtin_amdgcn_readfirstlane(vhor_arr[colg / P.C]);
     if (__builtin_amdgcn_readfirstlane(col_flags[colg]) == 0)
-        pw_phase1_body<true, HAS_INVALID, NR>(P, smem, colg, tile, recs, lutT, steps, rcp, vhor,
-                                              part_cost, part_idx);
+        pw_phase1_body<true, HAS_INVALID, NR>(P, smem, colg, tile, recs, lutT, steps, rcp, vhor, split,
+                                              nsplit, part_cost, part_idx);
     else
-        pw_phase1_body<false, HAS_INVALID, NR>(P, smem, colg, tile, recs, lutT, steps, rcp, vhor,
-                                               part_cost, part_idx);
+        pw_phase1_body<false, HAS_INVALID, NR>(P, smem, colg, tile, recs, lutT, steps, rcp, vhor, split,
+                                               nsplit, part_cost, part_idx);
 }
 
 template <bool FAST, bool HAS_INVALID>
@@ -1183,7 +1192,7 @@ __device__ __forceinline__ void pw_phase2_body(const DevParams& P, char* smem, i
                                                const float* __restrict__ odr,
                                                const float* __restrict__ rcp,
                                                const float* __restrict__ sv_arr, int vhor,
-                                               const float* __restrict__ part_cost,
+                                               int nsplit, const float* __restrict__ part_cost,
                                                const int* __restrict__ part_idx,
                                                StepRec* __restrict__ steps,
                                                float* __restrict__ cost_table,
@@ -1211,10 +1220,22 @@ __device__ __forceinline__ void pw_phase2_body(const DevParams& P, char* smem, i
     const int vTc = min(vT, H - 1);
     const RowRec my = load_rec(rcol + vTc + 1);
     const float* my_row = lcol + (size_t)(vTc + 1) * D;
-    PairBest b;
-    b.g = part_cost[((size_t)colg * 3 + 0) * 64 + lane]; b.ig = part_idx[((size_t)colg * 3 + 0) * 64 + lane];
-    b.o = part_cost[((size_t)colg * 3 + 1) * 64 + lane]; b.io = part_idx[((size_t)colg * 3 + 1) * 64 + lane];
-    b.s = part_cost[((size_t)colg * 3 + 2) * 64 + lane]; b.is = part_idx[((size_t)colg * 3 + 2) * 64 + lane];
+    PairBest b; /* partial minima of phase 1 (its nsplit workgroups merged: min cost, then smallest vB) */
+    {
+        const size_t o = (size_t)colg * nsplit * 3 * 64 + lane;
+        b.g = part_cost[o]; b.ig = part_idx[o];
+        b.o = part_cost[o + 64]; b.io = part_idx[o + 64];
+        b.s = part_cost[o + 128]; b.is = part_idx[o + 128];
+        for (int sp = 1; sp < nsplit; sp++) {
+            const size_t q = o + (size_t)sp * 3 * 64;
+            float c2 = part_cost[q]; int i2 = part_idx[q];
+            if ((c2 < b.g) || (c2 == b.g && c2 < IS_INF && (i2 / 3) < (b.ig / 3))) { b.g = c2; b.ig = i2; }
+            c2 = part_cost[q + 64]; i2 = part_idx[q + 64];
+            if ((c2 < b.o) || (c2 == b.o && c2 < IS_INF && (i2 / 3) < (b.io / 3))) { b.o = c2; b.io = i2; }
+            c2 = part_cost[q + 128]; i2 = part_idx[q + 128];
+            if ((c2 < b.s) || (c2 == b.s && c2 < IS_INF && (i2 / 3) < (b.is / 3))) { b.s = c2; b.is = i2; }
+        }
+    }
     __syncthreads();
 
     const int n_rows = min(IS_TILE, H - tile_lo);
@@ -1253,8 +1274,9 @@ __device__ __forceinline__ void pw_phase2_body(const DevParams& P, char* smem, i
 
 template <bool HAS_INVALID>
 __global__ __launch_bounds__(64) void k_pw_phase2(
-    const DevParams P, int col_base, int ncols, int tile, const RowRec* __restrict__ recs,
-    const float* __restrict__ lutT, const PriorRec* __restrict__ priors,
+    const DevParams P, int col_base, int ncols, int tile, int nsplit,
+    const RowRec* __restrict__ recs, const float* __restrict__ lutT,
+    const PriorRec* __restrict__ priors,
     const float* __restrict__ odr, const float* __restrict__ rcp,
     const float* __restrict__ sv_arr, const int* __restrict__ vhor_arr,
     const int* __restrict__ col_flags, const float* __restrict__ part_cost,
@@ -1266,10 +1288,10 @@ __global__ __launch_bounds__(64) void k_pw_phase2(
     const int vhor = __builtin_amdgcn_readfirstlane(vhor_arr[colg / P.C]);
     if (__builtin_amdgcn_readfirstlane(col_flags[colg]) == 0)
         pw_phase2_body<true, HAS_INVALID>(P, smem, colg, tile, recs, lutT, priors, odr, rcp, sv_arr, vhor,
-                                          part_cost, part_idx, steps, cost_table, index_table);
+                                          nsplit, part_cost, part_idx, steps, cost_table, index_table);
     else
         pw_phase2_body<false, HAS_INVALID>(P, smem, colg, tile, recs, lutT, priors, odr, rcp, sv_arr, vhor,
-                                           part_cost, part_idx, steps, cost_table, index_table);
+                                           nsplit, part_cost, part_idx, steps, cost_table, index_table);
 }
 
 /* ====================================================================================== */
@@ -1668,6 +1690,9 @@ hipError_t isk_launch_dp_pairwise(const DevParams* P, int ncols, int nwaves, con
      * phase-1 / phase-2 chains run on two streams, the second one phase behind the first, so
      * that the issue-bound phase 1 of one half shares the CUs with the latency-bound serial
      * phase 2 of the other. */
+    /* few columns: nsplit workgroups per (column, tile) in phase 1, up to ~one workgroup per CU x4 */
+    int nsplit = IS_PW_SPLIT_TARGET_WGS / (ncols > 0 ? ncols : 1);
+    nsplit = nsplit < 1 ? 1 : (nsplit > IS_PW_MAX_SPLIT ? IS_PW_MAX_SPLIT : nsplit);
     const bool split = aux != nullptr && ncols >= 2 * IS_PAIRWISE_SPLIT_MIN_COLS;
     const int c_mid = split ? (ncols / 2) : ncols;
     hipError_t e;
@@ -1678,18 +1703,18 @@ hipError_t isk_launch_dp_pairwise(const DevParams* P, int ncols, int nwaves, con
 #define IS_LAUNCH_P1(INV, c0, c1, st)                                                              \
     do {                                                                                           \
         if (IS_PW_PHASE1_ROW_REGS && P->D <= 128)                                                  \
-            hipLaunchKernelGGL((k_pw_phase1<INV, 2>), dim3((c1) - (c0)), dim3(nwaves * 64), lds1,  \
-                               st, *P, c0, c1, tile, recs, lutT, steps, rcp, vhor, col_flags,      \
-                               part_cost, part_idx);                                               \
+            hipLaunchKernelGGL((k_pw_phase1<INV, 2>), dim3(((c1) - (c0)) * nsplit),                \
+                               dim3(nwaves * 64), lds1, st, *P, c0, c1, tile, nsplit, recs, lutT,  \
+                               steps, rcp, vhor, col_flags, part_cost, part_idx);                  \
         else                                                                                       \
-            hipLaunchKernelGGL((k_pw_phase1<INV, 0>), dim3((c1) - (c0)), dim3(nwaves * 64), lds1,  \
-                               st, *P, c0, c1, tile, recs, lutT, steps, rcp, vhor, col_flags,      \
-                               part_cost, part_idx);                                               \
+            hipLaunchKernelGGL((k_pw_phase1<INV, 0>), dim3(((c1) - (c0)) * nsplit),                \
+                               dim3(nwaves * 64), lds1, st, *P, c0, c1, tile, nsplit, recs, lutT,  \
+                               steps, rcp, vhor, col_flags, part_cost, part_idx);                  \
     } while (0)
 #define IS_LAUNCH_P2(INV, c0, c1, st)                                                              \
     hipLaunchKernelGGL(k_pw_phase2<INV>, dim3((c1) - (c0)), dim3(64), lds2, st, *P, c0, c1, tile,  \
-                       recs, lutT, priors, odr, rcp, sv_arr, vhor, col_flags, part_cost, part_idx, \
-                       steps, cost_table, index_table)
+                       nsplit, recs, lutT, priors, odr, rcp, sv_arr, vhor, col_flags, part_cost,   \
+                       part_idx, steps, cost_table, index_table)
     const bool inv = P->invalid >= 0;
     for (int tile = 0; tile < P->ntiles; tile++) {
         if (inv) IS_LAUNCH_P1(true, 0, c_mid, stream); else IS_LAUNCH_P1(false, 0, c_mid, stream);
