@@ -125,6 +125,9 @@ int is_device_synchronize(void) { HIP_TRY(hipDeviceSynchronize()); return IS_OK;
 
 size_t is_scratch_bytes(const is_ctx* ctx) { return ctx ? ctx->scratch_bytes : 0; }
 
+static int ctx_init(is_ctx* c, const is_stixel_params* p, const float* obj_cost_lut,
+                    const float* obj_disparity_range, int max_batch, int device, int P2, int P2S);
+
 int is_ctx_create(const is_stixel_params* p, const float* obj_cost_lut,
                   const float* obj_disparity_range, int max_batch, int device, is_ctx** out_ctx) {
     if (!p || !obj_cost_lut || !obj_disparity_range || !out_ctx) return fail_arg("null pointer");
@@ -146,6 +149,20 @@ int is_ctx_create(const is_stixel_params* p, const float* obj_cost_lut,
     HIP_TRY(hipSetDevice(device));
     is_ctx* c = (is_ctx*)calloc(1, sizeof(is_ctx));
     if (!c) return IS_ENOMEM;
+    const int rc = ctx_init(c, p, obj_cost_lut, obj_disparity_range, max_batch, device, P2, P2S);
+    if (rc != IS_OK) { /* release whatever was created; keep the error text of the failure */
+        char keep[sizeof(g_err)];
+        memcpy(keep, g_err, sizeof(keep));
+        is_ctx_destroy(c);
+        memcpy(g_err, keep, sizeof(keep));
+        return rc;
+    }
+    *out_ctx = c;
+    return IS_OK;
+}
+
+static int ctx_init(is_ctx* c, const is_stixel_params* p, const float* obj_cost_lut,
+                    const float* obj_disparity_range, int max_batch, int device, int P2, int P2S) {
     c->params = *p;
     c->device = device;
     c->max_batch = max_batch;
@@ -181,10 +198,8 @@ int is_ctx_create(const is_stixel_params* p, const float* obj_cost_lut,
     c->nwaves_pairwise = IS_UNARY_WAVES;
     if (sizeof(int) * (6 * (size_t)d.H + 3 * (size_t)d.S + 4) > 160 * 1024 ||
         isk_unary_lds_bytes(&d) > 160 * 1024 || isk_pairwise_lds_bytes(&d, c->nwaves_pairwise) > 160 * 1024 ||
-        isk_prepare_lds_bytes(&d) > 160 * 1024) {
-        free(c);
+        isk_prepare_lds_bytes(&d) > 160 * 1024)
         return fail_arg("shape needs more than 160 KiB of LDS per workgroup");
-    }
 
     const size_t H = d.H, C = d.C, D = d.D, B = max_batch;
     size_t total = 0;
@@ -251,7 +266,6 @@ int is_ctx_create(const is_stixel_params* p, const float* obj_cost_lut,
     if (getenv("IS_DEBUG"))
         fprintf(stderr, "[is_core] unary DP: %d waves/WG, %zu B LDS/WG, occupancy API: %d WG/CU\n",
                 c->nwaves_unary, isk_unary_lds_bytes(&d), isk_debug_occupancy(&d, c->nwaves_unary));
-    *out_ctx = c;
     return IS_OK;
 }
 
@@ -262,12 +276,14 @@ int is_ctx_destroy(is_ctx* c) {
     hipFree(c->d_obj_cost_lut); hipFree(c->d_odr); hipFree(c->d_rcp); hipFree(c->d_col_flags); hipFree(c->d_ground);
     hipFree(c->d_vhor); hipFree(c->d_recs); hipFree(c->d_lutT); hipFree(c->d_priors); hipFree(c->d_steps); hipFree(c->d_part_cost); hipFree(c->d_part_idx); hipFree(c->d_sv);
     hipFree(c->d_cost_table); hipFree(c->d_index_table);
-    hipHostFree(c->h_ground_pinned); hipHostFree(c->h_vhor_pinned);
-    hipEventDestroy(c->staging_free);
+    if (c->h_ground_pinned) hipHostFree(c->h_ground_pinned);
+    if (c->h_vhor_pinned) hipHostFree(c->h_vhor_pinned);
+    if (c->staging_free) hipEventDestroy(c->staging_free);
     if (c->aux_stream) hipStreamDestroy(c->aux_stream);
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
     if (c->ev_join) hipEventDestroy(c->ev_join);
-    for (int i = 0; i < 4; i++) hipEventDestroy(c->ev[i]);
+    for (int i = 0; i < 4; i++)
+        if (c->ev[i]) hipEventDestroy(c->ev[i]);
     free(c);
     return IS_OK;
 }

@@ -530,7 +530,8 @@ __device__ __forceinline__ RowRec sload_rec(const RowRec* p) {
  *   (int -> float conversion and fp32 addition are monotone);
  *   (0.0f + k) + float(S) = k + float(S): float(int) is never -0, so the leading `0.0f +` of
  *   Cityscapes.h:67-79 cannot change the sum;
- *   FAST columns only: float(int64 difference) via exact binary64, x / h via fast_div, and
+ *   FAST columns only: float(int64 difference) via exact fp32 hi/lo parts (RowRec), x / h via
+ *   fast_div, and
  *   (int)floorf(max(mean,0)) = (int)fmaxf(mean,0) because the mean is finite there. */
 template <bool FAST, bool HAS_INVALID>
 __device__ __forceinline__ SegTerms eval_segment(const RowRec& my, const RowRec& rb, float height,
