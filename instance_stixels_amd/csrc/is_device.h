@@ -21,6 +21,9 @@
 #ifndef IS_UNARY_OCC
 #define IS_UNARY_OCC IS_UNARY_WAVES /* waves per SIMD the unary DP is compiled for (VGPR budget 512/OCC) */
 #endif
+#ifndef IS_CMPX_UPDATE
+#define IS_CMPX_UPDATE 1 /* running minima of the unary DP through v_cmpx + moves (take_if_less) */
+#endif
 #define IS_TILE 64
 #define IS_PW_MAX_SPLIT 4            /* phase-1 workgroups per (column, tile) at small batches */
 #define IS_PW_SPLIT_TARGET_WGS 1024 /* = 4 workgroups per CU */

@@ -666,6 +666,34 @@ __device__ __forceinline__ float pick_lut(const LutRow<NR>& row, int fni) {
     return v;
 }
 
+/* (best, best_v) <- (cost, vB) in the lanes with cost < best: v_cmpx + two moves under the
+ * resulting EXEC (8 issue cycles) instead of compare + two cndmask + the broadcast of vB (14).
+ * Only for steps in which every lane of the wave takes part. */
+__device__ __forceinline__ void take_if_less(float& best, int& best_v, float cost, int vB) {
+    unsigned long long saved;
+    asm("s_mov_b64 %[sv], exec\n\t"
+        "v_cmpx_lt_f32_e32 %[c], %[b]\n\t"
+        "v_mov_b32_e32 %[b], %[c]\n\t"
+        "v_mov_b32_e32 %[i], %[vb]\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [b] "+v"(best), [i] "+v"(best_v), [sv] "=&s"(saved)
+        : [c] "v"(cost), [vb] "s"(vB)
+        : "vcc");
+}
+
+/* same with a per-lane value to record */
+__device__ __forceinline__ void take_if_less_v(float& best, int& best_v, float cost, int v) {
+    unsigned long long saved;
+    asm("s_mov_b64 %[sv], exec\n\t"
+        "v_cmpx_lt_f32_e32 %[c], %[b]\n\t"
+        "v_mov_b32_e32 %[b], %[c]\n\t"
+        "v_mov_b32_e32 %[i], %[v]\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [b] "+v"(best), [i] "+v"(best_v), [sv] "=&s"(saved)
+        : [c] "v"(cost), [v] "v"(v)
+        : "vcc");
+}
+
 template <bool FAST, bool HAS_INVALID, bool SKY, bool DIAG, bool FIRST, int NR>
 __device__ __forceinline__ void unary_step(const DevParams& P, const RowRec& my, const RowRec& rb,
                                            const LutRow<NR>& lrow, const float* my_tile,
@@ -683,19 +711,33 @@ __device__ __forceinline__ void unary_step(const DevParams& P, const RowRec& my,
     const float pwih = P.pw * r;
     /* cost = dw*data + pw*(1/h) + sw*seg, left to right (:716-719, 762-765, 820-823) */
     const float cost_o = P.dw * od + pwih + P.sw * t.seg_o;
-    const bool uo = live && (cost_o < b.o);
-    b.o = uo ? cost_o : b.o;
-    b.vo = uo ? vB : b.vo;
+    /* full steps: every lane with vT < H is live, and rows vT >= H are never stored */
+    constexpr bool ALL_LANES = IS_CMPX_UPDATE && FAST && !DIAG && !FIRST;
+    if (ALL_LANES) {
+        take_if_less(b.o, b.vo, cost_o, vB);
+    } else {
+        const bool uo = live && (cost_o < b.o);
+        b.o = uo ? cost_o : b.o;
+        b.vo = uo ? vB : b.vo;
+    }
     if (SKY) {
         const float cost_s = P.dw * t.sd + pwih + P.sw * t.seg_s;
-        const bool us = live && (cost_s < b.s);
-        b.s = us ? cost_s : b.s;
-        b.vs = us ? vB : b.vs;
+        if (ALL_LANES) {
+            take_if_less(b.s, b.vs, cost_s, vB);
+        } else {
+            const bool us = live && (cost_s < b.s);
+            b.s = us ? cost_s : b.s;
+            b.vs = us ? vB : b.vs;
+        }
     } else {
         const float cost_g = P.dw * t.gd + pwih + P.sw * t.seg_g;
-        const bool ug = (FIRST ? (live && (vT <= vhor)) : live) && (cost_g < b.g);
-        b.g = ug ? cost_g : b.g;
-        b.vg = ug ? vB : b.vg;
+        if (ALL_LANES) {
+            take_if_less(b.g, b.vg, cost_g, vB);
+        } else {
+            const bool ug = (FIRST ? (live && (vT <= vhor)) : live) && (cost_g < b.g);
+            b.g = ug ? cost_g : b.g;
+            b.vg = ug ? vB : b.vg;
+        }
     }
 }
 
@@ -1012,19 +1054,29 @@ struct PairBest {
 
 /* One (vB >= 1, vT) evaluation of the pairwise model for the lane owning vT; `st` is the
  * wave-uniform StepRec of vB.  SKY: vB-1 >= vhor (:729), else ground (:687). */
-template <bool SKY>
+template <bool SKY, bool ALL_LANES = false>
 __device__ __forceinline__ void pairwise_step(const DevParams& P, const StepVals st, int vB,
                                               bool live, float od, const SegTerms& t, PairBest& b) {
+    /* ALL_LANES (phase 1): every lane with vT < H is live and rows vT >= H are never stored */
+    constexpr bool CMPX = IS_CMPX_UPDATE && ALL_LANES;
     if (SKY) { /* :729-775 */
         const float cost = P.dw * t.sd + st.pwmp + P.sw * t.seg_s;
-        const bool u = live && (cost < b.s);
-        b.s = u ? cost : b.s;
-        b.is = u ? st.idx_gs : b.is;
+        if (CMPX) {
+            take_if_less(b.s, b.is, cost, st.idx_gs);
+        } else {
+            const bool u = live && (cost < b.s);
+            b.s = u ? cost : b.s;
+            b.is = u ? st.idx_gs : b.is;
+        }
     } else { /* :687-728 */
         const float cost = P.dw * t.gd + st.pwmp + P.sw * t.seg_g;
-        const bool u = live && (cost < b.g);
-        b.g = u ? cost : b.g;
-        b.ig = u ? st.idx_gs : b.ig;
+        if (CMPX) {
+            take_if_less(b.g, b.ig, cost, st.idx_gs);
+        } else {
+            const bool u = live && (cost < b.g);
+            b.g = u ? cost : b.g;
+            b.ig = u ? st.idx_gs : b.ig;
+        }
     }
     /* object, :777-837 */
     const float fn = t.mean;
@@ -1038,9 +1090,13 @@ __device__ __forceinline__ void pairwise_step(const DevParams& P, const StepVals
     const int base_o = vB * 3 + IS_OBJECT;
     int idx = (p1 < p2) ? (base_o - 1) : base_o;
     idx = (p3 < m12) ? (base_o + 1) : idx;
-    const bool u = live && (cost < b.o);
-    b.o = u ? cost : b.o;
-    b.io = u ? idx : b.io;
+    if (CMPX) {
+        take_if_less_v(b.o, b.io, cost, idx);
+    } else {
+        const bool u = live && (cost < b.o);
+        b.o = u ? cost : b.o;
+        b.io = u ? idx : b.io;
+    }
 }
 
 /* The pairwise DP of one 64-row tile is split over two launches (per tile, bottom-up):
@@ -1129,7 +1185,7 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
         const int h = vTc + 1 - vB;
         const SegTerms t = eval_segment<FAST, HAS_INVALID>(my, rb, (float)h, s_rcp[h], D, P.iw);
         const float od = my_tile[t.fni] - pick_lut<NR>(row, t.fni);
-        pairwise_step<false>(P, st, vB, live, od, t, b);
+        pairwise_step<false, true>(P, st, vB, live, od, t, b);
     }
     for (; vB <= vB_last; vB += nw) { /* sky range */
         const RowRec rb = sload_rec(rcol + vB);
@@ -1139,7 +1195,7 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
         const int h = vTc + 1 - vB;
         const SegTerms t = eval_segment<FAST, HAS_INVALID>(my, rb, (float)h, s_rcp[h], D, P.iw);
         const float od = my_tile[t.fni] - pick_lut<NR>(row, t.fni);
-        pairwise_step<true>(P, st, vB, live, od, t, b);
+        pairwise_step<true, true>(P, st, vB, live, od, t, b);
     }
     /* merge the waves: min cost, ties -> smallest vB (a finite cost always has a real index) */
     __syncthreads();
