@@ -55,6 +55,35 @@ def test_small_cases_bit_exact(preset, rows, cols, D, ov):
     _assert_parity(case, got)
 
 
+def _random_case(k):
+    """Seeded random shape / weights / model parameters around the presets."""
+    rng = np.random.default_rng(9000 + k)
+    preset = ["drn_d_22_unary", "drn_d_38_unary", "drn_d_22_pairwise", "drn_d_38_pairwise"][k % 4]
+    rows = int(rng.integers(2, 40)) * 8
+    cols = int(rng.integers(1, 9)) * 8
+    D = int(rng.choice([16, 24, 32, 48, 64, 96, 128]))
+    ov = dict(disparity_weight=float(10.0 ** rng.uniform(-4, 0)),
+              segmentation_weight=float(10.0 ** rng.uniform(-1, 1.2)),
+              instance_weight=float(10.0 ** rng.uniform(-4, -1.5)),
+              pord=float(rng.uniform(0.05, 0.4)), pgrav=float(rng.uniform(0.02, 0.2)),
+              pblg=float(rng.uniform(0.01, 0.1)), epsilon=float(rng.uniform(1.0, 5.0)),
+              sigma_disparity_object=float(rng.uniform(0.5, 2.0)),
+              sigma_disparity_ground=float(rng.uniform(1.0, 3.0)))
+    if k % 3 == 0:
+        ov["invalid_disparity"] = 0.0
+    if k % 5 == 0:
+        ov["median_join"] = True
+    return preset, rows, cols, D, ov
+
+
+@pytest.mark.parametrize("k", range(24))
+def test_random_configs_bit_exact(k):
+    preset, rows, cols, D, ov = _random_case(k)
+    case = helpers.build_case(preset, rows, cols, D, seed=300 + k, n_images=2, **ov)
+    got = helpers.run_core(case)
+    _assert_parity(case, got)
+
+
 @pytest.mark.parametrize("preset", ["drn_d_38_unary", "drn_d_22_pairwise"])
 def test_config1_shape_512x1024x64(preset):
     case = helpers.build_case(preset, 512, 1024, 64, seed=11)
