@@ -190,16 +190,23 @@ __device__ __forceinline__ int32_t full_prefix(const int32_t* ps, int v) {
 
 __device__ __forceinline__ void store_instance_prefix(RowRec* o, int slow, int64_t mx, int64_t my,
                                                       int64_t mx2, int64_t my2) {
-    if (slow) {
-        RowRecWide* w = reinterpret_cast<RowRecWide*>(o);
-        w->MX = mx; w->MY = my; w->MX2 = mx2; w->MY2 = my2;
+    /* dwords 24..31 of the record as two 16-byte stores */
+    int4 a, b;
+    if (slow) { /* RowRecWide: four int64 */
+        a = make_int4((int)(uint32_t)mx, (int)(uint32_t)((uint64_t)mx >> 32), (int)(uint32_t)my,
+                      (int)(uint32_t)((uint64_t)my >> 32));
+        b = make_int4((int)(uint32_t)mx2, (int)(uint32_t)((uint64_t)mx2 >> 32), (int)(uint32_t)my2,
+                      (int)(uint32_t)((uint64_t)my2 >> 32));
     } else { /* exact fp32 encodings, see RowRec */
-        o->MX = (float)mx; o->MY = (float)my;
         const int64_t lo_mask = ((int64_t)1 << IS_FAST_SPLIT_BITS) - 1;
-        o->MX2l = (float)(mx2 & lo_mask); o->MX2h = (float)(mx2 - (mx2 & lo_mask));
-        o->MY2l = (float)(my2 & lo_mask); o->MY2h = (float)(my2 - (my2 & lo_mask));
-        o->pad[0] = 0.0f; o->pad[1] = 0.0f;
+        a = make_int4(__float_as_int((float)mx), __float_as_int((float)my),
+                      __float_as_int((float)(mx2 - (mx2 & lo_mask))), __float_as_int((float)(mx2 & lo_mask)));
+        b = make_int4(__float_as_int((float)(my2 - (my2 & lo_mask))), __float_as_int((float)(my2 & lo_mask)),
+                      0, 0);
     }
+    int4* d = reinterpret_cast<int4*>(o);
+    d[6] = a;
+    d[7] = b;
 }
 
 __global__ __launch_bounds__(PREP_THREADS) void k_prepare_columns(
@@ -305,42 +312,55 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_columns(
         s_seg[K * P2S + i] = (int32_t)(x * x);
     }
     __syncthreads();
-    if (tid < CH) {
-        int32_t* ch = s_seg + tid * P2S;
-        uint32_t run = 0;
-        for (int k = 0; k < P2S; k++) {
-            const uint32_t x = (uint32_t)ch[k];
-            ch[k] = (int32_t)run;
-            run += x;
+    /* one wave per channel (round robin): lane l owns P2S/64 consecutive entries */
+    {
+        const int lane = tid & 63, wv = tid >> 6, per = P2S >> 6;
+        for (int c = wv; c < CH; c += PREP_THREADS / 64) {
+            int32_t* ch = s_seg + c * P2S;
+            if (per >= 1) {
+                uint32_t local = 0;
+                for (int k = 0; k < per; k++) local += (uint32_t)ch[lane * per + k];
+                uint32_t inc = local; /* inclusive wave scan of the lane totals */
+#pragma unroll
+                for (int j = 1; j < 64; j <<= 1) {
+                    const uint32_t n = (uint32_t)__shfl_up((int)inc, j, 64);
+                    if (lane >= j) inc += n;
+                }
+                uint32_t run = inc - local;
+                for (int k = 0; k < per; k++) {
+                    const uint32_t x = (uint32_t)ch[lane * per + k];
+                    ch[lane * per + k] = (int32_t)run;
+                    run += x;
+                }
+            } else if (lane == 0) { /* P2S < 64: tiny columns */
+                uint32_t run = 0;
+                for (int k = 0; k < P2S; k++) {
+                    const uint32_t x = (uint32_t)ch[k];
+                    ch[k] = (int32_t)run;
+                    run += x;
+                }
+            }
         }
     }
     __syncthreads();
-    for (int v = tid; v <= H; v += PREP_THREADS) {
-        RowRecWide* o = (RowRecWide*)(rcol + v);
-        const int32_t f_g0 = full_prefix(s_seg + 0 * P2S, v);
-        const int32_t f_g1 = full_prefix(s_seg + 1 * P2S, v);
-        int32_t f_on[IS_N_ON], f_oi[IS_N_OI];
+    /* dwords 0..19 of every record (class prefixes + squared-offset prefix) as five 16-byte
+     * chunks: consecutive threads write consecutive chunks */
+    for (int i = tid; i < (H + 1) * 5; i += PREP_THREADS) {
+        const int v = i / 5, q = i - v * 5;
+        int32_t x[4];
 #pragma unroll
-        for (int c = 0; c < IS_N_ON; c++) f_on[c] = full_prefix(s_seg + (2 + c) * P2S, v);
-#pragma unroll
-        for (int c = 0; c < IS_N_OI; c++) f_oi[c] = full_prefix(s_seg + (11 + c) * P2S, v);
-        const int32_t f_sky = full_prefix(s_seg + 10 * P2S, v);
-        o->Fnic = (int32_t)((uint32_t)full_prefix(s_seg + (K + 1) * P2S, v) +
-                            (uint32_t)full_prefix(s_seg + K * P2S, v));
-        if (slow) {
-            o->Fg0 = f_g0; o->Fg1 = f_g1; o->Fsky = f_sky;
-#pragma unroll
-            for (int c = 0; c < IS_N_ON; c++) o->Fon[c] = f_on[c];
-#pragma unroll
-            for (int c = 0; c < IS_N_OI; c++) o->Foi[c] = f_oi[c];
-        } else {
-            RowRec* f = rcol + v;
-            f->Fg0 = (float)f_g0; f->Fg1 = (float)f_g1; f->Fsky = (float)f_sky;
-#pragma unroll
-            for (int c = 0; c < IS_N_ON; c++) f->Fon[c] = (float)f_on[c];
-#pragma unroll
-            for (int c = 0; c < IS_N_OI; c++) f->Foi[c] = (float)f_oi[c];
+        for (int j = 0; j < 4; j++) {
+            const int dw = q * 4 + j; /* dword of RowRec: Fg0 Fg1 Fon[8] Foi[8] Fsky Fnic */
+            if (dw == 19) {
+                x[j] = (int32_t)((uint32_t)full_prefix(s_seg + (K + 1) * P2S, v) +
+                                 (uint32_t)full_prefix(s_seg + K * P2S, v));
+            } else {
+                const int chn = dw < 10 ? dw : (dw < 18 ? dw + 1 : 10);
+                const int32_t f = full_prefix(s_seg + chn * P2S, v);
+                x[j] = slow ? f : __float_as_int((float)f);
+            }
         }
+        reinterpret_cast<int4*>(rcol + v)[q] = make_int4(x[0], x[1], x[2], x[3]);
     }
 
     /* ---- fp32 prefixes with the reference's block-scan association (:452-461) */
@@ -367,17 +387,24 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_columns(
         svcol[v] = x;
     }
     __syncthreads();
-    /* V: valid count */
-    for (int i = tid; i < P2; i += PREP_THREADS)
-        s_pyr[i] = (i < H && P.invalid >= 0) ? (float)(s_d[i] != P.invalid) : 0.0f;
-    __syncthreads();
-    blelloch_build(s_pyr, P2, P.log2P2);
-    for (int v = tid; v <= H; v += PREP_THREADS) {
-        const float x = blelloch_prefix(s_pyr, P2, P.log2P2, v);
-        rcol[v].V = x;
-        svcol[H + 1 + v] = x;
+    /* V: valid count (all zero without an invalid-disparity value: no scan needed) */
+    if (P.invalid >= 0) {
+        for (int i = tid; i < P2; i += PREP_THREADS)
+            s_pyr[i] = (i < H) ? (float)(s_d[i] != P.invalid) : 0.0f;
+        __syncthreads();
+        blelloch_build(s_pyr, P2, P.log2P2);
+        for (int v = tid; v <= H; v += PREP_THREADS) {
+            const float x = blelloch_prefix(s_pyr, P2, P.log2P2, v);
+            rcol[v].V = x;
+            svcol[H + 1 + v] = x;
+        }
+        __syncthreads();
+    } else {
+        for (int v = tid; v <= H; v += PREP_THREADS) {
+            rcol[v].V = 0.0f;
+            svcol[H + 1 + v] = 0.0f;
+        }
     }
-    __syncthreads();
     /* G: ground data cost, +inf at / above the horizon (:435-446) */
     for (int i = tid; i < P2; i += PREP_THREADS) {
         float x = 0.0f;
