@@ -6,6 +6,7 @@ TAG=${1:-r01}; shift || true
 ARGS=${@:---batch 8 --steps 2 --warmup 1 --no-cpu-baseline}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
+echo "python3 bench.py $ARGS" > $OUT/command.txt
 export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py $ARGS > $OUT/bench_trace.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA --output-format csv -d $OUT/pmc1 -- python3 bench.py $ARGS > $OUT/bench_pmc1.log 2>&1

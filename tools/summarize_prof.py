@@ -10,6 +10,9 @@ def load(pattern):
 
 def main(d, out):
     lines = []
+    cmd = os.path.join(d, "command.txt")
+    if os.path.exists(cmd):
+        lines.append("command under rocprofv3 (every pass): " + open(cmd).read().strip())
     st = load(os.path.join(d, "trace", "**", "*kernel_stats.csv"))
     lines.append("== rocprofv3 --kernel-trace --stats (kernel_stats.csv) ==")
     for r in st:
