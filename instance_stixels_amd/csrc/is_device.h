@@ -24,6 +24,9 @@
 #ifndef IS_CMPX_UPDATE
 #define IS_CMPX_UPDATE 1 /* running minima of the unary DP through v_cmpx + moves (take_if_less) */
 #endif
+#ifndef IS_SKIP_GROUND_ABOVE_HORIZON
+#define IS_SKIP_GROUND_ABOVE_HORIZON 1 /* tiles above the horizon: ground candidates cost +inf, skip them */
+#endif
 #define IS_TILE 64
 #define IS_PW_MAX_SPLIT 4            /* phase-1 workgroups per (column, tile) at small batches */
 #define IS_PW_SPLIT_TARGET_WGS 1024 /* = 4 workgroups per CU */

@@ -721,7 +721,7 @@ __device__ __forceinline__ void take_if_less_v(float& best, int& best_v, float c
         : "vcc");
 }
 
-template <bool FAST, bool HAS_INVALID, bool SKY, bool DIAG, bool FIRST, int NR>
+template <bool FAST, bool HAS_INVALID, bool SKY, bool DIAG, bool FIRST, int NR, bool NOGROUND = false>
 __device__ __forceinline__ void unary_step(const DevParams& P, const RowRec& my, const RowRec& rb,
                                            const LutRow<NR>& lrow, const float* my_tile,
                                            const float* s_rcp, int vT, int vTc, int vhor, int vB,
@@ -756,7 +756,10 @@ __device__ __forceinline__ void unary_step(const DevParams& P, const RowRec& my,
             b.s = us ? cost_s : b.s;
             b.vs = us ? vB : b.vs;
         }
-    } else {
+    } else if (!NOGROUND) {
+        /* NOGROUND: every lane of the tile lies at or above the horizon, where the ground data
+         * cost prefix is +inf (StixelsKernels.cu:435-446): dw * inf is inf (or NaN for dw = 0)
+         * and never passes the strict < test, so the candidate is not evaluated at all */
         const float cost_g = P.dw * t.gd + pwih + P.sw * t.seg_g;
         if (ALL_LANES) {
             take_if_less(b.g, b.vg, cost_g, vB);
@@ -768,7 +771,7 @@ __device__ __forceinline__ void unary_step(const DevParams& P, const RowRec& my,
     }
 }
 
-template <bool FAST, bool HAS_INVALID, bool SKY, bool DIAG, int NR>
+template <bool FAST, bool HAS_INVALID, bool SKY, bool DIAG, int NR, bool NOGROUND = false>
 __device__ __forceinline__ int unary_range(const DevParams& P, const RowRec& my,
                                            const RowRec* __restrict__ rcol,
                                            const float* __restrict__ lcol, const float* my_tile,
@@ -782,8 +785,8 @@ __device__ __forceinline__ int unary_range(const DevParams& P, const RowRec& my,
         const RowRec cur = sload_rec(rcol + vB);
         const LutRow<NR> row = next_row;
         load_lut_row<NR>(next_row, lrsrc, lcol, min(vB + nw, P.H), P.D, lane4); /* row H exists */
-        unary_step<FAST, HAS_INVALID, SKY, DIAG, false, NR>(P, my, cur, row, my_tile, s_rcp, vT, vTc,
-                                                            vhor, vB, hf, row_ok, b);
+        unary_step<FAST, HAS_INVALID, SKY, DIAG, false, NR, NOGROUND>(P, my, cur, row, my_tile, s_rcp, vT,
+                                                                      vTc, vhor, vB, hf, row_ok, b);
         hf -= nwf;
     }
     return vB;
@@ -816,9 +819,14 @@ __device__ __forceinline__ void unary_loop(const DevParams& P, const RowRec& my,
                                                                   vTc, vhor, 0, 0.0f, row_ok, b);
         vB += nw;
     }
-    vB = unary_range<FAST, HAS_INVALID, false, false, NR>(P, my, rcol, lcol, my_tile, s_rcp, vT, vTc,
-                                                          vhor, vB, nw, min(min(vhor, tile_lo), vB_end),
-                                                          row_ok, lane4, lrsrc, next_row, b);
+    if (IS_SKIP_GROUND_ABOVE_HORIZON && tile_lo >= vhor) /* whole tile at / above the horizon */
+        vB = unary_range<FAST, HAS_INVALID, false, false, NR, true>(
+            P, my, rcol, lcol, my_tile, s_rcp, vT, vTc, vhor, vB, nw, min(min(vhor, tile_lo), vB_end),
+            row_ok, lane4, lrsrc, next_row, b);
+    else
+        vB = unary_range<FAST, HAS_INVALID, false, false, NR>(P, my, rcol, lcol, my_tile, s_rcp, vT, vTc,
+                                                              vhor, vB, nw, min(min(vhor, tile_lo), vB_end),
+                                                              row_ok, lane4, lrsrc, next_row, b);
     vB = unary_range<FAST, HAS_INVALID, false, true, NR>(P, my, rcol, lcol, my_tile, s_rcp, vT, vTc,
                                                          vhor, vB, nw, min(vhor, vB_end), row_ok, lane4,
                                                          lrsrc, next_row, b);
