@@ -1089,7 +1089,7 @@ struct PairBest {
 
 /* One (vB >= 1, vT) evaluation of the pairwise model for the lane owning vT; `st` is the
  * wave-uniform StepRec of vB.  SKY: vB-1 >= vhor (:729), else ground (:687). */
-template <bool SKY, bool ALL_LANES = false>
+template <bool SKY, bool ALL_LANES = false, bool NOGROUND = false>
 __device__ __forceinline__ void pairwise_step(const DevParams& P, const StepVals st, int vB,
                                               bool live, float od, const SegTerms& t, PairBest& b) {
     /* ALL_LANES (phase 1): every lane with vT < H is live and rows vT >= H are never stored */
@@ -1103,7 +1103,7 @@ __device__ __forceinline__ void pairwise_step(const DevParams& P, const StepVals
             b.s = u ? cost : b.s;
             b.is = u ? st.idx_gs : b.is;
         }
-    } else { /* :687-728 */
+    } else if (!NOGROUND) { /* :687-728; NOGROUND: tile at / above the horizon, see unary_step */
         const float cost = P.dw * t.gd + st.pwmp + P.sw * t.seg_g;
         if (CMPX) {
             take_if_less(b.g, b.ig, cost, st.idx_gs);
@@ -1211,6 +1211,18 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
         const float cost = P.dw * od + P.pw * prior + P.sw * t.seg_o;
         b.o = (live && cost < b.o) ? cost : b.o;
         vB += nw;
+    }
+    if (IS_SKIP_GROUND_ABOVE_HORIZON && tile_lo >= vhor) {
+        for (; vB <= min(vhor, vB_last); vB += nw) { /* ground range, ground candidate = +inf */
+            const RowRec rb = sload_rec(rcol + vB);
+            const StepVals st = sload_step(scol + vB);
+            const LutRow<NR> row = next_row;
+            load_lut_row<NR>(next_row, lrsrc, lcol, min(vB + nw, H), D, lane4);
+            const int h = vTc + 1 - vB;
+            const SegTerms t = eval_segment<FAST, HAS_INVALID>(my, rb, (float)h, s_rcp[h], D, P.iw);
+            const float od = my_tile[t.fni] - pick_lut<NR>(row, t.fni);
+            pairwise_step<false, true, true>(P, st, vB, live, od, t, b);
+        }
     }
     for (; vB <= min(vhor, vB_last); vB += nw) { /* ground range: vB-1 < vhor */
         const RowRec rb = sload_rec(rcol + vB);
