@@ -642,6 +642,41 @@ __device__ __forceinline__ RowRec load_rec(const RowRec* p) {
     return r;
 }
 
+/* lutT rows tile_lo+1 .. tile_lo+64 of a column into the LDS tile (row stride D+1).  When the
+ * workgroup covers whole rows per sweep (nthreads a multiple of D) a thread keeps its column and
+ * walks the rows: no per-element division.  QUADS: 16-byte loads (needs D % 4 == 0 and
+ * 4 * nthreads a multiple of D); more registers, so the unary kernel (64 VGPRs, four loop nests)
+ * uses the dword form. */
+template <bool QUADS>
+__device__ __forceinline__ void stage_lut_tile(float* s_tile, const float* __restrict__ lcol, int tile_lo,
+                                               int H, int D, int tid, int nthreads) {
+    const int DP = D + 1;
+    if (QUADS && (D & 3) == 0 && ((4 * nthreads) % D) == 0) {
+        const int quads = D >> 2;            /* 16-byte chunks per row */
+        const int r0 = tid / quads, f = (tid - r0 * quads) * 4;
+        const int dr = nthreads / quads;     /* rows per sweep of the workgroup */
+        for (int r = r0; r < IS_TILE; r += dr) {
+            const int v = min(tile_lo + 1 + r, H);
+            const float4 x = *reinterpret_cast<const float4*>(lcol + (size_t)v * D + f);
+            float* d = s_tile + r * DP + f;
+            d[0] = x.x; d[1] = x.y; d[2] = x.z; d[3] = x.w;
+        }
+    } else if ((nthreads % D) == 0) {
+        const int r0 = tid / D, f = tid - r0 * D;
+        const int dr = nthreads / D;
+        for (int r = r0; r < IS_TILE; r += dr) {
+            const int v = min(tile_lo + 1 + r, H);
+            s_tile[r * DP + f] = lcol[(size_t)v * D + f];
+        }
+    } else {
+        for (int i = tid; i < IS_TILE * D; i += nthreads) {
+            const int r = i / D, f = i - r * D;
+            const int v = min(tile_lo + 1 + r, H);
+            s_tile[r * DP + f] = lcol[(size_t)v * D + f];
+        }
+    }
+}
+
 /* ====================================================================================== */
 /* A7-A9  unary DP: one workgroup = (column, 64-row tile)                                  */
 /* ====================================================================================== */
@@ -890,11 +925,7 @@ __global__ __launch_bounds__(IS_UNARY_WAVES * 64, IS_UNARY_OCC) void k_dp_unary(
     if (!first) __syncthreads(); /* the merge area of the previous tile aliases the LUT tile */
     first = false;
 
-    for (int i = tid; i < IS_TILE * D; i += blockDim.x) {
-        const int r = i / D, f = i - r * D;
-        const int v = min(tile_lo + 1 + r, H);
-        s_tile[r * DP + f] = lcol[(size_t)v * D + f];
-    }
+    stage_lut_tile<false>(s_tile, lcol, tile_lo, H, D, tid, (int)blockDim.x);
 
     const int vT = tile_lo + lane;
     const int vTc = min(vT, H - 1);
@@ -1172,11 +1203,7 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
     const float* lcol = lutT + (size_t)colg * (H + 1) * D;
     const StepRec* scol = steps + (size_t)colg * H;
 
-    for (int i = tid; i < IS_TILE * D; i += blockDim.x) {
-        const int r = i / D, f = i - r * D;
-        const int v = min(tile_lo + 1 + r, H);
-        s_tile[r * DP + f] = lcol[(size_t)v * D + f];
-    }
+    stage_lut_tile<true>(s_tile, lcol, tile_lo, H, D, tid, (int)blockDim.x);
     for (int i = tid; i <= H; i += blockDim.x) s_rcp[i] = rcp[i];
     const int vT = tile_lo + lane;
     const int vTc = min(vT, H - 1);
