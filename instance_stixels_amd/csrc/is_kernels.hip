@@ -453,18 +453,28 @@ __global__ __launch_bounds__(64) void k_object_lut(const DevParams P,
     float* lcol = lutT + (size_t)colg * (H + 1) * D;
     if (fn_ok) lcol[fn] = 0.0f; /* arr[0] = 0, :283-285 */
     float add = 0.0f;
-    for (int i = 0; i < H; i += LUT_BLOCK) {
+    /* the per-row costs of the NEXT block are fetched before this block's 32 row stores are issued:
+     * a wave's memory operations retire in order, so loads queued behind the stores would wait
+     * for the whole store latency */
+    float cn[LUT_BLOCK];
+    auto fetch = [&](int i, float (&c)[LUT_BLOCK]) {
         /* (int)d of the block's 32 rows: one coalesced load, then wave-uniform broadcasts */
         const int rl = i + (lane & (LUT_BLOCK - 1));
         int dis_l = 0; /* rows beyond the image use dis = 0, :244-247 */
         if (rl < H) dis_l = (int)dcol[rl];
         dis_l = min(max(dis_l, 0), D - 1); /* memory safety outside the input domain (Q8) */
-        float c[LUT_BLOCK];
 #pragma unroll
         for (int l = 0; l < LUT_BLOCK; l++) {
             const int dis = __builtin_amdgcn_readlane(dis_l, l);
             c[l] = cost_T[(size_t)dis * D + fnc];
         }
+    };
+    fetch(0, cn);
+    for (int i = 0; i < H; i += LUT_BLOCK) {
+        float c[LUT_BLOCK];
+#pragma unroll
+        for (int l = 0; l < LUT_BLOCK; l++) c[l] = cn[l];
+        if (i + LUT_BLOCK < H) fetch(i + LUT_BLOCK, cn);
         c[0] += add; /* :249-251 */
 #pragma unroll
         for (int j = 1; j < LUT_BLOCK; j <<= 1) { /* :255-263; descending l reads pre-step values */
