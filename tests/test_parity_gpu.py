@@ -107,6 +107,20 @@ def test_config2_full_frame_1024x2048x128(preset):
 
 
 @pytest.mark.parametrize("preset", ["drn_d_22_unary", "drn_d_38_pairwise"])
+def test_config3_batch_of_full_frames(preset):
+    """BASELINE configs[2]/[3] shape at a reduced batch: eight distinct 1024x2048x128 frames in ONE
+    call (2048 stixel columns: the batched launch geometry of bench.py, and for the pairwise model
+    the two-stream split), every frame checked against the oracle."""
+    case = helpers.build_case(preset, 1024, 2048, 128, seed=77, n_images=8)
+    got = helpers.run_core(case, want_tables=False)
+    cfg = case["cfg"]
+    for img in range(8):
+        ref = helpers.run_oracle(case, image=img)
+        errs = helpers.compare(ref, got, img, cfg, check_tables=False)
+        assert not errs, "image %d:\n" % img + "\n".join(errs[:10])
+
+
+@pytest.mark.parametrize("preset", ["drn_d_22_unary", "drn_d_38_pairwise"])
 def test_tall_frame_2048_rows(preset):
     """Beyond every structural limit of the reference (one thread per row, rows < 1024): the same
     formulas at 2048 rows, 32 tiles per column."""
