@@ -36,6 +36,8 @@ def parse():
     ap.add_argument("--cols", type=int, default=2048)
     ap.add_argument("--max-dis", type=int, default=128)
     ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic frames per rank")
+    ap.add_argument("--pcie", action="store_true",
+                    help="also measure value_incl_h2d_d2h (inputs from pinned host memory each step)")
     ap.add_argument("--no-single", action="store_true",
                     help="skip the extra single-frame (batch 1) measurement")
     ap.add_argument("--no-d2h", action="store_true",
@@ -246,6 +248,24 @@ def main():
         torch.cuda.synchronize(dev)
         d2h_value = B * k / (time.perf_counter() - t1)
 
+    # PCIe-inclusive figure for DESIGN.md (--pcie): inputs come from pinned host memory every step
+    # and the sections go back, all on the compute stream, nothing overlapped
+    pcie_value = None
+    if world == 1 and args.pcie:
+        h_big = torch.empty(d_big.shape, dtype=d_big.dtype, pin_memory=True).copy_(d_big)
+        h_seg = torch.empty(d_seg.shape, dtype=d_seg.dtype, pin_memory=True).copy_(d_seg)
+        h_out = torch.empty(d_sections.shape, dtype=d_sections.dtype, pin_memory=True)
+        def step_pcie():
+            d_big.copy_(h_big, non_blocking=True); d_seg.copy_(h_seg, non_blocking=True)
+            step(); h_out.copy_(d_sections, non_blocking=True)
+        step_pcie(); torch.cuda.synchronize(dev)
+        k = 3
+        t1 = time.perf_counter()
+        for _ in range(k):
+            step_pcie()
+        torch.cuda.synchronize(dev)
+        pcie_value = B * k / (time.perf_counter() - t1)
+
     if rank == 0:
         images = B * world * args.steps
         value = images / dt
@@ -286,6 +306,8 @@ def main():
         }
         if d2h_value is not None:
             out["value_incl_d2h"] = d2h_value
+        if pcie_value is not None:
+            out["value_incl_h2d_d2h"] = pcie_value
         if single is not None:
             out["single_frame"] = {"workload": "BASELINE configs[1]: one frame per call (batch 1), "
                                                "device-resident in/out",
