@@ -221,6 +221,40 @@ def test_pairwise_two_stream_split_matches_oracle():
         assert helpers.sections_equal(alone["sections"][0], got["sections"][img])
 
 
+@pytest.mark.parametrize("preset", ["drn_d_22_unary", "drn_d_38_pairwise"])
+def test_one_context_many_call_sizes_back_to_back(preset):
+    """One context, calls of very different sizes queued back to back on one stream WITHOUT
+    host synchronisation in between: small calls run their two prepare kernels on two streams and
+    split pairwise phase 1 over several workgroups, large pairwise calls use two streams for the
+    two half batches; all share the context's scratch buffers and its second stream."""
+    import torch
+    from instance_stixels_amd.core import Core
+    case = helpers.build_case(preset, 64, 2048, 32, seed=91, n_images=9)   # 256 columns / image
+    p, cfg = case["params"], case["cfg"]
+    dev = torch.device("cuda", 0)
+    core = Core(p, case["lut"], case["odr"], max_batch=9)
+    big = torch.from_numpy(case["disparity"]).to(dev)
+    seg = torch.from_numpy(case["segmentation"]).to(dev)
+    calls = [(0, 1), (0, 9), (3, 2), (1, 8), (8, 1), (0, 9), (4, 3)]          # (first image, count)
+    outs = []
+    for i0, n in calls:
+        joined = torch.empty((n, p.cols, p.rows), dtype=torch.float32, device=dev)
+        sec = torch.empty((n, p.cols, p.max_sections, 8), dtype=torch.int32, device=dev)
+        core.join_columns_ptr(big[i0:i0 + n].data_ptr(), big.shape[2], False, joined.data_ptr(), n)
+        core.compute_ptr(joined.data_ptr(), seg[i0:i0 + n].data_ptr(), case["gf"][i0:i0 + n],
+                         case["ng"][i0:i0 + n], case["ig"][i0:i0 + n], case["vhor"][i0:i0 + n],
+                         bool(cfg.pairwise), n, sec.data_ptr())
+        outs.append((joined, sec))                                            # keep buffers alive
+    torch.cuda.synchronize()
+    from instance_stixels_amd.config import SECTION_DTYPE
+    ref = [helpers.run_oracle(case, image=i)["sections"] for i in range(9)]
+    for (i0, n), (_, sec) in zip(calls, outs):
+        got = sec.cpu().numpy().view(SECTION_DTYPE).reshape(n, p.cols, p.max_sections)
+        for k in range(n):
+            assert helpers.sections_equal(ref[i0 + k], got[k]), (i0, n, k)
+    core.close()
+
+
 def test_batch_consistency_and_input_immutability():
     """Images of a batch are independent: a frame gives the same result at any batch position,
     and (unlike the reference) the segmentation input is left intact."""
