@@ -36,6 +36,8 @@ def parse():
     ap.add_argument("--cols", type=int, default=2048)
     ap.add_argument("--max-dis", type=int, default=128)
     ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic frames per rank")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise RCCL and run the gather pipeline even with one rank (plumbing test)")
     ap.add_argument("--pcie", action="store_true",
                     help="also measure value_incl_h2d_d2h (inputs from pinned host memory each step)")
     ap.add_argument("--no-single", action="store_true",
@@ -141,8 +143,14 @@ def main():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+    use_dist = world > 1 or args.force_dist  # --force-dist: RCCL plumbing with a single rank
+    if use_dist:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group("nccl", device_id=dev, rank=0, world_size=1)
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     cfg = make_config(args.preset, args.rows, args.cols, args.max_dis)
     B = args.batch
@@ -180,7 +188,7 @@ def main():
     stream = torch.cuda.current_stream(dev).cuda_stream
     # N > 1: the stixel outputs of every step are gathered on rank 0 (RCCL over xGMI); the gather
     # of step k overlaps the compute of step k+1 (double-buffered outputs)
-    pipe = PipelinedGather(d_sections, depth=2, dst=0) if (world > 1 and not args.no_gather) else None
+    pipe = PipelinedGather(d_sections, depth=2, dst=0) if (use_dist and not args.no_gather) else None
 
     def step():
         out = pipe.next_buffer() if pipe is not None else d_sections
@@ -194,7 +202,7 @@ def main():
         if pipe is not None:
             pipe.flush()
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -209,7 +217,7 @@ def main():
     # per-kernel durations of the LAST timed step, measured with HIP events on the launch stream
     kt = core.kernel_times_ms()
 
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -314,11 +322,22 @@ def main():
                                    "images_per_s": 1.0 / single, "ms_per_frame": single * 1e3}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg, frames[0], args.cpu_seconds)
-        print(json.dumps(out), flush=True)
+    else:
+        out = None
 
     core.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
+    # RCCL writes a version banner to the C-level stdout buffer, which would otherwise be flushed
+    # at exit, i.e. AFTER the result: flush everything first so that the JSON line is the last line
+    sys.stdout.flush()
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
+    if out is not None:
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
