@@ -326,16 +326,23 @@ def main():
         out = None
 
     core.close()
+
+    def flush_c_stdio():
+        sys.stdout.flush()
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+
+    # RCCL writes a version banner into the C-level stdout buffer, which would otherwise be flushed
+    # at process exit, i.e. AFTER the result: every rank flushes, all ranks meet, the process
+    # group goes away, and only then rank 0 prints -- the JSON line is the last line of the job
     if use_dist:
+        flush_c_stdio()
+        dist.barrier()
         dist.destroy_process_group()
-    # RCCL writes a version banner to the C-level stdout buffer, which would otherwise be flushed
-    # at exit, i.e. AFTER the result: flush everything first so that the JSON line is the last line
-    sys.stdout.flush()
-    try:
-        import ctypes
-        ctypes.CDLL(None).fflush(None)
-    except OSError:
-        pass
+    flush_c_stdio()
     if out is not None:
         print(json.dumps(out), flush=True)
 
