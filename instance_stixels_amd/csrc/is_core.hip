@@ -37,7 +37,10 @@ hipError_t isk_launch_backtrace(const DevParams*, int, int, const RowRec*, const
                                 const int32_t*, const int*, is_section*, hipStream_t);
 hipError_t isk_launch_compact(const DevParams*, const is_section*, float*, int32_t*, uint8_t*,
                               int32_t*, hipStream_t);
-hipError_t isk_set_lds_limits(const DevParams*, int);
+hipError_t isk_set_lds_prepare(const DevParams*);
+hipError_t isk_set_lds_unary(const DevParams*);
+hipError_t isk_set_lds_pairwise(const DevParams*, int);
+hipError_t isk_set_lds_backtrace(const DevParams*);
 int isk_debug_occupancy(const DevParams*, int);
 hipError_t isk_launch_flip_and_pad(const float*, int32_t*, int, int, int, int, int, hipStream_t);
 hipError_t isk_launch_vdisparity(const float*, int*, int*, uint8_t*, int, int, int, float, hipStream_t);
@@ -262,7 +265,10 @@ static int ctx_init(is_ctx* c, const is_stixel_params* p, const float* obj_cost_
         HIP_TRY(e);
         if (!same) return fail_arg("internal: (float)(1./h) != 1.0f/h for some h <= rows");
     }
-    HIP_TRY(isk_set_lds_limits(&d, c->nwaves_pairwise));
+    HIP_TRY(isk_set_lds_prepare(&d));
+    HIP_TRY(isk_set_lds_unary(&d));
+    HIP_TRY(isk_set_lds_pairwise(&d, c->nwaves_pairwise));
+    HIP_TRY(isk_set_lds_backtrace(&d));
     if (getenv("IS_DEBUG"))
         fprintf(stderr, "[is_core] unary DP: %d waves/WG, %zu B LDS/WG, occupancy API: %d WG/CU\n",
                 c->nwaves_unary, isk_unary_lds_bytes(&d), isk_debug_occupancy(&d, c->nwaves_unary));

@@ -1,0 +1,531 @@
+/* is_k_pairwise.hip -- the pairwise column DP (two launches per 64-row tile).  See is_kernels.h. */
+#include "is_kernels.h"
+
+/* ====================================================================================== */
+/* A7-A9  pairwise DP                                                                      */
+/* ====================================================================================== */
+/* Everything of a transition INTO a segment starting at vB that does not depend on the lane:
+ * the final costs of row vB-1 combined with the transition priors (StixelsKernels.cu:88-199,
+ * 687-837).  Built once, when row vB-1 becomes final, from the row's costs, the winning
+ * object chain (previous_mean) and the frame's PriorRec; read by every later segment through
+ * scalar loads.  64 bytes. */
+struct __attribute__((aligned(64))) StepRec {
+    float pwmp;      /* pw * fminf(p1, p2) of the ground (vB-1 < vhor) or sky transition       */
+    int idx_gs;      /* vB*3 + (p1 < p2 ? GROUND : OBJECT)                    :723-727, 769-773 */
+    float g_hi_thr, g_lo_thr;   /* g_prev + epsilon, g_prev - epsilon                 :132, 136 */
+    float p1_hi, p1_lo, p1_mid; /* cG + pw * GetPriorCostObjectFromGround, three cases :120-144 */
+    float o_hi_thr, o_lo_thr;   /* pm + dif, pm - dif                                 :159, 163 */
+    float p2_hi, p2_lo, p2_mid; /* cO + pw * GetPriorCostObjectFromObject, three cases :146-171 */
+    float p3_yes, p3_no;        /* cS + pw * GetPriorCostObjectFromSky, fn > eps or not :173-183 */
+    float pad0, pad1;
+};
+static_assert(sizeof(StepRec) == 64, "StepRec must be 64 bytes");
+typedef const __attribute__((address_space(4))) StepRec* cstep_t;
+
+struct StepVals { /* register copy of a StepRec, always passed by value */
+    float pwmp;
+    int idx_gs;
+    float g_hi_thr, g_lo_thr, p1_hi, p1_lo, p1_mid, o_hi_thr, o_lo_thr, p2_hi, p2_lo, p2_mid, p3_yes,
+        p3_no;
+};
+
+__device__ __forceinline__ void store_step(StepRec* dst, const StepVals v) {
+    float4* d = reinterpret_cast<float4*>(dst);
+    d[0] = make_float4(v.pwmp, __builtin_bit_cast(float, v.idx_gs), v.g_hi_thr, v.g_lo_thr);
+    d[1] = make_float4(v.p1_hi, v.p1_lo, v.p1_mid, v.o_hi_thr);
+    d[2] = make_float4(v.o_lo_thr, v.p2_hi, v.p2_lo, v.p2_mid);
+    d[3] = make_float4(v.p3_yes, v.p3_no, 0.0f, 0.0f);
+}
+
+/* A scalar-loaded value made opaque to the optimiser: without this, LLVM rewrites the selects
+ * between neighbouring record fields (p1_hi / p1_lo / p1_mid ...) into a per-lane indexed load
+ * from a scratch copy of the record. */
+__device__ __forceinline__ float opaque_s(float x) {
+    asm volatile("" : "+s"(x));
+    return x;
+}
+
+__device__ __forceinline__ StepVals sload_step(const StepRec* p) {
+    cstep_t q = (cstep_t)p;
+    StepVals r;
+    r.pwmp = q->pwmp; r.idx_gs = q->idx_gs;
+    r.g_hi_thr = q->g_hi_thr; r.g_lo_thr = q->g_lo_thr;
+    r.p1_hi = opaque_s(q->p1_hi); r.p1_lo = opaque_s(q->p1_lo); r.p1_mid = opaque_s(q->p1_mid);
+    r.o_hi_thr = q->o_hi_thr; r.o_lo_thr = q->o_lo_thr;
+    r.p2_hi = opaque_s(q->p2_hi); r.p2_lo = opaque_s(q->p2_lo); r.p2_mid = opaque_s(q->p2_mid);
+    r.p3_yes = opaque_s(q->p3_yes); r.p3_no = opaque_s(q->p3_no);
+    return r;
+}
+
+__device__ __forceinline__ float readlane_f(float x, int l) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), l));
+}
+
+/* -is_logf(v) + is_logf(v2) (NegFastLogDiv, :35-38) for TWO argument pairs at once: the lower
+ * half of the wave evaluates pair A, the upper half pair B, so the serial chain pays for one
+ * logarithm instead of two.  v is a compile-time-like constant whose log is passed in. */
+__device__ __forceinline__ void neg_fastlog_div2(float neg_log_va, float v2a, float neg_log_vb,
+                                                 float v2b, const double* s_invc,
+                                                 const double* s_logc, float* outa, float* outb) {
+    const bool upper = threadIdx.x >= 32;
+    const float arg = upper ? v2b : v2a;
+    const float l = is_logf_t(arg, s_invc, s_logc);
+    const float la = readlane_f(l, 0), lb = readlane_f(l, 32);
+    *outa = neg_log_va + la;
+    *outb = neg_log_vb + lb;
+}
+
+/* StepRec of vB = r + 1 from the final row r.  All inputs are wave-uniform; every lane computes
+ * the same values.  s_S / s_V: the column's disparity / valid-count prefixes in LDS. */
+template <bool HAS_INVALID>
+__device__ __forceinline__ StepVals make_step(const DevParams& P, const float* s_S, const float* s_V,
+                                             const float* s_odr, const double* s_invc,
+                                             const double* s_logc, cprior_t pr, int vhor, int r,
+                                             float cG, float cO, float cS, int obj_vB) {
+    const int vB = r + 1;
+    const float pw = P.pw;
+    StepVals st;
+    /* previous_mean = ComputeMean(previous_object_vB, previous_vT), :47-60, :675-685 */
+    float pm;
+    if (HAS_INVALID) {
+        const float valid_dif = s_V[r + 1] - s_V[obj_vB];
+        pm = (valid_dif == 0) ? 0 : (s_S[r + 1] - s_S[obj_vB]) / valid_dif;
+    } else {
+        pm = (s_S[r + 1] - s_S[obj_vB]) / (float)(r + 1 - obj_vB);
+    }
+    if (pm < 0) pm = 0;
+    const float pc = pr->pc;
+
+    if (r < vhor) { /* ground, :687-728 */
+        const float prev_cost = pr->g_from;
+        const float p1 = cG + pw * prev_cost;
+        const float p2 = cO + pw * prev_cost;
+        st.pwmp = pw * __builtin_fminf(p1, p2);
+        st.idx_gs = vB * 3 + ((p1 < p2) ? IS_GROUND : IS_OBJECT);
+    } else { /* sky, :729-775 */
+        const float p1 = cG + pw * pr->s_from_g;
+        const float so = (pm < P.epsilon) ? IS_INF : (P.log2c + pc); /* :88-96 */
+        const float p2 = cO + pw * so;
+        st.pwmp = pw * __builtin_fminf(p1, p2);
+        st.idx_gs = vB * 3 + ((p1 < p2) ? IS_GROUND : IS_OBJECT);
+    }
+    /* object from ground, :120-144 */
+    st.g_hi_thr = pr->g_prev + P.epsilon;
+    st.g_lo_thr = pr->g_prev - P.epsilon;
+    st.p1_hi = cG + pw * pr->og_hi;
+    st.p1_lo = cG + pw * pr->og_lo;
+    st.p1_mid = cG + pw * pr->og_mid;
+    /* object from object, :146-171 */
+    float base = (r < vhor) ? P.nlog07 : P.log2c;
+    base += pc;
+    int k = (int)pm;
+    k = min(max(k, 0), P.D - 1);
+    float dif = s_odr[k];
+    if (dif < 0.0f) dif = 0.0f;
+    st.o_hi_thr = pm + dif;
+    st.o_lo_thr = pm - dif;
+    float nl_hi, nl_lo;
+    neg_fastlog_div2(P.nlog_pord, P.max_disf - pm - dif, P.nlog_1mpord, st.o_lo_thr, s_invc, s_logc,
+                     &nl_hi, &nl_lo);
+    st.p2_hi = cO + pw * (base + nl_hi);
+    st.p2_lo = cO + pw * (base + nl_lo);
+    st.p2_mid = cO + pw * IS_INF;
+    /* object from sky, :173-183 */
+    st.p3_yes = cS + pw * pr->o_from_s;
+    st.p3_no = cS + pw * IS_INF;
+    return st;
+}
+
+struct PairBest {
+    float g, o, s;
+    int ig, io, is; /* vB*3 + prev type */
+};
+
+/* One (vB >= 1, vT) evaluation of the pairwise model for the lane owning vT; `st` is the
+ * wave-uniform StepRec of vB.  SKY: vB-1 >= vhor (:729), else ground (:687). */
+template <bool SKY, bool ALL_LANES = false, bool NOGROUND = false>
+__device__ __forceinline__ void pairwise_step(const DevParams& P, const StepVals st, int vB,
+                                              bool live, float od, const SegTerms& t, PairBest& b) {
+    /* ALL_LANES (phase 1): every lane with vT < H is live and rows vT >= H are never stored */
+    constexpr bool CMPX = IS_CMPX_UPDATE && ALL_LANES;
+    if (SKY) { /* :729-775 */
+        const float cost = P.dw * t.sd + st.pwmp + P.sw * t.seg_s;
+        if (CMPX) {
+            take_if_less(b.s, b.is, cost, st.idx_gs);
+        } else {
+            const bool u = live && (cost < b.s);
+            b.s = u ? cost : b.s;
+            b.is = u ? st.idx_gs : b.is;
+        }
+    } else if (!NOGROUND) { /* :687-728; NOGROUND: tile at / above the horizon, see unary_step */
+        const float cost = P.dw * t.gd + st.pwmp + P.sw * t.seg_g;
+        if (CMPX) {
+            take_if_less(b.g, b.ig, cost, st.idx_gs);
+        } else {
+            const bool u = live && (cost < b.g);
+            b.g = u ? cost : b.g;
+            b.ig = u ? st.idx_gs : b.ig;
+        }
+    }
+    /* object, :777-837 */
+    const float fn = t.mean;
+    const float p1 = (fn > st.g_hi_thr) ? st.p1_hi : ((fn < st.g_lo_thr) ? st.p1_lo : st.p1_mid);
+    const float p2 = (fn > st.o_hi_thr) ? st.p2_hi : ((fn < st.o_lo_thr) ? st.p2_lo : st.p2_mid);
+    const float p3 = (fn > P.epsilon) ? st.p3_yes : st.p3_no;
+    const float m12 = __builtin_fminf(p1, p2);
+    const float mp = __builtin_fminf(m12, p3);
+    const float cost = P.dw * od + P.pw * mp + P.sw * t.seg_o;
+    /* min_prev: OBJECT (1), GROUND (0) if p1 < p2, SKY (2) if p3 < fminf(p1, p2), :828-835 */
+    const int base_o = vB * 3 + IS_OBJECT;
+    int idx = (p1 < p2) ? (base_o - 1) : base_o;
+    idx = (p3 < m12) ? (base_o + 1) : idx;
+    if (CMPX) {
+        take_if_less_v(b.o, b.io, cost, idx);
+    } else {
+        const bool u = live && (cost < b.o);
+        b.o = u ? cost : b.o;
+        b.io = u ? idx : b.io;
+    }
+}
+
+/* The pairwise DP of one 64-row tile is split over two launches (per tile, bottom-up):
+ *
+ *  phase 1  k_pw_phase1: segments that START in earlier tiles (vB <= tile_lo).  Their
+ *           predecessor rows are final (StepRec written by earlier launches, read with scalar
+ *           loads), so all (vB, vT) pairs are independent: same structure, occupancy and issue
+ *           bound as the unary kernel.  Writes the merged partial minima of the tile.
+ *  phase 2  k_pw_phase2: the 64x64 diagonal block, where step vB needs the final row vB-1 of
+ *           the same tile: one wavefront per column walks the 63 steps; the finished row is
+ *           broadcast with v_readlane, its StepRec is computed uniformly and published.
+ *
+ * The serial chain of the reference (rows x __syncthreads, StixelsKernels.cu:600-603) is thus
+ * confined to phase 2, 1/16 of the pair evaluations at 1024 rows. */
+template <bool FAST, bool HAS_INVALID, int NR>
+__device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, int colg, int tile,
+                                               const RowRec* __restrict__ recs,
+                                               const float* __restrict__ lutT,
+                                               const StepRec* __restrict__ steps,
+                                               const float* __restrict__ rcp, int vhor,
+                                               int split, int nsplit,
+                                               float* __restrict__ part_cost,
+                                               int* __restrict__ part_idx) {
+    const int H = P.H, D = P.D;
+    const int DP = D + 1;
+    float* s_tile = (float*)smem;             /* [64][D+1] */
+    float* s_rcp = s_tile + IS_TILE * DP;     /* [H+1]     */
+    const int tid = threadIdx.x, lane = tid & 63;
+    /* `nsplit` workgroups share the vB range of one (column, tile): together they behave like
+     * one workgroup of nsplit * nwl waves (few columns = small batches: more of the chip works
+     * on the latency chain); their partial minima are merged by phase 2 */
+    const int nwl = blockDim.x >> 6;
+    const int wl = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nw = nwl * nsplit;
+    const int w = split * nwl + wl;
+    const int tile_lo = tile * IS_TILE;
+    const RowRec* rcol = recs + (size_t)colg * (H + 1);
+    const float* lcol = lutT + (size_t)colg * (H + 1) * D;
+    const StepRec* scol = steps + (size_t)colg * H;
+
+    stage_lut_tile<true>(s_tile, lcol, tile_lo, H, D, tid, (int)blockDim.x);
+    for (int i = tid; i <= H; i += blockDim.x) s_rcp[i] = rcp[i];
+    const int vT = tile_lo + lane;
+    const int vTc = min(vT, H - 1);
+    const RowRec my = load_rec(rcol + vTc + 1);
+    const float* my_tile = s_tile + lane * DP;
+    const bool live = vT < H;
+    __syncthreads();
+
+    PairBest b;
+    b.g = b.o = b.s = IS_INF;
+    b.ig = b.is = -1;
+    b.io = IS_OBJECT; /* :592 */
+    const int vB_last = min(tile_lo, H - 1);
+    int vB = w;
+    /* vB-side lutT row: fetched one step ahead, picked with ds_bpermute (see LutRow) */
+    const __amdgpu_buffer_rsrc_t lrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)lcol, 0, (H + 1) * D * (int)sizeof(float), 0x00020000);
+    const int lane4 = lane * 4;
+    LutRow<NR> next_row;
+    if (vB <= vB_last) load_lut_row<NR>(next_row, lrsrc, lcol, vB == 0 ? min(nw, H) : vB, D, lane4);
+    if (vB == 0) { /* first segment, :481-594 */
+        const RowRec rb = sload_rec(rcol);
+        const int h = vTc + 1;
+        const SegTerms t = eval_segment<FAST, HAS_INVALID>(my, rb, (float)h, s_rcp[h], D, P.iw);
+        const float od = my_tile[t.fni] - lcol[(unsigned)t.fni];
+        const bool below = vT <= vhor;
+        const float cost_g = P.dw * t.gd + P.pw * P.first_g + P.sw * t.seg_g;
+        const bool ug = live && below && (cost_g < b.g);
+        b.g = ug ? cost_g : b.g;
+        b.ig = ug ? IS_GROUND : b.ig;
+        const float prior = below ? P.first_o_below : P.first_o_above;
+        const float cost = P.dw * od + P.pw * prior + P.sw * t.seg_o;
+        b.o = (live && cost < b.o) ? cost : b.o;
+        vB += nw;
+    }
+    if (IS_SKIP_GROUND_ABOVE_HORIZON && tile_lo >= vhor) {
+        for (; vB <= min(vhor, vB_last); vB += nw) { /* ground range, ground candidate = +inf */
+            const RowRec rb = sload_rec(rcol + vB);
+            const StepVals st = sload_step(scol + vB);
+            const LutRow<NR> row = next_row;
+            load_lut_row<NR>(next_row, lrsrc, lcol, min(vB + nw, H), D, lane4);
+            const int h = vTc + 1 - vB;
+            const SegTerms t = eval_segment<FAST, HAS_INVALID>(my, rb, (float)h, s_rcp[h], D, P.iw);
+            const float od = my_tile[t.fni] - pick_lut<NR>(row, t.fni);
+            pairwise_step<false, true, true>(P, st, vB, live, od, t, b);
+        }
+    }
+    for (; vB <= min(vhor, vB_last); vB += nw) { /* ground range: vB-1 < vhor */
+        const RowRec rb = sload_rec(rcol + vB);
+        const StepVals st = sload_step(scol + vB);
+        const LutRow<NR> row = next_row;
+        load_lut_row<NR>(next_row, lrsrc, lcol, min(vB + nw, H), D, lane4);
+        const int h = vTc + 1 - vB;
+        const SegTerms t = eval_segment<FAST, HAS_INVALID>(my, rb, (float)h, s_rcp[h], D, P.iw);
+        const float od = my_tile[t.fni] - pick_lut<NR>(row, t.fni);
+        pairwise_step<false, true>(P, st, vB, live, od, t, b);
+    }
+    for (; vB <= vB_last; vB += nw) { /* sky range */
+        const RowRec rb = sload_rec(rcol + vB);
+        const StepVals st = sload_step(scol + vB);
+        const LutRow<NR> row = next_row;
+        load_lut_row<NR>(next_row, lrsrc, lcol, min(vB + nw, H), D, lane4);
+        const int h = vTc + 1 - vB;
+        const SegTerms t = eval_segment<FAST, HAS_INVALID>(my, rb, (float)h, s_rcp[h], D, P.iw);
+        const float od = my_tile[t.fni] - pick_lut<NR>(row, t.fni);
+        pairwise_step<true, true>(P, st, vB, live, od, t, b);
+    }
+    /* merge the waves: min cost, ties -> smallest vB (a finite cost always has a real index) */
+    __syncthreads();
+    float* m_cost = (float*)smem;               /* [nwl][3][64] (aliases the tile) */
+    int* m_idx = (int*)(m_cost + nwl * 3 * 64); /* [nwl][3][64] */
+    m_cost[(wl * 3 + 0) * 64 + lane] = b.g; m_idx[(wl * 3 + 0) * 64 + lane] = b.ig;
+    m_cost[(wl * 3 + 1) * 64 + lane] = b.o; m_idx[(wl * 3 + 1) * 64 + lane] = b.io;
+    m_cost[(wl * 3 + 2) * 64 + lane] = b.s; m_idx[(wl * 3 + 2) * 64 + lane] = b.is;
+    __syncthreads();
+    if (tid < 3 * 64) {
+        const int type = tid >> 6;
+        float c = m_cost[(0 * 3 + type) * 64 + lane];
+        int ix = m_idx[(0 * 3 + type) * 64 + lane];
+        for (int ww = 1; ww < nwl; ww++) {
+            const float c2 = m_cost[(ww * 3 + type) * 64 + lane];
+            const int ix2 = m_idx[(ww * 3 + type) * 64 + lane];
+            const bool take = (c2 < c) || (c2 == c && c2 < IS_INF && (ix2 / 3) < (ix / 3));
+            if (take) { c = c2; ix = ix2; }
+        }
+        const size_t o = (((size_t)colg * nsplit + split) * 3 + type) * 64 + lane;
+        part_cost[o] = c;
+        part_idx[o] = ix;
+    }
+}
+
+template <bool HAS_INVALID, int NR>
+__global__ __launch_bounds__(IS_UNARY_WAVES * 64, IS_UNARY_WAVES) void k_pw_phase1(
+    const DevParams P, int col_base, int ncols, int tile, int nsplit,
+    const RowRec* __restrict__ recs, const float* __restrict__ lutT,
+    const StepRec* __restrict__ steps, const float* __restrict__ rcp,
+    const int* __restrict__ vhor_arr, const int* __restrict__ col_flags,
+    float* __restrict__ part_cost, int* __restrict__ part_idx) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int colg = col_base + (int)(blockIdx.x / (unsigned)nsplit);
+    const int split = __builtin_amdgcn_readfirstlane((int)(blockIdx.x % (unsigned)nsplit));
+    if (colg >= ncols) return;
+    const int vhor = __builtin_amdgcn_readfirstlane(vhor_arr[colg / P.C]);
+    if (__builtin_amdgcn_readfirstlane(col_flags[colg]) == 0)
+        pw_phase1_body<true, HAS_INVALID, NR>(P, smem, colg, tile, recs, lutT, steps, rcp, vhor, split,
+                                              nsplit, part_cost, part_idx);
+    else
+        pw_phase1_body<false, HAS_INVALID, NR>(P, smem, colg, tile, recs, lutT, steps, rcp, vhor, split,
+                                               nsplit, part_cost, part_idx);
+}
+
+template <bool FAST, bool HAS_INVALID>
+__device__ __forceinline__ void pw_phase2_body(const DevParams& P, char* smem, int colg, int tile,
+                                               const RowRec* __restrict__ recs,
+                                               const float* __restrict__ lutT,
+                                               const PriorRec* __restrict__ priors,
+                                               const float* __restrict__ odr,
+                                               const float* __restrict__ rcp,
+                                               const float* __restrict__ sv_arr, int vhor,
+                                               int nsplit, const float* __restrict__ part_cost,
+                                               const int* __restrict__ part_idx,
+                                               StepRec* __restrict__ steps,
+                                               float* __restrict__ cost_table,
+                                               int32_t* __restrict__ index_table) {
+    const int H = P.H, D = P.D;
+    const int lane = threadIdx.x;
+    double* s_invc = (double*)smem;                    /* [32] */
+    double* s_logc = s_invc + IS_LOG_TABLE_SIZE;       /* [32] */
+    float* s_S = (float*)(s_logc + IS_LOG_TABLE_SIZE); /* [H+1] */
+    float* s_V = s_S + (H + 1);                        /* [H+1] */
+    float* s_odr = s_V + (H + 1);                      /* [D]   */
+    const int tile_lo = tile * IS_TILE;
+    const RowRec* rcol = recs + (size_t)colg * (H + 1);
+    const float* lcol = lutT + (size_t)colg * (H + 1) * D;
+    const PriorRec* pcol = priors + (size_t)(colg / P.C) * H;
+    StepRec* scol = steps + (size_t)colg * H;
+    const float* sv = sv_arr + (size_t)colg * 2 * (H + 1);
+    if (lane == 0) is_log_tables(s_invc, s_logc);
+    for (int i = lane; i <= H; i += 64) {
+        s_S[i] = sv[i];
+        if (HAS_INVALID) s_V[i] = sv[H + 1 + i];
+    }
+    for (int i = lane; i < D; i += 64) s_odr[i] = odr[i];
+    const int vT = tile_lo + lane;
+    const int vTc = min(vT, H - 1);
+    const RowRec my = load_rec(rcol + vTc + 1);
+    const float* my_row = lcol + (size_t)(vTc + 1) * D;
+    PairBest b; /* partial minima of phase 1 (its nsplit workgroups merged: min cost, then smallest vB) */
+    {
+        const size_t o = (size_t)colg * nsplit * 3 * 64 + lane;
+        b.g = part_cost[o]; b.ig = part_idx[o];
+        b.o = part_cost[o + 64]; b.io = part_idx[o + 64];
+        b.s = part_cost[o + 128]; b.is = part_idx[o + 128];
+        for (int sp = 1; sp < nsplit; sp++) {
+            const size_t q = o + (size_t)sp * 3 * 64;
+            float c2 = part_cost[q]; int i2 = part_idx[q];
+            if ((c2 < b.g) || (c2 == b.g && c2 < IS_INF && (i2 / 3) < (b.ig / 3))) { b.g = c2; b.ig = i2; }
+            c2 = part_cost[q + 64]; i2 = part_idx[q + 64];
+            if ((c2 < b.o) || (c2 == b.o && c2 < IS_INF && (i2 / 3) < (b.io / 3))) { b.o = c2; b.io = i2; }
+            c2 = part_cost[q + 128]; i2 = part_idx[q + 128];
+            if ((c2 < b.s) || (c2 == b.s && c2 < IS_INF && (i2 / 3) < (b.is / 3))) { b.s = c2; b.is = i2; }
+        }
+    }
+    __syncthreads();
+
+    const int n_rows = min(IS_TILE, H - tile_lo);
+    StepVals st;
+    st.pwmp = IS_INF; st.idx_gs = -1;
+    st.g_hi_thr = st.g_lo_thr = st.p1_hi = st.p1_lo = st.p1_mid = st.o_hi_thr = st.o_lo_thr = 0.0f;
+    st.p2_hi = st.p2_lo = st.p2_mid = st.p3_yes = st.p3_no = 0.0f;
+    for (int s = 0; s < n_rows; s++) {
+        const int r = tile_lo + s; /* row that becomes final in this step */
+        if (s > 0) { /* segments starting at vB = r: lanes vT >= r */
+            const RowRec rb = sload_rec(rcol + r);
+            const int hc = max(vTc + 1 - r, 1);
+            const bool live = (vT < H) && (vT >= r);
+            const SegTerms t = eval_segment<FAST, HAS_INVALID>(my, rb, (float)hc, rcp[hc], D, P.iw);
+            const float od = my_row[(unsigned)t.fni] - (lcol + (size_t)r * D)[(unsigned)t.fni];
+            if (r - 1 < vhor)
+                pairwise_step<false>(P, st, r, live, od, t, b);
+            else
+                pairwise_step<true>(P, st, r, live, od, t, b);
+        }
+        /* lane s holds the final values of row r: broadcast, derive the StepRec of vB = r+1 */
+        if (r + 1 < H) {
+            const float cG = readlane_f(b.g, s), cO = readlane_f(b.o, s), cS = readlane_f(b.s, s);
+            const int io = __builtin_amdgcn_readlane(b.io, s);
+            st = make_step<HAS_INVALID>(P, s_S, s_V, s_odr, s_invc, s_logc, (cprior_t)(pcol + r + 1), vhor,
+                                        r, cG, cO, cS, io / 3);
+            if (lane == 0) store_step(scol + r + 1, st);
+        }
+    }
+    if (vT < H) {
+        const size_t o = ((size_t)colg * H + vT) * 3;
+        cost_table[o + 0] = b.g; cost_table[o + 1] = b.o; cost_table[o + 2] = b.s;
+        index_table[o + 0] = b.ig; index_table[o + 1] = b.io; index_table[o + 2] = b.is;
+    }
+}
+
+template <bool HAS_INVALID>
+__global__ __launch_bounds__(64) void k_pw_phase2(
+    const DevParams P, int col_base, int ncols, int tile, int nsplit,
+    const RowRec* __restrict__ recs, const float* __restrict__ lutT,
+    const PriorRec* __restrict__ priors,
+    const float* __restrict__ odr, const float* __restrict__ rcp,
+    const float* __restrict__ sv_arr, const int* __restrict__ vhor_arr,
+    const int* __restrict__ col_flags, const float* __restrict__ part_cost,
+    const int* __restrict__ part_idx, StepRec* __restrict__ steps, float* __restrict__ cost_table,
+    int32_t* __restrict__ index_table) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int colg = col_base + blockIdx.x;
+    if (colg >= ncols) return;
+    const int vhor = __builtin_amdgcn_readfirstlane(vhor_arr[colg / P.C]);
+    if (__builtin_amdgcn_readfirstlane(col_flags[colg]) == 0)
+        pw_phase2_body<true, HAS_INVALID>(P, smem, colg, tile, recs, lutT, priors, odr, rcp, sv_arr, vhor,
+                                          nsplit, part_cost, part_idx, steps, cost_table, index_table);
+    else
+        pw_phase2_body<false, HAS_INVALID>(P, smem, colg, tile, recs, lutT, priors, odr, rcp, sv_arr, vhor,
+                                           nsplit, part_cost, part_idx, steps, cost_table, index_table);
+}
+
+extern "C" {
+
+size_t isk_pairwise_lds_bytes(const DevParams* P, int nwaves) { return isk_unary_lds_bytes(P); }
+size_t isk_phase2_lds_bytes(const DevParams* P) {
+    return sizeof(double) * 2 * IS_LOG_TABLE_SIZE + sizeof(float) * (2 * ((size_t)P->H + 1) + P->D) + 16;
+}
+
+hipError_t isk_launch_dp_pairwise(const DevParams* P, int ncols, int nwaves, const RowRec* recs,
+                                  const float* lutT, const PriorRec* priors, const float* odr,
+                                  const float* rcp, const float* sv_arr, const int* vhor,
+                                  const int* col_flags, StepRec* steps, float* part_cost,
+                                  int* part_idx, float* cost_table, int32_t* index_table,
+                                  hipStream_t stream, hipStream_t aux, hipEvent_t ev_fork,
+                                  hipEvent_t ev_join) {
+    const size_t lds1 = isk_pairwise_lds_bytes(P, nwaves);
+    const size_t lds2 = isk_phase2_lds_bytes(P);
+    /* Columns are independent: with enough of them the batch is cut in two halves whose
+     * phase-1 / phase-2 chains run on two streams, the second one phase behind the first, so
+     * that the issue-bound phase 1 of one half shares the CUs with the latency-bound serial
+     * phase 2 of the other. */
+    /* few columns: nsplit workgroups per (column, tile) in phase 1, up to ~one workgroup per CU x4 */
+    int nsplit = IS_PW_SPLIT_TARGET_WGS / (ncols > 0 ? ncols : 1);
+    nsplit = nsplit < 1 ? 1 : (nsplit > IS_PW_MAX_SPLIT ? IS_PW_MAX_SPLIT : nsplit);
+    const bool split = aux != nullptr && ncols >= 2 * IS_PAIRWISE_SPLIT_MIN_COLS;
+    const int c_mid = split ? (ncols / 2) : ncols;
+    hipError_t e;
+/* phase 1 with the vB-side lutT row in registers (LutRow<2>) measured SLOWER than the per-lane
+ * gather on MI355X (41.4 vs 38.0 ms per 64 frames): the pick costs more VALU than the gather's
+ * address arithmetic and phase 1 is issue-bound; kept selectable for later rounds */
+#define IS_PW_PHASE1_ROW_REGS 0
+#define IS_LAUNCH_P1(INV, c0, c1, st)                                                              \
+    do {                                                                                           \
+        if (IS_PW_PHASE1_ROW_REGS && P->D <= 128)                                                  \
+            hipLaunchKernelGGL((k_pw_phase1<INV, 2>), dim3(((c1) - (c0)) * nsplit),                \
+                               dim3(nwaves * 64), lds1, st, *P, c0, c1, tile, nsplit, recs, lutT,  \
+                               steps, rcp, vhor, col_flags, part_cost, part_idx);                  \
+        else                                                                                       \
+            hipLaunchKernelGGL((k_pw_phase1<INV, 0>), dim3(((c1) - (c0)) * nsplit),                \
+                               dim3(nwaves * 64), lds1, st, *P, c0, c1, tile, nsplit, recs, lutT,  \
+                               steps, rcp, vhor, col_flags, part_cost, part_idx);                  \
+    } while (0)
+#define IS_LAUNCH_P2(INV, c0, c1, st)                                                              \
+    hipLaunchKernelGGL(k_pw_phase2<INV>, dim3((c1) - (c0)), dim3(64), lds2, st, *P, c0, c1, tile,  \
+                       nsplit, recs, lutT, priors, odr, rcp, sv_arr, vhor, col_flags, part_cost,   \
+                       part_idx, steps, cost_table, index_table)
+    const bool inv = P->invalid >= 0;
+    for (int tile = 0; tile < P->ntiles; tile++) {
+        if (inv) IS_LAUNCH_P1(true, 0, c_mid, stream); else IS_LAUNCH_P1(false, 0, c_mid, stream);
+        if (split && tile == 0) { /* the second half starts one phase behind the first */
+            if ((e = hipEventRecord(ev_fork, stream)) != hipSuccess) return e;
+            if ((e = hipStreamWaitEvent(aux, ev_fork, 0)) != hipSuccess) return e;
+        }
+        if (inv) IS_LAUNCH_P2(true, 0, c_mid, stream); else IS_LAUNCH_P2(false, 0, c_mid, stream);
+        if (split) {
+            if (inv) IS_LAUNCH_P1(true, c_mid, ncols, aux); else IS_LAUNCH_P1(false, c_mid, ncols, aux);
+            if (inv) IS_LAUNCH_P2(true, c_mid, ncols, aux); else IS_LAUNCH_P2(false, c_mid, ncols, aux);
+        }
+    }
+#undef IS_LAUNCH_P1
+#undef IS_LAUNCH_P2
+    if (split) {
+        if ((e = hipEventRecord(ev_join, aux)) != hipSuccess) return e;
+        if ((e = hipStreamWaitEvent(stream, ev_join, 0)) != hipSuccess) return e;
+    }
+    return hipGetLastError();
+}
+
+hipError_t isk_set_lds_pairwise(const DevParams* P, int nwaves_pair) {
+    hipError_t e;
+    const int c = (int)isk_pairwise_lds_bytes(P, nwaves_pair);
+    e = hipFuncSetAttribute((const void*)k_pw_phase1<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, c);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void*)k_pw_phase1<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, c);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void*)k_pw_phase1<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, c);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void*)k_pw_phase1<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, c);
+    return e;
+}
+
+} /* extern "C" */

@@ -1,0 +1,458 @@
+/* is_k_prepare.hip -- per-column boundary records, object data-cost prefix table, pairwise
+ * prior tables.  See is_kernels.h. */
+#include "is_kernels.h"
+
+/* ====================================================================================== */
+/* A4-A6  per-column preparation                                                           */
+/* ====================================================================================== */
+#define PREP_THREADS 256
+
+/* Exclusive prefix of index i (0 <= i < n) with the association of the reference's
+ * work-efficient block scan ComputePrefixSum (StixelsKernels.h:73-103): the up-sweep builds a
+ * pairwise tree, the down-sweep gives a right child `parent + left subtree sum`, i.e. the
+ * left-sibling sums on the root-to-leaf path are added top-down starting from 0.
+ * pyr holds the tree: level b (n>>b nodes) at offset 2n - (2n>>b). */
+__device__ __forceinline__ float blelloch_prefix(const float* pyr, int n, int log2n, int i) {
+    float acc = 0.0f;
+    for (int b = log2n - 1; b >= 0; b--) {
+        const int node = i >> b;
+        if (node & 1) acc = acc + pyr[(2 * n - ((2 * n) >> b)) + node - 1];
+    }
+    return acc;
+}
+
+__device__ __forceinline__ void blelloch_build(float* pyr, int n, int log2n) {
+    for (int b = 1; b <= log2n; b++) {
+        const float* lo = pyr + (2 * n - ((2 * n) >> (b - 1)));
+        float* hi = pyr + (2 * n - ((2 * n) >> b));
+        for (int j = threadIdx.x; j < (n >> b); j += PREP_THREADS) hi[j] = lo[2 * j + 1] + lo[2 * j];
+        __syncthreads();
+    }
+}
+
+/* Exact exclusive block scan of one int64 per thread (any association is exact). */
+__device__ __forceinline__ int64_t block_excl_scan_i64(int64_t v, int64_t* s_wave /*[4]*/) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int64_t inc = v;
+#pragma unroll
+    for (int j = 1; j < 64; j <<= 1) {
+        const int64_t n = __shfl_up(inc, j, 64);
+        if (lane >= j) inc += n;
+    }
+    __syncthreads(); /* s_wave may still be read by the previous call */
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    int64_t base = 0;
+    for (int w = 0; w < wave; w++) base += s_wave[w];
+    return base + inc - v;
+}
+
+__device__ __forceinline__ float data_cost_sky(float d, const DevParams& P) {
+    /* GetDataCostSky, StixelsKernels.cu:201-215 */
+    float data_cost = P.pnex_sky_log;
+    if (d != P.invalid) {
+        const float pgaussian = P.norm_sky + d * d * P.inv_sigma2_sky;
+        const float p_data = __builtin_fminf(P.puniform_sky, pgaussian);
+        data_cost = p_data + P.nopnex_sky_log;
+    }
+    return data_cost;
+}
+__device__ __forceinline__ float data_cost_ground(float fn, float d, float norm_g, float inv_s2_g,
+                                                  const DevParams& P) {
+    /* GetDataCostGround, StixelsKernels.cu:217-234 */
+    float data_cost = P.pnex_gnd_log;
+    if (d != P.invalid) {
+        const float model_diff = (d - fn);
+        const float pgaussian = norm_g + model_diff * model_diff * inv_s2_g;
+        const float p_data = __builtin_fminf(P.puniform, pgaussian);
+        data_cost = p_data + P.nopnex_gnd_log;
+    }
+    return data_cost;
+}
+
+/* full-resolution prefix from the 1/8-resolution exclusive prefix ps (see RowRec) */
+__device__ __forceinline__ int32_t full_prefix(const int32_t* ps, int v) {
+    const int k = v >> 3, m = v & 7;
+    int32_t r = (int32_t)((uint32_t)ps[k] * 8u);
+    if (m) r = (int32_t)((uint32_t)r + (uint32_t)(ps[k + 1] - ps[k]) * (uint32_t)m);
+    return r;
+}
+
+__device__ __forceinline__ void store_instance_prefix(RowRec* o, int slow, int64_t mx, int64_t my,
+                                                      int64_t mx2, int64_t my2) {
+    /* dwords 24..31 of the record as two 16-byte stores */
+    int4 a, b;
+    if (slow) { /* RowRecWide: four int64 */
+        a = make_int4((int)(uint32_t)mx, (int)(uint32_t)((uint64_t)mx >> 32), (int)(uint32_t)my,
+                      (int)(uint32_t)((uint64_t)my >> 32));
+        b = make_int4((int)(uint32_t)mx2, (int)(uint32_t)((uint64_t)mx2 >> 32), (int)(uint32_t)my2,
+                      (int)(uint32_t)((uint64_t)my2 >> 32));
+    } else { /* exact fp32 encodings, see RowRec */
+        const int64_t lo_mask = ((int64_t)1 << IS_FAST_SPLIT_BITS) - 1;
+        a = make_int4(__float_as_int((float)mx), __float_as_int((float)my),
+                      __float_as_int((float)(mx2 - (mx2 & lo_mask))), __float_as_int((float)(mx2 & lo_mask)));
+        b = make_int4(__float_as_int((float)(my2 - (my2 & lo_mask))), __float_as_int((float)(my2 & lo_mask)),
+                      0, 0);
+    }
+    int4* d = reinterpret_cast<int4*>(o);
+    d[6] = a;
+    d[7] = b;
+}
+
+__global__ __launch_bounds__(PREP_THREADS) void k_prepare_columns(
+    const DevParams P, const float* __restrict__ joined, const int32_t* __restrict__ seg,
+    const float* __restrict__ ground /*[img][3][H]*/, const int* __restrict__ vhor_arr,
+    RowRec* __restrict__ recs, int* __restrict__ col_flags, float* __restrict__ sv_arr) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int H = P.H, P2 = P.P2, P2S = P.P2S, CH = P.CH, K = P.K;
+    float* s_d = (float*)smem;                          /* [P2]   disparity column        */
+    float* s_pyr = s_d + P2;                            /* [2*P2] scan tree                */
+    int32_t* s_seg = (int32_t*)(s_pyr + 2 * P2);        /* [CH][P2S]                       */
+    int64_t* s_wave = (int64_t*)(s_seg + CH * P2S);     /* [4]                             */
+
+    const int colg = blockIdx.x;
+    const int img = colg / P.C, col = colg % P.C;
+    const int vhor = vhor_arr[img];
+    const float* gfun = ground + (size_t)img * 3 * H;
+    const float* gnorm = gfun + H;
+    const float* gis2 = gnorm + H;
+    const float* dcol = joined + (size_t)colg * H;
+    const int32_t* scol = seg + (size_t)colg * CH * P2S;
+    RowRec* rcol = recs + (size_t)colg * (H + 1);
+    const int tid = threadIdx.x;
+
+    for (int i = tid; i < P2; i += PREP_THREADS) s_d[i] = (i < H) ? dcol[i] : 0.0f;
+    for (int i = tid; i < CH * P2S; i += PREP_THREADS) s_seg[i] = scol[i];
+    __syncthreads();
+
+    /* ---- instance-centre values per row from the RAW offsets (StixelsKernels.cu:401-409);
+     * thread t owns rows [t*R, t*R+R).  mx = 8*col + 3.5 + offx + 0.5 is an exact integer;
+     * my = trunc(row - offy + 0.5): n for n >= 0, n + 1 for n < 0 (truncation toward zero). */
+    const int R = (H + PREP_THREADS - 1) / PREP_THREADS;
+    const int r_lo = tid * R;
+    const int32_t* offy = s_seg + K * P2S;
+    const int32_t* offx = s_seg + (K + 1) * P2S;
+    int64_t sum_mx = 0, sum_my = 0, sum_mx2 = 0, sum_my2 = 0;
+    uint64_t abs_mx = 0, abs_my = 0;
+    int slow = 0; /* column needs the generic (int64 / IEEE-division) DP path, see RowRec */
+    for (int r = r_lo; r < r_lo + R && r < H; r++) {
+        const double fx = ((double)(P.column_step * col) + 0.5 * ((double)P.column_step - 1.0)) +
+                          (double)offx[r >> 3] + 0.5;
+        const int64_t mx = (int64_t)fx;
+        const int32_t n32 = (int32_t)((uint32_t)r - (uint32_t)offy[r >> 3]);
+        const int64_t my = (int64_t)((double)n32 + 0.5);
+        abs_mx += (uint64_t)(mx < 0 ? -mx : mx);
+        abs_my += (uint64_t)(my < 0 ? -my : my);
+        const float ad = __builtin_fabsf(s_d[r]);
+        slow |= !((ad == 0.0f) || (ad >= IS_FAST_DISP_MIN && ad <= IS_FAST_DISP_MAX));
+        sum_mx += mx;
+        sum_my += my;
+        sum_mx2 = (int64_t)((uint64_t)sum_mx2 + (uint64_t)mx * (uint64_t)mx);
+        sum_my2 = (int64_t)((uint64_t)sum_my2 + (uint64_t)my * (uint64_t)my);
+    }
+    { /* instance centres of a FAST column: sum|mx|, sum|my| < 2^23 (block totals through LDS) */
+        unsigned long long* s_abs = (unsigned long long*)s_wave;
+        if (tid < 2) s_abs[tid] = 0ull;
+        __syncthreads();
+        atomicAdd(&s_abs[0], (unsigned long long)abs_mx);
+        atomicAdd(&s_abs[1], (unsigned long long)abs_my);
+        __syncthreads();
+        slow |= (s_abs[0] >= (unsigned long long)IS_FAST_INSTANCE_LIMIT) |
+                (s_abs[1] >= (unsigned long long)IS_FAST_INSTANCE_LIMIT);
+        __syncthreads(); /* s_wave is reused by the scans below */
+    }
+    if (tid < K) { /* class channels of a FAST column: values >= 0, full-resolution total < 2^24 */
+        const int32_t* ch = s_seg + tid * P2S;
+        uint64_t total = 0;
+        int negative = 0;
+        for (int k = 0; k < P2S; k++) {
+            negative |= (ch[k] < 0);
+            total += (uint64_t)(uint32_t)ch[k];
+        }
+        slow |= negative | (total * IS_DOWNSAMPLE_FACTOR >= (uint64_t)IS_FAST_CLASS_LIMIT);
+    }
+    slow = __syncthreads_or(slow);
+    if (tid == 0) col_flags[colg] = slow;
+    int64_t base_mx = block_excl_scan_i64(sum_mx, s_wave);
+    int64_t base_my = block_excl_scan_i64(sum_my, s_wave);
+    int64_t base_mx2 = block_excl_scan_i64(sum_mx2, s_wave);
+    int64_t base_my2 = block_excl_scan_i64(sum_my2, s_wave);
+    /* the owner of rows [r_lo, r_lo+R) writes the exclusive prefix at those indices; the owner
+     * of row H-1 also writes index H (the total) */
+    for (int r = r_lo; r < r_lo + R && r < H; r++) {
+        store_instance_prefix(rcol + r, slow, base_mx, base_my, base_mx2, base_my2);
+        const double fx = ((double)(P.column_step * col) + 0.5 * ((double)P.column_step - 1.0)) +
+                          (double)offx[r >> 3] + 0.5;
+        const int64_t mx = (int64_t)fx;
+        const int32_t n32 = (int32_t)((uint32_t)r - (uint32_t)offy[r >> 3]);
+        const int64_t my = (int64_t)((double)n32 + 0.5);
+        base_mx += mx;
+        base_my += my;
+        base_mx2 = (int64_t)((uint64_t)base_mx2 + (uint64_t)mx * (uint64_t)mx);
+        base_my2 = (int64_t)((uint64_t)base_my2 + (uint64_t)my * (uint64_t)my);
+    }
+    if (r_lo <= H - 1 && H - 1 < r_lo + R)
+        store_instance_prefix(rcol + H, slow, base_mx, base_my, base_mx2, base_my2);
+    __syncthreads();
+
+    /* ---- square the offset channels in place (StixelsKernels.cu:411-416), then exclusive
+     * prefix of every channel at 1/8 resolution (:462-469); integer, so any order is exact */
+    for (int i = tid; i < 2 * P2S; i += PREP_THREADS) {
+        const uint32_t x = (uint32_t)s_seg[K * P2S + i];
+        s_seg[K * P2S + i] = (int32_t)(x * x);
+    }
+    __syncthreads();
+    /* one wave per channel (round robin): lane l owns P2S/64 consecutive entries */
+    {
+        const int lane = tid & 63, wv = tid >> 6, per = P2S >> 6;
+        for (int c = wv; c < CH; c += PREP_THREADS / 64) {
+            int32_t* ch = s_seg + c * P2S;
+            if (per >= 1) {
+                uint32_t local = 0;
+                for (int k = 0; k < per; k++) local += (uint32_t)ch[lane * per + k];
+                uint32_t inc = local; /* inclusive wave scan of the lane totals */
+#pragma unroll
+                for (int j = 1; j < 64; j <<= 1) {
+                    const uint32_t n = (uint32_t)__shfl_up((int)inc, j, 64);
+                    if (lane >= j) inc += n;
+                }
+                uint32_t run = inc - local;
+                for (int k = 0; k < per; k++) {
+                    const uint32_t x = (uint32_t)ch[lane * per + k];
+                    ch[lane * per + k] = (int32_t)run;
+                    run += x;
+                }
+            } else if (lane == 0) { /* P2S < 64: tiny columns */
+                uint32_t run = 0;
+                for (int k = 0; k < P2S; k++) {
+                    const uint32_t x = (uint32_t)ch[k];
+                    ch[k] = (int32_t)run;
+                    run += x;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    /* dwords 0..19 of every record (class prefixes + squared-offset prefix) as five 16-byte
+     * chunks: consecutive threads write consecutive chunks */
+    for (int i = tid; i < (H + 1) * 5; i += PREP_THREADS) {
+        const int v = i / 5, q = i - v * 5;
+        int32_t x[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int dw = q * 4 + j; /* dword of RowRec: Fg0 Fg1 Fon[8] Foi[8] Fsky Fnic */
+            if (dw == 19) {
+                x[j] = (int32_t)((uint32_t)full_prefix(s_seg + (K + 1) * P2S, v) +
+                                 (uint32_t)full_prefix(s_seg + K * P2S, v));
+            } else {
+                const int chn = dw < 10 ? dw : (dw < 18 ? dw + 1 : 10);
+                const int32_t f = full_prefix(s_seg + chn * P2S, v);
+                x[j] = slow ? f : __float_as_int((float)f);
+            }
+        }
+        reinterpret_cast<int4*>(rcol + v)[q] = make_int4(x[0], x[1], x[2], x[3]);
+    }
+
+    /* ---- fp32 prefixes with the reference's block-scan association (:452-461) */
+    /* S: disparity (valid-masked when invalid >= 0, :382-389) */
+    for (int i = tid; i < P2; i += PREP_THREADS) {
+        float x = 0.0f;
+        if (i < H) {
+            const float d = s_d[i];
+            if (P.invalid >= 0) {
+                const int va = d != P.invalid;
+                x = ((float)va) * d;
+            } else {
+                x = d;
+            }
+        }
+        s_pyr[i] = x;
+    }
+    __syncthreads();
+    blelloch_build(s_pyr, P2, P.log2P2);
+    float* svcol = sv_arr + (size_t)colg * 2 * (H + 1); /* compact copies for the pairwise phase 2 */
+    for (int v = tid; v <= H; v += PREP_THREADS) {
+        const float x = blelloch_prefix(s_pyr, P2, P.log2P2, v);
+        rcol[v].S = x;
+        svcol[v] = x;
+    }
+    __syncthreads();
+    /* V: valid count (all zero without an invalid-disparity value: no scan needed) */
+    if (P.invalid >= 0) {
+        for (int i = tid; i < P2; i += PREP_THREADS)
+            s_pyr[i] = (i < H) ? (float)(s_d[i] != P.invalid) : 0.0f;
+        __syncthreads();
+        blelloch_build(s_pyr, P2, P.log2P2);
+        for (int v = tid; v <= H; v += PREP_THREADS) {
+            const float x = blelloch_prefix(s_pyr, P2, P.log2P2, v);
+            rcol[v].V = x;
+            svcol[H + 1 + v] = x;
+        }
+        __syncthreads();
+    } else {
+        for (int v = tid; v <= H; v += PREP_THREADS) {
+            rcol[v].V = 0.0f;
+            svcol[H + 1 + v] = 0.0f;
+        }
+    }
+    /* G: ground data cost, +inf at / above the horizon (:435-446) */
+    for (int i = tid; i < P2; i += PREP_THREADS) {
+        float x = 0.0f;
+        if (i < H)
+            x = (i >= vhor) ? IS_INF : data_cost_ground(gfun[i], s_d[i], gnorm[i], gis2[i], P);
+        s_pyr[i] = x;
+    }
+    __syncthreads();
+    blelloch_build(s_pyr, P2, P.log2P2);
+    for (int v = tid; v <= H; v += PREP_THREADS) rcol[v].G = blelloch_prefix(s_pyr, P2, P.log2P2, v);
+    __syncthreads();
+    /* K: sky data cost, 0 below the horizon (:424-433) */
+    for (int i = tid; i < P2; i += PREP_THREADS) {
+        float x = 0.0f;
+        if (i < H) x = (i < vhor) ? 0.0f : data_cost_sky(s_d[i], P);
+        s_pyr[i] = x;
+    }
+    __syncthreads();
+    blelloch_build(s_pyr, P2, P.log2P2);
+    for (int v = tid; v <= H; v += PREP_THREADS) rcol[v].K = blelloch_prefix(s_pyr, P2, P.log2P2, v);
+}
+
+/* ====================================================================================== */
+/* A4  object data-cost prefix table (ComputeObjectLUT, StixelsKernels.cu:236-296, 959-978) */
+/* ====================================================================================== */
+/* lutT[v][fn] = prefix over rows of obj_cost_lut[fn][(int)d[row]] with the reference's
+ * association: per 32-row block a 32-lane Kogge-Stone network (shuffle distances 1,2,4,8,16)
+ * whose lane 0 first receives the running carry; blocks chained serially.
+ *
+ * The reference gives a warp one fn and lets lanes be rows (5 shuffles per block).  Here a LANE
+ * owns one fn and evaluates the same 32-input network on registers (129 fp32 adds per block, no
+ * cross-lane traffic); the 64 lanes of a wave are 64 consecutive fn, so every load of the
+ * transposed cost table and every store of a lutT row is one fully coalesced 256-byte access. */
+#define LUT_BLOCK 32
+__global__ __launch_bounds__(64) void k_object_lut(const DevParams P,
+                                                   const float* __restrict__ joined,
+                                                   const float* __restrict__ cost_T /*[dis][fn]*/,
+                                                   float* __restrict__ lutT) {
+    const int H = P.H, D = P.D;
+    const int colg = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int fn = blockIdx.y * 64 + lane;
+    const bool fn_ok = fn < D;
+    const int fnc = fn_ok ? fn : D - 1;
+    const float* dcol = joined + (size_t)colg * H;
+    float* lcol = lutT + (size_t)colg * (H + 1) * D;
+    if (fn_ok) lcol[fn] = 0.0f; /* arr[0] = 0, :283-285 */
+    float add = 0.0f;
+    /* the per-row costs of the NEXT block are fetched before this block's 32 row stores are issued:
+     * a wave's memory operations retire in order, so loads queued behind the stores would wait
+     * for the whole store latency */
+    float cn[LUT_BLOCK];
+    auto fetch = [&](int i, float (&c)[LUT_BLOCK]) {
+        /* (int)d of the block's 32 rows: one coalesced load, then wave-uniform broadcasts */
+        const int rl = i + (lane & (LUT_BLOCK - 1));
+        int dis_l = 0; /* rows beyond the image use dis = 0, :244-247 */
+        if (rl < H) dis_l = (int)dcol[rl];
+        dis_l = min(max(dis_l, 0), D - 1); /* memory safety outside the input domain (Q8) */
+#pragma unroll
+        for (int l = 0; l < LUT_BLOCK; l++) {
+            const int dis = __builtin_amdgcn_readlane(dis_l, l);
+            c[l] = cost_T[(size_t)dis * D + fnc];
+        }
+    };
+    fetch(0, cn);
+    for (int i = 0; i < H; i += LUT_BLOCK) {
+        float c[LUT_BLOCK];
+#pragma unroll
+        for (int l = 0; l < LUT_BLOCK; l++) c[l] = cn[l];
+        if (i + LUT_BLOCK < H) fetch(i + LUT_BLOCK, cn);
+        c[0] += add; /* :249-251 */
+#pragma unroll
+        for (int j = 1; j < LUT_BLOCK; j <<= 1) { /* :255-263; descending l reads pre-step values */
+#pragma unroll
+            for (int l = LUT_BLOCK - 1; l >= j; l--) c[l] += c[l - j];
+        }
+        if (fn_ok) {
+#pragma unroll
+            for (int l = 0; l < LUT_BLOCK; l++)
+                if (i + l < H) lcol[(size_t)(i + l + 1) * D + fn] = c[l]; /* :266 */
+        }
+        add = c[LUT_BLOCK - 1]; /* :268-272 */
+    }
+}
+
+/* ====================================================================================== */
+/* Pairwise transition priors that depend only on vB and the frame's ground model          */
+/* ====================================================================================== */
+__device__ __forceinline__ float neg_fastlog_div(float v, float v2) { /* :35-38 */
+    return -is_logf(v) + is_logf(v2);
+}
+
+__global__ void k_prior_tables(const DevParams P, const float* __restrict__ ground,
+                               PriorRec* __restrict__ priors, int n_images) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_images * P.H) return;
+    const int img = idx / P.H, vB = idx % P.H;
+    const float* gfun = ground + (size_t)img * 3 * P.H;
+    PriorRec r;
+    r.pc = neg_fastlog_div(1.0f, (float)(P.H - vB));
+    r.g_from = P.nlog03 + r.pc;
+    float gprev = (vB > 0) ? gfun[vB - 1] : 0.0f;
+    r.s_from_g = (gprev < 1.0f) ? r.pc : IS_INF;
+    r.o_from_s = neg_fastlog_div(1.0f, P.max_disf - P.epsilon) + r.pc;
+    const float base = P.nlog07 + r.pc;
+    if (gprev < 0.0f) gprev = 0.0f;
+    r.g_prev = gprev;
+    r.og_hi = base + neg_fastlog_div(P.pgrav, P.max_disf - gprev - P.epsilon);
+    r.og_lo = base + neg_fastlog_div(P.pblg, gprev - P.epsilon);
+    r.og_mid = base + neg_fastlog_div(1.0f - P.pgrav - P.pblg, 2.0f * P.epsilon);
+    priors[idx] = r;
+}
+
+extern "C" {
+
+size_t isk_prepare_lds_bytes(const DevParams* P) {
+    return sizeof(float) * (size_t)P->P2 * 3 + sizeof(int32_t) * (size_t)P->CH * P->P2S + 64;
+}
+
+hipError_t isk_launch_prepare(const DevParams* P, int ncols, const float* joined,
+                              const int32_t* seg, const float* ground, const int* vhor,
+                              const float* cost_T, RowRec* recs, float* lutT,
+                              int* col_flags, float* sv_arr, hipStream_t stream, hipStream_t aux,
+                              hipEvent_t ev_fork, hipEvent_t ev_join) {
+    /* The two prepare kernels are independent.  With few columns (a single frame = 256) neither
+     * fills the chip and both are latency chains, so they run side by side on two streams; with
+     * many columns they are throughput-bound (HBM writes) and stay in order on one stream. */
+    const bool side_by_side = aux != nullptr && ncols < IS_PREPARE_OVERLAP_MAX_COLS;
+    hipError_t e;
+    hipStream_t lut_stream = stream;
+    if (side_by_side) {
+        if ((e = hipEventRecord(ev_fork, stream)) != hipSuccess) return e;
+        if ((e = hipStreamWaitEvent(aux, ev_fork, 0)) != hipSuccess) return e;
+        lut_stream = aux;
+    }
+    hipLaunchKernelGGL(k_object_lut, dim3(ncols, (P->D + 63) / 64), dim3(64), 0, lut_stream, *P,
+                       joined, cost_T, lutT);
+    hipLaunchKernelGGL(k_prepare_columns, dim3(ncols), dim3(PREP_THREADS),
+                       isk_prepare_lds_bytes(P), stream, *P, joined, seg, ground, vhor, recs,
+                       col_flags, sv_arr);
+    if (side_by_side) {
+        if ((e = hipEventRecord(ev_join, aux)) != hipSuccess) return e;
+        if ((e = hipStreamWaitEvent(stream, ev_join, 0)) != hipSuccess) return e;
+    }
+    return hipGetLastError();
+}
+
+hipError_t isk_launch_priors(const DevParams* P, const float* ground, PriorRec* priors,
+                             int n_images, hipStream_t stream) {
+    const int n = n_images * P->H;
+    hipLaunchKernelGGL(k_prior_tables, dim3((n + 255) / 256), dim3(256), 0, stream, *P, ground,
+                       priors, n_images);
+    return hipGetLastError();
+}
+
+hipError_t isk_set_lds_prepare(const DevParams* P) {
+    return hipFuncSetAttribute((const void*)k_prepare_columns, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)isk_prepare_lds_bytes(P));
+}
+
+} /* extern "C" */

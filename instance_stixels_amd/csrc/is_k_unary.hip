@@ -1,0 +1,307 @@
+/* is_k_unary.hip -- the unary column DP.  See is_kernels.h. */
+#include "is_kernels.h"
+
+/* ====================================================================================== */
+/* A7-A9  unary DP: one workgroup = (column, 64-row tile)                                  */
+/* ====================================================================================== */
+/* In unary mode the predecessor cost is never added: cost_table[vT][t] is the
+ * minimum over vB of a single-segment cost, so all (vB, vT) pairs are independent and the only
+ * order that matters is the strict-< tie rule (smallest vB wins).  index_table holds the winning
+ * vB (or -1); the predecessor TYPE is resolved in k_backtrace from the final cost_table. */
+struct UnaryBest {
+    float g, o, s;
+    int vg, vo, vs;
+};
+
+/* One (vB, vT) evaluation of the unary model.
+ *   SKY   the segment's lower neighbour is at / above the horizon (vB-1 >= vhor, :729): the
+ *         non-object candidate is SKY, otherwise GROUND (:687); wave-uniform, so the caller runs
+ *         separate loops and each loop has ONE accumulator pair live in its body;
+ *   DIAG  the segment start may lie above this lane's vT (diagonal 64x64 block): masked lanes;
+ *   FIRST vB = 0: ground additionally needs vT <= vhor (:542-545). */
+template <bool FAST, bool HAS_INVALID, bool SKY, bool DIAG, bool FIRST, int NR, bool NOGROUND = false>
+__device__ __forceinline__ void unary_step(const DevParams& P, const RowRec& my, const RowRec& rb,
+                                           const LutRow<NR>& lrow, const float* my_tile,
+                                           const float* s_rcp, int vT, int vTc, int vhor, int vB,
+                                           float hf_full, bool row_ok, UnaryBest& b) {
+    const int h = vTc + 1 - vB;
+    const bool live = DIAG ? ((h > 0) && row_ok) : row_ok;
+    const int hc = DIAG ? max(h, 1) : h;
+    const float r = s_rcp[hc]; /* RN(1/h) = (float)(1./h) = inverse_height, :485, :608 */
+    /* full steps: the caller carries the height as a float (one 2-cycle subtraction per step
+     * instead of an integer update plus a conversion; integers < 2^24 are exact) */
+    const float hf = (DIAG || FIRST) ? (float)hc : hf_full;
+    const SegTerms t = eval_segment<FAST, HAS_INVALID>(my, rb, hf, r, P.D, P.iw);
+    const float od = my_tile[t.fni] - pick_lut<NR>(lrow, t.fni);
+    const float pwih = P.pw * r;
+    /* cost = dw*data + pw*(1/h) + sw*seg, left to right (:716-719, 762-765, 820-823) */
+    const float cost_o = P.dw * od + pwih + P.sw * t.seg_o;
+    /* full steps: every lane with vT < H is live, and rows vT >= H are never stored */
+    constexpr bool ALL_LANES = IS_CMPX_UPDATE && FAST && !DIAG && !FIRST;
+    if (ALL_LANES) {
+        take_if_less(b.o, b.vo, cost_o, vB);
+    } else {
+        const bool uo = live && (cost_o < b.o);
+        b.o = uo ? cost_o : b.o;
+        b.vo = uo ? vB : b.vo;
+    }
+    if (SKY) {
+        const float cost_s = P.dw * t.sd + pwih + P.sw * t.seg_s;
+        if (ALL_LANES) {
+            take_if_less(b.s, b.vs, cost_s, vB);
+        } else {
+            const bool us = live && (cost_s < b.s);
+            b.s = us ? cost_s : b.s;
+            b.vs = us ? vB : b.vs;
+        }
+    } else if (!NOGROUND) {
+        /* NOGROUND: every lane of the tile lies at or above the horizon, where the ground data
+         * cost prefix is +inf (StixelsKernels.cu:435-446): dw * inf is inf (or NaN for dw = 0)
+         * and never passes the strict < test, so the candidate is not evaluated at all */
+        const float cost_g = P.dw * t.gd + pwih + P.sw * t.seg_g;
+        if (ALL_LANES) {
+            take_if_less(b.g, b.vg, cost_g, vB);
+        } else {
+            const bool ug = (FIRST ? (live && (vT <= vhor)) : live) && (cost_g < b.g);
+            b.g = ug ? cost_g : b.g;
+            b.vg = ug ? vB : b.vg;
+        }
+    }
+}
+
+template <bool FAST, bool HAS_INVALID, bool SKY, bool DIAG, int NR, bool NOGROUND = false>
+__device__ __forceinline__ int unary_range(const DevParams& P, const RowRec& my,
+                                           const RowRec* __restrict__ rcol,
+                                           const float* __restrict__ lcol, const float* my_tile,
+                                           const float* s_rcp, int vT, int vTc, int vhor, int vB,
+                                           int nw, int bound, bool row_ok, int lane4,
+                                           __amdgpu_buffer_rsrc_t lrsrc, LutRow<NR>& next_row,
+                                           UnaryBest& b) {
+    float hf = (float)(vTc + 1 - vB);
+    const float nwf = (float)nw;
+    for (; vB <= bound; vB += nw) {
+        const RowRec cur = sload_rec(rcol + vB);
+        const LutRow<NR> row = next_row;
+        load_lut_row<NR>(next_row, lrsrc, lcol, min(vB + nw, P.H), P.D, lane4); /* row H exists */
+        unary_step<FAST, HAS_INVALID, SKY, DIAG, false, NR, NOGROUND>(P, my, cur, row, my_tile, s_rcp, vT,
+                                                                      vTc, vhor, vB, hf, row_ok, b);
+        hf -= nwf;
+    }
+    return vB;
+}
+
+/* The wave walks vB = w, w+nw, ... <= vB_end in ascending order through (at most) four ranges:
+ * ground/full, ground/diagonal, sky/full, sky/diagonal (ground while vB <= vhor; "full" while
+ * every lane of the tile has vT >= vB, i.e. vB <= tile_lo). */
+template <bool FAST, bool HAS_INVALID, int NR>
+__device__ __forceinline__ void unary_loop(const DevParams& P, const RowRec& my,
+                                           const RowRec* __restrict__ rcol,
+                                           const float* __restrict__ lcol, const float* my_tile,
+                                           const float* s_rcp, int vT, int vTc, int vhor, int w,
+                                           int nw, int tile_lo, int vB_end, int lane4,
+                                           __amdgpu_buffer_rsrc_t lrsrc, UnaryBest& b) {
+    const bool row_ok = vT < P.H;
+    int vB = w;
+    if (vB > vB_end) return;
+    LutRow<NR> next_row; /* lutT row of the step that comes next */
+    load_lut_row<NR>(next_row, lrsrc, lcol, vB, P.D, lane4);
+    if (vB == 0) { /* first segment (:481-594): ground + object */
+        const RowRec cur = sload_rec(rcol);
+        const LutRow<NR> row = next_row;
+        load_lut_row<NR>(next_row, lrsrc, lcol, min(nw, P.H), P.D, lane4);
+        if (tile_lo == 0)
+            unary_step<FAST, HAS_INVALID, false, true, true, NR>(P, my, cur, row, my_tile, s_rcp, vT,
+                                                                 vTc, vhor, 0, 0.0f, row_ok, b);
+        else
+            unary_step<FAST, HAS_INVALID, false, false, true, NR>(P, my, cur, row, my_tile, s_rcp, vT,
+                                                                  vTc, vhor, 0, 0.0f, row_ok, b);
+        vB += nw;
+    }
+    if (IS_SKIP_GROUND_ABOVE_HORIZON && tile_lo >= vhor) /* whole tile at / above the horizon */
+        vB = unary_range<FAST, HAS_INVALID, false, false, NR, true>(
+            P, my, rcol, lcol, my_tile, s_rcp, vT, vTc, vhor, vB, nw, min(min(vhor, tile_lo), vB_end),
+            row_ok, lane4, lrsrc, next_row, b);
+    else
+        vB = unary_range<FAST, HAS_INVALID, false, false, NR>(P, my, rcol, lcol, my_tile, s_rcp, vT, vTc,
+                                                              vhor, vB, nw, min(min(vhor, tile_lo), vB_end),
+                                                              row_ok, lane4, lrsrc, next_row, b);
+    vB = unary_range<FAST, HAS_INVALID, false, true, NR>(P, my, rcol, lcol, my_tile, s_rcp, vT, vTc,
+                                                         vhor, vB, nw, min(vhor, vB_end), row_ok, lane4,
+                                                         lrsrc, next_row, b);
+    vB = unary_range<FAST, HAS_INVALID, true, false, NR>(P, my, rcol, lcol, my_tile, s_rcp, vT, vTc,
+                                                         vhor, vB, nw, min(tile_lo, vB_end), row_ok,
+                                                         lane4, lrsrc, next_row, b);
+    unary_range<FAST, HAS_INVALID, true, true, NR>(P, my, rcol, lcol, my_tile, s_rcp, vT, vTc, vhor, vB,
+                                                   nw, vB_end, row_ok, lane4, lrsrc, next_row, b);
+}
+
+/* FASTCOLS: the launch handles only the columns of that encoding (col_flags), workgroups of the
+ * other kind leave at once.  Two lean kernels instead of one that carries both loop nests: no
+ * register spills, and the generic launch costs ~nothing when every column is FAST. */
+template <bool HAS_INVALID, int NR, bool FASTCOLS>
+__global__ __launch_bounds__(IS_UNARY_WAVES * 64, IS_UNARY_OCC) void k_dp_unary(const DevParams P, int ncols,
+                                                  const RowRec* __restrict__ recs,
+                                                  const float* __restrict__ lutT,
+                                                  const float* __restrict__ rcp,
+                                                  const int* __restrict__ vhor_arr,
+                                                  const int* __restrict__ col_flags,
+                                                  float* __restrict__ cost_table,
+                                                  int32_t* __restrict__ index_table,
+                                                  int pairs_per_wg) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int H = P.H, D = P.D;
+    const int DP = D + 1; /* padded row: conflict-free when lanes share fni */
+    float* s_rcp = (float*)smem;              /* [H+1 -> x4] RN(1/h), kept across both tiles   */
+    float* s_tile = s_rcp + ((H + 1 + 3) & ~3); /* [64][D+1] lutT rows tile_lo+1 .. tile_lo+64  */
+
+    /* XCD-aware order: blocks b, b+8, ... share an XCD/L2; keep all tiles of a column on one
+     * XCD (they gather from the same lutT) and start with the tallest tiles. */
+    const int nxcd = 8;
+    const int npairs = (P.ntiles + 1) / 2;
+    const int wg_per_col = (npairs + pairs_per_wg - 1) / pairs_per_wg;
+    /* (integer division runs on the VALU: pin the uniform results back into SGPRs) */
+    const int xcd = blockIdx.x % nxcd, q = blockIdx.x / nxcd;
+    const int wg_in_col = __builtin_amdgcn_readfirstlane(q % wg_per_col);
+    const int colg = __builtin_amdgcn_readfirstlane((q / wg_per_col) * nxcd + xcd);
+    if (colg >= ncols) return;
+    if ((__builtin_amdgcn_readfirstlane(col_flags[colg]) == 0) != FASTCOLS) return;
+    const int img = __builtin_amdgcn_readfirstlane(colg / P.C);
+    const int vhor = __builtin_amdgcn_readfirstlane(vhor_arr[img]);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int nw = blockDim.x >> 6;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const RowRec* rcol = recs + (size_t)colg * (H + 1);
+    const float* lcol = lutT + (size_t)colg * (H + 1) * D;
+    for (int i = tid; i <= H; i += blockDim.x) s_rcp[i] = rcp[i];
+    const __amdgpu_buffer_rsrc_t lrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)lcol, 0, (H + 1) * D * (int)sizeof(float), 0x00020000 /* raw, 32-bit data */);
+
+    /* a workgroup takes the tile pair (ntiles-1-pair, pair): every workgroup then carries the
+     * same number of (vB, vT) pairs, and the per-workgroup fixed costs are paid half as often */
+    bool first = true;
+    for (int pair = wg_in_col; pair < npairs; pair += wg_per_col) {
+    const int n_pass = (P.ntiles - 1 - pair == pair) ? 1 : 2;
+    for (int pass = 0; pass < n_pass; pass++) {
+    const int tile = pass == 0 ? (P.ntiles - 1 - pair) : pair;
+    const int tile_lo = tile * IS_TILE;
+    if (!first) __syncthreads(); /* the merge area of the previous tile aliases the LUT tile */
+    first = false;
+
+    stage_lut_tile<false>(s_tile, lcol, tile_lo, H, D, tid, (int)blockDim.x);
+
+    const int vT = tile_lo + lane;
+    const int vTc = min(vT, H - 1);
+    const RowRec my = load_rec(rcol + vTc + 1);
+    __syncthreads();
+
+    UnaryBest b;
+    b.g = b.o = b.s = IS_INF;
+    b.vg = b.vs = -1;
+    b.vo = 0; /* index_table[vT*3+OBJECT] = OBJECT at vB = 0, :592 */
+    const float* my_tile = s_tile + lane * DP;
+    const int vB_end = min(tile_lo + IS_TILE - 1, H - 1);
+    unary_loop<FASTCOLS, HAS_INVALID, NR>(P, my, rcol, lcol, my_tile, s_rcp, vT, vTc, vhor, w, nw, tile_lo,
+                                          vB_end, lane * 4, lrsrc, b);
+
+    /* merge the waves' partial minima: min cost, ties -> smallest vB (= first strict minimum
+     * of the reference's ascending-vB loop) */
+    __syncthreads();
+    float* m_cost = s_tile;                        /* [nw][3][64] (aliases the LUT tile) */
+    int* m_vb = (int*)(m_cost + nw * 3 * 64);      /* [nw][3][64] */
+    m_cost[(w * 3 + 0) * 64 + lane] = b.g; m_vb[(w * 3 + 0) * 64 + lane] = b.vg;
+    m_cost[(w * 3 + 1) * 64 + lane] = b.o; m_vb[(w * 3 + 1) * 64 + lane] = b.vo;
+    m_cost[(w * 3 + 2) * 64 + lane] = b.s; m_vb[(w * 3 + 2) * 64 + lane] = b.vs;
+    __syncthreads();
+    if (tid < 3 * 64) {
+        const int type = tid >> 6;
+        float c = m_cost[(0 * 3 + type) * 64 + lane];
+        int vb = m_vb[(0 * 3 + type) * 64 + lane];
+        for (int ww = 1; ww < nw; ww++) {
+            const float c2 = m_cost[(ww * 3 + type) * 64 + lane];
+            const int vb2 = m_vb[(ww * 3 + type) * 64 + lane];
+            const bool take = (c2 < c) || (c2 == c && vb2 >= 0 && (vb < 0 || vb2 < vb));
+            if (take) { c = c2; vb = vb2; }
+        }
+        /* final (cost, vB) of this type back to LDS: one wave then writes the three types of a
+         * row as 12 contiguous bytes (a wave-wide contiguous 768-byte store) instead of three
+         * waves writing every third dword */
+        m_cost[type * 64 + lane] = c;
+        m_vb[type * 64 + lane] = vb;
+    }
+    __syncthreads();
+    if (w == 0 && vT < H) {
+        const size_t o = ((size_t)colg * H + vT) * 3;
+        float* cd = cost_table + o;
+        int32_t* id = index_table + o;
+        cd[0] = m_cost[0 * 64 + lane]; cd[1] = m_cost[1 * 64 + lane]; cd[2] = m_cost[2 * 64 + lane];
+        id[0] = m_vb[0 * 64 + lane]; id[1] = m_vb[1 * 64 + lane]; id[2] = m_vb[2 * 64 + lane];
+    }
+    } /* pass */
+    } /* pair */
+}
+
+extern "C" {
+
+size_t isk_unary_lds_bytes(const DevParams* P) {
+    const size_t rcp = sizeof(float) * (((size_t)P->H + 1 + 3) & ~(size_t)3);
+    const size_t tile = sizeof(float) * (size_t)IS_TILE * (P->D + 1);
+    const size_t merge = (size_t)IS_UNARY_WAVES * 3 * 64 * 8; /* aliases the tile after the loop */
+    return rcp + (tile > merge ? tile : merge) + 16;
+}
+
+hipError_t isk_launch_dp_unary(const DevParams* P, int ncols, int nwaves, const RowRec* recs,
+                               const float* lutT, const float* rcp, const int* vhor,
+                               const int* col_flags, float* cost_table, int32_t* index_table,
+                               hipStream_t stream) {
+    const int groups = (ncols + 7) / 8;
+    /* one tile pair (big, small) per workgroup: equal-length workgroups pack best; measured on
+     * MI355X at batch 32: 1 pair 9.98 ms, 2 pairs 10.10 ms, 4 pairs 10.55 ms, single tiles 11.1 ms */
+    const int npairs = (P->ntiles + 1) / 2;
+    const int pairs_per_wg = 1;
+    const int wg_per_col = (npairs + pairs_per_wg - 1) / pairs_per_wg;
+    const dim3 grid(groups * 8 * wg_per_col);
+    const size_t lds = isk_unary_lds_bytes(P);
+    /* D <= 128: the vB-side lutT row travels in two registers per lane (LutRow<2>); wider
+     * tables gather per lane */
+#define IS_LAUNCH_UNARY(INV, NR)                                                                   \
+    do {                                                                                           \
+        hipLaunchKernelGGL((k_dp_unary<INV, NR, true>), grid, dim3(nwaves * 64), lds, stream, *P,  \
+                           ncols, recs, lutT, rcp, vhor, col_flags, cost_table, index_table,       \
+                           pairs_per_wg);                                                          \
+        hipLaunchKernelGGL((k_dp_unary<INV, NR, false>), grid, dim3(nwaves * 64), lds, stream, *P, \
+                           ncols, recs, lutT, rcp, vhor, col_flags, cost_table, index_table,       \
+                           pairs_per_wg);                                                          \
+    } while (0)
+    if (P->D <= 128) {
+        if (P->invalid >= 0) IS_LAUNCH_UNARY(true, 2); else IS_LAUNCH_UNARY(false, 2);
+    } else {
+        if (P->invalid >= 0) IS_LAUNCH_UNARY(true, 0); else IS_LAUNCH_UNARY(false, 0);
+    }
+#undef IS_LAUNCH_UNARY
+    return hipGetLastError();
+}
+
+int isk_debug_occupancy(const DevParams* P, int nwaves) {
+    int nb = -1;
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_dp_unary<false, 2, true>,
+                                                 nwaves * 64, isk_unary_lds_bytes(P));
+    return nb;
+}
+
+hipError_t isk_set_lds_unary(const DevParams* P) {
+    hipError_t e;
+    const int b = (int)isk_unary_lds_bytes(P);
+#define IS_SET_UNARY_LDS(INV, NR, FC)                                                             \
+    e = hipFuncSetAttribute((const void*)k_dp_unary<INV, NR, FC>,                                 \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, b);                       \
+    if (e != hipSuccess) return e
+    IS_SET_UNARY_LDS(true, 2, true); IS_SET_UNARY_LDS(true, 2, false);
+    IS_SET_UNARY_LDS(false, 2, true); IS_SET_UNARY_LDS(false, 2, false);
+    IS_SET_UNARY_LDS(true, 0, true); IS_SET_UNARY_LDS(true, 0, false);
+    IS_SET_UNARY_LDS(false, 0, true); IS_SET_UNARY_LDS(false, 0, false);
+#undef IS_SET_UNARY_LDS
+    return hipSuccess;
+}
+
+} /* extern "C" */

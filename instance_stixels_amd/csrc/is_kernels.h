@@ -1,0 +1,282 @@
+/*
+ * is_kernels.h -- shared device code of the gfx950 (CDNA4, wave64) kernels of the
+ * Instance-Stixels column DP (is_k_*.hip).  Nothing here is translated from the reference's
+ * CUDA: the reference runs one 1024-thread block per column with a barrier per vB and 126 global
+ * loads per (vB, vT) pair (/root/reference/InstanceStixels/src/StixelsKernels.cu:600-839); the
+ * kernels restructure the same arithmetic (bit-exactly, see DESIGN.md "Exact rewrites") as
+ *
+ *   is_k_frontend.hip   k_join_columns      A3   StixelsKernels.cu:980-1095   LDS-transposed
+ *                       k_flip_and_pad, k_vdisp_*  
+ *   is_k_prepare.hip    k_prepare_columns   A4-A6 StixelsKernels.cu:371-469 and
+ *                                           StixelsKernels.h:73-103: per-row boundary records
+ *                       k_object_lut        A4   StixelsKernels.cu:236-296, 959-978
+ *                       k_prior_tables      A9   StixelsKernels.cu:88-199 (DP-state independent)
+ *   is_k_unary.hip      k_dp_unary          A7-A9 StixelsKernels.cu:477-839, PAIRWISE=false:
+ *                                           independent (column, tile pair) work items, one lane
+ *                                           per vT, vB-side operands in SGPRs via scalar loads,
+ *                                           vT-side LUT rows in LDS
+ *   is_k_pairwise.hip   k_pw_phase1/2       A7-A9 PAIRWISE=true: per 64-row tile, a parallel
+ *                                           launch for segments starting in earlier tiles + a
+ *                                           one-wave-per-column diagonal walk
+ *   is_k_backtrace.hip  k_backtrace         A10  StixelsKernels.cu:843-955
+ *                       k_compact_instances A10  StixelsKernels.cu:926-942, canonical order (R9)
+ *
+ * This header: the segment evaluation and the LUT / record access helpers both DP kernels use.
+ * Numerics contract: IEEE fp32, no contraction (-ffp-contract=off), correctly rounded
+ * division, no fast-math; integer sums in wrapping int32 / int64 like the reference.
+ */
+#ifndef IS_KERNELS_H_
+#define IS_KERNELS_H_
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include "instance_stixels_core.h"
+#include "is_device.h"
+#include "is_numerics.h"
+
+#define IS_INF (__builtin_inff())
+
+typedef const __attribute__((address_space(4))) RowRec* crec_t;     /* scalar-load view */
+typedef const __attribute__((address_space(4))) PriorRec* cprior_t;
+
+/* workgroup LDS sizes (defined next to the kernels that use them) */
+extern "C" {
+size_t isk_prepare_lds_bytes(const DevParams* P);
+size_t isk_unary_lds_bytes(const DevParams* P);
+size_t isk_pairwise_lds_bytes(const DevParams* P, int nwaves);
+size_t isk_phase2_lds_bytes(const DevParams* P);
+}
+
+/* ====================================================================================== */
+/* Segment evaluation shared by both DP kernels                                            */
+/* ====================================================================================== */
+struct SegTerms {
+    float seg_g, seg_o, seg_s; /* semantic + instance terms of the three geometric classes */
+    float gd, sd;              /* ground / sky data terms                                   */
+    float mean;                /* un-floored, clamped (>= 0) object mean disparity          */
+    int fni;                   /* floor(mean), clamped to [0, D-1]                          */
+};
+
+/* v_cvt_u32_f32: round toward zero, saturating (negative -> 0, NaN -> 0) */
+__device__ __forceinline__ unsigned cvt_u32_sat(float x) {
+    unsigned u;
+    asm("v_cvt_u32_f32 %0, %1" : "=v"(u) : "v"(x));
+    return u;
+}
+
+/* a / h for an integer-valued h in [1, 11000] with r = RN(1/h): one multiplication and two
+ * FMAs give the correctly rounded IEEE quotient for every fp32 a in [2^-100, 2^100] and a = 0
+ * (exhaustively verified over all 2^23 mantissas x all h by tools/verify_exact_division.c). */
+__device__ __forceinline__ float fast_div(float a, float h, float r) {
+    const float q0 = a * r;
+    const float e0 = __builtin_fmaf(-q0, h, a);
+    return __builtin_fmaf(e0, r, q0);
+}
+
+/* wave-uniform record through the constant address space: scalar loads, values live in SGPRs */
+__device__ __forceinline__ RowRec sload_rec(const RowRec* p) {
+    crec_t q = (crec_t)p;
+    RowRec r;
+    r.Fg0 = q->Fg0; r.Fg1 = q->Fg1;
+#pragma unroll
+    for (int c = 0; c < IS_N_ON; c++) r.Fon[c] = q->Fon[c];
+#pragma unroll
+    for (int c = 0; c < IS_N_OI; c++) r.Foi[c] = q->Foi[c];
+    r.Fsky = q->Fsky; r.Fnic = q->Fnic;
+    r.G = q->G; r.K = q->K; r.S = q->S; r.V = q->V;
+    r.MX = q->MX; r.MY = q->MY; r.MX2h = q->MX2h; r.MX2l = q->MX2l;
+    r.MY2h = q->MY2h; r.MY2l = q->MY2l; r.pad[0] = q->pad[0]; r.pad[1] = q->pad[1];
+    return r;
+}
+
+/* `my` = record at vT+1 (per lane), `rb` = record at vB (wave-uniform copy in SGPRs), r = RN(1/h).
+ * Exact rewrites w.r.t. Cityscapes.h:44-118 / StixelsKernels.cu:62-86:
+ *   DownsampledSum(c) = my.F_c - rb.F_c;
+ *   min_c (k + float(S_c)) = k + float(min_c S_c) for classes sharing the additive term k
+ *   (int -> float conversion and fp32 addition are monotone);
+ *   (0.0f + k) + float(S) = k + float(S): float(int) is never -0, so the leading `0.0f +` of
+ *   Cityscapes.h:67-79 cannot change the sum;
+ *   FAST columns only: float(int64 difference) via exact fp32 hi/lo parts (RowRec), x / h via
+ *   fast_div, and
+ *   (int)floorf(max(mean,0)) = (int)fmaxf(mean,0) because the mean is finite there. */
+template <bool FAST, bool HAS_INVALID>
+__device__ __forceinline__ SegTerms eval_segment(const RowRec& my, const RowRec& rb, float height,
+                                                 float r, int D, float iw) {
+    SegTerms t;
+    const float nic = iw * (float)(my.Fnic - rb.Fnic); /* ComputeNonInstanceOffsetCost, :62-70, :496-499 */
+    float ic; /* ComputeInstanceOffsetCost, :72-86 */
+    float f_g, f_on, f_oi, f_sky; /* float(min_c DownsampledSum_c) per class group */
+    if (FAST) {
+        f_g = __builtin_fminf(my.Fg0 - rb.Fg0, my.Fg1 - rb.Fg1);
+        f_on = my.Fon[0] - rb.Fon[0];
+#pragma unroll
+        for (int c = 1; c < IS_N_ON; c++) f_on = __builtin_fminf(f_on, my.Fon[c] - rb.Fon[c]);
+        f_oi = my.Foi[0] - rb.Foi[0];
+#pragma unroll
+        for (int c = 1; c < IS_N_OI; c++) f_oi = __builtin_fminf(f_oi, my.Foi[c] - rb.Foi[c]);
+        f_sky = my.Fsky - rb.Fsky;
+        const float meanx = my.MX - rb.MX;
+        const float meany = my.MY - rb.MY;
+        const float meanx2 = (my.MX2h - rb.MX2h) + (my.MX2l - rb.MX2l);
+        const float meany2 = (my.MY2h - rb.MY2h) + (my.MY2l - rb.MY2l);
+        ic = iw * (meanx2 - fast_div(meanx * meanx, height, r) + meany2 -
+                   fast_div(meany * meany, height, r));
+    } else {
+        const RowRecWide& mw = reinterpret_cast<const RowRecWide&>(my);
+        const RowRecWide& bw = reinterpret_cast<const RowRecWide&>(rb);
+        f_g = (float)min(mw.Fg0 - bw.Fg0, mw.Fg1 - bw.Fg1);
+        int32_t s_on = mw.Fon[0] - bw.Fon[0];
+#pragma unroll
+        for (int c = 1; c < IS_N_ON; c++) s_on = min(s_on, mw.Fon[c] - bw.Fon[c]);
+        int32_t s_oi = mw.Foi[0] - bw.Foi[0];
+#pragma unroll
+        for (int c = 1; c < IS_N_OI; c++) s_oi = min(s_oi, mw.Foi[c] - bw.Foi[c]);
+        f_on = (float)s_on;
+        f_oi = (float)s_oi;
+        f_sky = (float)(mw.Fsky - bw.Fsky);
+        const float meanx = (float)(mw.MX - bw.MX);
+        const float meany = (float)(mw.MY - bw.MY);
+        const float meanx2 = (float)(mw.MX2 - bw.MX2);
+        const float meany2 = (float)(mw.MY2 - bw.MY2);
+        ic = iw * (meanx2 - meanx * meanx / height + meany2 - meany * meany / height);
+    }
+
+    t.seg_g = f_g + nic;
+    const float on = nic + f_on;
+    const float oi = ic + f_oi;
+    t.seg_o = FAST ? __builtin_fminf(oi, on) : ((oi < on) ? oi : on); /* both finite when FAST */
+    t.seg_s = f_sky + nic;
+
+    t.gd = my.G - rb.G;
+    t.sd = my.K - rb.K;
+    float mean; /* ComputeMean, :47-60 */
+    if (HAS_INVALID) {
+        const float valid_dif = my.V - rb.V;
+        mean = (valid_dif == 0) ? 0 : (my.S - rb.S) / valid_dif;
+    } else if (FAST) {
+        mean = fast_div(my.S - rb.S, height, r);
+    } else {
+        mean = (my.S - rb.S) / height;
+    }
+    if (FAST) {
+        /* :525-527; the mean is finite in FAST columns, and v_cvt_u32_f32 saturates (x < 0 -> 0),
+         * so the clamp at 0 is part of the conversion; = floorf for a finite mean >= 0 */
+        t.fni = (int)min(cvt_u32_sat(mean), (unsigned)(D - 1));
+        t.mean = __builtin_fmaxf(mean, 0.0f); /* (only the pairwise model reads it) */
+    } else {
+        if (mean < 0) mean = 0; /* :525-527 */
+        t.mean = mean;
+        const int fni = (int)__builtin_floorf(mean);
+        t.fni = min(max(fni, 0), D - 1); /* memory safety outside the input domain (Q8) */
+    }
+    return t;
+}
+
+__device__ __forceinline__ RowRec load_rec(const RowRec* p) {
+    RowRec r;
+    const int4* s = (const int4*)p;
+    int4* d = (int4*)&r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) d[i] = s[i];
+    return r;
+}
+
+/* lutT rows tile_lo+1 .. tile_lo+64 of a column into the LDS tile (row stride D+1).  When the
+ * workgroup covers whole rows per sweep (nthreads a multiple of D) a thread keeps its column and
+ * walks the rows: no per-element division.  QUADS: 16-byte loads (needs D % 4 == 0 and
+ * 4 * nthreads a multiple of D); more registers, so the unary kernel (64 VGPRs, four loop nests)
+ * uses the dword form. */
+template <bool QUADS>
+__device__ __forceinline__ void stage_lut_tile(float* s_tile, const float* __restrict__ lcol, int tile_lo,
+                                               int H, int D, int tid, int nthreads) {
+    const int DP = D + 1;
+    if (QUADS && (D & 3) == 0 && ((4 * nthreads) % D) == 0) {
+        const int quads = D >> 2;            /* 16-byte chunks per row */
+        const int r0 = tid / quads, f = (tid - r0 * quads) * 4;
+        const int dr = nthreads / quads;     /* rows per sweep of the workgroup */
+        for (int r = r0; r < IS_TILE; r += dr) {
+            const int v = min(tile_lo + 1 + r, H);
+            const float4 x = *reinterpret_cast<const float4*>(lcol + (size_t)v * D + f);
+            float* d = s_tile + r * DP + f;
+            d[0] = x.x; d[1] = x.y; d[2] = x.z; d[3] = x.w;
+        }
+    } else if ((nthreads % D) == 0) {
+        const int r0 = tid / D, f = tid - r0 * D;
+        const int dr = nthreads / D;
+        for (int r = r0; r < IS_TILE; r += dr) {
+            const int v = min(tile_lo + 1 + r, H);
+            s_tile[r * DP + f] = lcol[(size_t)v * D + f];
+        }
+    } else {
+        for (int i = tid; i < IS_TILE * D; i += nthreads) {
+            const int r = i / D, f = i - r * D;
+            const int v = min(tile_lo + 1 + r, H);
+            s_tile[r * DP + f] = lcol[(size_t)v * D + f];
+        }
+    }
+}
+
+/* vB-side row of lutT.  NR > 0: the wave holds the whole row in NR registers per lane (element
+ * j*64 + lane), fetched with coalesced loads one step AHEAD of its use -- the address does not
+ * depend on the segment -- and a lane picks its element fni with ds_bpermute (no memory access on
+ * the dependent chain mean -> fni -> LUT value).  NR == 0 (D > 64*NR_MAX): per-lane gather. */
+template <int NR>
+struct LutRow {
+    float r[NR > 0 ? NR : 1];
+    const float* lrow;
+};
+/* Whole-row fetch through a raw buffer resource of the column's lutT: scalar row offset (SALU),
+ * lane offset in a VGPR, no VALU address arithmetic; reads past the column return 0. */
+template <int NR>
+__device__ __forceinline__ void load_lut_row(LutRow<NR>& row, __amdgpu_buffer_rsrc_t lrsrc,
+                                             const float* __restrict__ lcol, int v, int D, int lane4) {
+    row.lrow = lcol + (size_t)v * D;
+#pragma unroll
+    for (int j = 0; j < NR; j++)
+        row.r[j] = __int_as_float(
+            __builtin_amdgcn_raw_buffer_load_b32(lrsrc, lane4, v * D * 4 + j * 256, 0));
+}
+template <int NR>
+__device__ __forceinline__ float pick_lut(const LutRow<NR>& row, int fni) {
+    if (NR == 0) return row.lrow[(unsigned)fni];
+    const int sel = fni << 2; /* ds_bpermute takes the source lane from address bits [7:2] */
+    float v = __int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(row.r[0])));
+#pragma unroll
+    for (int j = 1; j < NR; j++) {
+        const float vj = __int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(row.r[j])));
+        v = (fni >= 64 * j) ? vj : v;
+    }
+    return v;
+}
+
+/* (best, best_v) <- (cost, vB) in the lanes with cost < best: v_cmpx + two moves under the
+ * resulting EXEC (8 issue cycles) instead of compare + two cndmask + the broadcast of vB (14).
+ * Only for steps in which every lane of the wave takes part. */
+__device__ __forceinline__ void take_if_less(float& best, int& best_v, float cost, int vB) {
+    unsigned long long saved;
+    asm("s_mov_b64 %[sv], exec\n\t"
+        "v_cmpx_lt_f32_e32 %[c], %[b]\n\t"
+        "v_mov_b32_e32 %[b], %[c]\n\t"
+        "v_mov_b32_e32 %[i], %[vb]\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [b] "+v"(best), [i] "+v"(best_v), [sv] "=&s"(saved)
+        : [c] "v"(cost), [vb] "s"(vB)
+        : "vcc");
+}
+
+/* same with a per-lane value to record */
+__device__ __forceinline__ void take_if_less_v(float& best, int& best_v, float cost, int v) {
+    unsigned long long saved;
+    asm("s_mov_b64 %[sv], exec\n\t"
+        "v_cmpx_lt_f32_e32 %[c], %[b]\n\t"
+        "v_mov_b32_e32 %[b], %[c]\n\t"
+        "v_mov_b32_e32 %[i], %[v]\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [b] "+v"(best), [i] "+v"(best_v), [sv] "=&s"(saved)
+        : [c] "v"(cost), [v] "v"(v)
+        : "vcc");
+}
+
+#endif /* IS_KERNELS_H_ */
