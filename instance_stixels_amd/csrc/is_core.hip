@@ -277,19 +277,19 @@ static int ctx_init(is_ctx* c, const is_stixel_params* p, const float* obj_cost_
 
 int is_ctx_destroy(is_ctx* c) {
     if (!c) return IS_OK;
-    hipSetDevice(c->device);
-    hipDeviceSynchronize();
-    hipFree(c->d_obj_cost_lut); hipFree(c->d_odr); hipFree(c->d_rcp); hipFree(c->d_col_flags); hipFree(c->d_ground);
-    hipFree(c->d_vhor); hipFree(c->d_recs); hipFree(c->d_lutT); hipFree(c->d_priors); hipFree(c->d_steps); hipFree(c->d_part_cost); hipFree(c->d_part_idx); hipFree(c->d_sv);
-    hipFree(c->d_cost_table); hipFree(c->d_index_table);
-    if (c->h_ground_pinned) hipHostFree(c->h_ground_pinned);
-    if (c->h_vhor_pinned) hipHostFree(c->h_vhor_pinned);
-    if (c->staging_free) hipEventDestroy(c->staging_free);
-    if (c->aux_stream) hipStreamDestroy(c->aux_stream);
-    if (c->ev_fork) hipEventDestroy(c->ev_fork);
-    if (c->ev_join) hipEventDestroy(c->ev_join);
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    (void)hipFree(c->d_obj_cost_lut); (void)hipFree(c->d_odr); (void)hipFree(c->d_rcp); (void)hipFree(c->d_col_flags); (void)hipFree(c->d_ground);
+    (void)hipFree(c->d_vhor); (void)hipFree(c->d_recs); (void)hipFree(c->d_lutT); (void)hipFree(c->d_priors); (void)hipFree(c->d_steps); (void)hipFree(c->d_part_cost); (void)hipFree(c->d_part_idx); (void)hipFree(c->d_sv);
+    (void)hipFree(c->d_cost_table); (void)hipFree(c->d_index_table);
+    if (c->h_ground_pinned) (void)hipHostFree(c->h_ground_pinned);
+    if (c->h_vhor_pinned) (void)hipHostFree(c->h_vhor_pinned);
+    if (c->staging_free) (void)hipEventDestroy(c->staging_free);
+    if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     for (int i = 0; i < 4; i++)
-        if (c->ev[i]) hipEventDestroy(c->ev[i]);
+        if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     free(c);
     return IS_OK;
 }

@@ -284,7 +284,7 @@ hipError_t isk_launch_dp_unary(const DevParams* P, int ncols, int nwaves, const 
 
 int isk_debug_occupancy(const DevParams* P, int nwaves) {
     int nb = -1;
-    hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_dp_unary<false, 2, true>,
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_dp_unary<false, 2, true>,
                                                  nwaves * 64, isk_unary_lds_bytes(P));
     return nb;
 }
