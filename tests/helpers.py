@@ -30,6 +30,29 @@ def sub_case(case, images):
     return sub
 
 
+def make_hostile(case, seed):
+    """Overwrites whole stixel columns of a case with inputs outside the FAST encodings: negative
+    class values, offsets whose squares wrap int32, class totals next to 2^24, tiny / subnormal /
+    zero disparities, uniformly random disparities.  In place; returns the case."""
+    rng = np.random.default_rng(seed)
+    seg, d = case["segmentation"], case["disparity"]      # [n][C][21][P2S], [n][H][W]
+    rows, D = int(case["cfg"].rows), int(case["cfg"].max_dis)
+    for c in range(seg.shape[1]):
+        mode = rng.integers(0, 6)
+        px = d[:, :, 8 * c:8 * c + 8]
+        if mode == 0:
+            seg[:, c, :19] = rng.integers(-50, 400, seg[:, c, :19].shape)
+        elif mode == 1:
+            seg[:, c, 19:] = rng.integers(-16000, 16000, seg[:, c, 19:].shape)
+        elif mode == 2:
+            seg[:, c, :19] = rng.integers(0, 130000 // max(1, rows // 8), seg[:, c, :19].shape)
+        elif mode == 3:
+            px[...] = rng.choice([0.0, 1e-30, 3e-39, 0.5, D - 1.01], px.shape)
+        elif mode == 4:
+            px[...] = rng.uniform(0, D - 1.01, px.shape)
+    return case
+
+
 def run_oracle(case, image=0, col_range=None, joined=None):
     cfg = case["cfg"]
     if joined is None:

@@ -84,6 +84,17 @@ def test_random_configs_bit_exact(k):
     _assert_parity(case, got)
 
 
+@pytest.mark.parametrize("k", range(8))
+def test_hostile_inputs_bit_exact(k):
+    """Random configurations whose columns are overwritten with out-of-encoding inputs (generic
+    int32/int64 path, wrapping sums, subnormal disparities): still bit-exact, no faults."""
+    preset, rows, cols, D, ov = _random_case(k)
+    case = helpers.make_hostile(helpers.build_case(preset, rows, cols, D, seed=6000 + k, n_images=2, **ov),
+                                seed=7000 + k)
+    got = helpers.run_core(case)
+    _assert_parity(case, got)
+
+
 @pytest.mark.parametrize("preset", ["drn_d_38_unary", "drn_d_22_pairwise"])
 def test_config1_shape_512x1024x64(preset):
     case = helpers.build_case(preset, 512, 1024, 64, seed=11)
