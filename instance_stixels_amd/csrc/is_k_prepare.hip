@@ -121,8 +121,22 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_columns(
     RowRec* rcol = recs + (size_t)colg * (H + 1);
     const int tid = threadIdx.x;
 
-    for (int i = tid; i < P2; i += PREP_THREADS) s_d[i] = (i < H) ? dcol[i] : 0.0f;
-    for (int i = tid; i < CH * P2S; i += PREP_THREADS) s_seg[i] = scol[i];
+    /* column inputs into LDS with 16-byte loads (H is a multiple of 8; the segmentation column is
+     * 16-byte aligned when P2S is a multiple of 4) */
+    {
+        const float4* d4 = reinterpret_cast<const float4*>(dcol);
+        float4* sd4 = reinterpret_cast<float4*>(s_d);
+        for (int i = tid; i < (H >> 2); i += PREP_THREADS) sd4[i] = d4[i];
+        for (int i = H + tid; i < P2; i += PREP_THREADS) s_d[i] = 0.0f;
+        if ((P2S & 3) == 0) {
+            const int4* g4 = reinterpret_cast<const int4*>(scol);
+            int4* s4 = reinterpret_cast<int4*>(s_seg);
+#pragma unroll 6
+            for (int i = tid; i < ((CH * P2S) >> 2); i += PREP_THREADS) s4[i] = g4[i];
+        } else {
+            for (int i = tid; i < CH * P2S; i += PREP_THREADS) s_seg[i] = scol[i];
+        }
+    }
     __syncthreads();
 
     /* ---- instance-centre values per row from the RAW offsets (StixelsKernels.cu:401-409);
@@ -253,7 +267,15 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_columns(
         reinterpret_cast<int4*>(rcol + v)[q] = make_int4(x[0], x[1], x[2], x[3]);
     }
 
-    /* ---- fp32 prefixes with the reference's block-scan association (:452-461) */
+    /* ---- fp32 prefixes with the reference's block-scan association (:452-461).  A thread keeps
+     * the four prefixes of its rows (v = tid + k * PREP_THREADS) and writes dwords 20..23 of the
+     * record {G, K, S, V} as ONE 16-byte store per row at the end. */
+    constexpr int MAXR = 9; /* rows per thread held in registers: H + 1 <= 9 * 256 */
+    const bool regs = (H + 1) <= MAXR * PREP_THREADS;
+    float pS[MAXR], pV[MAXR], pG[MAXR], pK[MAXR];
+#pragma unroll
+    for (int k = 0; k < MAXR; k++) pS[k] = pV[k] = pG[k] = pK[k] = 0.0f;
+    float* svcol = sv_arr + (size_t)colg * 2 * (H + 1); /* compact copies for the pairwise phase 2 */
     /* S: disparity (valid-masked when invalid >= 0, :382-389) */
     for (int i = tid; i < P2; i += PREP_THREADS) {
         float x = 0.0f;
@@ -270,11 +292,18 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_columns(
     }
     __syncthreads();
     blelloch_build(s_pyr, P2, P.log2P2);
-    float* svcol = sv_arr + (size_t)colg * 2 * (H + 1); /* compact copies for the pairwise phase 2 */
-    for (int v = tid; v <= H; v += PREP_THREADS) {
-        const float x = blelloch_prefix(s_pyr, P2, P.log2P2, v);
-        rcol[v].S = x;
-        svcol[v] = x;
+    if (regs) {
+#pragma unroll
+        for (int k = 0; k < MAXR; k++) {
+            const int v = tid + k * PREP_THREADS;
+            if (v <= H) { pS[k] = blelloch_prefix(s_pyr, P2, P.log2P2, v); svcol[v] = pS[k]; }
+        }
+    } else {
+        for (int v = tid; v <= H; v += PREP_THREADS) {
+            const float x = blelloch_prefix(s_pyr, P2, P.log2P2, v);
+            rcol[v].S = x;
+            svcol[v] = x;
+        }
     }
     __syncthreads();
     /* V: valid count (all zero without an invalid-disparity value: no scan needed) */
@@ -283,15 +312,23 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_columns(
             s_pyr[i] = (i < H) ? (float)(s_d[i] != P.invalid) : 0.0f;
         __syncthreads();
         blelloch_build(s_pyr, P2, P.log2P2);
-        for (int v = tid; v <= H; v += PREP_THREADS) {
-            const float x = blelloch_prefix(s_pyr, P2, P.log2P2, v);
-            rcol[v].V = x;
-            svcol[H + 1 + v] = x;
+        if (regs) {
+#pragma unroll
+            for (int k = 0; k < MAXR; k++) {
+                const int v = tid + k * PREP_THREADS;
+                if (v <= H) { pV[k] = blelloch_prefix(s_pyr, P2, P.log2P2, v); svcol[H + 1 + v] = pV[k]; }
+            }
+        } else {
+            for (int v = tid; v <= H; v += PREP_THREADS) {
+                const float x = blelloch_prefix(s_pyr, P2, P.log2P2, v);
+                rcol[v].V = x;
+                svcol[H + 1 + v] = x;
+            }
         }
         __syncthreads();
     } else {
         for (int v = tid; v <= H; v += PREP_THREADS) {
-            rcol[v].V = 0.0f;
+            if (!regs) rcol[v].V = 0.0f;
             svcol[H + 1 + v] = 0.0f;
         }
     }
@@ -304,7 +341,15 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_columns(
     }
     __syncthreads();
     blelloch_build(s_pyr, P2, P.log2P2);
-    for (int v = tid; v <= H; v += PREP_THREADS) rcol[v].G = blelloch_prefix(s_pyr, P2, P.log2P2, v);
+    if (regs) {
+#pragma unroll
+        for (int k = 0; k < MAXR; k++) {
+            const int v = tid + k * PREP_THREADS;
+            if (v <= H) pG[k] = blelloch_prefix(s_pyr, P2, P.log2P2, v);
+        }
+    } else {
+        for (int v = tid; v <= H; v += PREP_THREADS) rcol[v].G = blelloch_prefix(s_pyr, P2, P.log2P2, v);
+    }
     __syncthreads();
     /* K: sky data cost, 0 below the horizon (:424-433) */
     for (int i = tid; i < P2; i += PREP_THREADS) {
@@ -314,7 +359,18 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_columns(
     }
     __syncthreads();
     blelloch_build(s_pyr, P2, P.log2P2);
-    for (int v = tid; v <= H; v += PREP_THREADS) rcol[v].K = blelloch_prefix(s_pyr, P2, P.log2P2, v);
+    if (regs) {
+#pragma unroll
+        for (int k = 0; k < MAXR; k++) {
+            const int v = tid + k * PREP_THREADS;
+            if (v <= H) {
+                pK[k] = blelloch_prefix(s_pyr, P2, P.log2P2, v);
+                reinterpret_cast<float4*>(rcol + v)[5] = make_float4(pG[k], pK[k], pS[k], pV[k]);
+            }
+        }
+    } else {
+        for (int v = tid; v <= H; v += PREP_THREADS) rcol[v].K = blelloch_prefix(s_pyr, P2, P.log2P2, v);
+    }
 }
 
 /* ====================================================================================== */
