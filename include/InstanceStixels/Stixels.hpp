@@ -72,6 +72,12 @@ public:
         int vhor;
         float camera_tilt, camera_height, alpha_ground;
     };
+    /* Device the next Initialize() creates its buffers on; default (-1): the calling thread's
+     * current HIP device at Initialize() time (one process per GPU: select the device before, as
+     * with the reference's CUDA code).  Every later call runs on that device whatever the
+     * caller's current device is. */
+    void SetDevice(int device) { m_device = device; }
+    int GetDevice() const { return m_device; }
     /* Host half of Initialize() (tables + parameter block); needs no device. */
     void PrecomputeHost();
     /* Like Initialize(), with device scratch for up to max_batch frames per ComputeBatch(). */
@@ -103,6 +109,8 @@ private:
     float ComputeObjectDisparityRange(const float previous_mean) const;
     float FastLog(float v) const;
     void FillHeader(StixelsData& d, float alpha_ground, int vhor_lib) const;
+    is_instance_buffers InstanceBuffers() const;
+    GroundModel m_ground; /* per-frame ground model, storage reused between frames */
 
     /* device (owned between Initialize and Finish, Stixels.cu:53-74, 136-163) */
     is_ctx* m_ctx = nullptr;
@@ -114,7 +122,15 @@ private:
     int32_t* d_instance_indices = nullptr;
     uint8_t* d_instance_core_candidates = nullptr;
     int32_t* d_instances_per_class = nullptr;
+    int32_t* d_instance_labels = nullptr;  /* the reference's d_instance_labels, Stixels.cu:66-68 */
+    int32_t* d_instance_packed = nullptr;  /* [1 + 3*classes*realcols*max_sections], see is_instance_buffers */
+    /* pinned host mirrors: Compute() ends with ONE stream synchronisation */
+    Section* h_stixels = nullptr;
+    int32_t* h_instance_head = nullptr;    /* [8 per-class counts] */
+    int32_t* h_instance_packed = nullptr;
     int m_max_batch = 1;
+    int m_device = -1;
+    bool m_labels_on_host = false; /* h_instance_packed holds the triples of the last frame */
 
     StixelParameters m_params{};
     int m_max_sections = MAX_STIXELS_PER_COLUMN;
@@ -149,7 +165,6 @@ private:
     float m_max_dis_log = 0, m_rows_log = 0;
     float m_puniform = 0, m_puniform_sky = 0, m_normalization_sky = 0, m_inv_sigma2_sky = 0;
     /* instances (host mirrors) */
-    std::vector<int32_t> m_instance_labels, m_instance_indices;
     std::vector<int> m_instances_per_class;
     int m_instance_classes = IS_INSTANCE_CLASSES;
 };

@@ -101,6 +101,15 @@ typedef struct is_instance_buffers {
     int32_t* d_indices;        /* [8][realcols*max_sections][2]  (column, section index) */
     uint8_t* d_core_candidates; /* [8][realcols*max_sections]    (bool)   */
     int32_t* d_instances_per_class; /* [8] */
+    /* [8][realcols*max_sections] cluster label of every candidate (the reference's
+     * d_instance_labels, Stixels.cu:660-666): 0.. per class, -1 = no instance.  NULL skips the
+     * clustering; non-NULL requires the three arrays above. */
+    int32_t* d_labels;
+    /* optional, [1 + 3*8*realcols*max_sections]: d_packed[0] = number of candidates of all
+     * classes, then one (column, section index, label) triple per candidate, classes ascending:
+     * what Stixels::GetInstanceStixels (Stixels.cu:744-776) needs, in one small copy.  Written
+     * together with d_labels; needs d_indices. */
+    int32_t* d_packed;
 } is_instance_buffers;
 
 typedef struct is_ctx is_ctx;
@@ -136,13 +145,31 @@ int is_join_columns(is_ctx* ctx, const float* d_disparity_big, int full_cols, in
  *   d_sections          device, [n_images][realcols][max_sections] is_section
  *   instances           per image (array of n_images) or NULL
  *   d_cost_table        optional device out, [n_images][realcols][rows][3] final DP costs
- *   d_index_table       optional device out, [n_images][realcols][rows][3] int32, vB*3+prev
- * Asynchronous with respect to the host: work is queued on `stream`. */
+ *   d_index_table       optional device out, [n_images][realcols][rows][3] int32.  PAIRWISE:
+ *                       vB*3 + predecessor type, the reference's encoding
+ *                       (StixelsKernels.cu:723-727).  UNARY: the winning vB only (-1 = no
+ *                       candidate) -- in unary mode the predecessor type depends only on the
+ *                       final cost_table[vB-1] and is resolved by the back-trace,
+ *                       so decoding a unary table with /3 and %3 is WRONG.
+ * Alignment: d_joined and d_segmentation are read with 16-byte vector loads; both must be
+ * 16-byte aligned (any hipMalloc / torch allocation is) -- checked, IS_EINVAL otherwise.
+ * Device: the call runs on the context's device whatever the caller's current device is (the
+ * current device is restored on return); `stream` must belong to that device.
+ * Asynchronous with respect to the host: work is queued on `stream`; the host arrays are copied
+ * into a ring of pinned staging slots before the call returns. */
 int is_compute(is_ctx* ctx, const float* d_joined, const int32_t* d_segmentation,
                const float* h_ground_function, const float* h_normalization_ground,
                const float* h_inv_sigma2_ground, const int* h_vhor, int pairwise,
                int n_images, is_section* d_sections, const is_instance_buffers* instances,
                float* d_cost_table, int32_t* d_index_table, void* stream);
+
+/* Replaces Stixels::ClusterInstances (Stixels.cu:639-681: one ML::dbscanFit per instance class
+ * with the size filter of the cuML fork) for the candidates of ONE image: size-filtered DBSCAN
+ * with the semantics of the reference's Python twin
+ * (tools/visualization/clustering_visualization.py:894-960) on the device, no host round trip.
+ * Reads d_centerofmass / d_core_candidates / d_instances_per_class, writes d_labels.
+ * is_compute() runs it by itself for every image whose d_labels is set. */
+int is_cluster_instances(is_ctx* ctx, const is_instance_buffers* instances, void* stream);
 
 /* Replaces the output wrapper of the reference's CNN export ("FlipAndPad",
  * tools/CNN_training/models/wrappers.py:35-61), i.e. the producer of d_segmentation:
@@ -165,6 +192,11 @@ int is_road_vdisparity(const float* d_disparity, int rows, int cols, int max_dis
  * (the reference's callers are all .cu files; ours may be plain C++). */
 int is_device_malloc(void** ptr, size_t bytes);
 int is_device_free(void* ptr);
+int is_host_malloc(void** ptr, size_t bytes); /* pinned host memory */
+int is_host_free(void* ptr);
+int is_get_device(int* device);               /* the calling thread's current HIP device */
+int is_set_device(int device);
+int is_ctx_device(const is_ctx* ctx);         /* the device a context lives on */
 int is_memcpy_h2d(void* dst, const void* src, size_t bytes, void* stream);
 int is_memcpy_d2h(void* dst, const void* src, size_t bytes, void* stream);
 int is_memset(void* dst, int value, size_t bytes, void* stream);

@@ -20,12 +20,15 @@ EXPORTS = [
     "is_device_free", "is_memcpy_h2d", "is_memcpy_d2h", "is_memset", "is_stream_synchronize",
     "is_device_synchronize", "is_last_error", "is_version", "is_set_kernel_timing",
     "is_get_kernel_times_ms", "is_scratch_bytes", "is_flip_and_pad", "is_road_vdisparity",
+    "is_cluster_instances", "is_host_malloc", "is_host_free", "is_get_device", "is_set_device",
+    "is_ctx_device",
 ]
 
 
 class InstanceBuffers(ctypes.Structure):
     _fields_ = [("d_centerofmass", ctypes.c_void_p), ("d_indices", ctypes.c_void_p),
-                ("d_core_candidates", ctypes.c_void_p), ("d_instances_per_class", ctypes.c_void_p)]
+                ("d_core_candidates", ctypes.c_void_p), ("d_instances_per_class", ctypes.c_void_p),
+                ("d_labels", ctypes.c_void_p), ("d_packed", ctypes.c_void_p)]
 
 
 class CoreError(RuntimeError):
@@ -67,6 +70,12 @@ def lib():
                                              ctypes.POINTER(cf)]
         L.is_flip_and_pad.argtypes = [vp, vp, ci, ci, ci, ci, ci, vp]
         L.is_road_vdisparity.argtypes = [vp, ci, ci, ci, cf, vp, vp, vp, vp]
+        L.is_cluster_instances.argtypes = [vp, ctypes.POINTER(InstanceBuffers), vp]
+        L.is_host_malloc.argtypes = [ctypes.POINTER(vp), ctypes.c_size_t]
+        L.is_host_free.argtypes = [vp]
+        L.is_get_device.argtypes = [ctypes.POINTER(ci)]
+        L.is_set_device.argtypes = [ci]
+        L.is_ctx_device.argtypes = [vp]
         L.is_scratch_bytes.argtypes = [vp]
         L.is_scratch_bytes.restype = ctypes.c_size_t
         _LIB = L
@@ -174,9 +183,11 @@ class Core:
             idx = torch.zeros((n, INSTANCE_CLASSES, C * S, 2), dtype=torch.int32, device=dev)
             core = torch.zeros((n, INSTANCE_CLASSES, C * S), dtype=torch.uint8, device=dev)
             per = torch.zeros((n, INSTANCE_CLASSES), dtype=torch.int32, device=dev)
-            inst_t = (com, idx, core, per)
+            lab = torch.full((n, INSTANCE_CLASSES, C * S), -9, dtype=torch.int32, device=dev)
+            inst_t = (com, idx, core, per, lab)
             inst_s = [InstanceBuffers(com[i].data_ptr(), idx[i].data_ptr(), core[i].data_ptr(),
-                                      per[i].data_ptr()) for i in range(n)]
+                                      per[i].data_ptr(), lab[i].data_ptr(), None)
+                      for i in range(n)]
         self.compute_ptr(d_joined.data_ptr(), seg.data_ptr(), ground_function,
                          normalization_ground, inv_sigma2_ground, vhor, pairwise, n,
                          sections.data_ptr(), inst_s,
@@ -193,7 +204,34 @@ class Core:
             out["inst_indices"] = inst_t[1].cpu().numpy()
             out["inst_core"] = inst_t[2].cpu().numpy()
             out["inst_per_class"] = inst_t[3].cpu().numpy()
+            out["inst_labels"] = inst_t[4].cpu().numpy()
         return out
+
+    def cluster_instances(self, centerofmass, core_candidates, per_class):
+        """Size-filtered DBSCAN (is_cluster_instances) of one image's candidate arrays given as
+        numpy: centerofmass [8][n_slots][2] f32, core_candidates [8][n_slots] u8, per_class [8].
+        Returns (labels [8][n_slots] int32, packed triples [total][3])."""
+        import torch
+        p = self.params
+        slots = p.cols * p.max_sections
+        dev = torch.device("cuda", self.device)
+        com = torch.from_numpy(np.ascontiguousarray(centerofmass, np.float32)).to(dev)
+        cand = torch.from_numpy(np.ascontiguousarray(core_candidates, np.uint8)).to(dev)
+        per = torch.from_numpy(np.ascontiguousarray(per_class, np.int32)).to(dev)
+        assert com.shape == (INSTANCE_CLASSES, slots, 2) and cand.shape == (INSTANCE_CLASSES, slots)
+        idx = torch.zeros((INSTANCE_CLASSES, slots, 2), dtype=torch.int32, device=dev)
+        idx[:, :, 0] = torch.arange(INSTANCE_CLASSES, device=dev, dtype=torch.int32)[:, None]
+        idx[:, :, 1] = torch.arange(slots, device=dev, dtype=torch.int32)[None, :]
+        lab = torch.full((INSTANCE_CLASSES, slots), -9, dtype=torch.int32, device=dev)
+        packed = torch.full((1 + 3 * INSTANCE_CLASSES * slots,), -9, dtype=torch.int32, device=dev)
+        ib = InstanceBuffers(com.data_ptr(), idx.data_ptr(), cand.data_ptr(), per.data_ptr(),
+                             lab.data_ptr(), packed.data_ptr())
+        _check(lib().is_cluster_instances(self._ctx, ctypes.byref(ib),
+                                          torch.cuda.current_stream(dev).cuda_stream),
+               "is_cluster_instances")
+        torch.cuda.synchronize(dev)
+        pk = packed.cpu().numpy()
+        return lab.cpu().numpy(), pk[1:1 + 3 * int(pk[0])].reshape(-1, 3)
 
 
 def flip_and_pad(cnn_out, rows_power2_segmentation, device=0):

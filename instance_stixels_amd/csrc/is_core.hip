@@ -42,6 +42,9 @@ hipError_t isk_set_lds_unary(const DevParams*);
 hipError_t isk_set_lds_pairwise(const DevParams*, int);
 hipError_t isk_set_lds_backtrace(const DevParams*);
 int isk_debug_occupancy(const DevParams*, int);
+hipError_t isk_launch_cluster(int, float, int, const float*, const uint8_t*, const int32_t*,
+                              const int32_t*, int32_t*, int32_t*, int32_t*, hipStream_t);
+size_t isk_phase2_lds_bytes(const DevParams* P);
 hipError_t isk_launch_flip_and_pad(const float*, int32_t*, int, int, int, int, int, hipStream_t);
 hipError_t isk_launch_vdisparity(const float*, int*, int*, uint8_t*, int, int, int, float, hipStream_t);
 }
@@ -63,6 +66,8 @@ static int fail_arg(const char* msg) {
         if (e__ != hipSuccess) return fail_hip(e__, #expr, __FILE__, __LINE__); \
     } while (0)
 
+#define IS_STAGE_SLOTS 4 /* pinned staging ring of the per-frame ground model */
+
 struct is_ctx {
     is_stixel_params params;
     DevParams dp;
@@ -77,12 +82,16 @@ struct is_ctx {
     /* per-call device inputs */
     float* d_ground;         /* [max_batch][3][H] */
     int* d_vhor;             /* [max_batch] */
-    float* h_ground_pinned;
-    int* h_vhor_pinned;
-    hipEvent_t staging_free; /* recorded after the H2D copies of the last call */
+    /* ring of pinned staging slots: a call blocks the host only when the slot it wants is still
+     * being read by the H2D copy of the call IS_STAGE_SLOTS calls ago */
+    float* h_ground_pinned[IS_STAGE_SLOTS];
+    int* h_vhor_pinned[IS_STAGE_SLOTS];
+    hipEvent_t staging_free[IS_STAGE_SLOTS]; /* recorded after the H2D copies of the slot's call */
+    bool staging_pending[IS_STAGE_SLOTS];
+    int stage_next;
     hipStream_t aux_stream;  /* second stream of the pairwise DP (two half batches in flight) */
     hipEvent_t ev_fork, ev_join;
-    bool staging_pending;
+    int32_t* d_cluster_scratch; /* [8][2][C*S] work arrays of k_cluster_instances */
     /* scratch */
     RowRec* d_recs;          /* [max_batch*C][H+1] */
     float* d_lutT;           /* [max_batch*C][H+1][D] */
@@ -106,11 +115,41 @@ static int ilog2_exact(int n) {
     return l;
 }
 
+/* Runs the enclosed calls on the context's device and puts the caller's current device back. */
+struct DeviceScope {
+    int prev = -1, want;
+    bool switched = false;
+    hipError_t err = hipSuccess;
+    explicit DeviceScope(int device) : want(device) {
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != want) {
+            err = hipSetDevice(want);
+            switched = err == hipSuccess;
+        }
+    }
+    ~DeviceScope() {
+        if (switched) (void)hipSetDevice(prev);
+    }
+};
+#define ON_CTX_DEVICE(c)                                                         \
+    DeviceScope dev_scope__((c)->device);                                        \
+    if (dev_scope__.err != hipSuccess)                                           \
+        return fail_hip(dev_scope__.err, "hipSetDevice(ctx->device)", __FILE__, __LINE__)
+
 const char* is_last_error(void) { return g_err; }
 const char* is_version(void) { return "instance_stixels_amd-core 0.1 (gfx950)"; }
 
 int is_device_malloc(void** ptr, size_t bytes) { HIP_TRY(hipMalloc(ptr, bytes)); return IS_OK; }
 int is_device_free(void* ptr) { HIP_TRY(hipFree(ptr)); return IS_OK; }
+int is_host_malloc(void** ptr, size_t bytes) { HIP_TRY(hipHostMalloc(ptr, bytes)); return IS_OK; }
+int is_host_free(void* ptr) { HIP_TRY(hipHostFree(ptr)); return IS_OK; }
+int is_get_device(int* device) {
+    if (!device) return fail_arg("null pointer");
+    HIP_TRY(hipGetDevice(device));
+    return IS_OK;
+}
+int is_set_device(int device) { HIP_TRY(hipSetDevice(device)); return IS_OK; }
+int is_ctx_device(const is_ctx* ctx) { return ctx ? ctx->device : -1; }
 int is_memcpy_h2d(void* dst, const void* src, size_t bytes, void* stream) {
     HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
     return IS_OK;
@@ -149,7 +188,9 @@ int is_ctx_create(const is_stixel_params* p, const float* obj_cost_lut,
     if (p->rows_power2 != P2 || p->rows_power2_segmentation != P2S)
         return fail_arg("rows_power2 / rows_power2_segmentation inconsistent with rows (Stixels.cu:131-133)");
 
-    HIP_TRY(hipSetDevice(device));
+    /* everything of the context is created on `device`; the caller's current device is put back */
+    DeviceScope scope(device);
+    if (scope.err != hipSuccess) return fail_hip(scope.err, "hipSetDevice(device)", __FILE__, __LINE__);
     is_ctx* c = (is_ctx*)calloc(1, sizeof(is_ctx));
     if (!c) return IS_ENOMEM;
     const int rc = ctx_init(c, p, obj_cost_lut, obj_disparity_range, max_batch, device, P2, P2S);
@@ -201,7 +242,8 @@ static int ctx_init(is_ctx* c, const is_stixel_params* p, const float* obj_cost_
     c->nwaves_pairwise = IS_UNARY_WAVES;
     if (sizeof(int) * (6 * (size_t)d.H + 3 * (size_t)d.S + 4) > 160 * 1024 ||
         isk_unary_lds_bytes(&d) > 160 * 1024 || isk_pairwise_lds_bytes(&d, c->nwaves_pairwise) > 160 * 1024 ||
-        isk_prepare_lds_bytes(&d) > 160 * 1024)
+        isk_prepare_lds_bytes(&d) > 160 * 1024 || isk_phase2_lds_bytes(&d) > 160 * 1024 ||
+        sizeof(int) * (size_t)d.C * IS_INSTANCE_CLASSES + 16 > 160 * 1024)
         return fail_arg("shape needs more than 160 KiB of LDS per workgroup");
 
     const size_t H = d.H, C = d.C, D = d.D, B = max_batch;
@@ -229,11 +271,14 @@ static int ctx_init(is_ctx* c, const is_stixel_params* p, const float* obj_cost_
     ALLOC(c->d_sv, sizeof(float) * B * C * 2 * (H + 1));
     ALLOC(c->d_cost_table, sizeof(float) * B * C * H * 3);
     ALLOC(c->d_index_table, sizeof(int32_t) * B * C * H * 3);
+    ALLOC(c->d_cluster_scratch, sizeof(int32_t) * IS_INSTANCE_CLASSES * 2 * C * (size_t)d.S);
 #undef ALLOC
     c->scratch_bytes = total;
-    HIP_TRY(hipHostMalloc((void**)&c->h_ground_pinned, sizeof(float) * B * 3 * H));
-    HIP_TRY(hipHostMalloc((void**)&c->h_vhor_pinned, sizeof(int) * B));
-    HIP_TRY(hipEventCreateWithFlags(&c->staging_free, hipEventDisableTiming));
+    for (int i = 0; i < IS_STAGE_SLOTS; i++) {
+        HIP_TRY(hipHostMalloc((void**)&c->h_ground_pinned[i], sizeof(float) * B * 3 * H));
+        HIP_TRY(hipHostMalloc((void**)&c->h_vhor_pinned[i], sizeof(int) * B));
+        HIP_TRY(hipEventCreateWithFlags(&c->staging_free[i], hipEventDisableTiming));
+    }
     HIP_TRY(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
@@ -277,14 +322,16 @@ static int ctx_init(is_ctx* c, const is_stixel_params* p, const float* obj_cost_
 
 int is_ctx_destroy(is_ctx* c) {
     if (!c) return IS_OK;
-    (void)hipSetDevice(c->device);
+    DeviceScope scope(c->device);
     (void)hipDeviceSynchronize();
     (void)hipFree(c->d_obj_cost_lut); (void)hipFree(c->d_odr); (void)hipFree(c->d_rcp); (void)hipFree(c->d_col_flags); (void)hipFree(c->d_ground);
     (void)hipFree(c->d_vhor); (void)hipFree(c->d_recs); (void)hipFree(c->d_lutT); (void)hipFree(c->d_priors); (void)hipFree(c->d_steps); (void)hipFree(c->d_part_cost); (void)hipFree(c->d_part_idx); (void)hipFree(c->d_sv);
-    (void)hipFree(c->d_cost_table); (void)hipFree(c->d_index_table);
-    if (c->h_ground_pinned) (void)hipHostFree(c->h_ground_pinned);
-    if (c->h_vhor_pinned) (void)hipHostFree(c->h_vhor_pinned);
-    if (c->staging_free) (void)hipEventDestroy(c->staging_free);
+    (void)hipFree(c->d_cost_table); (void)hipFree(c->d_index_table); (void)hipFree(c->d_cluster_scratch);
+    for (int i = 0; i < IS_STAGE_SLOTS; i++) {
+        if (c->h_ground_pinned[i]) (void)hipHostFree(c->h_ground_pinned[i]);
+        if (c->h_vhor_pinned[i]) (void)hipHostFree(c->h_vhor_pinned[i]);
+        if (c->staging_free[i]) (void)hipEventDestroy(c->staging_free[i]);
+    }
     if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
@@ -302,9 +349,22 @@ int is_join_columns(is_ctx* c, const float* d_big, int full_cols, int median_joi
     if (p.column_step > 16) return fail_arg("column_step > 16");
     if (p.width_margin + p.cols * p.column_step > full_cols)
         return fail_arg("full_cols smaller than width_margin + realcols*column_step");
+    ON_CTX_DEVICE(c);
     HIP_TRY(isk_launch_join(d_big, d_joined, p.rows, full_cols, p.cols, p.column_step,
                             p.width_margin, median_join, p.invalid_disparity, n_images,
                             (hipStream_t)stream));
+    return IS_OK;
+}
+
+int is_cluster_instances(is_ctx* c, const is_instance_buffers* ib, void* stream) {
+    if (!c || !ib) return fail_arg("null pointer");
+    if (!ib->d_labels || !ib->d_centerofmass || !ib->d_core_candidates || !ib->d_instances_per_class)
+        return fail_arg("d_labels, d_centerofmass, d_core_candidates and d_instances_per_class are required");
+    ON_CTX_DEVICE(c);
+    HIP_TRY(isk_launch_cluster(c->dp.C * c->dp.S, c->params.clustering_eps, c->params.clustering_min_pts,
+                               ib->d_centerofmass, ib->d_core_candidates, ib->d_instances_per_class,
+                               ib->d_indices, ib->d_labels, c->d_cluster_scratch, ib->d_packed,
+                               (hipStream_t)stream));
     return IS_OK;
 }
 
@@ -357,27 +417,37 @@ int is_compute(is_ctx* c, const float* d_joined, const int32_t* d_seg, const flo
     if (!c || !d_joined || !d_seg || !h_gf || !h_ng || !h_is2 || !h_vhor || !d_sections)
         return fail_arg("null pointer");
     if (n_images < 1 || n_images > c->max_batch) return fail_arg("n_images outside [1, max_batch]");
+    if ((((uintptr_t)d_joined) | ((uintptr_t)d_seg)) & 15)
+        return fail_arg("d_joined / d_segmentation must be 16-byte aligned (vector loads)");
+    if (instances)
+        for (int i = 0; i < n_images; i++)
+            if (instances[i].d_labels && (!instances[i].d_centerofmass || !instances[i].d_core_candidates ||
+                                          !instances[i].d_instances_per_class))
+                return fail_arg("d_labels needs d_centerofmass, d_core_candidates and d_instances_per_class");
+    ON_CTX_DEVICE(c);
     hipStream_t stream = (hipStream_t)stream_;
     const DevParams& P = c->dp;
     const size_t H = P.H;
     const int ncols = n_images * P.C;
 
     /* stage the per-frame ground model (the reference does 3 blocking cudaMemcpy per frame,
-     * Stixels.cu:479-493); pinned + async here, guarded against reuse by an event */
-    if (c->staging_pending) HIP_TRY(hipEventSynchronize(c->staging_free));
+     * Stixels.cu:479-493): pinned + async here, through a ring of slots each guarded by an event */
+    const int slot = c->stage_next;
+    c->stage_next = (slot + 1) % IS_STAGE_SLOTS;
+    if (c->staging_pending[slot]) HIP_TRY(hipEventSynchronize(c->staging_free[slot]));
     for (int i = 0; i < n_images; i++) {
-        float* dst = c->h_ground_pinned + (size_t)i * 3 * H;
+        float* dst = c->h_ground_pinned[slot] + (size_t)i * 3 * H;
         memcpy(dst, h_gf + (size_t)i * H, sizeof(float) * H);
         memcpy(dst + H, h_ng + (size_t)i * H, sizeof(float) * H);
         memcpy(dst + 2 * H, h_is2 + (size_t)i * H, sizeof(float) * H);
-        c->h_vhor_pinned[i] = h_vhor[i];
+        c->h_vhor_pinned[slot][i] = h_vhor[i];
     }
-    HIP_TRY(hipMemcpyAsync(c->d_ground, c->h_ground_pinned, sizeof(float) * n_images * 3 * H,
+    HIP_TRY(hipMemcpyAsync(c->d_ground, c->h_ground_pinned[slot], sizeof(float) * n_images * 3 * H,
                            hipMemcpyHostToDevice, stream));
-    HIP_TRY(hipMemcpyAsync(c->d_vhor, c->h_vhor_pinned, sizeof(int) * n_images,
+    HIP_TRY(hipMemcpyAsync(c->d_vhor, c->h_vhor_pinned[slot], sizeof(int) * n_images,
                            hipMemcpyHostToDevice, stream));
-    HIP_TRY(hipEventRecord(c->staging_free, stream));
-    c->staging_pending = true;
+    HIP_TRY(hipEventRecord(c->staging_free[slot], stream));
+    c->staging_pending[slot] = true;
 
     float* ct = d_cost_table ? d_cost_table : c->d_cost_table;
     int32_t* it = d_index_table ? d_index_table : c->d_index_table;
@@ -407,6 +477,11 @@ int is_compute(is_ctx* c, const float* d_joined, const int32_t* d_seg, const flo
             HIP_TRY(isk_launch_compact(&P, d_sections + (size_t)i * P.C * P.S, ib.d_centerofmass,
                                        ib.d_indices, ib.d_core_candidates, ib.d_instances_per_class,
                                        stream));
+            if (ib.d_labels) /* Stixels::ClusterInstances, Stixels.cu:613 */
+                HIP_TRY(isk_launch_cluster(P.C * P.S, c->params.clustering_eps,
+                                           c->params.clustering_min_pts, ib.d_centerofmass,
+                                           ib.d_core_candidates, ib.d_instances_per_class, ib.d_indices,
+                                           ib.d_labels, c->d_cluster_scratch, ib.d_packed, stream));
         }
     }
     if (c->timing) {

@@ -24,7 +24,8 @@ EXPORTS = [
     "ish_finish", "ish_is_initialized", "ish_real_cols", "ish_max_sections",
     "ish_get_parameters", "ish_get_luts", "ish_core_context", "ish_set_disparity_image",
     "ish_set_segmentation", "ish_set_road_parameters", "ish_get_ground_model", "ish_compute",
-    "ish_get_instance_stixels", "ish_get_3d_vertices", "ish_save_stixels",
+    "ish_get_instance_stixels", "ish_get_3d_vertices", "ish_save_stixels", "ish_time_compute",
+    "ish_set_device",
     "ire_create", "ire_destroy", "ire_initialize", "ire_finish", "ire_compute", "ire_get_binary",
     "ire_hough_lines",
 ]
@@ -75,6 +76,8 @@ def lib():
         L.ish_get_ground_model.argtypes = [vp, vp, vp, vp, ctypes.POINTER(ci)]
         L.ish_compute.argtypes = [vp, ci, vp, vp, ctypes.POINTER(cf), ctypes.POINTER(cf)]
         L.ish_get_instance_stixels.argtypes = [vp, vp, ci]
+        L.ish_time_compute.argtypes = [vp, ci, ci, ci, ctypes.POINTER(ctypes.c_double)]
+        L.ish_set_device.argtypes = [vp, ci]
         L.ish_get_3d_vertices.argtypes = [vp, vp, cf, ci, vp, ci]
         L.ish_save_stixels.argtypes = [vp, vp, vp, ci, cf, ci, ctypes.c_char_p]
         L.ire_create.restype = vp
@@ -137,6 +140,18 @@ class Stixels:
 
     def Initialize(self, max_batch=1):
         self._check(lib().ish_initialize(self._h, int(max_batch)), "Initialize")
+
+    def SetDevice(self, device):
+        """GPU of the next Initialize() (default: the caller's current HIP device)."""
+        self._check(lib().ish_set_device(self._h, int(device)), "SetDevice")
+
+    def time_compute(self, pairwise, n_iter=100, with_instances=False):
+        """Seconds per frame of n_iter Stixels::Compute() calls timed inside the C++ library."""
+        t = ctypes.c_double()
+        self._check(lib().ish_time_compute(self._h, int(bool(pairwise)), int(n_iter),
+                                           int(bool(with_instances)), ctypes.byref(t)),
+                    "time_compute")
+        return t.value
 
     def PrecomputeHost(self):
         """Host half of Initialize (tables + StixelParameters); needs no GPU."""

@@ -238,9 +238,6 @@ void Stixels::PrecomputeHost() {
     m_max_sections = MAX_STIXELS_PER_COLUMN;
     m_instance_classes = IS_INSTANCE_CLASSES;
 
-    const size_t inst_n = (size_t)m_instance_classes * m_realcols * m_max_sections;
-    m_instance_labels.assign(inst_n, -1);
-    m_instance_indices.assign(inst_n * 2, 0);
     m_instances_per_class.assign(m_instance_classes, 0);
 
     /* log LUT over [0, 1], Stixels.cu:79-84 */
@@ -316,9 +313,15 @@ void Stixels::InitializeBatch(int max_batch) { /* Stixels.cu:43-248 */
     const size_t inst_n = (size_t)m_instance_classes * m_realcols * m_max_sections;
     const int rows_power2_segmentation = m_params.rows_power2_segmentation;
 
-    /* device side: LUT upload + all buffers (Stixels.cu:53-74, 136-210) */
+    /* device side: LUT upload + all buffers (Stixels.cu:53-74, 136-210) on the caller's current
+     * device unless SetDevice() chose one */
+    int caller_device = 0;
+    IS_CHECK_RETURN(is_get_device(&caller_device));
+    const int device = m_device >= 0 ? m_device : caller_device;
+    m_device = device;
     IS_CHECK_RETURN(is_ctx_create(&m_params, m_obj_cost_lut.data(),
-                                  m_object_disparity_range.data(), m_max_batch, 0, &m_ctx));
+                                  m_object_disparity_range.data(), m_max_batch, device, &m_ctx));
+    if (caller_device != device) IS_CHECK_RETURN(is_set_device(device));
     const size_t B = m_max_batch;
     IS_CHECK_RETURN(is_device_malloc((void**)&d_stixels,
                                      B * m_realcols * m_max_sections * sizeof(Section)));
@@ -336,6 +339,14 @@ void Stixels::InitializeBatch(int max_batch) { /* Stixels.cu:43-248 */
                                      (size_t)m_rows * m_cols * sizeof(float)));
     IS_CHECK_RETURN(is_device_malloc((void**)&d_disparity,
                                      B * m_rows * m_realcols * sizeof(float)));
+    IS_CHECK_RETURN(is_device_malloc((void**)&d_instance_labels, inst_n * sizeof(int32_t)));
+    IS_CHECK_RETURN(is_device_malloc((void**)&d_instance_packed, (1 + 3 * inst_n) * sizeof(int32_t)));
+    IS_CHECK_RETURN(is_host_malloc((void**)&h_stixels,
+                                   (size_t)m_realcols * m_max_sections * sizeof(Section)));
+    IS_CHECK_RETURN(is_host_malloc((void**)&h_instance_head, 16 * sizeof(int32_t)));
+    IS_CHECK_RETURN(is_host_malloc((void**)&h_instance_packed, (1 + 3 * inst_n) * sizeof(int32_t)));
+    h_instance_packed[0] = 0;
+    if (caller_device != device) IS_CHECK_RETURN(is_set_device(caller_device));
     m_is_initialized = true;
 }
 
@@ -348,6 +359,13 @@ void Stixels::Finish() { /* Stixels.cu:250-283 */
     IS_CHECK_RETURN(is_device_free(d_instance_indices));
     IS_CHECK_RETURN(is_device_free(d_instance_core_candidates));
     IS_CHECK_RETURN(is_device_free(d_instances_per_class));
+    IS_CHECK_RETURN(is_device_free(d_instance_labels));
+    IS_CHECK_RETURN(is_device_free(d_instance_packed));
+    IS_CHECK_RETURN(is_host_free(h_stixels));
+    IS_CHECK_RETURN(is_host_free(h_instance_head));
+    IS_CHECK_RETURN(is_host_free(h_instance_packed));
+    d_instance_labels = nullptr; d_instance_packed = nullptr;
+    h_stixels = nullptr; h_instance_head = nullptr; h_instance_packed = nullptr;
     IS_CHECK_RETURN(is_ctx_destroy(m_ctx));
     m_ctx = nullptr;
     d_segmentation = nullptr; d_disparity_big = nullptr; d_disparity = nullptr;
@@ -367,8 +385,11 @@ void Stixels::SetSegmentation(const std::vector<int32_t>& segmentation) { /* :34
 }
 
 void Stixels::SetDisparityImage(const std::vector<pixel_t>& disp_im) { /* :348-355 */
+    /* the reference queues a cudaMemcpyAsync from the caller's pageable vector; the copy is
+     * finished here before returning, so the vector may be a temporary */
     IS_CHECK_RETURN(is_memcpy_h2d(d_disparity_big, disp_im.data(),
                                   sizeof(pixel_t) * disp_im.size(), nullptr));
+    IS_CHECK_RETURN(is_stream_synchronize(nullptr));
 }
 
 pixel_t* Stixels::GetInputDisparityImageOnDevice() { return d_disparity_big; } /* :357-359 */
@@ -394,30 +415,50 @@ float Stixels::Compute(const bool pairwise, StixelsData& stixels_data,
                        int32_t* d_segmentation_local) { /* Stixels.cu:449-637 */
     if (d_segmentation_local == nullptr) d_segmentation_local = d_segmentation;
 
-    GroundModel g;
+    GroundModel& g = m_ground;
     PrecomputeGround(m_vhor, m_camera_tilt, m_camera_height, m_alpha_ground, g); /* :463 */
     m_params.vhor = m_vhor;                                                       /* :532 */
 
     IS_CHECK_RETURN(is_join_columns(m_ctx, d_disparity_big, m_cols, m_median_join ? 1 : 0,
                                     d_disparity, 1, nullptr)); /* :509-511 */
+    /* the DP, the instance candidates and their clustering (ClusterInstances, :613) are queued
+     * back to back on the device; nothing returns to the host in between */
+    const is_instance_buffers ib = InstanceBuffers();
+    IS_CHECK_RETURN(is_compute(m_ctx, d_disparity, d_segmentation_local, g.function.data(),
+                               g.normalization.data(), g.inv_sigma2.data(), &m_vhor,
+                               pairwise ? 1 : 0, 1, d_stixels, &ib, nullptr, nullptr,
+                               nullptr)); /* :535-590 */
+    /* results into pinned memory, ONE synchronisation (:600, :629-633) */
+    const size_t n_sec = (size_t)m_realcols * m_max_sections;
+    IS_CHECK_RETURN(is_memcpy_d2h(h_stixels, d_stixels, n_sec * sizeof(Section), nullptr));
+    IS_CHECK_RETURN(is_memcpy_d2h(h_instance_head, d_instances_per_class,
+                                  m_instance_classes * sizeof(int32_t), nullptr));
+    IS_CHECK_RETURN(is_stream_synchronize(nullptr));
+    for (int k = 0; k < m_instance_classes; k++) m_instances_per_class[k] = h_instance_head[k];
+    m_labels_on_host = false;
+
+    FillHeader(stixels_data, m_alpha_ground, m_vhor);
+    /* sections of every column up to and including its terminator; what lies behind a
+     * terminator is unspecified (in the reference: whatever the device buffer held) */
+    Section* out = stixels_data.sections.data();
+    for (int c = 0; c < m_realcols; c++) {
+        const Section* src = h_stixels + (size_t)c * m_max_sections;
+        int n = 0;
+        while (n < m_max_sections - 1 && src[n].type != -1) n++;
+        std::memcpy(out + (size_t)c * m_max_sections, src, (size_t)(n + 1) * sizeof(Section));
+    }
+    return -1; /* the reference's timers are commented out, Stixels.cu:636 */
+}
+
+is_instance_buffers Stixels::InstanceBuffers() const {
     is_instance_buffers ib;
     ib.d_centerofmass = d_instance_centerofmass;
     ib.d_indices = d_instance_indices;
     ib.d_core_candidates = d_instance_core_candidates;
     ib.d_instances_per_class = d_instances_per_class;
-    IS_CHECK_RETURN(is_compute(m_ctx, d_disparity, d_segmentation_local, g.function.data(),
-                               g.normalization.data(), g.inv_sigma2.data(), &m_vhor,
-                               pairwise ? 1 : 0, 1, d_stixels, &ib, nullptr, nullptr,
-                               nullptr)); /* :535-590 */
-    IS_CHECK_RETURN(is_device_synchronize()); /* :600 */
-
-    ClusterInstances(); /* :613 */
-
-    FillHeader(stixels_data, m_alpha_ground, m_vhor);
-    IS_CHECK_RETURN(is_memcpy_d2h(stixels_data.sections.data(), d_stixels,
-                                  (size_t)m_realcols * m_max_sections * sizeof(Section), nullptr));
-    IS_CHECK_RETURN(is_stream_synchronize(nullptr));
-    return -1; /* the reference's timers are commented out, Stixels.cu:636 */
+    ib.d_labels = d_instance_labels;
+    ib.d_packed = d_instance_packed;
+    return ib;
 }
 
 void Stixels::ComputeBatch(bool pairwise, int n_images, const pixel_t* d_big,
@@ -453,99 +494,39 @@ void Stixels::ComputeBatch(bool pairwise, int n_images, const pixel_t* d_big,
 
 /* ---------------------------------------------------------------- instances */
 
-/* Size-filtered DBSCAN over the predicted instance centres of each instance class.
- * The reference calls a cuML fork whose source is not in its tree (Stixels.cu:639-681,
- * SURVEY.md §8f f1); the semantics implemented here are those of its Python twin
- * (/root/reference/tools/visualization/clustering_visualization.py:894-960): only stixels with
- * height >= size_filter ("core candidates") are clustered (eps, min_pts counted among
- * candidates, self included); every other stixel takes the label of its nearest core point if
- * that is within eps, else -1.  Labels are 0.. per class in order of discovery. */
+/* Size-filtered DBSCAN over the predicted instance centres of each instance class, on the
+ * device (k_cluster_instances, csrc/is_k_cluster.hip).  The reference calls a cuML fork whose
+ * source is not in its tree (Stixels.cu:639-681); the semantics are those of
+ * its Python twin (/root/reference/tools/visualization/clustering_visualization.py:894-960).
+ * Compute() already runs it; calling it again re-clusters the candidates of the last frame with
+ * the eps / min_pts of Initialize() (m_params, like the reference). */
 float Stixels::ClusterInstances() {
-    const float eps2 = m_params.clustering_eps * m_params.clustering_eps;
-    const int min_pts = m_params.clustering_min_pts;
-    const size_t per_class = (size_t)m_realcols * m_max_sections;
-
-    IS_CHECK_RETURN(is_memcpy_d2h(m_instances_per_class.data(), d_instances_per_class,
-                                  m_instance_classes * sizeof(int), nullptr));
-    IS_CHECK_RETURN(is_stream_synchronize(nullptr));
-    std::vector<float> com;
-    std::vector<uint8_t> cand;
-    for (int cls = 0; cls < m_instance_classes; cls++) {
-        const int n = m_instances_per_class[cls];
-        if (n <= 0) continue;
-        com.resize((size_t)n * 2);
-        cand.resize(n);
-        IS_CHECK_RETURN(is_memcpy_d2h(com.data(), d_instance_centerofmass + per_class * cls * 2,
-                                      sizeof(float) * 2 * n, nullptr));
-        IS_CHECK_RETURN(is_memcpy_d2h(cand.data(), d_instance_core_candidates + per_class * cls, n,
-                                      nullptr));
-        IS_CHECK_RETURN(is_stream_synchronize(nullptr));
-        int32_t* labels = m_instance_labels.data() + per_class * cls;
-        std::fill(labels, labels + n, -1);
-
-        auto dist2 = [&](int a, int b) {
-            const float dx = com[2 * a] - com[2 * b], dy = com[2 * a + 1] - com[2 * b + 1];
-            return dx * dx + dy * dy;
-        };
-        std::vector<int> large;
-        for (int i = 0; i < n; i++)
-            if (cand[i]) large.push_back(i);
-        if ((int)large.size() <= min_pts) continue; /* twin: X_large.shape[1] > min_samples */
-
-        std::vector<uint8_t> is_core(n, 0);
-        for (int a : large) {
-            int cnt = 0;
-            for (int b : large)
-                if (dist2(a, b) <= eps2) cnt++;
-            is_core[a] = cnt >= min_pts;
-        }
-        int next_label = 0;
-        std::vector<int> stack;
-        for (int seed : large) {
-            if (!is_core[seed] || labels[seed] != -1) continue;
-            labels[seed] = next_label;
-            stack.assign(1, seed);
-            while (!stack.empty()) {
-                const int a = stack.back();
-                stack.pop_back();
-                for (int b : large) {
-                    if (labels[b] != -1 || dist2(a, b) > eps2) continue;
-                    labels[b] = next_label;
-                    if (is_core[b]) stack.push_back(b);
-                }
-            }
-            next_label++;
-        }
-        for (int i = 0; i < n; i++) {
-            if (cand[i]) continue;
-            float best = eps2;
-            int best_core = -1;
-            for (int a : large) {
-                if (!is_core[a]) continue;
-                const float d = dist2(i, a);
-                if (d <= best && (best_core == -1 || d < best)) { best = d; best_core = a; }
-            }
-            if (best_core >= 0) labels[i] = labels[best_core];
-        }
-    }
+    const is_instance_buffers ib = InstanceBuffers();
+    IS_CHECK_RETURN(is_cluster_instances(m_ctx, &ib, nullptr));
+    m_labels_on_host = false;
     return -1;
 }
 
 std::map<std::pair<int, int>, int> Stixels::GetInstanceStixels() { /* Stixels.cu:744-776 */
-    const size_t per_class = (size_t)m_realcols * m_max_sections;
-    IS_CHECK_RETURN(is_memcpy_d2h(m_instance_indices.data(), d_instance_indices,
-                                  m_instance_classes * per_class * 2 * sizeof(int32_t), nullptr));
-    IS_CHECK_RETURN(is_stream_synchronize(nullptr));
-    std::map<std::pair<int, int>, int> mapping;
-    for (int cls = 0; cls < m_instance_classes; cls++) {
-        const int instances = m_instances_per_class[cls];
-        const size_t class_offset = per_class * cls;
-        for (int i = 0; i < instances; i++) {
-            const int u = m_instance_indices[class_offset * 2 + i * 2];
-            const int v = m_instance_indices[class_offset * 2 + i * 2 + 1];
-            mapping[std::make_pair(u, v)] = m_instance_labels[class_offset + i];
+    /* the reference copies the complete label and index arrays (4.8 MB, "~0.8 milliseconds",
+     * :745); here the device has packed (column, section, label) triples of the candidates */
+    if (!m_labels_on_host) {
+        int total = 0;
+        for (int k = 0; k < m_instance_classes; k++) total += m_instances_per_class[k];
+        if (total > 0) {
+            IS_CHECK_RETURN(is_memcpy_d2h(h_instance_packed, d_instance_packed,
+                                          (1 + 3 * (size_t)total) * sizeof(int32_t), nullptr));
+            IS_CHECK_RETURN(is_stream_synchronize(nullptr));
+        } else {
+            h_instance_packed[0] = 0;
         }
+        m_labels_on_host = true;
     }
+    std::map<std::pair<int, int>, int> mapping;
+    const int total = h_instance_packed[0];
+    const int32_t* t = h_instance_packed + 1;
+    for (int i = 0; i < total; i++)
+        mapping[std::make_pair(t[3 * i], t[3 * i + 1])] = t[3 * i + 2];
     return mapping;
 }
 

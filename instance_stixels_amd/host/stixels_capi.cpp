@@ -6,6 +6,7 @@
  * C++ exceptions are turned into a negative return code + message.
  */
 #include <cstring>
+#include <ctime>
 #include <exception>
 #include <string>
 
@@ -142,6 +143,31 @@ int ish_compute(void* h, int pairwise, Section* sections, int* hdr, float* alpha
         hdr[4] = d.max_dis; hdr[5] = d.column_step; hdr[6] = d.semantic_classes; hdr[7] = d.vhor;
         *alpha_ground = d.alpha_ground;
     });
+}
+
+/* Times n_iter calls of Stixels::Compute() on the frame set before (SetDisparityImage /
+ * SetSegmentation / SetRoadParameters), StixelsData reused like a C++ caller's loop would; with
+ * `with_instances` every frame also fetches GetInstanceStixels().  -> seconds per frame. */
+int ish_time_compute(void* h, int pairwise, int n_iter, int with_instances, double* s_per_frame) {
+    return guard([&] {
+        Stixels* s = (Stixels*)h;
+        StixelsData d;
+        for (int i = 0; i < 3; i++) s->Compute(pairwise != 0, d);
+        timespec t0, t1;
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        size_t sink = 0;
+        for (int i = 0; i < n_iter; i++) {
+            s->Compute(pairwise != 0, d);
+            if (with_instances) sink += s->GetInstanceStixels().size();
+        }
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        (void)sink;
+        *s_per_frame = ((t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec)) / n_iter;
+    });
+}
+
+int ish_set_device(void* h, int device) {
+    return guard([&] { ((Stixels*)h)->SetDevice(device); });
 }
 
 /* GetInstanceStixels(): triples (column, section, label); returns the count (<= cap) or <0. */

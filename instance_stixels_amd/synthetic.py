@@ -39,7 +39,13 @@ def rows_power2_segmentation(rows: int) -> int:  # Stixels.cu:132-133
 
 
 def make_frame(cfg: StixelConfig, seed: int = 0, n_slabs: int = 6, hole_fraction: float = 0.05,
-               zero_segmentation: bool = False) -> Frame:
+               zero_segmentation: bool = False, offset_scale: float = 8.0) -> Frame:
+    """offset_scale: the offset channels hold int(offset_scale * offset in full-resolution
+    pixels).  The kernel adds the channel value to the pixel position as it is
+    (StixelsKernels.cu:401-405), so 1.0 makes the predicted centres of an object coincide (what a
+    trained CNN delivers; used by the clustering tests); the default 8.0 is the bench / parity
+    data of round 1 (centres scattered 8x wider: hardly any instance clusters), kept so that
+    throughput numbers stay comparable across rounds."""
     rng = np.random.Generator(np.random.PCG64(seed))
     H, W, D = int(cfg.rows), int(cfg.cols), int(cfg.max_dis)
     C = cfg.realcols
@@ -103,8 +109,8 @@ def make_frame(cfg: StixelConfig, seed: int = 0, n_slabs: int = 6, hole_fraction
         ox = ox + rng.normal(0.0, 2.0, ox.shape)
         # the reference's convention: my = row - offy (rows counted from the bottom), so a
         # positive stored y offset points DOWN in the image (StixelsKernels.cu:400-405)
-        off_y = (8.0 * -oy).astype(np.int32)
-        off_x = (8.0 * ox).astype(np.int32)
+        off_y = (offset_scale * -oy).astype(np.int32)
+        off_x = (offset_scale * ox).astype(np.int32)
         # flip rows: index 0 = bottom of the image
         seg[:, :K, :Hs] = sem[::-1].transpose(1, 2, 0)
         seg[:, K, :Hs] = off_y[::-1].T

@@ -191,3 +191,77 @@ def flip_and_pad(cnn_out: np.ndarray, p2s: int) -> np.ndarray:
 
 def logf(x: float) -> float:
     return float(lib().orc_logf(ctypes.c_float(x)))
+
+
+def cluster_instances(centerofmass, core_candidates, eps, min_pts):
+    """CPU twin of the size-filtered DBSCAN of ONE instance class.
+
+    Restates `assign_instances`
+    (/root/reference/tools/visualization/clustering_visualization.py:894-960), the Python twin of
+    the reference's cuML call (/root/reference/InstanceStixels/src/Stixels.cu:639-681), with the
+    DBSCAN it delegates to sklearn written out: large points (core_candidates, i.e.
+    height >= size_filter, :921-922) are clustered only when there are more than `min_pts` of them
+    (:932); a large point is a core point when >= min_pts large points (itself included) lie
+    within eps; clusters grow from the core points in index order and are numbered in that order;
+    a non-core large point keeps the first cluster that reaches it; every small point takes the
+    label of its nearest core point (first on ties) when that lies within eps (:941-955).
+    Distances in float32: dx*dx + dy*dy <= eps*eps.  Returns int32 labels, -1 = none.
+    Parity pin: tests/golden/f1_f2_reference_python.npz holds labels produced by the reference's
+    own assign_instances (tests/golden/make_reference_python_golden.py)."""
+    X = np.ascontiguousarray(centerofmass, np.float32).reshape(-1, 2)
+    cand = np.ascontiguousarray(core_candidates).astype(bool).reshape(-1)
+    n = X.shape[0]
+    labels = np.full(n, -1, np.int32)
+    large = np.nonzero(cand)[0]
+    if n == 0 or large.size <= min_pts:
+        return labels
+    eps2 = np.float32(eps) * np.float32(eps)
+
+    def d2(a, b):  # [len(a)][len(b)] float32, no contraction
+        dx = X[a, 0][:, None] - X[b, 0][None, :]
+        dy = X[a, 1][:, None] - X[b, 1][None, :]
+        return dx * dx + dy * dy
+
+    with np.errstate(invalid="ignore", over="ignore"):
+        near = d2(large, large) <= eps2                 # NaN coordinates: never a neighbour
+    is_core = near.sum(axis=1) >= min_pts
+    lab_l = np.full(large.size, -1, np.int32)
+    nxt = 0
+    for seed in range(large.size):                       # sklearn's dbscan_inner, in index order
+        if lab_l[seed] != -1 or not is_core[seed]:
+            continue
+        stack = [seed]
+        while stack:
+            i = stack.pop()
+            if lab_l[i] == -1:
+                lab_l[i] = nxt
+                if is_core[i]:
+                    stack.extend(int(v) for v in np.nonzero(near[i] & (lab_l == -1))[0])
+        nxt += 1
+    labels[large] = lab_l
+    cores = large[is_core]
+    small = np.nonzero(~cand)[0]
+    if cores.size and small.size:
+        with np.errstate(invalid="ignore", over="ignore"):
+            dist = d2(small, cores)
+        dist = np.where(np.isnan(dist), np.float32(np.inf), dist)
+        closest = dist.argmin(axis=1)
+        dmin = dist[np.arange(small.size), closest]
+        ok = dmin <= eps2
+        labels[small[ok]] = labels[cores[closest[ok]]]
+    return labels
+
+
+def same_partition(a, b):
+    """True when two label vectors describe the same clustering up to a renaming of the cluster
+    ids (-1 = unlabelled must match exactly)."""
+    a, b = np.asarray(a).reshape(-1), np.asarray(b).reshape(-1)
+    if a.shape != b.shape or not np.array_equal(a < 0, b < 0):
+        return False
+    fwd, bwd = {}, {}
+    for x, y in zip(a.tolist(), b.tolist()):
+        if x < 0:
+            continue
+        if fwd.setdefault(x, y) != y or bwd.setdefault(y, x) != x:
+            return False
+    return True
