@@ -206,8 +206,8 @@ def cluster_instances(centerofmass, core_candidates, eps, min_pts):
     a non-core large point keeps the first cluster that reaches it; every small point takes the
     label of its nearest core point (first on ties) when that lies within eps (:941-955).
     Distances in float32: dx*dx + dy*dy <= eps*eps.  Returns int32 labels, -1 = none.
-    Parity pin: tests/golden/f1_f2_reference_python.npz holds labels produced by the reference's
-    own assign_instances (tests/golden/make_reference_python_golden.py)."""
+    Parity pin: tests/golden/reference_python/f1_f2_reference_python.npz holds labels produced by the reference's
+    own assign_instances (tests/golden/reference_python/make_golden.py)."""
     X = np.ascontiguousarray(centerofmass, np.float32).reshape(-1, 2)
     cand = np.ascontiguousarray(core_candidates).astype(bool).reshape(-1)
     n = X.shape[0]

@@ -1,4 +1,4 @@
-"""Generates tests/golden/f1_f2_reference_python.npz -- the pin of SURVEY rows f1 / f2.
+"""Generates tests/golden/reference_python/f1_f2_reference_python.npz -- the pin of SURVEY rows f1 / f2.
 
 BUILD-CONTAINER ONLY: reads /root/reference at generation time; only the resulting vectors (data)
 are committed and travel to the GPU box.
@@ -21,7 +21,7 @@ Pipeline per case (small frames, CPU only):
   product  Stixels::SaveStixels with the twin-oracle labels -> text B
   reference read_stixel_file(text B)          -> parsed instance labels (label + class*1000)
 
-    python tests/golden/make_reference_python_golden.py
+    python tests/golden/reference_python/make_golden.py
 """
 import ast
 import copy
@@ -34,7 +34,7 @@ import contextlib
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-ROOT = os.path.dirname(os.path.dirname(HERE))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(HERE)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
@@ -108,14 +108,11 @@ def main():
             ref_labels = np.array([s.get("instance_label", -2)
                                    for col in labelled for s in col], np.int32)  # -2: class < 11
             # ---- candidate arrays per instance class as the twin derives them (class, size)
-            sec_flat = np.array([secs[c][i] for c, i in order])
             for cls in range(11, 19):
                 m = rp[:, 3] == cls
                 if not m.any():
                     continue
                 Xc = rf[m][:, 2:4]
-                size = rp[m, 2] - rp[m, 1] + 1
-                large = size >= cfg.size_filter
                 # margin: no pair may sit on the eps boundary (float32 vs float64 evaluation)
                 d2 = ((Xc[:, None, :] - Xc[None, :, :]) ** 2).sum(-1)
                 margin = np.abs(d2 - float(cfg.eps) ** 2).min() / float(cfg.eps) ** 2

@@ -1,9 +1,9 @@
 """SURVEY rows f1 (size-filtered DBSCAN + GetInstanceStixels) and f2 (SaveStixels text,
 Get3DVertices), value level.
 
-Pins: tests/golden/f1_f2_reference_python.npz was produced by the reference's OWN Python
+Pins: tests/golden/reference_python/f1_f2_reference_python.npz was produced by the reference's OWN Python
 (`read_stixel_file`, `assign_instances` of tools/visualization/clustering_visualization.py, run in
-the build container by tests/golden/make_reference_python_golden.py): the text files in it were
+the build container by tests/golden/reference_python/make_golden.py): the text files in it were
 parsed by the reference reader and the instance labels in it were assigned by the reference twin
 of the cuML call.  Everything else is checked against the oracle (oracle.cluster_instances, an
 independent text formatter, a numpy restatement of Get3DVertices).
@@ -18,7 +18,8 @@ from instance_stixels_amd import host, synthetic, make_config
 from instance_stixels_amd.config import SECTION_DTYPE
 from oracle import oracle
 
-GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "f1_f2_reference_python.npz"))
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_python",
+                            "f1_f2_reference_python.npz"))
 N_CASES = int(GOLD["n_cases"])
 
 
