@@ -23,12 +23,12 @@ size_t isk_unary_lds_bytes(const DevParams* P);
 size_t isk_pairwise_lds_bytes(const DevParams* P, int nwaves);
 hipError_t isk_launch_join(const float*, float*, int, int, int, int, int, int, float, int, hipStream_t);
 hipError_t isk_launch_prepare(const DevParams*, int, const float*, const int32_t*, const float*,
-                              const int*, const float*, RowRec*, float*, int*, float*, hipStream_t,
-                              hipStream_t, hipEvent_t, hipEvent_t);
+                              const int*, const float*, RowRec*, float*, int*, float*, PruneRec*,
+                              hipStream_t, hipStream_t, hipEvent_t, hipEvent_t);
 struct StepRec;
 hipError_t isk_launch_priors(const DevParams*, const float*, PriorRec*, int, hipStream_t);
 hipError_t isk_launch_dp_unary(const DevParams*, int, int, const RowRec*, const float*, const float*,
-                               const int*, const int*, float*, int32_t*, hipStream_t);
+                               const int*, const int*, const PruneRec*, float*, int32_t*, hipStream_t);
 hipError_t isk_launch_dp_pairwise(const DevParams*, int, int, const RowRec*, const float*,
                                   const PriorRec*, const float*, const float*, const float*,
                                   const int*, const int*, StepRec*, float*, int*, float*, int32_t*,
@@ -49,6 +49,7 @@ hipError_t isk_launch_flip_and_pad(const float*, int32_t*, int, int, int, int, i
 hipError_t isk_launch_vdisparity(const float*, int*, int*, uint8_t*, int, int, int, float, hipStream_t);
 }
 
+#define IS_FLT_HUGE 1e30f
 static thread_local char g_err[512] = "";
 
 static int fail_hip(hipError_t e, const char* what, const char* file, int line) {
@@ -79,6 +80,7 @@ struct is_ctx {
     float* d_odr;            /* [D]     object_disparity_range */
     float* d_rcp;            /* [H+1]   RN(1/h) = (float)(1./h), the reference's inverse_height */
     int* d_col_flags;        /* [max_batch*C] 0 = FAST column, see RowRec */
+    PruneRec* d_prune;       /* [max_batch*C] branch-and-bound slacks of the column */
     /* per-call device inputs */
     float* d_ground;         /* [max_batch][3][H] */
     int* d_vhor;             /* [max_batch] */
@@ -236,6 +238,28 @@ static int ctx_init(is_ctx* c, const is_stixel_params* p, const float* obj_cost_
     d.first_o_above = d.rows_log + 0.0f + d.max_dis_log;
     d.size_filter = p->clustering_size_filter;
     d.column_step = p->column_step;
+    {
+        /* branch-and-bound constants (PruneRec, is_device.h).  gamma_d bounds the relative error of
+         * a prefix computed by a summation tree of depth d: Blelloch needs <= 2 log2(P2) additions
+         * on a path, the object LUT's carry chain H/32 + 5; a generous d covers both. */
+        const double depth = 2.0 * ilog2_exact(P2) + (double)d.H / 32.0 + 8.0;
+        const double gamma = 1.01 * depth * 0x1p-24;
+        d.gamma2 = (float)(2.0 * gamma * 1.001);
+        double max_abs = 0.0, min_v = 0.0;
+        bool finite = true;
+        for (size_t i = 0; i < (size_t)d.D * d.D; i++) {
+            const double v = obj_cost_lut[i];
+            if (!(fabs(v) < 1e30)) finite = false; /* also catches NaN */
+            if (fabs(v) > max_abs) max_abs = fabs(v);
+            if (v < min_v) min_v = v;
+        }
+        const bool weights_ok = d.dw >= 0.0f && d.sw >= 0.0f && d.iw >= 0.0f && d.pw >= 0.0f &&
+                                d.dw < IS_FLT_HUGE && d.sw < IS_FLT_HUGE && d.iw < IS_FLT_HUGE;
+        if (finite && weights_ok && !getenv("IS_NO_PRUNE"))
+            d.sigma_od = (float)(((0.0 - min_v) * d.H + 2.0 * gamma * d.H * max_abs) * 1.001);
+        else
+            d.sigma_od = __builtin_inff(); /* pruning off */
+    }
 
     /* waves per DP workgroup: the LUT tile is 64*(D+1) floats; keep >= 16 waves per CU */
     c->nwaves_unary = IS_UNARY_WAVES;
@@ -257,6 +281,7 @@ static int ctx_init(is_ctx* c, const is_stixel_params* p, const float* obj_cost_
     ALLOC(c->d_odr, sizeof(float) * D);
     ALLOC(c->d_rcp, sizeof(float) * (H + 1));
     ALLOC(c->d_col_flags, sizeof(int) * B * C);
+    ALLOC(c->d_prune, sizeof(PruneRec) * B * C);
     ALLOC(c->d_ground, sizeof(float) * B * 3 * H);
     ALLOC(c->d_vhor, sizeof(int) * B);
     ALLOC(c->d_recs, sizeof(RowRec) * B * C * (H + 1));
@@ -324,7 +349,7 @@ int is_ctx_destroy(is_ctx* c) {
     if (!c) return IS_OK;
     DeviceScope scope(c->device);
     (void)hipDeviceSynchronize();
-    (void)hipFree(c->d_obj_cost_lut); (void)hipFree(c->d_odr); (void)hipFree(c->d_rcp); (void)hipFree(c->d_col_flags); (void)hipFree(c->d_ground);
+    (void)hipFree(c->d_obj_cost_lut); (void)hipFree(c->d_odr); (void)hipFree(c->d_rcp); (void)hipFree(c->d_col_flags); (void)hipFree(c->d_prune); (void)hipFree(c->d_ground);
     (void)hipFree(c->d_vhor); (void)hipFree(c->d_recs); (void)hipFree(c->d_lutT); (void)hipFree(c->d_priors); (void)hipFree(c->d_steps); (void)hipFree(c->d_part_cost); (void)hipFree(c->d_part_idx); (void)hipFree(c->d_sv);
     (void)hipFree(c->d_cost_table); (void)hipFree(c->d_index_table); (void)hipFree(c->d_cluster_scratch);
     for (int i = 0; i < IS_STAGE_SLOTS; i++) {
@@ -454,8 +479,8 @@ int is_compute(is_ctx* c, const float* d_joined, const int32_t* d_seg, const flo
 
     if (c->timing) HIP_TRY(hipEventRecord(c->ev[0], stream));
     HIP_TRY(isk_launch_prepare(&P, ncols, d_joined, d_seg, c->d_ground, c->d_vhor,
-                               c->d_obj_cost_lut, c->d_recs, c->d_lutT, c->d_col_flags, c->d_sv, stream,
-                               c->aux_stream, c->ev_fork, c->ev_join));
+                               c->d_obj_cost_lut, c->d_recs, c->d_lutT, c->d_col_flags, c->d_sv,
+                               c->d_prune, stream, c->aux_stream, c->ev_fork, c->ev_join));
     if (pairwise) HIP_TRY(isk_launch_priors(&P, c->d_ground, c->d_priors, n_images, stream));
     if (c->timing) HIP_TRY(hipEventRecord(c->ev[1], stream));
     if (pairwise)
@@ -465,7 +490,7 @@ int is_compute(is_ctx* c, const float* d_joined, const int32_t* d_seg, const flo
                                        stream, c->aux_stream, c->ev_fork, c->ev_join));
     else
         HIP_TRY(isk_launch_dp_unary(&P, ncols, c->nwaves_unary, c->d_recs, c->d_lutT, c->d_rcp,
-                                    c->d_vhor, c->d_col_flags, ct, it, stream));
+                                    c->d_vhor, c->d_col_flags, c->d_prune, ct, it, stream));
     if (c->timing) HIP_TRY(hipEventRecord(c->ev[2], stream));
     HIP_TRY(isk_launch_backtrace(&P, ncols, pairwise ? 1 : 0, c->d_recs, ct, it, c->d_col_flags,
                                  d_sections, stream));

@@ -24,6 +24,9 @@
 #ifndef IS_CMPX_UPDATE
 #define IS_CMPX_UPDATE 1 /* running minima of the unary DP through v_cmpx + moves (take_if_less) */
 #endif
+#ifndef IS_PRUNE
+#define IS_PRUNE 1 /* exact branch-and-bound on vB in FAST columns (descending vB, early exit) */
+#endif
 #ifndef IS_SKIP_GROUND_ABOVE_HORIZON
 #define IS_SKIP_GROUND_ABOVE_HORIZON 1 /* tiles above the horizon: ground candidates cost +inf, skip them */
 #endif
@@ -100,6 +103,20 @@ struct __attribute__((aligned(32))) PriorRec {
 };
 static_assert(sizeof(PriorRec) == 32, "PriorRec must be 32 bytes");
 
+/* Per-column constants of the exact branch-and-bound on vB (DESIGN.md "Pruning").  Every E is
+ * a non-negative fp32 slack; +inf in E1o switches the pruning of the column off (every lower
+ * bound becomes -inf).  Written by k_prepare_columns, read with scalar loads.
+ *   E1x = dw * sigma_x, sigma_x >= -(smallest possible data term of a segment): the data terms are
+ *         differences of fp32 tree-summed prefixes of per-row costs; sigma covers negative per-row
+ *         costs (nu * H) and the summation error (2 * gamma * sum|x|);
+ *   E2  >= -(smallest possible instance term ic): the computed sum(x^2) - (sum x)^2 / h can be
+ *         negative only through rounding, by at most 8 * 2^-24 * iw * (sum mx^2 + sum my^2). */
+struct __attribute__((aligned(32))) PruneRec {
+    float E1o, E1g, E1s, E2;
+    float pad[4];
+};
+static_assert(sizeof(PruneRec) == 32, "PruneRec must be 32 bytes");
+
 struct DevParams {
     int H, C, D, P2, P2S, CH, K, S;
     int ntiles;        /* ceil(H / IS_TILE) */
@@ -118,6 +135,11 @@ struct DevParams {
     float first_o_below, first_o_above; /* GetPriorCostObjectFirst :189-194 */
     int size_filter;
     int column_step;
+    /* branch-and-bound (see PruneRec): object data-term slack from the host's obj_cost_lut
+     * (+inf = pruning disabled: negative / non-finite weights or non-finite table), and
+     * 2 * gamma_d, the relative error bound of the tree-summed prefixes */
+    float sigma_od;
+    float gamma2;
 };
 
 #endif /* IS_DEVICE_H_ */

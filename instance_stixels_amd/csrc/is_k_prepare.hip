@@ -47,6 +47,24 @@ __device__ __forceinline__ int64_t block_excl_scan_i64(int64_t v, int64_t* s_wav
     return base + inc - v;
 }
 
+/* (sum, min) over the block; s_red holds 8 floats.  Only used for slack bounds (PruneRec), which
+ * carry their own safety factor, so the summation order does not matter. */
+__device__ __forceinline__ float2 block_sum_min(float s, float m, float* s_red) {
+#pragma unroll
+    for (int j = 32; j >= 1; j >>= 1) {
+        s += __shfl_xor(s, j, 64);
+        m = __builtin_fminf(m, __shfl_xor(m, j, 64));
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) { s_red[wave] = s; s_red[4 + wave] = m; }
+    __syncthreads();
+    float2 r;
+    r.x = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+    r.y = __builtin_fminf(__builtin_fminf(s_red[4], s_red[5]), __builtin_fminf(s_red[6], s_red[7]));
+    return r;
+}
+
 __device__ __forceinline__ float data_cost_sky(float d, const DevParams& P) {
     /* GetDataCostSky, StixelsKernels.cu:201-215 */
     float data_cost = P.pnex_sky_log;
@@ -102,13 +120,16 @@ __device__ __forceinline__ void store_instance_prefix(RowRec* o, int slow, int64
 __global__ __launch_bounds__(PREP_THREADS) void k_prepare_columns(
     const DevParams P, const float* __restrict__ joined, const int32_t* __restrict__ seg,
     const float* __restrict__ ground /*[img][3][H]*/, const int* __restrict__ vhor_arr,
-    RowRec* __restrict__ recs, int* __restrict__ col_flags, float* __restrict__ sv_arr) {
+    RowRec* __restrict__ recs, int* __restrict__ col_flags, float* __restrict__ sv_arr,
+    PruneRec* __restrict__ prune) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int H = P.H, P2 = P.P2, P2S = P.P2S, CH = P.CH, K = P.K;
     float* s_d = (float*)smem;                          /* [P2]   disparity column        */
     float* s_pyr = s_d + P2;                            /* [2*P2] scan tree                */
     int32_t* s_seg = (int32_t*)(s_pyr + 2 * P2);        /* [CH][P2S]                       */
     int64_t* s_wave = (int64_t*)(s_seg + CH * P2S);     /* [4]                             */
+    float* s_red = (float*)(s_wave + 4);                /* [8] block reductions            */
+    float* s_tot = s_red + 8;                           /* [2] sum mx^2 + my^2 of the column */
 
     const int colg = blockIdx.x;
     const int img = colg / P.C, col = colg % P.C;
@@ -205,8 +226,10 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_columns(
         base_mx2 = (int64_t)((uint64_t)base_mx2 + (uint64_t)mx * (uint64_t)mx);
         base_my2 = (int64_t)((uint64_t)base_my2 + (uint64_t)my * (uint64_t)my);
     }
-    if (r_lo <= H - 1 && H - 1 < r_lo + R)
+    if (r_lo <= H - 1 && H - 1 < r_lo + R) {
         store_instance_prefix(rcol + H, slow, base_mx, base_my, base_mx2, base_my2);
+        s_tot[0] = (float)((double)base_mx2 + (double)base_my2); /* column totals (PruneRec.E2) */
+    }
     __syncthreads();
 
     /* ---- square the offset channels in place (StixelsKernels.cu:411-416), then exclusive
@@ -216,6 +239,26 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_columns(
         s_seg[K * P2S + i] = (int32_t)(x * x);
     }
     __syncthreads();
+    /* branch-and-bound precondition: the non-instance offset term is >= 0 and monotone when no
+     * squared entry is negative as int32 (the reference squares in wrapping int32) and the
+     * full-resolution total stays below 2^31 */
+    int nic_bad = 0;
+    {
+        unsigned long long sq_sum = 0;
+        for (int i = tid; i < 2 * P2S; i += PREP_THREADS) {
+            const int32_t v = s_seg[K * P2S + i];
+            nic_bad |= v < 0;
+            sq_sum += (unsigned long long)(uint32_t)v;
+        }
+        unsigned long long* s_abs = (unsigned long long*)s_wave;
+        if (tid == 0) s_abs[0] = 0ull;
+        __syncthreads();
+        atomicAdd(&s_abs[0], sq_sum);
+        __syncthreads();
+        nic_bad |= (s_abs[0] * IS_DOWNSAMPLE_FACTOR) >= (1ull << 31);
+        __syncthreads();
+    }
+    nic_bad = __syncthreads_or(nic_bad);
     /* one wave per channel (round robin): lane l owns P2S/64 consecutive entries */
     {
         const int lane = tid & 63, wv = tid >> 6, per = P2S >> 6;
@@ -333,12 +376,16 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_columns(
         }
     }
     /* G: ground data cost, +inf at / above the horizon (:435-446) */
+    float g_abs = 0.0f, g_min = 0.0f; /* over the finite rows: slack of the ground data term */
     for (int i = tid; i < P2; i += PREP_THREADS) {
         float x = 0.0f;
-        if (i < H)
+        if (i < H) {
             x = (i >= vhor) ? IS_INF : data_cost_ground(gfun[i], s_d[i], gnorm[i], gis2[i], P);
+            if (i < vhor) { g_abs += __builtin_fabsf(x); g_min = __builtin_fminf(g_min, x); }
+        }
         s_pyr[i] = x;
     }
+    const float2 g_red = block_sum_min(g_abs, g_min, s_red);
     __syncthreads();
     blelloch_build(s_pyr, P2, P.log2P2);
     if (regs) {
@@ -352,10 +399,34 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_columns(
     }
     __syncthreads();
     /* K: sky data cost, 0 below the horizon (:424-433) */
+    float k_abs = 0.0f, k_min = 0.0f;
     for (int i = tid; i < P2; i += PREP_THREADS) {
         float x = 0.0f;
         if (i < H) x = (i < vhor) ? 0.0f : data_cost_sky(s_d[i], P);
+        k_abs += __builtin_fabsf(x);
+        k_min = __builtin_fminf(k_min, x);
         s_pyr[i] = x;
+    }
+    const float2 k_red = block_sum_min(k_abs, k_min, s_red);
+    if (tid == 0) {
+        /* PruneRec: see is_device.h.  A prefix difference P[a] - P[b] of per-row values x >= -nu
+         * with sum|x| = T is >= -(nu * H + gamma2 * T); NaN anywhere makes the slack NaN, and a NaN
+         * slack makes every bound NaN, which never passes the `>` test: no pruning. */
+        const float safe = 1.0f + 0x1p-10f;
+        const float hf = (float)H;
+        const float sig_g = ((0.0f - g_red.y) * hf + P.gamma2 * g_red.x) * safe;
+        const float sig_k = ((0.0f - k_red.y) * hf + P.gamma2 * k_red.x) * safe;
+        PruneRec pr;
+        pr.E1o = P.dw * P.sigma_od;
+        pr.E1g = P.dw * sig_g;
+        pr.E1s = P.dw * sig_k;
+        pr.E2 = P.iw * (0x1p-21f * safe) * s_tot[0]; /* 8 * 2^-24 * (sum mx^2 + sum my^2) */
+        /* 0 * inf above would be NaN = off as well; make the "off" states explicit */
+        if (slow || nic_bad || !(P.sigma_od < IS_INF) || !(pr.E1g < IS_INF) || !(pr.E1s < IS_INF) ||
+            !(pr.E2 < IS_INF))
+            pr.E1o = IS_INF;
+        pr.pad[0] = pr.pad[1] = pr.pad[2] = pr.pad[3] = 0.0f;
+        prune[colg] = pr;
     }
     __syncthreads();
     blelloch_build(s_pyr, P2, P.log2P2);
@@ -467,14 +538,14 @@ __global__ void k_prior_tables(const DevParams P, const float* __restrict__ grou
 extern "C" {
 
 size_t isk_prepare_lds_bytes(const DevParams* P) {
-    return sizeof(float) * (size_t)P->P2 * 3 + sizeof(int32_t) * (size_t)P->CH * P->P2S + 64;
+    return sizeof(float) * (size_t)P->P2 * 3 + sizeof(int32_t) * (size_t)P->CH * P->P2S + 192;
 }
 
 hipError_t isk_launch_prepare(const DevParams* P, int ncols, const float* joined,
                               const int32_t* seg, const float* ground, const int* vhor,
                               const float* cost_T, RowRec* recs, float* lutT,
-                              int* col_flags, float* sv_arr, hipStream_t stream, hipStream_t aux,
-                              hipEvent_t ev_fork, hipEvent_t ev_join) {
+                              int* col_flags, float* sv_arr, PruneRec* prune, hipStream_t stream,
+                              hipStream_t aux, hipEvent_t ev_fork, hipEvent_t ev_join) {
     /* The two prepare kernels are independent.  With few columns (a single frame = 256) neither
      * fills the chip and both are latency chains, so they run side by side on two streams; with
      * many columns they are throughput-bound (HBM writes) and stay in order on one stream. */
@@ -490,7 +561,7 @@ hipError_t isk_launch_prepare(const DevParams* P, int ncols, const float* joined
                        joined, cost_T, lutT);
     hipLaunchKernelGGL(k_prepare_columns, dim3(ncols), dim3(PREP_THREADS),
                        isk_prepare_lds_bytes(P), stream, *P, joined, seg, ground, vhor, recs,
-                       col_flags, sv_arr);
+                       col_flags, sv_arr, prune);
     if (side_by_side) {
         if ((e = hipEventRecord(ev_join, aux)) != hipSuccess) return e;
         if ((e = hipStreamWaitEvent(stream, ev_join, 0)) != hipSuccess) return e;

@@ -135,6 +135,159 @@ __device__ __forceinline__ void unary_loop(const DevParams& P, const RowRec& my,
                                                    nw, vB_end, row_ok, lane4, lrsrc, next_row, b);
 }
 
+
+/* ====================================================================================== */
+/* FAST columns: descending vB with an exact branch-and-bound (DESIGN.md "Pruning")        */
+/* ====================================================================================== */
+/* A wave walks its vB values DOWNWARDS.  After a full step at vB, every candidate vB' <= vB of
+ * lane vT costs at least
+ *     LB_o = fl(fl(sw * min(f_on, fl(f_oi - E2))) - E1o)          (object)
+ *     LB_g = fl(fl(sw * f_g) - E1g),  LB_s = fl(fl(sw * f_sky) - E1s)
+ * where f_* are the class-group minima of the segment (vB, vT) just evaluated: they are exact
+ * integers that can only grow when the segment grows (class values >= 0 in FAST columns), the
+ * terms left out are >= 0 (nic, pw / h) or >= -E (data terms, ic: PruneRec), and fp32 addition /
+ * multiplication by a non-negative constant are monotone under round-to-nearest, so the bound
+ * holds for the COMPUTED costs, not just the real-valued ones.  Once LB > best in every lane and
+ * every type that can still receive candidates, the wave stops: nothing below can win, and nothing
+ * below can tie (ties go to the smaller vB, hence the strict >). */
+template <bool HAS_INVALID, bool SKY, bool DIAG, bool FIRST, int NR, bool NOGROUND>
+__device__ __forceinline__ SegTerms unary_step_desc(const DevParams& P, const RowRec& my,
+                                                    const RowRec& rb, const LutRow<NR>& lrow,
+                                                    const float* my_tile, const float* s_rcp, int vT,
+                                                    int vTc, int vhor, int vB, float hf_full,
+                                                    bool row_ok, UnaryBest& b) {
+    const int h = vTc + 1 - vB;
+    const bool live = DIAG ? ((h > 0) && row_ok) : row_ok;
+    const int hc = DIAG ? max(h, 1) : h;
+    const float r = s_rcp[hc];
+    const float hf = (DIAG || FIRST) ? (float)hc : hf_full;
+    const SegTerms t = eval_segment<true, HAS_INVALID>(my, rb, hf, r, P.D, P.iw);
+    const float od = my_tile[t.fni] - pick_lut<NR>(lrow, t.fni);
+    const float pwih = P.pw * r;
+    const float cost_o = P.dw * od + pwih + P.sw * t.seg_o;
+    constexpr bool ALL_LANES = IS_CMPX_UPDATE && !DIAG && !FIRST;
+    if (ALL_LANES) {
+        take_if_le(b.o, b.vo, cost_o, vB);
+    } else {
+        const bool uo = live && (cost_o <= b.o);
+        b.o = uo ? cost_o : b.o;
+        b.vo = uo ? vB : b.vo;
+    }
+    if (SKY) {
+        const float cost_s = P.dw * t.sd + pwih + P.sw * t.seg_s;
+        if (ALL_LANES) {
+            take_if_le(b.s, b.vs, cost_s, vB);
+        } else {
+            const bool us = live && (cost_s <= b.s);
+            b.s = us ? cost_s : b.s;
+            b.vs = us ? vB : b.vs;
+        }
+    } else if (!NOGROUND) {
+        const float cost_g = P.dw * t.gd + pwih + P.sw * t.seg_g;
+        if (ALL_LANES) {
+            take_if_le(b.g, b.vg, cost_g, vB);
+        } else {
+            const bool ug = (FIRST ? (live && (vT <= vhor)) : live) && (cost_g <= b.g);
+            b.g = ug ? cost_g : b.g;
+            b.vg = ug ? vB : b.vg;
+        }
+    }
+    return t;
+}
+
+struct PruneVals { /* register copy of a PruneRec + the lanes that need no bound */
+    float E1o, E1g, E1s, E2;
+    unsigned long long dead;  /* lanes with vT >= H: never stored                         */
+    unsigned long long gdead; /* dead, or the ground data term of the lane is +inf for good */
+};
+
+template <bool SKY, bool NOGROUND>
+__device__ __forceinline__ bool nothing_below_can_win(const DevParams& P, const PruneVals& pv,
+                                                      const SegTerms& t, const UnaryBest& b) {
+    const float lb_o = P.sw * __builtin_fminf(t.f_on, t.f_oi - pv.E2) - pv.E1o;
+    unsigned long long ok = __builtin_amdgcn_ballot_w64(lb_o > b.o) | pv.dead;
+    if (SKY) {
+        const float lb_s = P.sw * t.f_sky - pv.E1s;
+        ok &= __builtin_amdgcn_ballot_w64(lb_s > b.s) | pv.dead;
+    } else if (!NOGROUND) {
+        const float lb_g = P.sw * t.f_g - pv.E1g;
+        ok &= __builtin_amdgcn_ballot_w64(lb_g > b.g) | pv.gdead;
+    }
+    return ok == ~0ull;
+}
+
+/* steps vB, vB - nw, ... >= lower; returns the next vB, or INT_MIN once the wave is done */
+#define IS_WAVE_DONE (-0x40000000)
+template <bool HAS_INVALID, bool SKY, bool DIAG, bool PRUNE, int NR, bool NOGROUND>
+__device__ __forceinline__ int unary_range_desc(const DevParams& P, const RowRec& my,
+                                                const RowRec* __restrict__ rcol,
+                                                const float* __restrict__ lcol, const float* my_tile,
+                                                const float* s_rcp, int vT, int vTc, int vhor, int vB,
+                                                int nw, int lower, bool row_ok, int lane4,
+                                                __amdgpu_buffer_rsrc_t lrsrc, LutRow<NR>& next_row,
+                                                const PruneVals& pv, UnaryBest& b) {
+    float hf = (float)(vTc + 1 - vB);
+    const float nwf = (float)nw;
+    for (; vB >= lower; vB -= nw) {
+        const RowRec cur = sload_rec(rcol + vB);
+        const LutRow<NR> row = next_row;
+        load_lut_row<NR>(next_row, lrsrc, lcol, max(vB - nw, 0), P.D, lane4);
+        const SegTerms t = unary_step_desc<HAS_INVALID, SKY, DIAG, false, NR, NOGROUND>(
+            P, my, cur, row, my_tile, s_rcp, vT, vTc, vhor, vB, hf, row_ok, b);
+        hf += nwf;
+        if (PRUNE && IS_PRUNE && nothing_below_can_win<SKY, NOGROUND>(P, pv, t, b)) return IS_WAVE_DONE;
+    }
+    return vB;
+}
+
+template <bool HAS_INVALID, int NR>
+__device__ __forceinline__ void unary_loop_desc(const DevParams& P, const RowRec& my,
+                                                const RowRec* __restrict__ rcol,
+                                                const float* __restrict__ lcol, const float* my_tile,
+                                                const float* s_rcp, int vT, int vTc, int vhor, int w,
+                                                int nw, int tile_lo, int vB_end, int lane4,
+                                                __amdgpu_buffer_rsrc_t lrsrc, const PruneRec* prec,
+                                                UnaryBest& b) {
+    const bool row_ok = vT < P.H;
+    if (w > vB_end) return;
+    int vB = vB_end - (vB_end - w) % nw; /* the wave's largest vB: vB == w (mod nw) */
+    PruneVals pv;
+    {
+        cprune_t q = (cprune_t)prec;
+        pv.E1o = q->E1o; pv.E1g = q->E1g; pv.E1s = q->E1s; pv.E2 = q->E2;
+        pv.dead = ~__builtin_amdgcn_ballot_w64(row_ok);
+        pv.gdead = pv.dead | __builtin_amdgcn_ballot_w64(my.G == IS_INF);
+    }
+    LutRow<NR> next_row;
+    load_lut_row<NR>(next_row, lrsrc, lcol, vB, P.D, lane4);
+    const bool nog = IS_SKIP_GROUND_ABOVE_HORIZON && tile_lo >= vhor;
+#define IS_RANGE(SKY, DIAG, PRUNE, NOG, lower)                                                     \
+    vB = unary_range_desc<HAS_INVALID, SKY, DIAG, PRUNE, NR, NOG>(P, my, rcol, lcol, my_tile, s_rcp,   \
+                                                                  vT, vTc, vhor, vB, nw, lower, row_ok, \
+                                                                  lane4, lrsrc, next_row, pv, b);  \
+    if (vB == IS_WAVE_DONE) return
+    /* (the horizon may lie outside the image: vhor < 0 or vhor >= H; vB = 0 is the FIRST step) */
+    IS_RANGE(true, true, false, false, max(max(vhor, tile_lo) + 1, 1)); /* sky, diagonal block */
+    IS_RANGE(true, false, true, false, max(vhor + 1, 1));               /* sky, whole wave live */
+    IS_RANGE(false, true, false, false, max(tile_lo + 1, 1));   /* ground, diagonal block    */
+    if (nog) {
+        IS_RANGE(false, false, true, true, 1);                  /* ground candidates are +inf */
+    } else {
+        IS_RANGE(false, false, true, false, 1);
+    }
+#undef IS_RANGE
+    if (vB == 0) { /* first segment (:481-594): ground + object */
+        const RowRec cur = sload_rec(rcol);
+        const LutRow<NR> row = next_row;
+        if (tile_lo == 0)
+            unary_step_desc<HAS_INVALID, false, true, true, NR, false>(P, my, cur, row, my_tile, s_rcp, vT,
+                                                                       vTc, vhor, 0, 0.0f, row_ok, b);
+        else
+            unary_step_desc<HAS_INVALID, false, false, true, NR, false>(P, my, cur, row, my_tile, s_rcp, vT,
+                                                                        vTc, vhor, 0, 0.0f, row_ok, b);
+    }
+}
+
 /* FASTCOLS: the launch handles only the columns of that encoding (col_flags), workgroups of the
  * other kind leave at once.  Two lean kernels instead of one that carries both loop nests: no
  * register spills, and the generic launch costs ~nothing when every column is FAST. */
@@ -145,6 +298,7 @@ __global__ __launch_bounds__(IS_UNARY_WAVES * 64, IS_UNARY_OCC) void k_dp_unary(
                                                   const float* __restrict__ rcp,
                                                   const int* __restrict__ vhor_arr,
                                                   const int* __restrict__ col_flags,
+                                                  const PruneRec* __restrict__ prune,
                                                   float* __restrict__ cost_table,
                                                   int32_t* __restrict__ index_table,
                                                   int pairs_per_wg) {
@@ -201,8 +355,12 @@ __global__ __launch_bounds__(IS_UNARY_WAVES * 64, IS_UNARY_OCC) void k_dp_unary(
     b.vo = 0; /* index_table[vT*3+OBJECT] = OBJECT at vB = 0, :592 */
     const float* my_tile = s_tile + lane * DP;
     const int vB_end = min(tile_lo + IS_TILE - 1, H - 1);
-    unary_loop<FASTCOLS, HAS_INVALID, NR>(P, my, rcol, lcol, my_tile, s_rcp, vT, vTc, vhor, w, nw, tile_lo,
-                                          vB_end, lane * 4, lrsrc, b);
+    if (FASTCOLS)
+        unary_loop_desc<HAS_INVALID, NR>(P, my, rcol, lcol, my_tile, s_rcp, vT, vTc, vhor, w, nw, tile_lo,
+                                         vB_end, lane * 4, lrsrc, prune + colg, b);
+    else
+        unary_loop<false, HAS_INVALID, NR>(P, my, rcol, lcol, my_tile, s_rcp, vT, vTc, vhor, w, nw, tile_lo,
+                                           vB_end, lane * 4, lrsrc, b);
 
     /* merge the waves' partial minima: min cost, ties -> smallest vB (= first strict minimum
      * of the reference's ascending-vB loop) */
@@ -223,6 +381,9 @@ __global__ __launch_bounds__(IS_UNARY_WAVES * 64, IS_UNARY_OCC) void k_dp_unary(
             const bool take = (c2 < c) || (c2 == c && vb2 >= 0 && (vb < 0 || vb2 < vb));
             if (take) { c = c2; vb = vb2; }
         }
+        /* a row without a finite candidate keeps the initial index (the descending walk records
+         * +inf candidates, the reference's strict < never does; :592 for the object type) */
+        if (!(c < IS_INF)) vb = (type == IS_OBJECT) ? 0 : -1;
         /* final (cost, vB) of this type back to LDS: one wave then writes the three types of a
          * row as 12 contiguous bytes (a wave-wide contiguous 768-byte store) instead of three
          * waves writing every third dword */
@@ -252,8 +413,8 @@ size_t isk_unary_lds_bytes(const DevParams* P) {
 
 hipError_t isk_launch_dp_unary(const DevParams* P, int ncols, int nwaves, const RowRec* recs,
                                const float* lutT, const float* rcp, const int* vhor,
-                               const int* col_flags, float* cost_table, int32_t* index_table,
-                               hipStream_t stream) {
+                               const int* col_flags, const PruneRec* prune, float* cost_table,
+                               int32_t* index_table, hipStream_t stream) {
     const int groups = (ncols + 7) / 8;
     /* one tile pair (big, small) per workgroup: equal-length workgroups pack best; measured on
      * MI355X at batch 32: 1 pair 9.98 ms, 2 pairs 10.10 ms, 4 pairs 10.55 ms, single tiles 11.1 ms */
@@ -267,11 +428,11 @@ hipError_t isk_launch_dp_unary(const DevParams* P, int ncols, int nwaves, const 
 #define IS_LAUNCH_UNARY(INV, NR)                                                                   \
     do {                                                                                           \
         hipLaunchKernelGGL((k_dp_unary<INV, NR, true>), grid, dim3(nwaves * 64), lds, stream, *P,  \
-                           ncols, recs, lutT, rcp, vhor, col_flags, cost_table, index_table,       \
-                           pairs_per_wg);                                                          \
+                           ncols, recs, lutT, rcp, vhor, col_flags, prune, cost_table,             \
+                           index_table, pairs_per_wg);                                             \
         hipLaunchKernelGGL((k_dp_unary<INV, NR, false>), grid, dim3(nwaves * 64), lds, stream, *P, \
-                           ncols, recs, lutT, rcp, vhor, col_flags, cost_table, index_table,       \
-                           pairs_per_wg);                                                          \
+                           ncols, recs, lutT, rcp, vhor, col_flags, prune, cost_table,             \
+                           index_table, pairs_per_wg);                                             \
     } while (0)
     if (P->D <= 128) {
         if (P->invalid >= 0) IS_LAUNCH_UNARY(true, 2); else IS_LAUNCH_UNARY(false, 2);

@@ -57,6 +57,9 @@ struct SegTerms {
     float gd, sd;              /* ground / sky data terms                                   */
     float mean;                /* un-floored, clamped (>= 0) object mean disparity          */
     int fni;                   /* floor(mean), clamped to [0, D-1]                          */
+    /* float(min_c DownsampledSum_c) of the class groups: non-decreasing when the segment grows
+     * in a FAST column (class values >= 0) -- the lower bounds of the branch-and-bound */
+    float f_g, f_on, f_oi, f_sky;
 };
 
 /* v_cvt_u32_f32: round toward zero, saturating (negative -> 0, NaN -> 0) */
@@ -143,6 +146,7 @@ __device__ __forceinline__ SegTerms eval_segment(const RowRec& my, const RowRec&
         ic = iw * (meanx2 - meanx * meanx / height + meany2 - meany * meany / height);
     }
 
+    t.f_g = f_g; t.f_on = f_on; t.f_oi = f_oi; t.f_sky = f_sky;
     t.seg_g = f_g + nic;
     const float on = nic + f_on;
     const float oi = ic + f_oi;
@@ -265,6 +269,24 @@ __device__ __forceinline__ void take_if_less(float& best, int& best_v, float cos
         : [c] "v"(cost), [vb] "s"(vB)
         : "vcc");
 }
+
+/* (best, best_v) <- (cost, vB) in the lanes with cost <= best: the update of a DESCENDING walk
+ * over vB (among equal costs the smallest vB must win, as in the reference's ascending loop with
+ * a strict <).  A +inf candidate "wins" against the initial +inf; the merge restores the initial
+ * index for rows whose final cost is +inf. */
+__device__ __forceinline__ void take_if_le(float& best, int& best_v, float cost, int vB) {
+    unsigned long long saved;
+    asm("s_mov_b64 %[sv], exec\n\t"
+        "v_cmpx_le_f32_e32 %[c], %[b]\n\t"
+        "v_mov_b32_e32 %[b], %[c]\n\t"
+        "v_mov_b32_e32 %[i], %[vb]\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [b] "+v"(best), [i] "+v"(best_v), [sv] "=&s"(saved)
+        : [c] "v"(cost), [vb] "s"(vB)
+        : "vcc");
+}
+
+typedef const __attribute__((address_space(4))) PruneRec* cprune_t;
 
 /* same with a per-lane value to record */
 __device__ __forceinline__ void take_if_less_v(float& best, int& best_v, float cost, int v) {

@@ -298,7 +298,7 @@ def test_device_clustering_edge_cases():
     few = np.zeros(60, bool)
     few[:4] = True                                   # n_large == min_pts: nothing labelled
     far = (np.arange(60)[:, None] * np.array([[1000.0, 0.0]])).astype(np.float32)
-    chain = np.stack([np.arange(300) * 20.0, np.zeros(300)], axis=1).astype(np.float32)  # one long cluster
+    chain = np.stack([np.arange(300) * 10.0, np.zeros(300)], axis=1).astype(np.float32)  # one long cluster
     rev = chain[::-1].copy()                         # roots propagate against the index order
     dup = np.repeat(np.array([[5.0, 5.0], [500.0, 5.0]], np.float32), 30, axis=0)
     nan = X.copy()
