@@ -288,6 +288,27 @@ __device__ __forceinline__ void unary_loop_desc(const DevParams& P, const RowRec
     }
 }
 
+#ifdef IS_ABL_PHASES
+/* debug build only: cycles (s_memtime) spent by wave 0 of every workgroup pass in staging / loop /
+ * wait-for-other-waves / merge+store, summed over the launch */
+__device__ unsigned long long g_phase[8];
+#define IS_PHASE_MARK(k)                                                                  \
+    do {                                                                                  \
+        const unsigned long long now__ = __builtin_readcyclecounter();                    \
+        if (threadIdx.x == 0) atomicAdd(&g_phase[k], now__ - t_phase);                    \
+        t_phase = now__;                                                                  \
+    } while (0)
+extern "C" void isk_debug_phases_old(unsigned long long* out, int reset) {
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase), sizeof(g_phase));
+    if (reset) {
+        unsigned long long z[8] = {0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof(z));
+    }
+}
+#else
+#define IS_PHASE_MARK(k)
+#endif
+
 /* FASTCOLS: the launch handles only the columns of that encoding (col_flags), workgroups of the
  * other kind leave at once.  Two lean kernels instead of one that carries both loop nests: no
  * register spills, and the generic launch costs ~nothing when every column is FAST. */
@@ -341,6 +362,9 @@ __global__ __launch_bounds__(IS_UNARY_WAVES * 64, IS_UNARY_OCC) void k_dp_unary(
     const int tile_lo = tile * IS_TILE;
     if (!first) __syncthreads(); /* the merge area of the previous tile aliases the LUT tile */
     first = false;
+#ifdef IS_ABL_PHASES
+    unsigned long long t_phase = __builtin_readcyclecounter();
+#endif
 
     stage_lut_tile<false>(s_tile, lcol, tile_lo, H, D, tid, (int)blockDim.x);
 
@@ -348,6 +372,7 @@ __global__ __launch_bounds__(IS_UNARY_WAVES * 64, IS_UNARY_OCC) void k_dp_unary(
     const int vTc = min(vT, H - 1);
     const RowRec my = load_rec(rcol + vTc + 1);
     __syncthreads();
+    IS_PHASE_MARK(0);
 
     UnaryBest b;
     b.g = b.o = b.s = IS_INF;
@@ -355,16 +380,20 @@ __global__ __launch_bounds__(IS_UNARY_WAVES * 64, IS_UNARY_OCC) void k_dp_unary(
     b.vo = 0; /* index_table[vT*3+OBJECT] = OBJECT at vB = 0, :592 */
     const float* my_tile = s_tile + lane * DP;
     const int vB_end = min(tile_lo + IS_TILE - 1, H - 1);
+#ifndef IS_ABL_NOLOOP
     if (FASTCOLS)
         unary_loop_desc<HAS_INVALID, NR>(P, my, rcol, lcol, my_tile, s_rcp, vT, vTc, vhor, w, nw, tile_lo,
                                          vB_end, lane * 4, lrsrc, prune + colg, b);
     else
         unary_loop<false, HAS_INVALID, NR>(P, my, rcol, lcol, my_tile, s_rcp, vT, vTc, vhor, w, nw, tile_lo,
                                            vB_end, lane * 4, lrsrc, b);
+#endif
+    IS_PHASE_MARK(1);
 
     /* merge the waves' partial minima: min cost, ties -> smallest vB (= first strict minimum
      * of the reference's ascending-vB loop) */
     __syncthreads();
+    IS_PHASE_MARK(2);
     float* m_cost = s_tile;                        /* [nw][3][64] (aliases the LUT tile) */
     int* m_vb = (int*)(m_cost + nw * 3 * 64);      /* [nw][3][64] */
     m_cost[(w * 3 + 0) * 64 + lane] = b.g; m_vb[(w * 3 + 0) * 64 + lane] = b.vg;
@@ -398,9 +427,14 @@ __global__ __launch_bounds__(IS_UNARY_WAVES * 64, IS_UNARY_OCC) void k_dp_unary(
         cd[0] = m_cost[0 * 64 + lane]; cd[1] = m_cost[1 * 64 + lane]; cd[2] = m_cost[2 * 64 + lane];
         id[0] = m_vb[0 * 64 + lane]; id[1] = m_vb[1 * 64 + lane]; id[2] = m_vb[2 * 64 + lane];
     }
+    IS_PHASE_MARK(3);
     } /* pass */
     } /* pair */
 }
+
+extern "C" hipError_t isk_launch_dp_unary_fast(const DevParams*, int, const RowRec*, const float*,
+                                               const float*, const int*, const int*, const PruneRec*,
+                                               float*, int32_t*, hipStream_t);
 
 extern "C" {
 
@@ -415,6 +449,17 @@ hipError_t isk_launch_dp_unary(const DevParams* P, int ncols, int nwaves, const 
                                const float* lutT, const float* rcp, const int* vhor,
                                const int* col_flags, const PruneRec* prune, float* cost_table,
                                int32_t* index_table, hipStream_t stream) {
+    /* FAST columns: the chunk-staged kernel of is_k_unary_fast.hip whenever the shape allows it;
+     * then only the generic columns are left for this file's kernel */
+    /* (measured on MI355X, batch 64: 10.1 ms against 9.3 ms of the tile-pair kernel below -- its
+     * chunks arrive later than a wave evaluates them; selected with IS_CHUNK_KERNEL=1 until the
+     * prefetch distance is fixed) */
+    const bool fast_kernel = isk_unary_fast_chunk_rows(P) > 0 && getenv("IS_CHUNK_KERNEL") != nullptr;
+    if (fast_kernel) {
+        const hipError_t e = isk_launch_dp_unary_fast(P, ncols, recs, lutT, rcp, vhor, col_flags, prune,
+                                                      cost_table, index_table, stream);
+        if (e != hipSuccess) return e;
+    }
     const int groups = (ncols + 7) / 8;
     /* one tile pair (big, small) per workgroup: equal-length workgroups pack best; measured on
      * MI355X at batch 32: 1 pair 9.98 ms, 2 pairs 10.10 ms, 4 pairs 10.55 ms, single tiles 11.1 ms */
@@ -427,9 +472,10 @@ hipError_t isk_launch_dp_unary(const DevParams* P, int ncols, int nwaves, const 
      * tables gather per lane */
 #define IS_LAUNCH_UNARY(INV, NR)                                                                   \
     do {                                                                                           \
-        hipLaunchKernelGGL((k_dp_unary<INV, NR, true>), grid, dim3(nwaves * 64), lds, stream, *P,  \
-                           ncols, recs, lutT, rcp, vhor, col_flags, prune, cost_table,             \
-                           index_table, pairs_per_wg);                                             \
+        if (!fast_kernel)                                                                          \
+            hipLaunchKernelGGL((k_dp_unary<INV, NR, true>), grid, dim3(nwaves * 64), lds, stream,  \
+                               *P, ncols, recs, lutT, rcp, vhor, col_flags, prune, cost_table,     \
+                               index_table, pairs_per_wg);                                         \
         hipLaunchKernelGGL((k_dp_unary<INV, NR, false>), grid, dim3(nwaves * 64), lds, stream, *P, \
                            ncols, recs, lutT, rcp, vhor, col_flags, prune, cost_table,             \
                            index_table, pairs_per_wg);                                             \
@@ -462,7 +508,7 @@ hipError_t isk_set_lds_unary(const DevParams* P) {
     IS_SET_UNARY_LDS(true, 0, true); IS_SET_UNARY_LDS(true, 0, false);
     IS_SET_UNARY_LDS(false, 0, true); IS_SET_UNARY_LDS(false, 0, false);
 #undef IS_SET_UNARY_LDS
-    return hipSuccess;
+    return isk_set_lds_unary_fast(P);
 }
 
 } /* extern "C" */

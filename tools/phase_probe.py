@@ -1,0 +1,17 @@
+"""Debug (GPU box): phase cycle counters of a libis_core_abl.so built with -DIS_ABL_PHASES."""
+import ctypes, os, subprocess, sys, json
+os.environ["IS_CORE_LIB"] = "instance_stixels_amd/lib/libis_core_abl.so"
+sys.path.insert(0, ".")
+sys.argv = ["bench.py", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-single", "--no-d2h"] + sys.argv[1:]
+import runpy
+from instance_stixels_amd import core
+L = core.lib()
+out = (ctypes.c_ulonglong * 8)()
+try:
+    runpy.run_path("bench.py", run_name="__main__")
+finally:
+    L.isk_debug_phases(out, 1)
+    v = list(out)
+    tot = sum(v[:4]) or 1
+    print("phases (cycles of wave 0 per WG, summed): prologue %.3g process %.3g store+barrier %.3g merge %.3g  -> %s; chunks %d" % (
+        v[0], v[1], v[2], v[3], ["%.1f%%" % (100.0 * x / tot) for x in v[:4]], v[5]))
