@@ -31,7 +31,8 @@ hipError_t isk_launch_dp_unary(const DevParams*, int, int, const RowRec*, const 
                                const int*, const int*, const PruneRec*, float*, int32_t*, hipStream_t);
 hipError_t isk_launch_dp_pairwise(const DevParams*, int, int, const RowRec*, const float*,
                                   const PriorRec*, const float*, const float*, const float*,
-                                  const int*, const int*, StepRec*, float*, int*, float*, int32_t*,
+                                  const int*, const int*, const PruneRec*, StepRec*, float*, int*,
+                                  float*, int32_t*,
                                   hipStream_t, hipStream_t, hipEvent_t, hipEvent_t);
 hipError_t isk_launch_backtrace(const DevParams*, int, int, const RowRec*, const float*,
                                 const int32_t*, const int*, is_section*, hipStream_t);
@@ -486,7 +487,8 @@ int is_compute(is_ctx* c, const float* d_joined, const int32_t* d_seg, const flo
     if (pairwise)
         HIP_TRY(isk_launch_dp_pairwise(&P, ncols, c->nwaves_pairwise, c->d_recs, c->d_lutT,
                                        c->d_priors, c->d_odr, c->d_rcp, c->d_sv, c->d_vhor,
-                                       c->d_col_flags, c->d_steps, c->d_part_cost, c->d_part_idx, ct, it,
+                                       c->d_col_flags, c->d_prune, c->d_steps, c->d_part_cost,
+                                       c->d_part_idx, ct, it,
                                        stream, c->aux_stream, c->ev_fork, c->ev_join));
     else
         HIP_TRY(isk_launch_dp_unary(&P, ncols, c->nwaves_unary, c->d_recs, c->d_lutT, c->d_rcp,

@@ -17,7 +17,10 @@ struct __attribute__((aligned(64))) StepRec {
     float o_hi_thr, o_lo_thr;   /* pm + dif, pm - dif                                 :159, 163 */
     float p2_hi, p2_lo, p2_mid; /* cO + pw * GetPriorCostObjectFromObject, three cases :146-171 */
     float p3_yes, p3_no;        /* cS + pw * GetPriorCostObjectFromSky, fn > eps or not :173-183 */
-    float pad0, pad1;
+    /* branch-and-bound (DESIGN.md "Pruning"): running minima over vB' <= vB (and the first-segment
+     * priors of vB' = 0) of what a segment starting at vB' adds before its own data / semantic
+     * terms: q_o = pw * (smallest of the eight p fields), q_gs = pwmp */
+    float q_o, q_gs;
 };
 static_assert(sizeof(StepRec) == 64, "StepRec must be 64 bytes");
 typedef const __attribute__((address_space(4))) StepRec* cstep_t;
@@ -26,7 +29,7 @@ struct StepVals { /* register copy of a StepRec, always passed by value */
     float pwmp;
     int idx_gs;
     float g_hi_thr, g_lo_thr, p1_hi, p1_lo, p1_mid, o_hi_thr, o_lo_thr, p2_hi, p2_lo, p2_mid, p3_yes,
-        p3_no;
+        p3_no, q_o, q_gs;
 };
 
 __device__ __forceinline__ void store_step(StepRec* dst, const StepVals v) {
@@ -34,7 +37,7 @@ __device__ __forceinline__ void store_step(StepRec* dst, const StepVals v) {
     d[0] = make_float4(v.pwmp, __builtin_bit_cast(float, v.idx_gs), v.g_hi_thr, v.g_lo_thr);
     d[1] = make_float4(v.p1_hi, v.p1_lo, v.p1_mid, v.o_hi_thr);
     d[2] = make_float4(v.o_lo_thr, v.p2_hi, v.p2_lo, v.p2_mid);
-    d[3] = make_float4(v.p3_yes, v.p3_no, 0.0f, 0.0f);
+    d[3] = make_float4(v.p3_yes, v.p3_no, v.q_o, v.q_gs);
 }
 
 /* A scalar-loaded value made opaque to the optimiser: without this, LLVM rewrites the selects
@@ -54,6 +57,7 @@ __device__ __forceinline__ StepVals sload_step(const StepRec* p) {
     r.o_hi_thr = q->o_hi_thr; r.o_lo_thr = q->o_lo_thr;
     r.p2_hi = opaque_s(q->p2_hi); r.p2_lo = opaque_s(q->p2_lo); r.p2_mid = opaque_s(q->p2_mid);
     r.p3_yes = opaque_s(q->p3_yes); r.p3_no = opaque_s(q->p3_no);
+    r.q_o = q->q_o; r.q_gs = q->q_gs;
     return r;
 }
 
@@ -143,14 +147,19 @@ struct PairBest {
 
 /* One (vB >= 1, vT) evaluation of the pairwise model for the lane owning vT; `st` is the
  * wave-uniform StepRec of vB.  SKY: vB-1 >= vhor (:729), else ground (:687). */
-template <bool SKY, bool ALL_LANES = false, bool NOGROUND = false>
+/* DESC: the caller walks vB downwards, so a candidate of EQUAL cost replaces the best one (the
+ * reference's ascending strict < keeps the smallest vB among equal costs) */
+template <bool SKY, bool ALL_LANES = false, bool NOGROUND = false, bool DESC = false>
 __device__ __forceinline__ void pairwise_step(const DevParams& P, const StepVals st, int vB,
                                               bool live, float od, const SegTerms& t, PairBest& b) {
     /* ALL_LANES (phase 1): every lane with vT < H is live and rows vT >= H are never stored */
     constexpr bool CMPX = IS_CMPX_UPDATE && ALL_LANES;
+    static_assert(!DESC || CMPX, "descending walks are whole-wave steps");
     if (SKY) { /* :729-775 */
         const float cost = P.dw * t.sd + st.pwmp + P.sw * t.seg_s;
-        if (CMPX) {
+        if (CMPX && DESC) {
+            take_if_le(b.s, b.is, cost, st.idx_gs);
+        } else if (CMPX) {
             take_if_less(b.s, b.is, cost, st.idx_gs);
         } else {
             const bool u = live && (cost < b.s);
@@ -159,7 +168,9 @@ __device__ __forceinline__ void pairwise_step(const DevParams& P, const StepVals
         }
     } else if (!NOGROUND) { /* :687-728; NOGROUND: tile at / above the horizon, see unary_step */
         const float cost = P.dw * t.gd + st.pwmp + P.sw * t.seg_g;
-        if (CMPX) {
+        if (CMPX && DESC) {
+            take_if_le(b.g, b.ig, cost, st.idx_gs);
+        } else if (CMPX) {
             take_if_less(b.g, b.ig, cost, st.idx_gs);
         } else {
             const bool u = live && (cost < b.g);
@@ -179,7 +190,9 @@ __device__ __forceinline__ void pairwise_step(const DevParams& P, const StepVals
     const int base_o = vB * 3 + IS_OBJECT;
     int idx = (p1 < p2) ? (base_o - 1) : base_o;
     idx = (p3 < m12) ? (base_o + 1) : idx;
-    if (CMPX) {
+    if (CMPX && DESC) {
+        take_if_le_v(b.o, b.io, cost, idx);
+    } else if (CMPX) {
         take_if_less_v(b.o, b.io, cost, idx);
     } else {
         const bool u = live && (cost < b.o);
@@ -207,6 +220,7 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
                                                const StepRec* __restrict__ steps,
                                                const float* __restrict__ rcp, int vhor,
                                                int split, int nsplit,
+                                               const PruneRec* __restrict__ prec,
                                                float* __restrict__ part_cost,
                                                int* __restrict__ part_idx) {
     const int H = P.H, D = P.D;
@@ -240,30 +254,107 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
     b.ig = b.is = -1;
     b.io = IS_OBJECT; /* :592 */
     const int vB_last = min(tile_lo, H - 1);
-    int vB = w;
-    /* vB-side lutT row: fetched one step ahead, picked with ds_bpermute (see LutRow) */
     const __amdgpu_buffer_rsrc_t lrsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void*)lcol, 0, (H + 1) * D * (int)sizeof(float), 0x00020000);
     const int lane4 = lane * 4;
-    LutRow<NR> next_row;
-    if (vB <= vB_last) load_lut_row<NR>(next_row, lrsrc, lcol, vB == 0 ? min(nw, H) : vB, D, lane4);
-    if (vB == 0) { /* first segment, :481-594 */
-        const RowRec rb = sload_rec(rcol);
-        const int h = vTc + 1;
-        const SegTerms t = eval_segment<FAST, HAS_INVALID>(my, rb, (float)h, s_rcp[h], D, P.iw);
-        const float od = my_tile[t.fni] - lcol[(unsigned)t.fni];
-        const bool below = vT <= vhor;
-        const float cost_g = P.dw * t.gd + P.pw * P.first_g + P.sw * t.seg_g;
-        const bool ug = live && below && (cost_g < b.g);
-        b.g = ug ? cost_g : b.g;
-        b.ig = ug ? IS_GROUND : b.ig;
-        const float prior = below ? P.first_o_below : P.first_o_above;
-        const float cost = P.dw * od + P.pw * prior + P.sw * t.seg_o;
-        b.o = (live && cost < b.o) ? cost : b.o;
-        vB += nw;
-    }
-    if (IS_SKIP_GROUND_ABOVE_HORIZON && tile_lo >= vhor) {
-        for (; vB <= min(vhor, vB_last); vB += nw) { /* ground range, ground candidate = +inf */
+    if (FAST && IS_PRUNE) {
+        /* FAST columns: vB downwards with the exact branch-and-bound of DESIGN.md "Pruning".  A
+         * candidate vB' <= vB of lane vT costs at least
+         *     fl(fl(Q[vB] - E1) + fl(sw * m))      m = the class-group minimum of (vB, vT)
+         * where Q[vB] (StepRec.q_o / q_gs) is the smallest transition term pw * min_prev any
+         * vB' <= vB can contribute (running minimum kept by phase 2) and E1 / E2 are the slacks of
+         * PruneRec: same monotonicity argument as in the unary kernel (is_k_unary.hip). */
+        if (w <= vB_last) {
+            cprune_t pq = (cprune_t)prec;
+            const float E1o = pq->E1o, E2 = pq->E2;
+            const float E1gs = __builtin_fmaxf(pq->E1g, pq->E1s);
+            const unsigned long long dead = ~__builtin_amdgcn_ballot_w64(live);
+            const unsigned long long gdead = dead | __builtin_amdgcn_ballot_w64(my.G == IS_INF);
+            const bool nog = IS_SKIP_GROUND_ABOVE_HORIZON && tile_lo >= vhor;
+            int vB = vB_last - (vB_last - w) % nw; /* the wave's largest vB */
+            LutRow<NR> next_row;
+            load_lut_row<NR>(next_row, lrsrc, lcol, vB, D, lane4);
+            bool done = false;
+#define IS_P1_STEP(SKY, NOG)                                                                       \
+            const RowRec rb = sload_rec(rcol + vB);                                                \
+            const StepVals st = sload_step(scol + vB);                                             \
+            const LutRow<NR> row = next_row;                                                       \
+            load_lut_row<NR>(next_row, lrsrc, lcol, max(vB - nw, 0), D, lane4);                    \
+            const int h = vTc + 1 - vB;                                                            \
+            const SegTerms t = eval_segment<true, HAS_INVALID>(my, rb, (float)h, s_rcp[h], D, P.iw); \
+            const float od = my_tile[t.fni] - pick_lut<NR>(row, t.fni);                            \
+            pairwise_step<SKY, true, NOG, true>(P, st, vB, live, od, t, b);                        \
+            const float lb_o = (st.q_o - E1o) + P.sw * __builtin_fminf(t.f_on, t.f_oi - E2);       \
+            unsigned long long ok = __builtin_amdgcn_ballot_w64(lb_o > b.o) | dead
+            for (; vB >= max(vhor + 1, 1); vB -= nw) { /* sky range: vB - 1 >= vhor */
+                IS_P1_STEP(true, false);
+                const float lb_s = (st.q_gs - E1gs) + P.sw * t.f_sky;
+                ok &= __builtin_amdgcn_ballot_w64(lb_s > b.s) | dead;
+                if (ok == ~0ull) { done = true; break; }
+            }
+            if (!done && nog) {
+                for (; vB >= 1; vB -= nw) { /* ground range, ground candidates are +inf */
+                    IS_P1_STEP(false, true);
+                    if (ok == ~0ull) { done = true; break; }
+                }
+            } else if (!done) {
+                for (; vB >= 1; vB -= nw) { /* ground range: vB - 1 < vhor */
+                    IS_P1_STEP(false, false);
+                    const float lb_g = (st.q_gs - E1gs) + P.sw * t.f_g;
+                    ok &= __builtin_amdgcn_ballot_w64(lb_g > b.g) | gdead;
+                    if (ok == ~0ull) { done = true; break; }
+                }
+            }
+#undef IS_P1_STEP
+            if (!done && vB == 0) { /* first segment, :481-594 */
+                const RowRec rb = sload_rec(rcol);
+                const int h = vTc + 1;
+                const SegTerms t = eval_segment<true, HAS_INVALID>(my, rb, (float)h, s_rcp[h], D, P.iw);
+                const float od = my_tile[t.fni] - lcol[(unsigned)t.fni];
+                const bool below = vT <= vhor;
+                const float cost_g = P.dw * t.gd + P.pw * P.first_g + P.sw * t.seg_g;
+                const bool ug = live && below && (cost_g <= b.g);
+                b.g = ug ? cost_g : b.g;
+                b.ig = ug ? IS_GROUND : b.ig;
+                const float prior = below ? P.first_o_below : P.first_o_above;
+                const float cost = P.dw * od + P.pw * prior + P.sw * t.seg_o;
+                const bool uo = live && (cost <= b.o);
+                b.o = uo ? cost : b.o;
+                b.io = uo ? IS_OBJECT : b.io;
+            }
+        }
+    } else {
+        int vB = w;
+        LutRow<NR> next_row;
+        if (vB <= vB_last) load_lut_row<NR>(next_row, lrsrc, lcol, vB == 0 ? min(nw, H) : vB, D, lane4);
+        if (vB == 0) { /* first segment, :481-594 */
+            const RowRec rb = sload_rec(rcol);
+            const int h = vTc + 1;
+            const SegTerms t = eval_segment<FAST, HAS_INVALID>(my, rb, (float)h, s_rcp[h], D, P.iw);
+            const float od = my_tile[t.fni] - lcol[(unsigned)t.fni];
+            const bool below = vT <= vhor;
+            const float cost_g = P.dw * t.gd + P.pw * P.first_g + P.sw * t.seg_g;
+            const bool ug = live && below && (cost_g < b.g);
+            b.g = ug ? cost_g : b.g;
+            b.ig = ug ? IS_GROUND : b.ig;
+            const float prior = below ? P.first_o_below : P.first_o_above;
+            const float cost = P.dw * od + P.pw * prior + P.sw * t.seg_o;
+            b.o = (live && cost < b.o) ? cost : b.o;
+            vB += nw;
+        }
+        if (IS_SKIP_GROUND_ABOVE_HORIZON && tile_lo >= vhor) {
+            for (; vB <= min(vhor, vB_last); vB += nw) { /* ground range, ground candidate = +inf */
+                const RowRec rb = sload_rec(rcol + vB);
+                const StepVals st = sload_step(scol + vB);
+                const LutRow<NR> row = next_row;
+                load_lut_row<NR>(next_row, lrsrc, lcol, min(vB + nw, H), D, lane4);
+                const int h = vTc + 1 - vB;
+                const SegTerms t = eval_segment<FAST, HAS_INVALID>(my, rb, (float)h, s_rcp[h], D, P.iw);
+                const float od = my_tile[t.fni] - pick_lut<NR>(row, t.fni);
+                pairwise_step<false, true, true>(P, st, vB, live, od, t, b);
+            }
+        }
+        for (; vB <= min(vhor, vB_last); vB += nw) { /* ground range: vB-1 < vhor */
             const RowRec rb = sload_rec(rcol + vB);
             const StepVals st = sload_step(scol + vB);
             const LutRow<NR> row = next_row;
@@ -271,28 +362,18 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
             const int h = vTc + 1 - vB;
             const SegTerms t = eval_segment<FAST, HAS_INVALID>(my, rb, (float)h, s_rcp[h], D, P.iw);
             const float od = my_tile[t.fni] - pick_lut<NR>(row, t.fni);
-            pairwise_step<false, true, true>(P, st, vB, live, od, t, b);
+            pairwise_step<false, true>(P, st, vB, live, od, t, b);
         }
-    }
-    for (; vB <= min(vhor, vB_last); vB += nw) { /* ground range: vB-1 < vhor */
-        const RowRec rb = sload_rec(rcol + vB);
-        const StepVals st = sload_step(scol + vB);
-        const LutRow<NR> row = next_row;
-        load_lut_row<NR>(next_row, lrsrc, lcol, min(vB + nw, H), D, lane4);
-        const int h = vTc + 1 - vB;
-        const SegTerms t = eval_segment<FAST, HAS_INVALID>(my, rb, (float)h, s_rcp[h], D, P.iw);
-        const float od = my_tile[t.fni] - pick_lut<NR>(row, t.fni);
-        pairwise_step<false, true>(P, st, vB, live, od, t, b);
-    }
-    for (; vB <= vB_last; vB += nw) { /* sky range */
-        const RowRec rb = sload_rec(rcol + vB);
-        const StepVals st = sload_step(scol + vB);
-        const LutRow<NR> row = next_row;
-        load_lut_row<NR>(next_row, lrsrc, lcol, min(vB + nw, H), D, lane4);
-        const int h = vTc + 1 - vB;
-        const SegTerms t = eval_segment<FAST, HAS_INVALID>(my, rb, (float)h, s_rcp[h], D, P.iw);
-        const float od = my_tile[t.fni] - pick_lut<NR>(row, t.fni);
-        pairwise_step<true, true>(P, st, vB, live, od, t, b);
+        for (; vB <= vB_last; vB += nw) { /* sky range */
+            const RowRec rb = sload_rec(rcol + vB);
+            const StepVals st = sload_step(scol + vB);
+            const LutRow<NR> row = next_row;
+            load_lut_row<NR>(next_row, lrsrc, lcol, min(vB + nw, H), D, lane4);
+            const int h = vTc + 1 - vB;
+            const SegTerms t = eval_segment<FAST, HAS_INVALID>(my, rb, (float)h, s_rcp[h], D, P.iw);
+            const float od = my_tile[t.fni] - pick_lut<NR>(row, t.fni);
+            pairwise_step<true, true>(P, st, vB, live, od, t, b);
+        }
     }
     /* merge the waves: min cost, ties -> smallest vB (a finite cost always has a real index) */
     __syncthreads();
@@ -312,6 +393,9 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
             const bool take = (c2 < c) || (c2 == c && c2 < IS_INF && (ix2 / 3) < (ix / 3));
             if (take) { c = c2; ix = ix2; }
         }
+        /* a row without a finite candidate keeps the initial index (a descending walk records
+         * +inf candidates, the reference's strict < never does; :592 for the object type) */
+        if (!(c < IS_INF)) ix = (type == IS_OBJECT) ? IS_OBJECT : -1;
         const size_t o = (((size_t)colg * nsplit + split) * 3 + type) * 64 + lane;
         part_cost[o] = c;
         part_idx[o] = ix;
@@ -324,7 +408,7 @@ __global__ __launch_bounds__(IS_UNARY_WAVES * 64, IS_UNARY_WAVES) void k_pw_phas
     const RowRec* __restrict__ recs, const float* __restrict__ lutT,
     const StepRec* __restrict__ steps, const float* __restrict__ rcp,
     const int* __restrict__ vhor_arr, const int* __restrict__ col_flags,
-    float* __restrict__ part_cost, int* __restrict__ part_idx) {
+    const PruneRec* __restrict__ prune, float* __restrict__ part_cost, int* __restrict__ part_idx) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int colg = col_base + (int)(blockIdx.x / (unsigned)nsplit);
     const int split = __builtin_amdgcn_readfirstlane((int)(blockIdx.x % (unsigned)nsplit));
@@ -332,10 +416,10 @@ __global__ __launch_bounds__(IS_UNARY_WAVES * 64, IS_UNARY_WAVES) void k_pw_phas
     const int vhor = __builtin_amdgcn_readfirstlane(vhor_arr[colg / P.C]);
     if (__builtin_amdgcn_readfirstlane(col_flags[colg]) == 0)
         pw_phase1_body<true, HAS_INVALID, NR>(P, smem, colg, tile, recs, lutT, steps, rcp, vhor, split,
-                                              nsplit, part_cost, part_idx);
+                                              nsplit, prune + colg, part_cost, part_idx);
     else
         pw_phase1_body<false, HAS_INVALID, NR>(P, smem, colg, tile, recs, lutT, steps, rcp, vhor, split,
-                                               nsplit, part_cost, part_idx);
+                                               nsplit, prune + colg, part_cost, part_idx);
 }
 
 template <bool FAST, bool HAS_INVALID>
@@ -397,6 +481,17 @@ __device__ __forceinline__ void pw_phase2_body(const DevParams& P, char* smem, i
     st.pwmp = IS_INF; st.idx_gs = -1;
     st.g_hi_thr = st.g_lo_thr = st.p1_hi = st.p1_lo = st.p1_mid = st.o_hi_thr = st.o_lo_thr = 0.0f;
     st.p2_hi = st.p2_lo = st.p2_mid = st.p3_yes = st.p3_no = 0.0f;
+    /* running minima of the transition terms (StepRec.q_o / q_gs): continue the previous tile's */
+    float q_o, q_gs;
+    if (tile_lo == 0) {
+        q_o = P.pw * __builtin_fminf(P.first_o_below, P.first_o_above); /* vB' = 0, :189-194 */
+        q_gs = P.pw * P.first_g;                                         /* :196-199 */
+    } else {
+        cstep_t prev = (cstep_t)(scol + tile_lo);
+        q_o = prev->q_o;
+        q_gs = prev->q_gs;
+    }
+    st.q_o = q_o; st.q_gs = q_gs;
     for (int s = 0; s < n_rows; s++) {
         const int r = tile_lo + s; /* row that becomes final in this step */
         if (s > 0) { /* segments starting at vB = r: lanes vT >= r */
@@ -416,6 +511,13 @@ __device__ __forceinline__ void pw_phase2_body(const DevParams& P, char* smem, i
             const int io = __builtin_amdgcn_readlane(b.io, s);
             st = make_step<HAS_INVALID>(P, s_S, s_V, s_odr, s_invc, s_logc, (cprior_t)(pcol + r + 1), vhor,
                                         r, cG, cO, cS, io / 3);
+            /* fminf skips NaN fields: a candidate that selects one costs NaN and never wins */
+            const float m8 = __builtin_fminf(
+                __builtin_fminf(__builtin_fminf(st.p1_hi, st.p1_lo), __builtin_fminf(st.p1_mid, st.p2_hi)),
+                __builtin_fminf(__builtin_fminf(st.p2_lo, st.p2_mid), __builtin_fminf(st.p3_yes, st.p3_no)));
+            q_o = __builtin_fminf(q_o, P.pw * m8);
+            q_gs = __builtin_fminf(q_gs, st.pwmp);
+            st.q_o = q_o; st.q_gs = q_gs;
             if (lane == 0) store_step(scol + r + 1, st);
         }
     }
@@ -458,8 +560,9 @@ size_t isk_phase2_lds_bytes(const DevParams* P) {
 hipError_t isk_launch_dp_pairwise(const DevParams* P, int ncols, int nwaves, const RowRec* recs,
                                   const float* lutT, const PriorRec* priors, const float* odr,
                                   const float* rcp, const float* sv_arr, const int* vhor,
-                                  const int* col_flags, StepRec* steps, float* part_cost,
-                                  int* part_idx, float* cost_table, int32_t* index_table,
+                                  const int* col_flags, const PruneRec* prune, StepRec* steps,
+                                  float* part_cost, int* part_idx, float* cost_table,
+                                  int32_t* index_table,
                                   hipStream_t stream, hipStream_t aux, hipEvent_t ev_fork,
                                   hipEvent_t ev_join) {
     const size_t lds1 = isk_pairwise_lds_bytes(P, nwaves);
@@ -483,11 +586,11 @@ hipError_t isk_launch_dp_pairwise(const DevParams* P, int ncols, int nwaves, con
         if (IS_PW_PHASE1_ROW_REGS && P->D <= 128)                                                  \
             hipLaunchKernelGGL((k_pw_phase1<INV, 2>), dim3(((c1) - (c0)) * nsplit),                \
                                dim3(nwaves * 64), lds1, st, *P, c0, c1, tile, nsplit, recs, lutT,  \
-                               steps, rcp, vhor, col_flags, part_cost, part_idx);                  \
+                               steps, rcp, vhor, col_flags, prune, part_cost, part_idx);           \
         else                                                                                       \
             hipLaunchKernelGGL((k_pw_phase1<INV, 0>), dim3(((c1) - (c0)) * nsplit),                \
                                dim3(nwaves * 64), lds1, st, *P, c0, c1, tile, nsplit, recs, lutT,  \
-                               steps, rcp, vhor, col_flags, part_cost, part_idx);                  \
+                               steps, rcp, vhor, col_flags, prune, part_cost, part_idx);           \
     } while (0)
 #define IS_LAUNCH_P2(INV, c0, c1, st)                                                              \
     hipLaunchKernelGGL(k_pw_phase2<INV>, dim3((c1) - (c0)), dim3(64), lds2, st, *P, c0, c1, tile,  \

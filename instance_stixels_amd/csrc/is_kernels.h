@@ -289,6 +289,18 @@ __device__ __forceinline__ void take_if_le(float& best, int& best_v, float cost,
         : "vcc");
 }
 
+__device__ __forceinline__ void take_if_le_v(float& best, int& best_v, float cost, int v) {
+    unsigned long long saved;
+    asm("s_mov_b64 %[sv], exec\n\t"
+        "v_cmpx_le_f32_e32 %[c], %[b]\n\t"
+        "v_mov_b32_e32 %[b], %[c]\n\t"
+        "v_mov_b32_e32 %[i], %[v]\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [b] "+v"(best), [i] "+v"(best_v), [sv] "=&s"(saved)
+        : [c] "v"(cost), [v] "v"(v)
+        : "vcc");
+}
+
 typedef const __attribute__((address_space(4))) PruneRec* cprune_t;
 
 /* same with a per-lane value to record */
