@@ -33,7 +33,7 @@ hipError_t isk_launch_dp_pairwise(const DevParams*, int, int, const RowRec*, con
                                   const PriorRec*, const float*, const float*, const float*,
                                   const int*, const int*, const PruneRec*, StepRec*, float*, int*,
                                   float*, int32_t*,
-                                  hipStream_t, hipStream_t, hipEvent_t, hipEvent_t);
+                                  hipStream_t, hipStream_t*, int, hipEvent_t, hipEvent_t*);
 hipError_t isk_launch_backtrace(const DevParams*, int, int, const RowRec*, const float*,
                                 const int32_t*, const int*, is_section*, hipStream_t);
 hipError_t isk_launch_compact(const DevParams*, const is_section*, float*, int32_t*, uint8_t*,
@@ -92,8 +92,10 @@ struct is_ctx {
     hipEvent_t staging_free[IS_STAGE_SLOTS]; /* recorded after the H2D copies of the slot's call */
     bool staging_pending[IS_STAGE_SLOTS];
     int stage_next;
-    hipStream_t aux_stream;  /* second stream of the pairwise DP (two half batches in flight) */
+    hipStream_t aux_stream;  /* = aux_streams[0]: second stream of the prepare kernels */
+    hipStream_t aux_streams[IS_AUX_STREAMS]; /* column groups of the pairwise DP in flight */
     hipEvent_t ev_fork, ev_join;
+    hipEvent_t ev_joins[IS_AUX_STREAMS];
     int32_t* d_cluster_scratch; /* [8][2][C*S] work arrays of k_cluster_instances */
     /* scratch */
     RowRec* d_recs;          /* [max_batch*C][H+1] */
@@ -305,7 +307,11 @@ static int ctx_init(is_ctx* c, const is_stixel_params* p, const float* obj_cost_
         HIP_TRY(hipHostMalloc((void**)&c->h_vhor_pinned[i], sizeof(int) * B));
         HIP_TRY(hipEventCreateWithFlags(&c->staging_free[i], hipEventDisableTiming));
     }
-    HIP_TRY(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
+    for (int i = 0; i < IS_AUX_STREAMS; i++) {
+        HIP_TRY(hipStreamCreateWithFlags(&c->aux_streams[i], hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&c->ev_joins[i], hipEventDisableTiming));
+    }
+    c->aux_stream = c->aux_streams[0];
     HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     for (int i = 0; i < 4; i++) HIP_TRY(hipEventCreate(&c->ev[i]));
@@ -358,7 +364,10 @@ int is_ctx_destroy(is_ctx* c) {
         if (c->h_vhor_pinned[i]) (void)hipHostFree(c->h_vhor_pinned[i]);
         if (c->staging_free[i]) (void)hipEventDestroy(c->staging_free[i]);
     }
-    if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
+    for (int i = 0; i < IS_AUX_STREAMS; i++) {
+        if (c->aux_streams[i]) (void)hipStreamDestroy(c->aux_streams[i]);
+        if (c->ev_joins[i]) (void)hipEventDestroy(c->ev_joins[i]);
+    }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     for (int i = 0; i < 4; i++)
@@ -489,7 +498,7 @@ int is_compute(is_ctx* c, const float* d_joined, const int32_t* d_seg, const flo
                                        c->d_priors, c->d_odr, c->d_rcp, c->d_sv, c->d_vhor,
                                        c->d_col_flags, c->d_prune, c->d_steps, c->d_part_cost,
                                        c->d_part_idx, ct, it,
-                                       stream, c->aux_stream, c->ev_fork, c->ev_join));
+                                       stream, c->aux_streams, IS_AUX_STREAMS, c->ev_fork, c->ev_joins));
     else
         HIP_TRY(isk_launch_dp_unary(&P, ncols, c->nwaves_unary, c->d_recs, c->d_lutT, c->d_rcp,
                                     c->d_vhor, c->d_col_flags, c->d_prune, ct, it, stream));

@@ -440,8 +440,8 @@ __device__ __forceinline__ void pw_phase2_body(const DevParams& P, char* smem, i
     double* s_invc = (double*)smem;                    /* [32] */
     double* s_logc = s_invc + IS_LOG_TABLE_SIZE;       /* [32] */
     float* s_S = (float*)(s_logc + IS_LOG_TABLE_SIZE); /* [H+1] */
-    float* s_V = s_S + (H + 1);                        /* [H+1] */
-    float* s_odr = s_V + (H + 1);                      /* [D]   */
+    float* s_V = s_S + (H + 1);                        /* [H+1], only with an invalid value */
+    float* s_odr = s_V + (HAS_INVALID ? (H + 1) : 0);  /* [D]   */
     const int tile_lo = tile * IS_TILE;
     const RowRec* rcol = recs + (size_t)colg * (H + 1);
     const float* lcol = lutT + (size_t)colg * (H + 1) * D;
@@ -499,7 +499,11 @@ __device__ __forceinline__ void pw_phase2_body(const DevParams& P, char* smem, i
             const int hc = max(vTc + 1 - r, 1);
             const bool live = (vT < H) && (vT >= r);
             const SegTerms t = eval_segment<FAST, HAS_INVALID>(my, rb, (float)hc, rcp[hc], D, P.iw);
+#ifdef IS_ABL_P2_NOGATHER
+            const float od = (float)t.fni;
+#else
             const float od = my_row[(unsigned)t.fni] - (lcol + (size_t)r * D)[(unsigned)t.fni];
+#endif
             if (r - 1 < vhor)
                 pairwise_step<false>(P, st, r, live, od, t, b);
             else
@@ -554,7 +558,16 @@ extern "C" {
 
 size_t isk_pairwise_lds_bytes(const DevParams* P, int nwaves) { return isk_unary_lds_bytes(P); }
 size_t isk_phase2_lds_bytes(const DevParams* P) {
-    return sizeof(double) * 2 * IS_LOG_TABLE_SIZE + sizeof(float) * (2 * ((size_t)P->H + 1) + P->D) + 16;
+    /* the valid-count prefix is staged only when the configuration has an invalid-disparity value:
+     * the kernel's occupancy is LDS-bound (one wave per column, 64 serial steps per tile) */
+    const size_t sv = (P->invalid >= 0 ? 2 : 1) * ((size_t)P->H + 1);
+    size_t need = sizeof(double) * 2 * IS_LOG_TABLE_SIZE + sizeof(float) * (sv + P->D) + 16;
+    /* occupancy throttle: the kernel is bound by the throughput of its per-lane lutT gathers (64
+     * cache lines per wave and step); more resident waves only thrash the L1 (measured on MI355X at
+     * batch 64: 30 waves / CU 35.3 ms per step, 17 waves / CU 29.9 ms) */
+    size_t floor_bytes = 9 * 1024 + 256;
+    if (const char* e = getenv("IS_P2_LDS")) floor_bytes = (size_t)atoi(e);
+    return need > floor_bytes ? need : floor_bytes;
 }
 
 hipError_t isk_launch_dp_pairwise(const DevParams* P, int ncols, int nwaves, const RowRec* recs,
@@ -563,24 +576,35 @@ hipError_t isk_launch_dp_pairwise(const DevParams* P, int ncols, int nwaves, con
                                   const int* col_flags, const PruneRec* prune, StepRec* steps,
                                   float* part_cost, int* part_idx, float* cost_table,
                                   int32_t* index_table,
-                                  hipStream_t stream, hipStream_t aux, hipEvent_t ev_fork,
-                                  hipEvent_t ev_join) {
+                                  hipStream_t stream, hipStream_t* aux, int n_aux,
+                                  hipEvent_t ev_fork, hipEvent_t* ev_join) {
     const size_t lds1 = isk_pairwise_lds_bytes(P, nwaves);
     const size_t lds2 = isk_phase2_lds_bytes(P);
-    /* Columns are independent: with enough of them the batch is cut in two halves whose
-     * phase-1 / phase-2 chains run on two streams, the second one phase behind the first, so
-     * that the issue-bound phase 1 of one half shares the CUs with the latency-bound serial
-     * phase 2 of the other. */
+    /* Columns are independent: with enough of them the batch is cut into groups whose
+     * phase-1 / phase-2 chains (2 x ntiles dependent launches each) run on their own streams, so
+     * that the tails and the latency-bound serial phase 2 of one group share the CUs with the
+     * other groups' launches. */
     /* few columns: nsplit workgroups per (column, tile) in phase 1, up to ~one workgroup per CU x4 */
     int nsplit = IS_PW_SPLIT_TARGET_WGS / (ncols > 0 ? ncols : 1);
     nsplit = nsplit < 1 ? 1 : (nsplit > IS_PW_MAX_SPLIT ? IS_PW_MAX_SPLIT : nsplit);
-    const bool split = aux != nullptr && ncols >= 2 * IS_PAIRWISE_SPLIT_MIN_COLS;
-    const int c_mid = split ? (ncols / 2) : ncols;
+    int groups = ncols / IS_PAIRWISE_SPLIT_MIN_COLS;
+    groups = groups < 1 ? 1 : groups;
+    /* measured on MI355X at batch 64 after the pruning of phase 1: 1 group 29.8 ms, 2 groups 30.2,
+     * 4 groups 30.1, 8 groups 30.6 per step -- launches of different streams barely overlap, so the
+     * default is one group; IS_PW_GROUPS overrides */
+    if (groups > IS_PAIRWISE_MAX_GROUPS) groups = IS_PAIRWISE_MAX_GROUPS;
+    if (groups > n_aux + 1) groups = n_aux + 1;
+    if (const char* gs = getenv("IS_PW_GROUPS")) {
+        const int g = atoi(gs);
+        if (g >= 1 && g <= n_aux + 1) groups = g;
+    }
     hipError_t e;
-/* phase 1 with the vB-side lutT row in registers (LutRow<2>) measured SLOWER than the per-lane
- * gather on MI355X (41.4 vs 38.0 ms per 64 frames): the pick costs more VALU than the gather's
- * address arithmetic and phase 1 is issue-bound; kept selectable for later rounds */
-#define IS_PW_PHASE1_ROW_REGS 0
+/* the vB-side lutT row in registers (LutRow<2>, D <= 128): slower than the per-lane gather while
+ * phase 1 was issue-bound (41.4 vs 38.0 ms per 64 frames, round 1), faster now that the pruned
+ * phase 1 is latency-bound (30.4 vs 31.2 ms): no memory access on the chain mean -> fn -> value */
+#ifndef IS_PW_PHASE1_ROW_REGS
+#define IS_PW_PHASE1_ROW_REGS 1
+#endif
 #define IS_LAUNCH_P1(INV, c0, c1, st)                                                              \
     do {                                                                                           \
         if (IS_PW_PHASE1_ROW_REGS && P->D <= 128)                                                  \
@@ -597,23 +621,25 @@ hipError_t isk_launch_dp_pairwise(const DevParams* P, int ncols, int nwaves, con
                        nsplit, recs, lutT, priors, odr, rcp, sv_arr, vhor, col_flags, part_cost,   \
                        part_idx, steps, cost_table, index_table)
     const bool inv = P->invalid >= 0;
+    if (groups > 1) {
+        if ((e = hipEventRecord(ev_fork, stream)) != hipSuccess) return e;
+        for (int g = 1; g < groups; g++)
+            if ((e = hipStreamWaitEvent(aux[g - 1], ev_fork, 0)) != hipSuccess) return e;
+    }
     for (int tile = 0; tile < P->ntiles; tile++) {
-        if (inv) IS_LAUNCH_P1(true, 0, c_mid, stream); else IS_LAUNCH_P1(false, 0, c_mid, stream);
-        if (split && tile == 0) { /* the second half starts one phase behind the first */
-            if ((e = hipEventRecord(ev_fork, stream)) != hipSuccess) return e;
-            if ((e = hipStreamWaitEvent(aux, ev_fork, 0)) != hipSuccess) return e;
-        }
-        if (inv) IS_LAUNCH_P2(true, 0, c_mid, stream); else IS_LAUNCH_P2(false, 0, c_mid, stream);
-        if (split) {
-            if (inv) IS_LAUNCH_P1(true, c_mid, ncols, aux); else IS_LAUNCH_P1(false, c_mid, ncols, aux);
-            if (inv) IS_LAUNCH_P2(true, c_mid, ncols, aux); else IS_LAUNCH_P2(false, c_mid, ncols, aux);
+        for (int g = 0; g < groups; g++) {
+            const int c0 = (int)((long long)ncols * g / groups);
+            const int c1 = (int)((long long)ncols * (g + 1) / groups);
+            hipStream_t st = g == 0 ? stream : aux[g - 1];
+            if (inv) IS_LAUNCH_P1(true, c0, c1, st); else IS_LAUNCH_P1(false, c0, c1, st);
+            if (inv) IS_LAUNCH_P2(true, c0, c1, st); else IS_LAUNCH_P2(false, c0, c1, st);
         }
     }
 #undef IS_LAUNCH_P1
 #undef IS_LAUNCH_P2
-    if (split) {
-        if ((e = hipEventRecord(ev_join, aux)) != hipSuccess) return e;
-        if ((e = hipStreamWaitEvent(stream, ev_join, 0)) != hipSuccess) return e;
+    for (int g = 1; g < groups; g++) {
+        if ((e = hipEventRecord(ev_join[g - 1], aux[g - 1])) != hipSuccess) return e;
+        if ((e = hipStreamWaitEvent(stream, ev_join[g - 1], 0)) != hipSuccess) return e;
     }
     return hipGetLastError();
 }
