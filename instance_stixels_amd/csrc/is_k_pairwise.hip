@@ -68,20 +68,32 @@ __device__ __forceinline__ float readlane_f(float x, int l) {
 /* -is_logf(v) + is_logf(v2) (NegFastLogDiv, :35-38) for TWO argument pairs at once: the lower
  * half of the wave evaluates pair A, the upper half pair B, so the serial chain pays for one
  * logarithm instead of two.  v is a compile-time-like constant whose log is passed in. */
+template <bool TWO_COLS = false>
 __device__ __forceinline__ void neg_fastlog_div2(float neg_log_va, float v2a, float neg_log_vb,
                                                  float v2b, const double* s_invc,
                                                  const double* s_logc, float* outa, float* outb) {
-    const bool upper = threadIdx.x >= 32;
-    const float arg = upper ? v2b : v2a;
-    const float l = is_logf_t(arg, s_invc, s_logc);
-    const float la = readlane_f(l, 0), lb = readlane_f(l, 32);
-    *outa = neg_log_va + la;
-    *outb = neg_log_vb + lb;
+    if (TWO_COLS) {
+        /* two columns per wave (one per 32-lane half): the quarters of the wave evaluate the two
+         * logarithms of their half's column */
+        const int lane = threadIdx.x;
+        const float arg = (lane & 16) ? v2b : v2a;
+        const float l = is_logf_t(arg, s_invc, s_logc);
+        const float la = __shfl(l, lane & 32, 64), lb = __shfl(l, (lane & 32) + 16, 64);
+        *outa = neg_log_va + la;
+        *outb = neg_log_vb + lb;
+    } else {
+        const bool upper = threadIdx.x >= 32;
+        const float arg = upper ? v2b : v2a;
+        const float l = is_logf_t(arg, s_invc, s_logc);
+        const float la = readlane_f(l, 0), lb = readlane_f(l, 32);
+        *outa = neg_log_va + la;
+        *outb = neg_log_vb + lb;
+    }
 }
 
 /* StepRec of vB = r + 1 from the final row r.  All inputs are wave-uniform; every lane computes
  * the same values.  s_S / s_V: the column's disparity / valid-count prefixes in LDS. */
-template <bool HAS_INVALID>
+template <bool HAS_INVALID, bool TWO_COLS = false>
 __device__ __forceinline__ StepVals make_step(const DevParams& P, const float* s_S, const float* s_V,
                                              const float* s_odr, const double* s_invc,
                                              const double* s_logc, cprior_t pr, int vhor, int r,
@@ -129,8 +141,8 @@ __device__ __forceinline__ StepVals make_step(const DevParams& P, const float* s
     st.o_hi_thr = pm + dif;
     st.o_lo_thr = pm - dif;
     float nl_hi, nl_lo;
-    neg_fastlog_div2(P.nlog_pord, P.max_disf - pm - dif, P.nlog_1mpord, st.o_lo_thr, s_invc, s_logc,
-                     &nl_hi, &nl_lo);
+    neg_fastlog_div2<TWO_COLS>(P.nlog_pord, P.max_disf - pm - dif, P.nlog_1mpord, st.o_lo_thr, s_invc,
+                               s_logc, &nl_hi, &nl_lo);
     st.p2_hi = cO + pw * (base + nl_hi);
     st.p2_lo = cO + pw * (base + nl_lo);
     st.p2_mid = cO + pw * IS_INF;
@@ -541,10 +553,14 @@ __global__ __launch_bounds__(64) void k_pw_phase2(
     const float* __restrict__ sv_arr, const int* __restrict__ vhor_arr,
     const int* __restrict__ col_flags, const float* __restrict__ part_cost,
     const int* __restrict__ part_idx, StepRec* __restrict__ steps, float* __restrict__ cost_table,
-    int32_t* __restrict__ index_table) {
+    int32_t* __restrict__ index_table, int pairs_elsewhere) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int colg = col_base + blockIdx.x;
     if (colg >= ncols) return;
+    /* pairs of FAST columns are walked by k_pw_phase2x2 (two columns per wave) */
+    if (pairs_elsewhere && __builtin_amdgcn_readfirstlane(col_flags[colg]) == 0 &&
+        __builtin_amdgcn_readfirstlane(col_flags[col_base + (((int)blockIdx.x) ^ 1)]) == 0)
+        return;
     const int vhor = __builtin_amdgcn_readfirstlane(vhor_arr[colg / P.C]);
     if (__builtin_amdgcn_readfirstlane(col_flags[colg]) == 0)
         pw_phase2_body<true, HAS_INVALID>(P, smem, colg, tile, recs, lutT, priors, odr, rcp, sv_arr, vhor,
@@ -554,9 +570,177 @@ __global__ __launch_bounds__(64) void k_pw_phase2(
                                            nsplit, part_cost, part_idx, steps, cost_table, index_table);
 }
 
+
+/* ====================================================================================== */
+/* Phase 2 with TWO columns per wavefront                                                  */
+/* ====================================================================================== */
+/* Half of make_step's ~240 VALU instructions per serial step are wave-uniform work that all 64
+ * lanes repeat, and the diagonal 64x64 block leaves half the lanes idle.  Here lanes 0..31 walk
+ * column A and lanes 32..63 column B over 32-row sub-tiles:
+ *     rows lo .. lo+31          32 serial steps (diagonal 32x32 block + StepRec of the next row)
+ *     rows lo+32 .. lo+63       32 independent steps for the segments that start in the first
+ *                               sub-tile (their StepRecs are kept in LDS), then 32 serial steps
+ * i.e. 64 serial + 32 independent wave-steps per tile for TWO columns instead of 2 x 64 serial ones.
+ * What was wave-uniform (the vB record, the StepRec, previous_mean, the logarithms) is now uniform
+ * per half and lives in VGPRs; both columns belong to the same image (even C), so the ground / sky
+ * switch stays a scalar branch.  FAST columns only; other pairs are left to k_pw_phase2. */
+__device__ __forceinline__ StepVals lds_step(const float* p) {
+    const float4* q = reinterpret_cast<const float4*>(p);
+    const float4 a = q[0], b = q[1], c = q[2], d = q[3];
+    StepVals r;
+    r.pwmp = a.x; r.idx_gs = __builtin_bit_cast(int, a.y); r.g_hi_thr = a.z; r.g_lo_thr = a.w;
+    r.p1_hi = b.x; r.p1_lo = b.y; r.p1_mid = b.z; r.o_hi_thr = b.w;
+    r.o_lo_thr = c.x; r.p2_hi = c.y; r.p2_lo = c.z; r.p2_mid = c.w;
+    r.p3_yes = d.x; r.p3_no = d.y; r.q_o = d.z; r.q_gs = d.w;
+    return r;
+}
+
+template <bool HAS_INVALID>
+__global__ __launch_bounds__(64) void k_pw_phase2x2(
+    const DevParams P, int col_base, int ncols, int tile, int nsplit,
+    const RowRec* __restrict__ recs, const float* __restrict__ lutT,
+    const PriorRec* __restrict__ priors, const float* __restrict__ odr,
+    const float* __restrict__ rcp, const float* __restrict__ sv_arr,
+    const int* __restrict__ vhor_arr, const int* __restrict__ col_flags,
+    const float* __restrict__ part_cost, const int* __restrict__ part_idx,
+    StepRec* __restrict__ steps, float* __restrict__ cost_table, int32_t* __restrict__ index_table) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int colA = col_base + 2 * (int)blockIdx.x;
+    if (colA + 1 >= ncols) return; /* (ncols is even when this kernel is used) */
+    if ((__builtin_amdgcn_readfirstlane(col_flags[colA]) | __builtin_amdgcn_readfirstlane(col_flags[colA + 1])) != 0)
+        return; /* a generic column: both are walked by k_pw_phase2 */
+    const int H = P.H, D = P.D;
+    const int lane = threadIdx.x, half = lane >> 5, l = lane & 31, hb = lane & 32;
+    const int colg = colA + half;
+    const int vhor = __builtin_amdgcn_readfirstlane(vhor_arr[colA / P.C]);
+
+    double* s_invc = (double*)smem;                    /* [32] */
+    double* s_logc = s_invc + IS_LOG_TABLE_SIZE;       /* [32] */
+    float* s_S2 = (float*)(s_logc + IS_LOG_TABLE_SIZE); /* [2][H+1] */
+    float* s_V2 = s_S2 + 2 * (H + 1);                  /* [2][H+1], only with an invalid value */
+    float* s_odr = s_V2 + (HAS_INVALID ? 2 * (H + 1) : 0); /* [D] */
+    float* s_steps = (float*)(((uintptr_t)(s_odr + D) + 15) & ~(uintptr_t)15); /* [2][32][16] */
+    if (lane == 0) is_log_tables(s_invc, s_logc);
+    for (int i = lane; i < 2 * (H + 1); i += 64) {
+        const int c = i / (H + 1), k = i - c * (H + 1);
+        const float* sv = sv_arr + (size_t)(colA + c) * 2 * (H + 1);
+        s_S2[i] = sv[k];
+        if (HAS_INVALID) s_V2[i] = sv[H + 1 + k];
+    }
+    for (int i = lane; i < D; i += 64) s_odr[i] = odr[i];
+    const float* s_S = s_S2 + half * (H + 1);
+    const float* s_V = s_V2 + half * (H + 1);
+    float* my_steps = s_steps + half * 32 * 16;
+
+    const int tile_lo = tile * IS_TILE;
+    const RowRec* rcol = recs + (size_t)colg * (H + 1);
+    const float* lcol = lutT + (size_t)colg * (H + 1) * D;
+    const PriorRec* pcol = priors + (size_t)(colA / P.C) * H;
+    StepRec* scol = steps + (size_t)colg * H;
+    __syncthreads();
+
+    StepVals st;
+    st.pwmp = IS_INF; st.idx_gs = -1;
+    st.g_hi_thr = st.g_lo_thr = st.p1_hi = st.p1_lo = st.p1_mid = st.o_hi_thr = st.o_lo_thr = 0.0f;
+    st.p2_hi = st.p2_lo = st.p2_mid = st.p3_yes = st.p3_no = 0.0f;
+    float q_o, q_gs; /* running minima of the transition terms, see StepRec */
+    if (tile_lo == 0) {
+        q_o = P.pw * __builtin_fminf(P.first_o_below, P.first_o_above);
+        q_gs = P.pw * P.first_g;
+    } else {
+        q_o = scol[tile_lo].q_o;
+        q_gs = scol[tile_lo].q_gs;
+    }
+    st.q_o = q_o; st.q_gs = q_gs;
+
+    for (int h2 = 0; h2 < 2; h2++) {
+        const int lo = tile_lo + 32 * h2;
+        if (lo >= H) break;
+        const int vT = lo + l;
+        const int vTc = min(vT, H - 1);
+        const bool row_ok = vT < H;
+        const RowRec my = load_rec(rcol + vTc + 1);
+        const float* my_row = lcol + (size_t)(vTc + 1) * D;
+        PairBest b; /* partial minima of phase 1 (its nsplit workgroups merged) */
+        {
+            const size_t o = (size_t)colg * nsplit * 3 * 64 + 32 * h2 + l;
+            b.g = part_cost[o]; b.ig = part_idx[o];
+            b.o = part_cost[o + 64]; b.io = part_idx[o + 64];
+            b.s = part_cost[o + 128]; b.is = part_idx[o + 128];
+            for (int sp = 1; sp < nsplit; sp++) {
+                const size_t q = o + (size_t)sp * 3 * 64;
+                float c2 = part_cost[q]; int i2 = part_idx[q];
+                if ((c2 < b.g) || (c2 == b.g && c2 < IS_INF && (i2 / 3) < (b.ig / 3))) { b.g = c2; b.ig = i2; }
+                c2 = part_cost[q + 64]; i2 = part_idx[q + 64];
+                if ((c2 < b.o) || (c2 == b.o && c2 < IS_INF && (i2 / 3) < (b.io / 3))) { b.o = c2; b.io = i2; }
+                c2 = part_cost[q + 128]; i2 = part_idx[q + 128];
+                if ((c2 < b.s) || (c2 == b.s && c2 < IS_INF && (i2 / 3) < (b.is / 3))) { b.s = c2; b.is = i2; }
+            }
+        }
+        if (h2 == 1) {
+            /* segments of the second sub-tile that start in the first one: vB = tile_lo+1 .. lo,
+             * every lane is at or above them; ascending vB with the strict <, as the reference */
+            for (int j = 0; j < 32; j++) {
+                const int vB = tile_lo + 1 + j;
+                const RowRec rb = load_rec(rcol + vB);
+                const StepVals sj = lds_step(my_steps + j * 16);
+                const int h = vTc + 1 - vB;
+                const SegTerms t = eval_segment<true, HAS_INVALID>(my, rb, (float)h, rcp[h], D, P.iw);
+                const float od = my_row[(unsigned)t.fni] - (lcol + (size_t)vB * D)[(unsigned)t.fni];
+                if (vB - 1 < vhor)
+                    pairwise_step<false>(P, sj, vB, row_ok, od, t, b);
+                else
+                    pairwise_step<true>(P, sj, vB, row_ok, od, t, b);
+            }
+        }
+        const int n_rows = min(32, H - lo);
+        for (int s = 0; s < n_rows; s++) {
+            const int r = lo + s; /* row that becomes final in this step */
+            if (s > 0) { /* segments starting at vB = r: lanes vT >= r */
+                const RowRec rb = load_rec(rcol + r);
+                const int hc = max(vTc + 1 - r, 1);
+                const bool live = row_ok && (vT >= r);
+                const SegTerms t = eval_segment<true, HAS_INVALID>(my, rb, (float)hc, rcp[hc], D, P.iw);
+                const float od = my_row[(unsigned)t.fni] - (lcol + (size_t)r * D)[(unsigned)t.fni];
+                if (r - 1 < vhor)
+                    pairwise_step<false>(P, st, r, live, od, t, b);
+                else
+                    pairwise_step<true>(P, st, r, live, od, t, b);
+            }
+            if (r + 1 < H) { /* lane s of each half holds the final row r of its column */
+                const float cG = __shfl(b.g, hb + s, 64), cO = __shfl(b.o, hb + s, 64);
+                const float cS = __shfl(b.s, hb + s, 64);
+                const int io = __shfl(b.io, hb + s, 64);
+                st = make_step<HAS_INVALID, true>(P, s_S, s_V, s_odr, s_invc, s_logc,
+                                                  (cprior_t)(pcol + r + 1), vhor, r, cG, cO, cS, io / 3);
+                const float m8 = __builtin_fminf(
+                    __builtin_fminf(__builtin_fminf(st.p1_hi, st.p1_lo), __builtin_fminf(st.p1_mid, st.p2_hi)),
+                    __builtin_fminf(__builtin_fminf(st.p2_lo, st.p2_mid), __builtin_fminf(st.p3_yes, st.p3_no)));
+                q_o = __builtin_fminf(q_o, P.pw * m8);
+                q_gs = __builtin_fminf(q_gs, st.pwmp);
+                st.q_o = q_o; st.q_gs = q_gs;
+                if (l == 0) {
+                    store_step(scol + r + 1, st);
+                    if (h2 == 0) store_step(reinterpret_cast<StepRec*>(my_steps + s * 16), st);
+                }
+            }
+        }
+        if (row_ok) {
+            const size_t o = ((size_t)colg * H + vT) * 3;
+            cost_table[o + 0] = b.g; cost_table[o + 1] = b.o; cost_table[o + 2] = b.s;
+            index_table[o + 0] = b.ig; index_table[o + 1] = b.io; index_table[o + 2] = b.is;
+        }
+    }
+}
+
 extern "C" {
 
 size_t isk_pairwise_lds_bytes(const DevParams* P, int nwaves) { return isk_unary_lds_bytes(P); }
+size_t isk_phase2x2_lds_bytes(const DevParams* P) {
+    const size_t sv = (P->invalid >= 0 ? 4 : 2) * ((size_t)P->H + 1);
+    return sizeof(double) * 2 * IS_LOG_TABLE_SIZE + sizeof(float) * (sv + P->D) + 16 +
+           sizeof(float) * 2 * 32 * 16 + 16;
+}
 size_t isk_phase2_lds_bytes(const DevParams* P) {
     /* the valid-count prefix is staged only when the configuration has an invalid-disparity value:
      * the kernel's occupancy is LDS-bound (one wave per column, 64 serial steps per tile) */
@@ -580,6 +764,13 @@ hipError_t isk_launch_dp_pairwise(const DevParams* P, int ncols, int nwaves, con
                                   hipEvent_t ev_fork, hipEvent_t* ev_join) {
     const size_t lds1 = isk_pairwise_lds_bytes(P, nwaves);
     const size_t lds2 = isk_phase2_lds_bytes(P);
+    const size_t lds2x2 = isk_phase2x2_lds_bytes(P);
+    /* two columns per wave: the columns of a pair must share the image (even C) and the groups
+     * below must start at even columns */
+    /* (measured on MI355X, batch 64: 30.8 ms per step against 29.9 ms with one column per wave --
+     * the per-half operands cost 60 more VGPRs, 3 waves per SIMD and a global load on every serial
+     * step; opt-in with IS_P2X2=1 until the vB record is prefetched) */
+    const bool x2 = (P->C % 2) == 0 && lds2x2 <= 64 * 1024 && getenv("IS_P2X2") != nullptr;
     /* Columns are independent: with enough of them the batch is cut into groups whose
      * phase-1 / phase-2 chains (2 x ntiles dependent launches each) run on their own streams, so
      * that the tails and the latency-bound serial phase 2 of one group share the CUs with the
@@ -617,9 +808,16 @@ hipError_t isk_launch_dp_pairwise(const DevParams* P, int ncols, int nwaves, con
                                steps, rcp, vhor, col_flags, prune, part_cost, part_idx);           \
     } while (0)
 #define IS_LAUNCH_P2(INV, c0, c1, st)                                                              \
-    hipLaunchKernelGGL(k_pw_phase2<INV>, dim3((c1) - (c0)), dim3(64), lds2, st, *P, c0, c1, tile,  \
-                       nsplit, recs, lutT, priors, odr, rcp, sv_arr, vhor, col_flags, part_cost,   \
-                       part_idx, steps, cost_table, index_table)
+    do {                                                                                           \
+        if (x2)                                                                                    \
+            hipLaunchKernelGGL(k_pw_phase2x2<INV>, dim3(((c1) - (c0)) / 2), dim3(64), lds2x2, st,  \
+                               *P, c0, c1, tile, nsplit, recs, lutT, priors, odr, rcp, sv_arr,     \
+                               vhor, col_flags, part_cost, part_idx, steps, cost_table,            \
+                               index_table);                                                       \
+        hipLaunchKernelGGL(k_pw_phase2<INV>, dim3((c1) - (c0)), dim3(64), lds2, st, *P, c0, c1,    \
+                           tile, nsplit, recs, lutT, priors, odr, rcp, sv_arr, vhor, col_flags,    \
+                           part_cost, part_idx, steps, cost_table, index_table, x2 ? 1 : 0);       \
+    } while (0)
     const bool inv = P->invalid >= 0;
     if (groups > 1) {
         if ((e = hipEventRecord(ev_fork, stream)) != hipSuccess) return e;
@@ -628,8 +826,8 @@ hipError_t isk_launch_dp_pairwise(const DevParams* P, int ncols, int nwaves, con
     }
     for (int tile = 0; tile < P->ntiles; tile++) {
         for (int g = 0; g < groups; g++) {
-            const int c0 = (int)((long long)ncols * g / groups);
-            const int c1 = (int)((long long)ncols * (g + 1) / groups);
+            const int c0 = (int)((long long)ncols * g / groups) & ~1;
+            const int c1 = g + 1 == groups ? ncols : ((int)((long long)ncols * (g + 1) / groups) & ~1);
             hipStream_t st = g == 0 ? stream : aux[g - 1];
             if (inv) IS_LAUNCH_P1(true, c0, c1, st); else IS_LAUNCH_P1(false, c0, c1, st);
             if (inv) IS_LAUNCH_P2(true, c0, c1, st); else IS_LAUNCH_P2(false, c0, c1, st);

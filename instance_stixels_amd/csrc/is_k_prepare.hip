@@ -424,7 +424,7 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_columns(
         /* 0 * inf above would be NaN = off as well; make the "off" states explicit */
         if (slow || nic_bad || !(P.sigma_od < IS_INF) || !(pr.E1g < IS_INF) || !(pr.E1s < IS_INF) ||
             !(pr.E2 < IS_INF))
-            pr.E1o = IS_INF;
+            pr.E1o = pr.E1g = pr.E1s = IS_INF; /* every type: the bounds are tested one by one */
         pr.pad[0] = pr.pad[1] = pr.pad[2] = pr.pad[3] = 0.0f;
         prune[colg] = pr;
     }

@@ -25,6 +25,7 @@ def study(preset, ncols=24, seed=17, rows=1024, cols=2048, D=128, slack_rel=1e-5
     pw = float(case["params"].prior_weight)
     vhor = int(case["vhor"][0])
     tot_full = tot_eval = 0
+    n_cheap = [0]; n_full = [0]
     per_tile_full = np.zeros(H // 64)
     per_tile_eval = np.zeros(H // 64)
     for c in sel:
@@ -46,8 +47,11 @@ def study(preset, ncols=24, seed=17, rows=1024, cols=2048, D=128, slack_rel=1e-5
                 # full steps of this wave: vB = w, w+8, ... <= lo ; walked downwards
                 vbs = np.arange(w, lo + 1, NW)[::-1]
                 n_eval = 0
+                o_done = gs_done = False
                 for vB in vbs:
                     n_eval += 1
+                    if o_done: n_cheap[0] += 1
+                    else: n_full[0] += 1
                     d = F[:, vT + 1] - F[:, vB][:, None]      # [19][64]
                     lb_o = sw * d[obj].min(axis=0)
                     lb_g = sw * np.minimum(d[0], d[1])
@@ -62,12 +66,14 @@ def study(preset, ncols=24, seed=17, rows=1024, cols=2048, D=128, slack_rel=1e-5
                     done_s = (vB <= vhor) or np.all(lb_s >= best[:, 2])
                     if lo < vhor and vB > vhor:
                         done_g = False
-                    if done_o and done_g and done_s:
+                    o_done = o_done or done_o
+                    if o_done and done_g and done_s:
                         break
                 tot_full += len(vbs)
                 tot_eval += n_eval
                 per_tile_full[T] += len(vbs)
                 per_tile_eval[T] += n_eval
+    print(f"  object still live in {n_full[0]} steps, gs-only (cheap) in {n_cheap[0]} steps of {tot_full} full steps")
     print(f"{preset}: vhor {vhor}; full steps evaluated {tot_eval}/{tot_full} = {tot_eval / tot_full:.3f}")
     print("  per tile:", " ".join(f"{e / max(f, 1):.2f}" for e, f in zip(per_tile_eval, per_tile_full)))
     # DP time model: diag steps are not pruned: iterations = full + diag(8 per wave per tile)
