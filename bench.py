@@ -47,6 +47,14 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=6.0)
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--verify", action="store_true",
+                    help="after the timed region: check frames of the timed output against the oracle")
+    ap.add_argument("--no-variants", action="store_true",
+                    help="skip the extra figures (pruning off, invalid-disparity kernels, generic "
+                         "column encoding, the C++ host class)")
+    ap.add_argument("--min-seconds", type=float, default=2.0,
+                    help="repeat the timed K-step block until this much time has been measured; "
+                         "the MEDIAN block is reported")
     return ap.parse_args()
 
 
@@ -113,9 +121,9 @@ def cpu_baseline(cfg, frame, target_seconds):
 
 def committed_traffic(cfg, B, H, W, D):
     """HBM bytes per launch of the dominant DP kernel from the committed PMC passes
-    (profiles/r01_traffic.json; counters cannot be read from inside the timed run), or None when
+    (profiles/r02_traffic.json; counters cannot be read from inside the timed run), or None when
     that profile was taken on another mode / shape / batch."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_traffic.json")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_traffic.json")
     try:
         with open(path) as fh:
             t = json.load(fh).get("pairwise" if cfg.pairwise else "unary")
@@ -126,12 +134,144 @@ def committed_traffic(cfg, B, H, W, D):
     return (2.0 * t["fetch_size_kb"] + t["write_size_kb"]) * 1024.0
 
 
+
+def verify_frames(cfg, frames, pick, d_sections, B, C, S):
+    """Oracle check of the first, the middle (where a two-stream split would cut the batch) and
+    the last frame of the batch that was just timed.  Returns a dict for the JSON line; raises
+    SystemExit when a frame differs."""
+    import torch
+    from oracle import oracle
+    from instance_stixels_amd.config import SECTION_DTYPE
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import helpers
+    params, lut, odr = oracle.host_initialize(cfg)
+    checked = []
+    for i in sorted({0, B // 2 - 1 if B > 1 else 0, B // 2, B - 1}):
+        if i < 0 or i >= B:
+            continue
+        f = frames[pick[i]]
+        gf, ng, ig, vh = oracle.host_ground(cfg, f.vhor_image, f.camera_tilt, f.camera_height,
+                                            f.alpha_ground)
+        joined = oracle.join_columns(cfg, f.disparity)
+        ref = oracle.compute(params, lut, odr, joined, f.segmentation, gf, ng, ig, vh, cfg.pairwise,
+                             want_tables=False)
+        got = d_sections[i].cpu().numpy().view(SECTION_DTYPE).reshape(C, S)
+        if not helpers.sections_equal(ref["sections"], got):
+            raise SystemExit(f"bench.py --verify: frame {i} of the timed batch differs from the oracle")
+        checked.append(i)
+    return {"frames_checked": checked, "against": "oracle (bit-exact Section arrays)", "ok": True}
+
+
+def measure_variants(args, cfg, frames, pick, dev, local_rank):
+    """Throughput of the same step on the other kernel variants the library contains: pruning
+    switched off (the worst case of the branch-and-bound: every (vB, vT) pair is evaluated), an
+    invalid-disparity value with 5 % holes (HAS_INVALID kernels), all columns in the generic
+    int32/int64 encoding, and a single frame through the C++ `Stixels::Compute` host class."""
+    import torch
+    from instance_stixels_amd import make_config, host
+    from instance_stixels_amd.core import Core
+    B = args.batch
+    H, W, D = int(cfg.rows), int(cfg.cols), int(cfg.max_dis)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    out = {}
+
+    def run(tag, vcfg, disp, seg, env=None, steps=3):
+        st = host.Stixels()
+        st.SetConfig(vcfg)
+        st.PrecomputeHost()
+        params = st.GetParameters()
+        lut, odr = st.GetLUTs()
+        gfs, ngs, igs, vhs = [], [], [], []
+        for f in frames:
+            st.SetRoadParameters(f.vhor_image, f.camera_tilt, f.camera_height, f.alpha_ground)
+            gf, ng, ig, vh = st.GetGroundModel()
+            gfs.append(gf); ngs.append(ng); igs.append(ig); vhs.append(vh)
+        st.close()
+        gf = np.stack([gfs[i] for i in pick]); ng = np.stack([ngs[i] for i in pick])
+        ig = np.stack([igs[i] for i in pick]); vh = np.array([vhs[i] for i in pick], np.int32)
+        old = {k: os.environ.get(k) for k in (env or {})}
+        os.environ.update(env or {})
+        try:
+            core = Core(params, lut, odr, max_batch=B, device=local_rank)
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        C, S = params.cols, params.max_sections
+        d_joined = torch.empty((B, C, H), dtype=torch.float32, device=dev)
+        d_sections = torch.empty((B, C, S, 8), dtype=torch.int32, device=dev)
+
+        def step():
+            core.join_columns_ptr(disp.data_ptr(), W, vcfg.median_join, d_joined.data_ptr(), B, stream)
+            core.compute_ptr(d_joined.data_ptr(), seg.data_ptr(), gf, ng, ig, vh, vcfg.pairwise, B,
+                             d_sections.data_ptr(), None, None, None, stream)
+        step()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize(dev)
+        out[tag] = {"images_per_s": B * steps / (time.perf_counter() - t0), "steps": steps}
+        core.close()
+        del d_joined, d_sections
+
+    idx = torch.tensor(pick, device=dev)
+    disp = torch.from_numpy(np.stack([f.disparity for f in frames])).to(dev)[idx].contiguous()
+    seg = torch.from_numpy(np.stack([f.segmentation for f in frames])).to(dev)[idx].contiguous()
+    run("pruning_off", cfg, disp, seg, env={"IS_NO_PRUNE": "1"})
+    out["pruning_off"]["what"] = ("IS_NO_PRUNE=1: the exact branch-and-bound never fires, every "
+                                  "(vB, vT) pair is evaluated (data-independent worst case)")
+    # invalid-disparity value 0 with 5 % holes: the HAS_INVALID kernel variants
+    icfg = make_config(args.preset, H, W, D, invalid_disparity=0.0)
+    g = torch.Generator(device=dev); g.manual_seed(5)
+    holes = torch.rand(disp.shape, device=dev, generator=g) < 0.05
+    run("invalid_disparity_0", icfg, torch.where(holes, torch.zeros_like(disp), disp), seg)
+    out["invalid_disparity_0"]["what"] = "invalid_disparity = 0, 5 % of the pixels invalid (HAS_INVALID kernels)"
+    del holes
+    # every column in the generic encoding: one negative class value per column
+    gseg = seg.clone()
+    gseg[:, :, 0, 0] = -1
+    run("generic_encoding", cfg, disp, gseg, steps=2)
+    out["generic_encoding"]["what"] = ("one negative class value per column: int32 / int64 records, "
+                                       "IEEE division, no pruning (the hostile-input path)")
+    del gseg, disp, seg
+    # BASELINE configs[1] through the C++ host class: Stixels::Compute() incl. the device-side
+    # clustering, the D2H copy of the sections and one synchronisation per frame
+    st = host.Stixels()
+    st.SetConfig(cfg)
+    st.SetDevice(local_rank)
+    st.Initialize()
+    f = frames[0]
+    st.SetDisparityImage(f.disparity)
+    st.SetSegmentation(f.segmentation)
+    st.SetRoadParameters(f.vhor_image, f.camera_tilt, f.camera_height, f.alpha_ground)
+    t_plain = st.time_compute(cfg.pairwise, 200, False)
+    t_inst = st.time_compute(cfg.pairwise, 200, True)
+    st.close()
+    out["stixels_compute_host_class"] = {
+        "images_per_s": 1.0 / t_plain, "ms_per_frame": t_plain * 1e3,
+        "images_per_s_with_GetInstanceStixels": 1.0 / t_inst,
+        "what": "one frame per Stixels::Compute() call, timed inside the C++ library "
+                "(ish_time_compute): ground model on the host, JoinColumns + DP + back-trace + "
+                "instance candidates + clustering on the device, sections copied to the host"}
+    return out
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if args.gpus != world:
+        # one process per GPU: N > 1 must come from `python -m torch.distributed.run
+        # --nproc-per-node N ... bench.py --gpus N` (nothing here re-executes a process that may
+        # have touched the GPU); checked before torch is imported
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE is {world}: launch with "
+                         f"python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} "
+                         f"--master-addr 127.0.0.1 --master-port <P> bench.py --gpus {args.gpus} ...")
 
     import torch
     import torch.distributed as dist
@@ -209,18 +349,29 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
+
+    def timed_block():
+        """EXACTLY args.steps steps between barrier + synchronize on both sides; max over ranks."""
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        d = time.perf_counter() - t0
+        if use_dist:
+            t = torch.tensor([d], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            d = float(t.item())
+        return d
+
+    # the K-step block is repeated until --min-seconds have been measured (every rank sees the
+    # same max-reduced times, so all ranks stop together) and the MEDIAN block is reported: a
+    # 0.3 s measurement is over before a power / utilisation sampler sees the GPU busy
+    blocks = [timed_block()]
+    while sum(blocks) < args.min_seconds and len(blocks) < 200:
+        blocks.append(timed_block())
+    dt = float(np.median(blocks))
     # per-kernel durations of the LAST timed step, measured with HIP events on the launch stream
     kt = core.kernel_times_ms()
-
-    if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
 
     # BASELINE.json configs[1] (ONE 1024x2048 frame per call) next to the batched headline value:
     # the same entry points with n_images = 1, i.e. the latency a per-frame caller sees
@@ -274,6 +425,26 @@ def main():
         torch.cuda.synchronize(dev)
         pcie_value = B * k / (time.perf_counter() - t1)
 
+    # ---- --verify: frames of the TIMED output (the batch geometry the value is measured on)
+    verify = None
+    if args.verify and rank == 0:
+        verify = verify_frames(cfg, frames, pick, d_sections if pipe is None else pipe.last_local(),
+                               B, C, S)
+        if pipe is not None:  # what the RCCL gather delivered to rank 0 is what the ranks computed
+            got = pipe.last_gathered()
+            same = bool(torch.equal(got[0], pipe.last_local()))
+            verify["rccl_gather"] = {"tensors": len(got), "bytes_per_rank": got[0].numel() * 4,
+                                     "rank0_copy_equals_local": same}
+            if not same:
+                raise SystemExit("bench.py --verify: gathered copy of rank 0 differs from its output")
+
+    # ---- extra figures (N = 1): other kernel variants of the same step, never part of `value`
+    variants = None
+    if world == 1 and not args.no_variants:
+        core.close()
+        variants = measure_variants(args, cfg, frames, pick, dev, local_rank)
+        core = Core(params, lut, odr, max_batch=1, device=local_rank)  # closed again below
+
     if rank == 0:
         images = B * world * args.steps
         value = images / dt
@@ -306,7 +477,7 @@ def main():
                          "note": "the column DP is bound by VALU issue, not by HBM (SURVEY.md "
                                  "H1, DESIGN.md section 5): see the valu fields; traffic = "
                                  "(2*FETCH_SIZE + WRITE_SIZE) per launch from the committed "
-                                 "rocprofv3 PMC passes (profiles/r01_traffic.json)"},
+                                 "rocprofv3 PMC passes (profiles/r02_traffic.json)"},
             "valu": {"pair_evals_per_s": pairs_img * B / dp_s,
                      "pair_evals_per_image": pairs_img,
                      "lane_ops_peak_per_s": VALU_PEAK_LANEOPS},
@@ -320,6 +491,15 @@ def main():
             out["single_frame"] = {"workload": "BASELINE configs[1]: one frame per call (batch 1), "
                                                "device-resident in/out",
                                    "images_per_s": 1.0 / single, "ms_per_frame": single * 1e3}
+        out["timed_blocks"] = {"count": len(blocks), "steps_per_block": args.steps,
+                               "seconds": [round(x, 5) for x in blocks], "reported": "median"}
+        if traffic is not None:
+            out["roofline"]["measured_hbm_gbps"] = traffic / dp_s / 1e9
+            out["roofline"]["measured_hbm_frac"] = traffic / dp_s / 1e9 / HBM_PEAK_GBS
+        if verify is not None:
+            out["verify"] = verify
+        if variants is not None:
+            out["variants"] = variants
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg, frames[0], args.cpu_seconds)
     else:

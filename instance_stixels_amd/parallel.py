@@ -80,6 +80,14 @@ class PipelinedGather:
         self.step += 1
         return slot
 
+    def last_local(self) -> torch.Tensor:
+        """This rank's output buffer of the most recent step (valid after flush())."""
+        return self.buffers[(self.step - 1) % self.depth]
+
+    def last_gathered(self):
+        """On `dst` after flush(): the list of all ranks' outputs of the most recent step."""
+        return None if self.gathered is None else self.gathered[(self.step - 1) % self.depth]
+
     def flush(self):
         for i, w in enumerate(self.inflight):
             if w is not None:

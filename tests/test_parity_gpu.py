@@ -132,6 +132,42 @@ def test_config3_batch_of_full_frames(preset):
 
 
 @pytest.mark.parametrize("preset", ["drn_d_22_unary", "drn_d_38_pairwise"])
+def test_batch64_launch_geometry(preset):
+    """BASELINE configs[2] / the per-GPU share of configs[3]: 64 full 1024x2048x128 frames in ONE
+    call -- 16 384 columns, the launch geometry bench.py times (12 GB of scratch, the two-stream
+    split of the pairwise DP, 131 072 unary workgroups).  Four distinct frames with per-image road
+    parameters; the first, last, the images either side of the middle of the batch and four more
+    are compared with the oracle."""
+    from oracle import oracle
+    case4 = helpers.build_case(preset, 1024, 2048, 128, seed=41, n_images=4)
+    cfg = case4["cfg"]
+    n = 64
+    pick = [i % 4 for i in range(n)]
+    case = dict(case4)
+    case["frames"] = [case4["frames"][k] for k in pick]
+    case["disparity"] = case4["disparity"][pick]
+    case["segmentation"] = case4["segmentation"][pick]
+    gf, ng, ig, vh = [], [], [], []
+    for i, k in enumerate(pick):   # a different horizon for (almost) every image of the batch
+        f = case4["frames"][k]
+        g = oracle.host_ground(cfg, f.vhor_image + (i % 13) - 6, f.camera_tilt,
+                               f.camera_height + 0.01 * (i % 5), f.alpha_ground)
+        gf.append(g[0]); ng.append(g[1]); ig.append(g[2]); vh.append(g[3])
+    case["gf"], case["ng"], case["ig"] = np.stack(gf), np.stack(ng), np.stack(ig)
+    case["vhor"] = np.array(vh, np.int32)
+    got = helpers.run_core(case, want_tables=False)
+    _assert_parity(case, got, images=[0, 1, 31, 32, 33, 47, 62, 63])
+
+
+def test_config5_pairwise_256_bins_column_subset():
+    """BASELINE configs[4] in PAIRWISE mode: D = 256 takes the per-lane gather of the vB-side LUT
+    value (LutRow<0>) in phase 1; every 16th column of a 1024x4096x256 frame against the oracle."""
+    case = helpers.build_case("drn_d_38_pairwise", 1024, 4096, 256, seed=16)
+    got = helpers.run_core(case, want_tables=True)
+    _assert_parity(case, got, cols=list(range(0, case["cfg"].realcols, 16)))
+
+
+@pytest.mark.parametrize("preset", ["drn_d_22_unary", "drn_d_38_pairwise"])
 def test_tall_frame_2048_rows(preset):
     """Beyond every structural limit of the reference (one thread per row, rows < 1024): the same
     formulas at 2048 rows, 32 tiles per column."""
