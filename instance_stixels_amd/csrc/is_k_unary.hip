@@ -451,10 +451,9 @@ hipError_t isk_launch_dp_unary(const DevParams* P, int ncols, int nwaves, const 
                                int32_t* index_table, hipStream_t stream) {
     /* FAST columns: the chunk-staged kernel of is_k_unary_fast.hip whenever the shape allows it;
      * then only the generic columns are left for this file's kernel */
-    /* (measured on MI355X, batch 64: 10.1 ms against 9.3 ms of the tile-pair kernel below -- its
-     * chunks arrive later than a wave evaluates them; selected with IS_CHUNK_KERNEL=1 until the
-     * prefetch distance is fixed) */
-    const bool fast_kernel = isk_unary_fast_chunk_rows(P) > 0 && getenv("IS_CHUNK_KERNEL") != nullptr;
+    /* (measured on MI355X, batch 64: 8.7 ms against 9.3 ms of the tile-pair kernel below, and no
+     * scratch; IS_NO_RING_KERNEL=1 selects the old kernel for comparisons) */
+    const bool fast_kernel = isk_unary_fast_chunk_rows(P) > 0 && getenv("IS_NO_RING_KERNEL") == nullptr;
     if (fast_kernel) {
         const hipError_t e = isk_launch_dp_unary_fast(P, ncols, recs, lutT, rcp, vhor, col_flags, prune,
                                                       cost_table, index_table, stream);

@@ -4,28 +4,27 @@
  * shrinks to its 64 diagonal steps plus a few dozen steps below the tile, so the kernel is no
  * longer bound by VALU issue but by the latency of what every step fetches.  k_dp_unary (the
  * kernel of the generic columns, is_k_unary.hip) takes the vB-side record through scalar loads
- * and the vB-side lutT row through a buffer load per wave and step: ~1.4 us of exposed latency
- * per step once the other waves no longer cover it.  Here NOTHING inside the step loop touches
+ * and the vB-side lutT row through a buffer load per wave and step: ~1 us of exposed latency
+ * per step once the other waves no longer cover it.  Here NOTHING inside the step loop waits for
  * global memory:
  *
- *   - the workgroup (8 waves, one lane per vT of the tile) walks vB downwards in CHUNKS of
- *     `chunk_rows` rows; the chunk's records (128 B each) and lutT rows are staged in LDS by all
- *     512 threads with 16-byte loads, double buffered: chunk k+1 is in flight (registers) while
- *     chunk k is evaluated, one barrier per chunk;
- *   - inside a chunk wave w takes vB = c_hi - w, c_hi - w - 8, ...: the record comes out of LDS
- *     with eight broadcast ds_read_b128, the two LUT values with per-lane ds_read_b32;
- *   - a wave whose bound says that nothing below can win (nothing_below_can_win) stops
- *     evaluating; the workgroup leaves the chunk loop when all eight have stopped.
+ *   - a wave (one lane per vT of the tile) walks its vB values downwards and owns a RING of K LDS
+ *     slots, each holding the lutT row and the 128-byte record of one vB;
+ *   - the slots are filled by `global_load_lds` (LDS-DMA: no VGPRs, no waiting), K steps ahead
+ *     of their use; `s_waitcnt vmcnt(NV * (K - 1))` before a step guarantees that its own slot
+ *     has landed while the K - 1 younger prefetches stay in flight (loads return in order);
+ *   - the record comes out of LDS with eight broadcast ds_read_b128, the two LUT values with
+ *     per-lane ds_read_b32; no barrier inside the loop: the waves of a workgroup only share the
+ *     tile's lutT rows (vT side), the 1/h table and the final merge;
+ *   - a wave whose bound says that nothing below can win leaves its loop.
  *
- * LDS per workgroup at 1024 x 128: 4 KB (1/h) + 33 KB (vT tile) + 2 x 20.5 KB (chunks) = 78 KB,
- * two workgroups per CU, 128 VGPRs, no scratch.
+ * LDS per workgroup at 1024 x 128: 4 KB (1/h) + 33 KB (vT tile) + 8 x 8 x (512 + 128) B (rings)
+ * = 77 KB, two workgroups per CU, <= 128 VGPRs, no scratch.
  */
 #include "is_kernels.h"
 
 #define ISF_WAVES 8
 #define ISF_THREADS (ISF_WAVES * 64)
-#define ISF_MAXQ 4 /* float4 per thread of one chunk's lutT rows: chunk_rows * D <= 8192 */
-/* (the kernels take the actual count NQ <= ISF_MAXQ as a template parameter: registers) */
 
 struct UnaryBestF {
     float g, o, s;
@@ -109,54 +108,15 @@ __device__ __forceinline__ bool fast_nothing_below(const DevParams& P, const Pru
     return ok == ~0ull;
 }
 
-/* registers of one chunk in flight */
-template <int NQ>
-struct ChunkRegs {
-    float4 rows[NQ];
-    float4 rec;
-};
-
-template <int NQ>
-__device__ __forceinline__ void chunk_fetch(ChunkRegs<NQ>& cr, const float* __restrict__ lcol,
-                                            const RowRec* __restrict__ rcol, int c_lo, int n_rows,
-                                            int D, int tid) {
-    const int n4 = (n_rows * D) >> 2; /* D % 4 == 0 */
-    const float4* src = reinterpret_cast<const float4*>(lcol + (size_t)c_lo * D);
-#pragma unroll
-    for (int q = 0; q < NQ; q++) {
-        const int i = tid + q * ISF_THREADS;
-        if (i < n4) cr.rows[q] = src[i];
-    }
-    if (tid < n_rows * 8) cr.rec = reinterpret_cast<const float4*>(rcol + c_lo)[tid];
-}
-
-template <int NQ>
-__device__ __forceinline__ void chunk_store(const ChunkRegs<NQ>& cr, float* b_rows, float* b_recs,
-                                            int n_rows, int D, int tid) {
-    const int DP = D + 1;
-    const int n4 = (n_rows * D) >> 2;
-#pragma unroll
-    for (int q = 0; q < NQ; q++) {
-        const int i = tid + q * ISF_THREADS;
-        if (i < n4) {
-            const int e = i << 2;
-            const int r = e / D, f = e - r * D;
-            float* d = b_rows + r * DP + f;
-            d[0] = cr.rows[q].x; d[1] = cr.rows[q].y; d[2] = cr.rows[q].z; d[3] = cr.rows[q].w;
-        }
-    }
-    if (tid < n_rows * 8) reinterpret_cast<float4*>(b_recs)[tid] = cr.rec;
-}
-
 #ifdef IS_ABL_PHASES
 __device__ unsigned long long g_fphase[8];
+#define ISF_MARK_INIT() unsigned long long t_phase = __builtin_readcyclecounter()
 #define ISF_MARK(k)                                                                       \
     do {                                                                                  \
         const unsigned long long now__ = __builtin_readcyclecounter();                    \
         if (threadIdx.x == 0) atomicAdd(&g_fphase[k], now__ - t_phase);                   \
         t_phase = now__;                                                                  \
     } while (0)
-#define ISF_COUNT(k) do { if (threadIdx.x == 0) atomicAdd(&g_fphase[k], 1ull); } while (0)
 extern "C" void isk_debug_phases(unsigned long long* out, int reset) {
     (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fphase), sizeof(g_fphase));
     if (reset) {
@@ -165,24 +125,77 @@ extern "C" void isk_debug_phases(unsigned long long* out, int reset) {
     }
 }
 #else
+#define ISF_MARK_INIT()
 #define ISF_MARK(k)
-#define ISF_COUNT(k)
 #endif
 
-template <bool HAS_INVALID, int NQ>
+typedef __attribute__((address_space(3))) void* isf_lds_t;
+typedef const __attribute__((address_space(1))) void* isf_glb_t;
+
+#define ISF_RING 8     /* slots per wave: prefetch distance in steps */
+#define ISF_REC_F 32   /* floats of a record slot */
+
+/* s_waitcnt vmcnt(n), expcnt / lgkmcnt untouched (gfx9 encoding) */
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+    __builtin_amdgcn_s_waitcnt((N & 0xF) | ((N >> 4) << 14) | (7 << 4) | (0xF << 8));
+    asm volatile("" ::: "memory"); /* the LDS reads of the slot stay behind the wait */
+}
+
+/* One LDS-DMA instruction: lane l's dword at gaddr goes to LDS byte address lds_base + 4 l.
+ * Written as inline assembly on purpose: for `__builtin_amdgcn_global_load_lds` the compiler
+ * inserts s_waitcnt vmcnt(0) in front of every LDS read that might alias the target -- here all of
+ * them --, which would wait for the youngest prefetch at every step and serialise the ring.  The
+ * waits are placed by hand instead (wait_vmcnt). */
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm" /* m0 is the DMA's LDS base: clobbered on purpose */
+__device__ __forceinline__ void dma_dword(const float* gaddr, unsigned lds_base) {
+    asm volatile("s_mov_b32 m0, %1\n\t"
+                 "s_nop 0\n\t"
+                 "global_load_lds_dword %0, off"
+                 :
+                 : "v"(gaddr), "s"(lds_base)
+                 : "memory", "m0");
+}
+#pragma clang diagnostic pop
+
+__device__ __forceinline__ unsigned lds_addr(const float* p) {
+    return __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(isf_lds_t)p);
+}
+
+/* LDS-DMA of the lutT row and the record of vB into one ring slot: NVR + 1 VMEM instructions,
+ * always issued (a uniform count for wait_vmcnt), no registers, no waiting. */
+template <int NVR>
+__device__ __forceinline__ void ring_prefetch(const float* __restrict__ lcol,
+                                              const RowRec* __restrict__ rcol, int vB, int D,
+                                              float* slot_row, float* slot_rec, int lane) {
+    const float* row = lcol + (size_t)vB * D;
+    const unsigned base = lds_addr(slot_row);
+#pragma unroll
+    for (int j = 0; j < NVR; j++) {
+        const int f = min(lane + 64 * j, D - 1); /* lanes beyond the row re-read its last element */
+        dma_dword(row + f, base + 256 * j);
+    }
+    if (lane < ISF_REC_F) /* 32 lanes x 4 B = the record; the instruction is issued by every wave */
+        dma_dword((const float*)(rcol + vB) + lane, lds_addr(slot_rec));
+}
+
+template <bool HAS_INVALID, int NVR>
 __global__ __launch_bounds__(ISF_THREADS, 4) void k_dp_unary_fast(
     const DevParams P, int ncols, const RowRec* __restrict__ recs, const float* __restrict__ lutT,
     const float* __restrict__ rcp, const int* __restrict__ vhor_arr,
     const int* __restrict__ col_flags, const PruneRec* __restrict__ prune,
-    float* __restrict__ cost_table, int32_t* __restrict__ index_table, int chunk_rows) {
+    float* __restrict__ cost_table, int32_t* __restrict__ index_table) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int H = P.H, D = P.D;
     const int DP = D + 1;
-    const int CR = chunk_rows;
-    float* s_rcp = (float*)smem;                       /* [H+1 -> x4]                        */
-    float* s_tile = s_rcp + ((H + 1 + 3) & ~3);        /* [64][D+1] lutT rows tile_lo+1 ..    */
-    float* s_buf = s_tile + ((IS_TILE * DP + 3) & ~3); /* 2 x { rows [CR][D+1], recs [CR][32] } */
-    const int buf_floats = ((CR * DP + 3) & ~3) + CR * 32;
+    constexpr int K = ISF_RING;
+    constexpr int ROWF = 64 * NVR;             /* floats of a row slot */
+    constexpr int SLOT = ROWF + ISF_REC_F;     /* floats of a ring slot */
+    float* s_rcp = (float*)smem;                        /* [H+1 -> x4]                       */
+    float* s_tile = s_rcp + ((H + 1 + 3) & ~3);         /* [64][D+1] lutT rows tile_lo+1 ..   */
+    float* s_ring = s_tile + ((IS_TILE * DP + 3) & ~3); /* [8 waves][K][SLOT]                */
 
     /* XCD-aware order: blocks b, b+8, ... share an XCD/L2; the tiles of a column stay on one XCD
      * (they fetch the same lutT rows) and the tallest tiles start first */
@@ -203,18 +216,20 @@ __global__ __launch_bounds__(ISF_THREADS, 4) void k_dp_unary_fast(
     const int vTc = min(vT, H - 1);
     const bool row_ok = vT < H;
     const int vB_end = min(tile_lo + IS_TILE - 1, H - 1);
+    float* my_ring = s_ring + (size_t)w * K * SLOT;
+    ISF_MARK_INIT();
 
-#ifdef IS_ABL_PHASES
-    unsigned long long t_phase = __builtin_readcyclecounter();
-#endif
-    /* ---- prologue: 1/h table, the tile's lutT rows, this lane's record, the first chunk */
-    ChunkRegs<NQ> cr;
-    int c_hi = vB_end, c_lo = max(c_hi - CR + 1, 0);
-    chunk_fetch(cr, lcol, rcol, c_lo, c_hi - c_lo + 1, D, tid);
+    /* ---- prologue: the wave's first K slots are requested first, then the tile's lutT rows,
+     * the 1/h table and this lane's record.  The wave's steps: vB_top, vB_top - 8, ... >= 0
+     * (H >= 8 = the number of waves, so vB_top >= 0). */
+    const int vB_top = vB_end - w;
+#pragma unroll
+    for (int i = 0; i < K; i++)
+        ring_prefetch<NVR>(lcol, rcol, max(vB_top - ISF_WAVES * i, 0), D, my_ring + i * SLOT,
+                           my_ring + i * SLOT + ROWF, lane);
     const RowRec my = load_rec(rcol + vTc + 1);
     for (int i = tid; i <= H; i += ISF_THREADS) s_rcp[i] = rcp[i];
     stage_lut_tile<true>(s_tile, lcol, tile_lo, H, D, tid, ISF_THREADS);
-    chunk_store(cr, s_buf, s_buf + ((CR * DP + 3) & ~3), c_hi - c_lo + 1, D, tid);
 
     PruneValsF pv;
     {
@@ -229,77 +244,62 @@ __global__ __launch_bounds__(ISF_THREADS, 4) void k_dp_unary_fast(
     b.vo = 0; /* index_table[vT*3+OBJECT] = OBJECT at vB = 0, :592 */
     const float* my_tile = s_tile + lane * DP;
     const bool nog = IS_SKIP_GROUND_ABOVE_HORIZON && tile_lo >= vhor;
-    bool done = false; /* wave-uniform: nothing below can win any more */
-    __syncthreads();
+    __syncthreads(); /* the tile and the 1/h table: the only data the waves share */
     ISF_MARK(0);
 
-    /* ---- chunk loop, vB downwards */
-    for (int k = 0;; k++) {
-        const int n_lo = max(c_lo - CR, 0); /* next chunk = [n_lo, c_lo - 1] */
-        const bool more = c_lo > 0;
-        if (more) chunk_fetch(cr, lcol, rcol, n_lo, c_lo - n_lo, D, tid);
-
-        const float* b_rows = s_buf + (k & 1) * buf_floats;
-        const float* b_recs = b_rows + ((CR * DP + 3) & ~3);
-        if (!done) {
-            for (int vB = c_hi - w; vB >= c_lo; vB -= ISF_WAVES) {
-                const int j = vB - c_lo;
-#ifdef IS_FAST_SREC
-                const RowRec rb = sload_rec(rcol + vB);
-#else
-                const RowRec rb = lds_rec(b_recs + j * 32);
-#endif
-                const float* lrow = b_rows + j * DP;
-                const bool diag = vB > tile_lo;
-                if (vB == 0) { /* first segment (:481-594): ground + object */
-                    if (diag)
-                        fast_step<HAS_INVALID, false, true, true, false>(P, my, rb, lrow, my_tile, s_rcp, vT,
-                                                                         vTc, vhor, 0, row_ok, b);
-                    else
-                        fast_step<HAS_INVALID, false, false, true, false>(P, my, rb, lrow, my_tile, s_rcp, vT,
-                                                                          vTc, vhor, 0, row_ok, b);
-                } else if (vB > vhor) { /* vB - 1 >= vhor: sky + object (:729) */
-                    if (diag) {
-                        fast_step<HAS_INVALID, true, true, false, false>(P, my, rb, lrow, my_tile, s_rcp, vT,
-                                                                         vTc, vhor, vB, row_ok, b);
-                    } else {
-                        const SegTerms t = fast_step<HAS_INVALID, true, false, false, false>(
-                            P, my, rb, lrow, my_tile, s_rcp, vT, vTc, vhor, vB, row_ok, b);
-                        if (IS_PRUNE && fast_nothing_below<true, false>(P, pv, t, b)) { done = true; break; }
-                    }
-                } else { /* ground + object (:687) */
-                    if (diag) {
-                        fast_step<HAS_INVALID, false, true, false, false>(P, my, rb, lrow, my_tile, s_rcp, vT,
-                                                                          vTc, vhor, vB, row_ok, b);
-                    } else if (nog) {
-                        const SegTerms t = fast_step<HAS_INVALID, false, false, false, true>(
-                            P, my, rb, lrow, my_tile, s_rcp, vT, vTc, vhor, vB, row_ok, b);
-                        if (IS_PRUNE && fast_nothing_below<false, true>(P, pv, t, b)) { done = true; break; }
-                    } else {
-                        const SegTerms t = fast_step<HAS_INVALID, false, false, false, false>(
-                            P, my, rb, lrow, my_tile, s_rcp, vT, vTc, vhor, vB, row_ok, b);
-                        if (IS_PRUNE && fast_nothing_below<false, false>(P, pv, t, b)) { done = true; break; }
-                    }
-                }
+    /* ---- the wave's walk, vB downwards; slot i % K holds step i */
+    int slot = 0;
+    for (int vB = vB_top; vB >= 0; vB -= ISF_WAVES) {
+        wait_vmcnt<(NVR + 1) * (K - 1)>(); /* this step's slot has landed; K - 1 prefetches in flight */
+        float* s_row = my_ring + slot * SLOT;
+        const RowRec rb = lds_rec(s_row + ROWF);
+        const float* lrow = s_row;
+        const bool diag = vB > tile_lo;
+        bool done = false;
+        if (vB == 0) { /* first segment (:481-594): ground + object */
+            if (diag)
+                fast_step<HAS_INVALID, false, true, true, false>(P, my, rb, lrow, my_tile, s_rcp, vT, vTc, vhor,
+                                                                 0, row_ok, b);
+            else
+                fast_step<HAS_INVALID, false, false, true, false>(P, my, rb, lrow, my_tile, s_rcp, vT, vTc,
+                                                                  vhor, 0, row_ok, b);
+        } else if (vB > vhor) { /* vB - 1 >= vhor: sky + object (:729) */
+            if (diag) {
+                fast_step<HAS_INVALID, true, true, false, false>(P, my, rb, lrow, my_tile, s_rcp, vT, vTc, vhor,
+                                                                 vB, row_ok, b);
+            } else {
+                const SegTerms t = fast_step<HAS_INVALID, true, false, false, false>(
+                    P, my, rb, lrow, my_tile, s_rcp, vT, vTc, vhor, vB, row_ok, b);
+                done = IS_PRUNE && fast_nothing_below<true, false>(P, pv, t, b);
+            }
+        } else { /* ground + object (:687) */
+            if (diag) {
+                fast_step<HAS_INVALID, false, true, false, false>(P, my, rb, lrow, my_tile, s_rcp, vT, vTc, vhor,
+                                                                  vB, row_ok, b);
+            } else if (nog) {
+                const SegTerms t = fast_step<HAS_INVALID, false, false, false, true>(
+                    P, my, rb, lrow, my_tile, s_rcp, vT, vTc, vhor, vB, row_ok, b);
+                done = IS_PRUNE && fast_nothing_below<false, true>(P, pv, t, b);
+            } else {
+                const SegTerms t = fast_step<HAS_INVALID, false, false, false, false>(
+                    P, my, rb, lrow, my_tile, s_rcp, vT, vTc, vhor, vB, row_ok, b);
+                done = IS_PRUNE && fast_nothing_below<false, false>(P, pv, t, b);
             }
         }
-        ISF_MARK(1);
-        ISF_COUNT(5);
-        if (!more) break;
-        /* the other buffer was last read while chunk k-1 was evaluated, i.e. before the barrier
-         * that ended iteration k-1 */
-        float* n_rows_p = s_buf + ((k + 1) & 1) * buf_floats;
-        chunk_store(cr, n_rows_p, n_rows_p + ((CR * DP + 3) & ~3), c_lo - n_lo, D, tid);
-        c_hi = c_lo - 1;
-        c_lo = n_lo;
-        const bool all_done = __syncthreads_and(done);
-        ISF_MARK(2);
-        if (all_done) break;
+        if (done) break; /* nothing below can win any more */
+        /* refill the slot just consumed (its reads have returned: their values were used) */
+        asm volatile("" ::: "memory");
+        ring_prefetch<NVR>(lcol, rcol, max(vB - ISF_WAVES * K, 0), D, s_row, s_row + ROWF, lane);
+        slot = (slot + 1 == K) ? 0 : slot + 1;
     }
+    ISF_MARK(1);
 
-    /* ---- merge the waves' partial minima: min cost, ties -> smallest vB */
+    /* ---- merge the waves' partial minima: min cost, ties -> smallest vB.  The rings may still
+     * receive prefetched slots: everything has to land before the merge area reuses them. */
+    wait_vmcnt<0>();
     __syncthreads();
-    float* m_cost = s_buf;                               /* [8][3][64] */
+    ISF_MARK(2);
+    float* m_cost = s_ring;                              /* [8][3][64] */
     int* m_vb = (int*)(m_cost + ISF_WAVES * 3 * 64);     /* [8][3][64] */
     m_cost[(w * 3 + 0) * 64 + lane] = b.g; m_vb[(w * 3 + 0) * 64 + lane] = b.vg;
     m_cost[(w * 3 + 1) * 64 + lane] = b.o; m_vb[(w * 3 + 1) * 64 + lane] = b.vo;
@@ -335,42 +335,41 @@ __global__ __launch_bounds__(ISF_THREADS, 4) void k_dp_unary_fast(
 
 extern "C" {
 
-size_t isk_unary_fast_lds_bytes(const DevParams* P, int chunk_rows) {
-    const size_t DP = (size_t)P->D + 1;
-    const size_t rcp = ((size_t)P->H + 1 + 3) & ~(size_t)3;
-    const size_t tile = ((size_t)IS_TILE * DP + 3) & ~(size_t)3;
-    const size_t buf = (((size_t)chunk_rows * DP + 3) & ~(size_t)3) + (size_t)chunk_rows * 32;
-    size_t two = 2 * buf;
-    const size_t merge = (size_t)ISF_WAVES * 3 * 64 * 2;
-    if (two < merge) two = merge;
-    return sizeof(float) * (rcp + tile + two) + 16;
-}
-
-/* Largest chunk (rows) the shape allows: D % 4 == 0 (16-byte row loads), a chunk's rows fit the
- * per-thread registers, and two workgroups (or at least one) fit a CU's 160 KiB of LDS.
- * 0 = the shape cannot use this kernel. */
-int isk_unary_fast_chunk_rows(const DevParams* P) {
-    if ((P->D & 3) != 0) return 0;
-    for (int pass = 0; pass < 2; pass++) {
-        const size_t limit = pass == 0 ? 80 * 1024 : 160 * 1024;
-        for (int cr = 32; cr >= 8; cr >>= 1) {
-            if ((size_t)cr * P->D > (size_t)ISF_MAXQ * 4 * ISF_THREADS) continue;
-            if (isk_unary_fast_lds_bytes(P, cr) <= limit) return cr;
-        }
-    }
+/* NVR = 64-lane loads per lutT row; 0 = the shape cannot use this kernel */
+static int isf_nvr(const DevParams* P) {
+    if (P->D <= 128) return 2;
+    if (P->D <= 256) return 4;
     return 0;
 }
 
+size_t isk_unary_fast_lds_bytes(const DevParams* P, int nvr) {
+    const size_t DP = (size_t)P->D + 1;
+    const size_t rcp = ((size_t)P->H + 1 + 3) & ~(size_t)3;
+    const size_t tile = ((size_t)IS_TILE * DP + 3) & ~(size_t)3;
+    size_t ring = (size_t)ISF_WAVES * ISF_RING * (64 * (size_t)nvr + ISF_REC_F);
+    const size_t merge = (size_t)ISF_WAVES * 3 * 64 * 2;
+    if (ring < merge) ring = merge;
+    return sizeof(float) * (rcp + tile + ring) + 16;
+}
+
+/* nonzero (the row-load count) when the shape can use the kernel: a workgroup must fit the CU's
+ * 160 KiB of LDS */
+int isk_unary_fast_chunk_rows(const DevParams* P) {
+    const int nvr = isf_nvr(P);
+    if (nvr == 0 || P->H < ISF_WAVES) return 0;
+    return isk_unary_fast_lds_bytes(P, nvr) <= 160 * 1024 ? nvr : 0;
+}
+
 hipError_t isk_set_lds_unary_fast(const DevParams* P) {
-    const int cr = isk_unary_fast_chunk_rows(P);
-    if (cr == 0) return hipSuccess;
-    const int b = (int)isk_unary_fast_lds_bytes(P, cr);
+    const int nvr = isk_unary_fast_chunk_rows(P);
+    if (nvr == 0) return hipSuccess;
+    const int b = (int)isk_unary_fast_lds_bytes(P, nvr);
     hipError_t e = hipSuccess;
-#define ISF_SET(INV, NQ)                                                                          \
+#define ISF_SET(INV, NVR)                                                                         \
     if (e == hipSuccess)                                                                          \
-    e = hipFuncSetAttribute((const void*)k_dp_unary_fast<INV, NQ>,                                \
+    e = hipFuncSetAttribute((const void*)k_dp_unary_fast<INV, NVR>,                               \
                             hipFuncAttributeMaxDynamicSharedMemorySize, b)
-    ISF_SET(true, 2); ISF_SET(false, 2); ISF_SET(true, ISF_MAXQ); ISF_SET(false, ISF_MAXQ);
+    if (nvr == 2) { ISF_SET(true, 2); ISF_SET(false, 2); } else { ISF_SET(true, 4); ISF_SET(false, 4); }
 #undef ISF_SET
     return e;
 }
@@ -380,18 +379,17 @@ hipError_t isk_launch_dp_unary_fast(const DevParams* P, int ncols, const RowRec*
                                     const float* lutT, const float* rcp, const int* vhor,
                                     const int* col_flags, const PruneRec* prune, float* cost_table,
                                     int32_t* index_table, hipStream_t stream) {
-    const int cr = isk_unary_fast_chunk_rows(P);
+    const int nvr = isk_unary_fast_chunk_rows(P);
     const int groups = (ncols + 7) / 8;
     const dim3 grid(groups * 8 * P->ntiles);
-    const size_t lds = isk_unary_fast_lds_bytes(P, cr);
-    const bool small = (size_t)cr * P->D <= (size_t)2 * 4 * ISF_THREADS;
-#define ISF_LAUNCH(INV, NQ)                                                                       \
-    hipLaunchKernelGGL((k_dp_unary_fast<INV, NQ>), grid, dim3(ISF_THREADS), lds, stream, *P, ncols,  \
-                       recs, lutT, rcp, vhor, col_flags, prune, cost_table, index_table, cr)
+    const size_t lds = isk_unary_fast_lds_bytes(P, nvr);
+#define ISF_LAUNCH(INV, NVR)                                                                      \
+    hipLaunchKernelGGL((k_dp_unary_fast<INV, NVR>), grid, dim3(ISF_THREADS), lds, stream, *P, ncols, \
+                       recs, lutT, rcp, vhor, col_flags, prune, cost_table, index_table)
     if (P->invalid >= 0) {
-        if (small) ISF_LAUNCH(true, 2); else ISF_LAUNCH(true, ISF_MAXQ);
+        if (nvr == 2) ISF_LAUNCH(true, 2); else ISF_LAUNCH(true, 4);
     } else {
-        if (small) ISF_LAUNCH(false, 2); else ISF_LAUNCH(false, ISF_MAXQ);
+        if (nvr == 2) ISF_LAUNCH(false, 2); else ISF_LAUNCH(false, 4);
     }
 #undef ISF_LAUNCH
     return hipGetLastError();

@@ -13,5 +13,5 @@ finally:
     L.isk_debug_phases(out, 1)
     v = list(out)
     tot = sum(v[:4]) or 1
-    print("phases (cycles of wave 0 per WG, summed): prologue %.3g process %.3g store+barrier %.3g merge %.3g  -> %s; chunks %d" % (
+    print("phases (cycles of wave 0 per WG, summed): prologue %.3g loop %.3g wait-for-waves %.3g merge %.3g  -> %s; (%d)" % (
         v[0], v[1], v[2], v[3], ["%.1f%%" % (100.0 * x / tot) for x in v[:4]], v[5]))
