@@ -166,7 +166,7 @@ __device__ __forceinline__ void pairwise_step(const DevParams& P, const StepVals
                                               bool live, float od, const SegTerms& t, PairBest& b) {
     /* ALL_LANES (phase 1): every lane with vT < H is live and rows vT >= H are never stored */
     constexpr bool CMPX = IS_CMPX_UPDATE && ALL_LANES;
-    static_assert(!DESC || CMPX, "descending walks are whole-wave steps");
+    /* (a DESC walk without the v_cmpx form compares with <= as well) */
     if (SKY) { /* :729-775 */
         const float cost = P.dw * t.sd + st.pwmp + P.sw * t.seg_s;
         if (CMPX && DESC) {
@@ -174,7 +174,7 @@ __device__ __forceinline__ void pairwise_step(const DevParams& P, const StepVals
         } else if (CMPX) {
             take_if_less(b.s, b.is, cost, st.idx_gs);
         } else {
-            const bool u = live && (cost < b.s);
+            const bool u = live && (DESC ? (cost <= b.s) : (cost < b.s));
             b.s = u ? cost : b.s;
             b.is = u ? st.idx_gs : b.is;
         }
@@ -185,7 +185,7 @@ __device__ __forceinline__ void pairwise_step(const DevParams& P, const StepVals
         } else if (CMPX) {
             take_if_less(b.g, b.ig, cost, st.idx_gs);
         } else {
-            const bool u = live && (cost < b.g);
+            const bool u = live && (DESC ? (cost <= b.g) : (cost < b.g));
             b.g = u ? cost : b.g;
             b.ig = u ? st.idx_gs : b.ig;
         }
@@ -207,7 +207,7 @@ __device__ __forceinline__ void pairwise_step(const DevParams& P, const StepVals
     } else if (CMPX) {
         take_if_less_v(b.o, b.io, cost, idx);
     } else {
-        const bool u = live && (cost < b.o);
+        const bool u = live && (DESC ? (cost <= b.o) : (cost < b.o));
         b.o = u ? cost : b.o;
         b.io = u ? idx : b.io;
     }
@@ -420,11 +420,13 @@ __global__ __launch_bounds__(IS_UNARY_WAVES * 64, IS_UNARY_WAVES) void k_pw_phas
     const RowRec* __restrict__ recs, const float* __restrict__ lutT,
     const StepRec* __restrict__ steps, const float* __restrict__ rcp,
     const int* __restrict__ vhor_arr, const int* __restrict__ col_flags,
-    const PruneRec* __restrict__ prune, float* __restrict__ part_cost, int* __restrict__ part_idx) {
+    const PruneRec* __restrict__ prune, float* __restrict__ part_cost, int* __restrict__ part_idx,
+    int fast_elsewhere) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int colg = col_base + (int)(blockIdx.x / (unsigned)nsplit);
     const int split = __builtin_amdgcn_readfirstlane((int)(blockIdx.x % (unsigned)nsplit));
     if (colg >= ncols) return;
+    if (fast_elsewhere && __builtin_amdgcn_readfirstlane(col_flags[colg]) == 0) return; /* k_pw_phase1_ring */
     const int vhor = __builtin_amdgcn_readfirstlane(vhor_arr[colg / P.C]);
     if (__builtin_amdgcn_readfirstlane(col_flags[colg]) == 0)
         pw_phase1_body<true, HAS_INVALID, NR>(P, smem, colg, tile, recs, lutT, steps, rcp, vhor, split,
@@ -571,6 +573,184 @@ __global__ __launch_bounds__(64) void k_pw_phase2(
 }
 
 
+
+__device__ __forceinline__ StepVals lds_step(const float* p) {
+    const float4* q = reinterpret_cast<const float4*>(p);
+    const float4 a = q[0], b = q[1], c = q[2], d = q[3];
+    StepVals r;
+    r.pwmp = a.x; r.idx_gs = __builtin_bit_cast(int, a.y); r.g_hi_thr = a.z; r.g_lo_thr = a.w;
+    r.p1_hi = b.x; r.p1_lo = b.y; r.p1_mid = b.z; r.o_hi_thr = b.w;
+    r.o_lo_thr = c.x; r.p2_hi = c.y; r.p2_lo = c.z; r.p2_mid = c.w;
+    r.p3_yes = d.x; r.p3_no = d.y; r.q_o = d.z; r.q_gs = d.w;
+    return r;
+}
+
+/* ====================================================================================== */
+/* Phase 1 of FAST columns with a wave-private LDS-DMA ring                                */
+/* ====================================================================================== */
+/* Same walk as the FAST branch of pw_phase1_body (vB downwards, branch-and-bound), but nothing
+ * inside the step loop waits for global memory: every wave owns a ring of K slots holding the
+ * lutT row, the 128-byte record and the 64-byte StepRec of one vB, filled by LDS-DMA K steps
+ * ahead (see is_k_unary_fast.hip for the mechanism).  Record and StepRec come out of LDS with
+ * broadcast ds_read_b128; 2 workgroups per CU, <= 128 VGPRs, no scratch. */
+#define ISP_RING 7        /* slots per wave */
+#define ISP_STEP_F 16     /* floats of a StepRec slot */
+
+template <int NVR>
+__device__ __forceinline__ void p1_ring_prefetch(const float* __restrict__ lcol,
+                                                 const RowRec* __restrict__ rcol,
+                                                 const StepRec* __restrict__ scol, int vB, int D,
+                                                 float* slot, int lane) {
+    constexpr int ROWF = 64 * NVR;
+    const float* row = lcol + (size_t)vB * D;
+    const unsigned base = lds_addr(slot);
+#pragma unroll
+    for (int j = 0; j < NVR; j++) {
+        const int f = min(lane + 64 * j, D - 1);
+        dma_dword(row + f, base + 256 * j);
+    }
+    /* lanes 0..31: the record, lanes 32..47: the StepRec (vB = 0 has none: its slot content is
+     * never read) -- ONE instruction: a lane's dword goes to base + 4 * lane */
+    const float* src = (lane < ISF_REC_F) ? ((const float*)(rcol + vB) + lane)
+                                          : ((const float*)(scol + max(vB, 1)) + (lane - ISF_REC_F));
+    if (lane < ISF_REC_F + ISP_STEP_F) dma_dword(src, base + 4 * ROWF);
+}
+
+template <bool HAS_INVALID, int NVR>
+__global__ __launch_bounds__(IS_UNARY_WAVES * 64, 4) void k_pw_phase1_ring(
+    const DevParams P, int col_base, int ncols, int tile, int nsplit,
+    const RowRec* __restrict__ recs, const float* __restrict__ lutT,
+    const StepRec* __restrict__ steps, const float* __restrict__ rcp,
+    const int* __restrict__ vhor_arr, const int* __restrict__ col_flags,
+    const PruneRec* __restrict__ prune, float* __restrict__ part_cost, int* __restrict__ part_idx) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int colg = col_base + (int)(blockIdx.x / (unsigned)nsplit);
+    const int split = __builtin_amdgcn_readfirstlane((int)(blockIdx.x % (unsigned)nsplit));
+    if (colg >= ncols) return;
+    if (__builtin_amdgcn_readfirstlane(col_flags[colg]) != 0) return; /* generic: k_pw_phase1 */
+    const int vhor = __builtin_amdgcn_readfirstlane(vhor_arr[colg / P.C]);
+    const int H = P.H, D = P.D;
+    const int DP = D + 1;
+    constexpr int K = ISP_RING;
+    constexpr int ROWF = 64 * NVR;
+    constexpr int SLOT = ROWF + ISF_REC_F + ISP_STEP_F;
+    constexpr int NV = NVR + 1; /* VMEM instructions per prefetched slot */
+    float* s_tile = (float*)smem;                         /* [64][D+1] */
+    float* s_rcp = s_tile + ((IS_TILE * DP + 3) & ~3);    /* [H+1 -> x4] */
+    float* s_ring = s_rcp + ((H + 1 + 3) & ~3);           /* [waves][K][SLOT] */
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int nwl = blockDim.x >> 6;
+    const int wl = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nw = nwl * nsplit;
+    const int w = split * nwl + wl;
+    const int tile_lo = tile * IS_TILE;
+    const RowRec* rcol = recs + (size_t)colg * (H + 1);
+    const float* lcol = lutT + (size_t)colg * (H + 1) * D;
+    const StepRec* scol = steps + (size_t)colg * H;
+    float* my_ring = s_ring + (size_t)wl * K * SLOT;
+    const int vB_last = min(tile_lo, H - 1);
+    const int vT = tile_lo + lane;
+    const int vTc = min(vT, H - 1);
+    const bool live = vT < H;
+    const bool active = w <= vB_last; /* wave-uniform: the wave has steps at all */
+    const int vB_top = active ? vB_last - (vB_last - w) % nw : 0;
+
+    if (active) {
+#pragma unroll
+        for (int i = 0; i < K; i++)
+            p1_ring_prefetch<NVR>(lcol, rcol, scol, max(vB_top - nw * i, 0), D, my_ring + i * SLOT, lane);
+    }
+    const RowRec my = load_rec(rcol + vTc + 1);
+    for (int i = tid; i <= H; i += blockDim.x) s_rcp[i] = rcp[i];
+    stage_lut_tile<true>(s_tile, lcol, tile_lo, H, D, tid, (int)blockDim.x);
+    const float* my_tile = s_tile + lane * DP;
+
+    PairBest b;
+    b.g = b.o = b.s = IS_INF;
+    b.ig = b.is = -1;
+    b.io = IS_OBJECT; /* :592 */
+    cprune_t pq = (cprune_t)(prune + colg);
+    const float E1o = pq->E1o, E2 = pq->E2;
+    const float E1gs = __builtin_fmaxf(pq->E1g, pq->E1s);
+    const unsigned long long dead = ~__builtin_amdgcn_ballot_w64(live);
+    const unsigned long long gdead = dead | __builtin_amdgcn_ballot_w64(my.G == IS_INF);
+    const bool nog = IS_SKIP_GROUND_ABOVE_HORIZON && tile_lo >= vhor;
+    __syncthreads();
+
+    if (active) {
+        int slot = 0;
+        for (int vB = vB_top; vB >= 0; vB -= nw) {
+            wait_vmcnt<NV * (K - 1)>();
+            float* sl = my_ring + slot * SLOT;
+            const RowRec rb = lds_rec(sl + ROWF);
+            const float* lrow = sl;
+            const int h = vTc + 1 - vB;
+            const SegTerms t = eval_segment<true, HAS_INVALID>(my, rb, (float)h, s_rcp[h], D, P.iw);
+            const float od = my_tile[t.fni] - lrow[t.fni];
+            bool done = false;
+            if (vB == 0) { /* first segment, :481-594 (its bounds are part of q_o / q_gs) */
+                const bool below = vT <= vhor;
+                const float cost_g = P.dw * t.gd + P.pw * P.first_g + P.sw * t.seg_g;
+                const bool ug = live && below && (cost_g <= b.g);
+                b.g = ug ? cost_g : b.g;
+                b.ig = ug ? IS_GROUND : b.ig;
+                const float prior = below ? P.first_o_below : P.first_o_above;
+                const float cost = P.dw * od + P.pw * prior + P.sw * t.seg_o;
+                const bool uo = live && (cost <= b.o);
+                b.o = uo ? cost : b.o;
+                b.io = uo ? IS_OBJECT : b.io;
+            } else {
+                const StepVals st = lds_step(sl + ROWF + ISF_REC_F);
+                const float lb_o = (st.q_o - E1o) + P.sw * __builtin_fminf(t.f_on, t.f_oi - E2);
+                if (vB > vhor) { /* sky range: vB - 1 >= vhor */
+                    pairwise_step<true, false, false, true>(P, st, vB, live, od, t, b);
+                    unsigned long long ok = __builtin_amdgcn_ballot_w64(lb_o > b.o) | dead;
+                    const float lb_s = (st.q_gs - E1gs) + P.sw * t.f_sky;
+                    ok &= __builtin_amdgcn_ballot_w64(lb_s > b.s) | dead;
+                    done = ok == ~0ull;
+                } else if (nog) { /* ground range of a tile at / above the horizon: object only */
+                    pairwise_step<false, false, true, true>(P, st, vB, live, od, t, b);
+                    done = (__builtin_amdgcn_ballot_w64(lb_o > b.o) | dead) == ~0ull;
+                } else {
+                    pairwise_step<false, false, false, true>(P, st, vB, live, od, t, b);
+                    unsigned long long ok = __builtin_amdgcn_ballot_w64(lb_o > b.o) | dead;
+                    const float lb_g = (st.q_gs - E1gs) + P.sw * t.f_g;
+                    ok &= __builtin_amdgcn_ballot_w64(lb_g > b.g) | gdead;
+                    done = ok == ~0ull;
+                }
+            }
+            if (IS_PRUNE && done) break;
+            asm volatile("" ::: "memory");
+            p1_ring_prefetch<NVR>(lcol, rcol, scol, max(vB - nw * K, 0), D, sl, lane);
+            slot = (slot + 1 == K) ? 0 : slot + 1;
+        }
+    }
+    /* merge the waves: min cost, ties -> smallest vB; the rings must be quiet before reuse */
+    wait_vmcnt<0>();
+    __syncthreads();
+    float* m_cost = s_ring;                          /* [nwl][3][64] */
+    int* m_idx = (int*)(m_cost + nwl * 3 * 64);      /* [nwl][3][64] */
+    m_cost[(wl * 3 + 0) * 64 + lane] = b.g; m_idx[(wl * 3 + 0) * 64 + lane] = b.ig;
+    m_cost[(wl * 3 + 1) * 64 + lane] = b.o; m_idx[(wl * 3 + 1) * 64 + lane] = b.io;
+    m_cost[(wl * 3 + 2) * 64 + lane] = b.s; m_idx[(wl * 3 + 2) * 64 + lane] = b.is;
+    __syncthreads();
+    if (tid < 3 * 64) {
+        const int type = tid >> 6;
+        float c = m_cost[(0 * 3 + type) * 64 + lane];
+        int ix = m_idx[(0 * 3 + type) * 64 + lane];
+        for (int ww = 1; ww < nwl; ww++) {
+            const float c2 = m_cost[(ww * 3 + type) * 64 + lane];
+            const int ix2 = m_idx[(ww * 3 + type) * 64 + lane];
+            const bool take = (c2 < c) || (c2 == c && c2 < IS_INF && (ix2 / 3) < (ix / 3));
+            if (take) { c = c2; ix = ix2; }
+        }
+        if (!(c < IS_INF)) ix = (type == IS_OBJECT) ? IS_OBJECT : -1;
+        const size_t o = (((size_t)colg * nsplit + split) * 3 + type) * 64 + lane;
+        part_cost[o] = c;
+        part_idx[o] = ix;
+    }
+}
+
 /* ====================================================================================== */
 /* Phase 2 with TWO columns per wavefront                                                  */
 /* ====================================================================================== */
@@ -584,17 +764,6 @@ __global__ __launch_bounds__(64) void k_pw_phase2(
  * What was wave-uniform (the vB record, the StepRec, previous_mean, the logarithms) is now uniform
  * per half and lives in VGPRs; both columns belong to the same image (even C), so the ground / sky
  * switch stays a scalar branch.  FAST columns only; other pairs are left to k_pw_phase2. */
-__device__ __forceinline__ StepVals lds_step(const float* p) {
-    const float4* q = reinterpret_cast<const float4*>(p);
-    const float4 a = q[0], b = q[1], c = q[2], d = q[3];
-    StepVals r;
-    r.pwmp = a.x; r.idx_gs = __builtin_bit_cast(int, a.y); r.g_hi_thr = a.z; r.g_lo_thr = a.w;
-    r.p1_hi = b.x; r.p1_lo = b.y; r.p1_mid = b.z; r.o_hi_thr = b.w;
-    r.o_lo_thr = c.x; r.p2_hi = c.y; r.p2_lo = c.z; r.p2_mid = c.w;
-    r.p3_yes = d.x; r.p3_no = d.y; r.q_o = d.z; r.q_gs = d.w;
-    return r;
-}
-
 template <bool HAS_INVALID>
 __global__ __launch_bounds__(64) void k_pw_phase2x2(
     const DevParams P, int col_base, int ncols, int tile, int nsplit,
@@ -736,6 +905,15 @@ __global__ __launch_bounds__(64) void k_pw_phase2x2(
 extern "C" {
 
 size_t isk_pairwise_lds_bytes(const DevParams* P, int nwaves) { return isk_unary_lds_bytes(P); }
+size_t isk_phase1_ring_lds_bytes(const DevParams* P, int nwaves, int nvr) {
+    const size_t DP = (size_t)P->D + 1;
+    const size_t tile = ((size_t)IS_TILE * DP + 3) & ~(size_t)3;
+    const size_t rcp = ((size_t)P->H + 1 + 3) & ~(size_t)3;
+    size_t ring = (size_t)nwaves * ISP_RING * (64 * (size_t)nvr + ISF_REC_F + ISP_STEP_F);
+    const size_t merge = (size_t)nwaves * 3 * 64 * 2;
+    if (ring < merge) ring = merge;
+    return sizeof(float) * (tile + rcp + ring) + 16;
+}
 size_t isk_phase2x2_lds_bytes(const DevParams* P) {
     const size_t sv = (P->invalid >= 0 ? 4 : 2) * ((size_t)P->H + 1);
     return sizeof(double) * 2 * IS_LOG_TABLE_SIZE + sizeof(float) * (sv + P->D) + 16 +
@@ -765,6 +943,13 @@ hipError_t isk_launch_dp_pairwise(const DevParams* P, int ncols, int nwaves, con
     const size_t lds1 = isk_pairwise_lds_bytes(P, nwaves);
     const size_t lds2 = isk_phase2_lds_bytes(P);
     const size_t lds2x2 = isk_phase2x2_lds_bytes(P);
+    /* FAST columns: the LDS-DMA ring kernel whenever the shape allows it */
+    int ring_nvr = P->D <= 128 ? 2 : (P->D <= 256 ? 4 : 0);
+    const size_t lds1r = isk_phase1_ring_lds_bytes(P, nwaves, ring_nvr);
+    if (lds1r > 160 * 1024 || nwaves != IS_UNARY_WAVES || getenv("IS_NO_RING_KERNEL")) ring_nvr = 0;
+    const int ring_nvr_all = ring_nvr;
+    int ring_from_tile = 0;
+    if (const char* e = getenv("IS_RING_FROM_TILE")) ring_from_tile = atoi(e);
     /* two columns per wave: the columns of a pair must share the image (even C) and the groups
      * below must start at even columns */
     /* (measured on MI355X, batch 64: 30.8 ms per step against 29.9 ms with one column per wave --
@@ -798,14 +983,24 @@ hipError_t isk_launch_dp_pairwise(const DevParams* P, int ncols, int nwaves, con
 #endif
 #define IS_LAUNCH_P1(INV, c0, c1, st)                                                              \
     do {                                                                                           \
+        if (ring_nvr == 2)                                                                         \
+            hipLaunchKernelGGL((k_pw_phase1_ring<INV, 2>), dim3(((c1) - (c0)) * nsplit),           \
+                               dim3(nwaves * 64), lds1r, st, *P, c0, c1, tile, nsplit, recs, lutT, \
+                               steps, rcp, vhor, col_flags, prune, part_cost, part_idx);           \
+        else if (ring_nvr == 4)                                                                    \
+            hipLaunchKernelGGL((k_pw_phase1_ring<INV, 4>), dim3(((c1) - (c0)) * nsplit),           \
+                               dim3(nwaves * 64), lds1r, st, *P, c0, c1, tile, nsplit, recs, lutT, \
+                               steps, rcp, vhor, col_flags, prune, part_cost, part_idx);           \
         if (IS_PW_PHASE1_ROW_REGS && P->D <= 128)                                                  \
             hipLaunchKernelGGL((k_pw_phase1<INV, 2>), dim3(((c1) - (c0)) * nsplit),                \
                                dim3(nwaves * 64), lds1, st, *P, c0, c1, tile, nsplit, recs, lutT,  \
-                               steps, rcp, vhor, col_flags, prune, part_cost, part_idx);           \
+                               steps, rcp, vhor, col_flags, prune, part_cost, part_idx,            \
+                               ring_nvr != 0);                                                     \
         else                                                                                       \
             hipLaunchKernelGGL((k_pw_phase1<INV, 0>), dim3(((c1) - (c0)) * nsplit),                \
                                dim3(nwaves * 64), lds1, st, *P, c0, c1, tile, nsplit, recs, lutT,  \
-                               steps, rcp, vhor, col_flags, prune, part_cost, part_idx);           \
+                               steps, rcp, vhor, col_flags, prune, part_cost, part_idx,            \
+                               ring_nvr != 0);                                                     \
     } while (0)
 #define IS_LAUNCH_P2(INV, c0, c1, st)                                                              \
     do {                                                                                           \
@@ -825,6 +1020,7 @@ hipError_t isk_launch_dp_pairwise(const DevParams* P, int ncols, int nwaves, con
             if ((e = hipStreamWaitEvent(aux[g - 1], ev_fork, 0)) != hipSuccess) return e;
     }
     for (int tile = 0; tile < P->ntiles; tile++) {
+        ring_nvr = tile >= ring_from_tile ? ring_nvr_all : 0;
         for (int g = 0; g < groups; g++) {
             const int c0 = (int)((long long)ncols * g / groups) & ~1;
             const int c1 = g + 1 == groups ? ncols : ((int)((long long)ncols * (g + 1) / groups) & ~1);
@@ -852,6 +1048,17 @@ hipError_t isk_set_lds_pairwise(const DevParams* P, int nwaves_pair) {
     e = hipFuncSetAttribute((const void*)k_pw_phase1<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, c);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void*)k_pw_phase1<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, c);
+    if (e != hipSuccess) return e;
+    for (int nvr = 2; nvr <= 4; nvr += 2) {
+        const size_t r = isk_phase1_ring_lds_bytes(P, nwaves_pair, nvr);
+        if (r > 160 * 1024) continue;
+        const void* f1 = nvr == 2 ? (const void*)k_pw_phase1_ring<true, 2> : (const void*)k_pw_phase1_ring<true, 4>;
+        const void* f0 = nvr == 2 ? (const void*)k_pw_phase1_ring<false, 2> : (const void*)k_pw_phase1_ring<false, 4>;
+        e = hipFuncSetAttribute(f1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)r);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute(f0, hipFuncAttributeMaxDynamicSharedMemorySize, (int)r);
+        if (e != hipSuccess) return e;
+    }
     return e;
 }
 

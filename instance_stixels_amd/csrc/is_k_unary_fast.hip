@@ -31,15 +31,6 @@ struct UnaryBestF {
     int vg, vo, vs;
 };
 
-__device__ __forceinline__ RowRec lds_rec(const float* p) {
-    RowRec r;
-    const float4* s = reinterpret_cast<const float4*>(p);
-    float4* d = reinterpret_cast<float4*>(&r);
-#pragma unroll
-    for (int i = 0; i < 8; i++) d[i] = s[i];
-    return r;
-}
-
 /* One (vB, vT) evaluation; semantics of unary_step (is_k_unary.hip) with the `<=` update of a
  * descending walk.  lrow: the lutT row of vB in LDS. */
 template <bool HAS_INVALID, bool SKY, bool DIAG, bool FIRST, bool NOGROUND>
@@ -128,41 +119,6 @@ extern "C" void isk_debug_phases(unsigned long long* out, int reset) {
 #define ISF_MARK_INIT()
 #define ISF_MARK(k)
 #endif
-
-typedef __attribute__((address_space(3))) void* isf_lds_t;
-typedef const __attribute__((address_space(1))) void* isf_glb_t;
-
-#define ISF_RING 8     /* slots per wave: prefetch distance in steps */
-#define ISF_REC_F 32   /* floats of a record slot */
-
-/* s_waitcnt vmcnt(n), expcnt / lgkmcnt untouched (gfx9 encoding) */
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
-    __builtin_amdgcn_s_waitcnt((N & 0xF) | ((N >> 4) << 14) | (7 << 4) | (0xF << 8));
-    asm volatile("" ::: "memory"); /* the LDS reads of the slot stay behind the wait */
-}
-
-/* One LDS-DMA instruction: lane l's dword at gaddr goes to LDS byte address lds_base + 4 l.
- * Written as inline assembly on purpose: for `__builtin_amdgcn_global_load_lds` the compiler
- * inserts s_waitcnt vmcnt(0) in front of every LDS read that might alias the target -- here all of
- * them --, which would wait for the youngest prefetch at every step and serialise the ring.  The
- * waits are placed by hand instead (wait_vmcnt). */
-#pragma clang diagnostic push
-#pragma clang diagnostic ignored "-Winline-asm" /* m0 is the DMA's LDS base: clobbered on purpose */
-__device__ __forceinline__ void dma_dword(const float* gaddr, unsigned lds_base) {
-    asm volatile("s_mov_b32 m0, %1\n\t"
-                 "s_nop 0\n\t"
-                 "global_load_lds_dword %0, off"
-                 :
-                 : "v"(gaddr), "s"(lds_base)
-                 : "memory", "m0");
-}
-#pragma clang diagnostic pop
-
-__device__ __forceinline__ unsigned lds_addr(const float* p) {
-    return __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(isf_lds_t)p);
-}
 
 /* LDS-DMA of the lutT row and the record of vB into one ring slot: NVR + 1 VMEM instructions,
  * always issued (a uniform count for wait_vmcnt), no registers, no waiting. */

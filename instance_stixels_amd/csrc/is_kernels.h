@@ -48,6 +48,7 @@ size_t isk_unary_lds_bytes(const DevParams* P);
 size_t isk_pairwise_lds_bytes(const DevParams* P, int nwaves);
 size_t isk_phase2_lds_bytes(const DevParams* P);
 size_t isk_phase2x2_lds_bytes(const DevParams* P);
+size_t isk_phase1_ring_lds_bytes(const DevParams* P, int nwaves, int nvr);
 size_t isk_unary_fast_lds_bytes(const DevParams* P, int chunk_rows);
 int isk_unary_fast_chunk_rows(const DevParams* P);
 hipError_t isk_set_lds_unary_fast(const DevParams* P);
@@ -316,5 +317,54 @@ __device__ __forceinline__ void take_if_less_v(float& best, int& best_v, float c
         : [c] "v"(cost), [v] "v"(v)
         : "vcc");
 }
+
+/* ====================================================================================== */
+/* Wave-private LDS rings filled by LDS-DMA (is_k_unary_fast.hip, k_pw_phase1_ring)         */
+/* ====================================================================================== */
+#define ISF_RING 8     /* slots per wave: prefetch distance in steps (unary) */
+#define ISF_REC_F 32   /* floats of a record slot */
+
+typedef __attribute__((address_space(3))) void* isf_lds_t;
+typedef const __attribute__((address_space(1))) void* isf_glb_t;
+
+
+/* s_waitcnt vmcnt(n), expcnt / lgkmcnt untouched (gfx9 encoding) */
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+    __builtin_amdgcn_s_waitcnt((N & 0xF) | ((N >> 4) << 14) | (7 << 4) | (0xF << 8));
+    asm volatile("" ::: "memory"); /* the LDS reads of the slot stay behind the wait */
+}
+
+/* One LDS-DMA instruction: lane l's dword at gaddr goes to LDS byte address lds_base + 4 l.
+ * Written as inline assembly on purpose: for `__builtin_amdgcn_global_load_lds` the compiler
+ * inserts s_waitcnt vmcnt(0) in front of every LDS read that might alias the target -- here all of
+ * them --, which would wait for the youngest prefetch at every step and serialise the ring.  The
+ * waits are placed by hand instead (wait_vmcnt). */
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm" /* m0 is the DMA's LDS base: clobbered on purpose */
+__device__ __forceinline__ void dma_dword(const float* gaddr, unsigned lds_base) {
+    asm volatile("s_mov_b32 m0, %1\n\t"
+                 "s_nop 0\n\t"
+                 "global_load_lds_dword %0, off"
+                 :
+                 : "v"(gaddr), "s"(lds_base)
+                 : "memory", "m0");
+}
+#pragma clang diagnostic pop
+
+__device__ __forceinline__ unsigned lds_addr(const float* p) {
+    return __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(isf_lds_t)p);
+}
+
+__device__ __forceinline__ RowRec lds_rec(const float* p) {
+    RowRec r;
+    const float4* s = reinterpret_cast<const float4*>(p);
+    float4* d = reinterpret_cast<float4*>(&r);
+#pragma unroll
+    for (int i = 0; i < 8; i++) d[i] = s[i];
+    return r;
+}
+
 
 #endif /* IS_KERNELS_H_ */
