@@ -68,32 +68,20 @@ __device__ __forceinline__ float readlane_f(float x, int l) {
 /* -is_logf(v) + is_logf(v2) (NegFastLogDiv, :35-38) for TWO argument pairs at once: the lower
  * half of the wave evaluates pair A, the upper half pair B, so the serial chain pays for one
  * logarithm instead of two.  v is a compile-time-like constant whose log is passed in. */
-template <bool TWO_COLS = false>
 __device__ __forceinline__ void neg_fastlog_div2(float neg_log_va, float v2a, float neg_log_vb,
                                                  float v2b, const double* s_invc,
                                                  const double* s_logc, float* outa, float* outb) {
-    if (TWO_COLS) {
-        /* two columns per wave (one per 32-lane half): the quarters of the wave evaluate the two
-         * logarithms of their half's column */
-        const int lane = threadIdx.x;
-        const float arg = (lane & 16) ? v2b : v2a;
-        const float l = is_logf_t(arg, s_invc, s_logc);
-        const float la = __shfl(l, lane & 32, 64), lb = __shfl(l, (lane & 32) + 16, 64);
-        *outa = neg_log_va + la;
-        *outb = neg_log_vb + lb;
-    } else {
-        const bool upper = threadIdx.x >= 32;
-        const float arg = upper ? v2b : v2a;
-        const float l = is_logf_t(arg, s_invc, s_logc);
-        const float la = readlane_f(l, 0), lb = readlane_f(l, 32);
-        *outa = neg_log_va + la;
-        *outb = neg_log_vb + lb;
-    }
+    const bool upper = threadIdx.x >= 32;
+    const float arg = upper ? v2b : v2a;
+    const float l = is_logf_t(arg, s_invc, s_logc);
+    const float la = readlane_f(l, 0), lb = readlane_f(l, 32);
+    *outa = neg_log_va + la;
+    *outb = neg_log_vb + lb;
 }
 
 /* StepRec of vB = r + 1 from the final row r.  All inputs are wave-uniform; every lane computes
  * the same values.  s_S / s_V: the column's disparity / valid-count prefixes in LDS. */
-template <bool HAS_INVALID, bool TWO_COLS = false>
+template <bool HAS_INVALID>
 __device__ __forceinline__ StepVals make_step(const DevParams& P, const float* s_S, const float* s_V,
                                              const float* s_odr, const double* s_invc,
                                              const double* s_logc, cprior_t pr, int vhor, int r,
@@ -141,8 +129,8 @@ __device__ __forceinline__ StepVals make_step(const DevParams& P, const float* s
     st.o_hi_thr = pm + dif;
     st.o_lo_thr = pm - dif;
     float nl_hi, nl_lo;
-    neg_fastlog_div2<TWO_COLS>(P.nlog_pord, P.max_disf - pm - dif, P.nlog_1mpord, st.o_lo_thr, s_invc,
-                               s_logc, &nl_hi, &nl_lo);
+    neg_fastlog_div2(P.nlog_pord, P.max_disf - pm - dif, P.nlog_1mpord, st.o_lo_thr, s_invc, s_logc,
+                     &nl_hi, &nl_lo);
     st.p2_hi = cO + pw * (base + nl_hi);
     st.p2_lo = cO + pw * (base + nl_lo);
     st.p2_mid = cO + pw * IS_INF;
@@ -166,7 +154,7 @@ __device__ __forceinline__ void pairwise_step(const DevParams& P, const StepVals
                                               bool live, float od, const SegTerms& t, PairBest& b) {
     /* ALL_LANES (phase 1): every lane with vT < H is live and rows vT >= H are never stored */
     constexpr bool CMPX = IS_CMPX_UPDATE && ALL_LANES;
-    /* (a DESC walk without the v_cmpx form compares with <= as well) */
+    static_assert(!DESC || CMPX, "descending walks are whole-wave steps");
     if (SKY) { /* :729-775 */
         const float cost = P.dw * t.sd + st.pwmp + P.sw * t.seg_s;
         if (CMPX && DESC) {
@@ -174,7 +162,7 @@ __device__ __forceinline__ void pairwise_step(const DevParams& P, const StepVals
         } else if (CMPX) {
             take_if_less(b.s, b.is, cost, st.idx_gs);
         } else {
-            const bool u = live && (DESC ? (cost <= b.s) : (cost < b.s));
+            const bool u = live && (cost < b.s);
             b.s = u ? cost : b.s;
             b.is = u ? st.idx_gs : b.is;
         }
@@ -185,7 +173,7 @@ __device__ __forceinline__ void pairwise_step(const DevParams& P, const StepVals
         } else if (CMPX) {
             take_if_less(b.g, b.ig, cost, st.idx_gs);
         } else {
-            const bool u = live && (DESC ? (cost <= b.g) : (cost < b.g));
+            const bool u = live && (cost < b.g);
             b.g = u ? cost : b.g;
             b.ig = u ? st.idx_gs : b.ig;
         }
@@ -207,7 +195,7 @@ __device__ __forceinline__ void pairwise_step(const DevParams& P, const StepVals
     } else if (CMPX) {
         take_if_less_v(b.o, b.io, cost, idx);
     } else {
-        const bool u = live && (DESC ? (cost <= b.o) : (cost < b.o));
+        const bool u = live && (cost < b.o);
         b.o = u ? cost : b.o;
         b.io = u ? idx : b.io;
     }
@@ -286,7 +274,16 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
             int vB = vB_last - (vB_last - w) % nw; /* the wave's largest vB */
             LutRow<NR> next_row;
             load_lut_row<NR>(next_row, lrsrc, lcol, vB, D, lane4);
-            bool done = false;
+            /* The bounds are sticky per type (a bound that holds at vB holds at every smaller vB:
+             * the class minima only grow, the running minima q only grow, the best cost cannot
+             * change any more).  The OBJECT bound -- minimum over the object classes only --
+             * explodes as soon as the segment leaves an object, long before the ground / sky bound
+             * of a homogeneous road or sky region does (there every split is a near-optimal
+             * candidate, nothing can be pruned).  Once the object type is closed the remaining
+             * candidates are ground / sky ones: two class differences, no instance term, no mean,
+             * no LUT access -- a fifth of the instructions of a full step; they are evaluated FOUR
+             * vB at a time so that one scalar-load latency covers four steps. */
+            bool done = false, o_closed = false;
 #define IS_P1_STEP(SKY, NOG)                                                                       \
             const RowRec rb = sload_rec(rcol + vB);                                                \
             const StepVals st = sload_step(scol + vB);                                             \
@@ -297,27 +294,76 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
             const float od = my_tile[t.fni] - pick_lut<NR>(row, t.fni);                            \
             pairwise_step<SKY, true, NOG, true>(P, st, vB, live, od, t, b);                        \
             const float lb_o = (st.q_o - E1o) + P.sw * __builtin_fminf(t.f_on, t.f_oi - E2);       \
-            unsigned long long ok = __builtin_amdgcn_ballot_w64(lb_o > b.o) | dead
-            for (; vB >= max(vhor + 1, 1); vB -= nw) { /* sky range: vB - 1 >= vhor */
+            const bool ok_o = (__builtin_amdgcn_ballot_w64(lb_o > b.o) | dead) == ~0ull
+            /* ground / sky candidates of up to four vB (vB, vB - nw, ...) >= lo; closes `x_closed`
+             * when the bound of the last one holds; leaves vB at the next unvisited value */
+#define IS_P1_GS4(SKY, lo, x_dead, x_closed)                                                       \
+            {                                                                                      \
+                const int n_here = min(4, (vB - (lo)) / nw + 1);                                   \
+                float c_f[4], c_cost[4];                                                           \
+                int c_idx[4];                                                                      \
+                float c_q[4];                                                                      \
+                _Pragma("unroll") for (int j = 0; j < 4; j++) {                                    \
+                    const int vj = max(vB - j * nw, (lo)); /* clamped: the loads are unconditional */ \
+                    crec_t rq = (crec_t)(rcol + vj);                                               \
+                    cstep_t sq = (cstep_t)(scol + vj);                                             \
+                    const float nic = P.iw * (float)(my.Fnic - rq->Fnic);                          \
+                    c_f[j] = (SKY) ? (my.Fsky - rq->Fsky)                                          \
+                                   : __builtin_fminf(my.Fg0 - rq->Fg0, my.Fg1 - rq->Fg1);         \
+                    const float data = (SKY) ? (my.K - rq->K) : (my.G - rq->G);                    \
+                    c_cost[j] = P.dw * data + sq->pwmp + P.sw * (c_f[j] + nic);                    \
+                    c_idx[j] = sq->idx_gs;                                                         \
+                    c_q[j] = sq->q_gs;                                                             \
+                }                                                                                  \
+                float f_last = c_f[0], q_last = c_q[0];                                            \
+                _Pragma("unroll") for (int j = 0; j < 4; j++) {                                    \
+                    if (j < n_here) {                                                              \
+                        if (SKY) take_if_le(b.s, b.is, c_cost[j], c_idx[j]);                       \
+                        else take_if_le(b.g, b.ig, c_cost[j], c_idx[j]);                           \
+                        f_last = c_f[j]; q_last = c_q[j];                                          \
+                    }                                                                              \
+                }                                                                                  \
+                const float lb_x = (q_last - E1gs) + P.sw * f_last;                                \
+                if ((__builtin_amdgcn_ballot_w64(lb_x > ((SKY) ? b.s : b.g)) | (x_dead)) == ~0ull) \
+                    x_closed = true;                                                               \
+                vB -= n_here * nw;                                                                 \
+            }
+            const int sky_lo = max(vhor + 1, 1);
+            for (; vB >= sky_lo; vB -= nw) { /* sky range: vB - 1 >= vhor */
                 IS_P1_STEP(true, false);
                 const float lb_s = (st.q_gs - E1gs) + P.sw * t.f_sky;
-                ok &= __builtin_amdgcn_ballot_w64(lb_s > b.s) | dead;
-                if (ok == ~0ull) { done = true; break; }
+                const bool ok_s = (__builtin_amdgcn_ballot_w64(lb_s > b.s) | dead) == ~0ull;
+                if (ok_o && ok_s) { done = true; break; }
+                if (ok_o) { o_closed = true; vB -= nw; break; }
+            }
+            if (!done && o_closed) {
+                /* a tile with a sky range lies above the horizon: no ground candidates, and the
+                 * first segment's object candidate is closed too -- only sky candidates are left */
+                bool s_closed = false;
+                while (vB >= sky_lo && !s_closed) IS_P1_GS4(true, sky_lo, dead, s_closed)
+                done = true;
             }
             if (!done && nog) {
                 for (; vB >= 1; vB -= nw) { /* ground range, ground candidates are +inf */
                     IS_P1_STEP(false, true);
-                    if (ok == ~0ull) { done = true; break; }
+                    if (ok_o) { done = true; break; }
                 }
             } else if (!done) {
                 for (; vB >= 1; vB -= nw) { /* ground range: vB - 1 < vhor */
                     IS_P1_STEP(false, false);
                     const float lb_g = (st.q_gs - E1gs) + P.sw * t.f_g;
-                    ok &= __builtin_amdgcn_ballot_w64(lb_g > b.g) | gdead;
-                    if (ok == ~0ull) { done = true; break; }
+                    const bool ok_g = (__builtin_amdgcn_ballot_w64(lb_g > b.g) | gdead) == ~0ull;
+                    if (ok_o && ok_g) { done = true; break; }
+                    if (ok_o) { o_closed = true; vB -= nw; break; }
+                }
+                if (!done && o_closed) {
+                    bool g_closed = false;
+                    while (vB >= 1 && !g_closed) IS_P1_GS4(false, 1, gdead, g_closed)
+                    if (g_closed) done = true; /* else vB <= 0: the first segment is still to come */
                 }
             }
 #undef IS_P1_STEP
+#undef IS_P1_GS4
             if (!done && vB == 0) { /* first segment, :481-594 */
                 const RowRec rb = sload_rec(rcol);
                 const int h = vTc + 1;
@@ -420,13 +466,11 @@ __global__ __launch_bounds__(IS_UNARY_WAVES * 64, IS_UNARY_WAVES) void k_pw_phas
     const RowRec* __restrict__ recs, const float* __restrict__ lutT,
     const StepRec* __restrict__ steps, const float* __restrict__ rcp,
     const int* __restrict__ vhor_arr, const int* __restrict__ col_flags,
-    const PruneRec* __restrict__ prune, float* __restrict__ part_cost, int* __restrict__ part_idx,
-    int fast_elsewhere) {
+    const PruneRec* __restrict__ prune, float* __restrict__ part_cost, int* __restrict__ part_idx) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int colg = col_base + (int)(blockIdx.x / (unsigned)nsplit);
     const int split = __builtin_amdgcn_readfirstlane((int)(blockIdx.x % (unsigned)nsplit));
     if (colg >= ncols) return;
-    if (fast_elsewhere && __builtin_amdgcn_readfirstlane(col_flags[colg]) == 0) return; /* k_pw_phase1_ring */
     const int vhor = __builtin_amdgcn_readfirstlane(vhor_arr[colg / P.C]);
     if (__builtin_amdgcn_readfirstlane(col_flags[colg]) == 0)
         pw_phase1_body<true, HAS_INVALID, NR>(P, smem, colg, tile, recs, lutT, steps, rcp, vhor, split,
@@ -555,14 +599,10 @@ __global__ __launch_bounds__(64) void k_pw_phase2(
     const float* __restrict__ sv_arr, const int* __restrict__ vhor_arr,
     const int* __restrict__ col_flags, const float* __restrict__ part_cost,
     const int* __restrict__ part_idx, StepRec* __restrict__ steps, float* __restrict__ cost_table,
-    int32_t* __restrict__ index_table, int pairs_elsewhere) {
+    int32_t* __restrict__ index_table) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int colg = col_base + blockIdx.x;
     if (colg >= ncols) return;
-    /* pairs of FAST columns are walked by k_pw_phase2x2 (two columns per wave) */
-    if (pairs_elsewhere && __builtin_amdgcn_readfirstlane(col_flags[colg]) == 0 &&
-        __builtin_amdgcn_readfirstlane(col_flags[col_base + (((int)blockIdx.x) ^ 1)]) == 0)
-        return;
     const int vhor = __builtin_amdgcn_readfirstlane(vhor_arr[colg / P.C]);
     if (__builtin_amdgcn_readfirstlane(col_flags[colg]) == 0)
         pw_phase2_body<true, HAS_INVALID>(P, smem, colg, tile, recs, lutT, priors, odr, rcp, sv_arr, vhor,
@@ -572,353 +612,9 @@ __global__ __launch_bounds__(64) void k_pw_phase2(
                                            nsplit, part_cost, part_idx, steps, cost_table, index_table);
 }
 
-
-
-__device__ __forceinline__ StepVals lds_step(const float* p) {
-    const float4* q = reinterpret_cast<const float4*>(p);
-    const float4 a = q[0], b = q[1], c = q[2], d = q[3];
-    StepVals r;
-    r.pwmp = a.x; r.idx_gs = __builtin_bit_cast(int, a.y); r.g_hi_thr = a.z; r.g_lo_thr = a.w;
-    r.p1_hi = b.x; r.p1_lo = b.y; r.p1_mid = b.z; r.o_hi_thr = b.w;
-    r.o_lo_thr = c.x; r.p2_hi = c.y; r.p2_lo = c.z; r.p2_mid = c.w;
-    r.p3_yes = d.x; r.p3_no = d.y; r.q_o = d.z; r.q_gs = d.w;
-    return r;
-}
-
-/* ====================================================================================== */
-/* Phase 1 of FAST columns with a wave-private LDS-DMA ring                                */
-/* ====================================================================================== */
-/* Same walk as the FAST branch of pw_phase1_body (vB downwards, branch-and-bound), but nothing
- * inside the step loop waits for global memory: every wave owns a ring of K slots holding the
- * lutT row, the 128-byte record and the 64-byte StepRec of one vB, filled by LDS-DMA K steps
- * ahead (see is_k_unary_fast.hip for the mechanism).  Record and StepRec come out of LDS with
- * broadcast ds_read_b128; 2 workgroups per CU, <= 128 VGPRs, no scratch. */
-#define ISP_RING 7        /* slots per wave */
-#define ISP_STEP_F 16     /* floats of a StepRec slot */
-
-template <int NVR>
-__device__ __forceinline__ void p1_ring_prefetch(const float* __restrict__ lcol,
-                                                 const RowRec* __restrict__ rcol,
-                                                 const StepRec* __restrict__ scol, int vB, int D,
-                                                 float* slot, int lane) {
-    constexpr int ROWF = 64 * NVR;
-    const float* row = lcol + (size_t)vB * D;
-    const unsigned base = lds_addr(slot);
-#pragma unroll
-    for (int j = 0; j < NVR; j++) {
-        const int f = min(lane + 64 * j, D - 1);
-        dma_dword(row + f, base + 256 * j);
-    }
-    /* lanes 0..31: the record, lanes 32..47: the StepRec (vB = 0 has none: its slot content is
-     * never read) -- ONE instruction: a lane's dword goes to base + 4 * lane */
-    const float* src = (lane < ISF_REC_F) ? ((const float*)(rcol + vB) + lane)
-                                          : ((const float*)(scol + max(vB, 1)) + (lane - ISF_REC_F));
-    if (lane < ISF_REC_F + ISP_STEP_F) dma_dword(src, base + 4 * ROWF);
-}
-
-template <bool HAS_INVALID, int NVR>
-__global__ __launch_bounds__(IS_UNARY_WAVES * 64, 4) void k_pw_phase1_ring(
-    const DevParams P, int col_base, int ncols, int tile, int nsplit,
-    const RowRec* __restrict__ recs, const float* __restrict__ lutT,
-    const StepRec* __restrict__ steps, const float* __restrict__ rcp,
-    const int* __restrict__ vhor_arr, const int* __restrict__ col_flags,
-    const PruneRec* __restrict__ prune, float* __restrict__ part_cost, int* __restrict__ part_idx) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int colg = col_base + (int)(blockIdx.x / (unsigned)nsplit);
-    const int split = __builtin_amdgcn_readfirstlane((int)(blockIdx.x % (unsigned)nsplit));
-    if (colg >= ncols) return;
-    if (__builtin_amdgcn_readfirstlane(col_flags[colg]) != 0) return; /* generic: k_pw_phase1 */
-    const int vhor = __builtin_amdgcn_readfirstlane(vhor_arr[colg / P.C]);
-    const int H = P.H, D = P.D;
-    const int DP = D + 1;
-    constexpr int K = ISP_RING;
-    constexpr int ROWF = 64 * NVR;
-    constexpr int SLOT = ROWF + ISF_REC_F + ISP_STEP_F;
-    constexpr int NV = NVR + 1; /* VMEM instructions per prefetched slot */
-    float* s_tile = (float*)smem;                         /* [64][D+1] */
-    float* s_rcp = s_tile + ((IS_TILE * DP + 3) & ~3);    /* [H+1 -> x4] */
-    float* s_ring = s_rcp + ((H + 1 + 3) & ~3);           /* [waves][K][SLOT] */
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int nwl = blockDim.x >> 6;
-    const int wl = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nw = nwl * nsplit;
-    const int w = split * nwl + wl;
-    const int tile_lo = tile * IS_TILE;
-    const RowRec* rcol = recs + (size_t)colg * (H + 1);
-    const float* lcol = lutT + (size_t)colg * (H + 1) * D;
-    const StepRec* scol = steps + (size_t)colg * H;
-    float* my_ring = s_ring + (size_t)wl * K * SLOT;
-    const int vB_last = min(tile_lo, H - 1);
-    const int vT = tile_lo + lane;
-    const int vTc = min(vT, H - 1);
-    const bool live = vT < H;
-    const bool active = w <= vB_last; /* wave-uniform: the wave has steps at all */
-    const int vB_top = active ? vB_last - (vB_last - w) % nw : 0;
-
-    if (active) {
-#pragma unroll
-        for (int i = 0; i < K; i++)
-            p1_ring_prefetch<NVR>(lcol, rcol, scol, max(vB_top - nw * i, 0), D, my_ring + i * SLOT, lane);
-    }
-    const RowRec my = load_rec(rcol + vTc + 1);
-    for (int i = tid; i <= H; i += blockDim.x) s_rcp[i] = rcp[i];
-    stage_lut_tile<true>(s_tile, lcol, tile_lo, H, D, tid, (int)blockDim.x);
-    const float* my_tile = s_tile + lane * DP;
-
-    PairBest b;
-    b.g = b.o = b.s = IS_INF;
-    b.ig = b.is = -1;
-    b.io = IS_OBJECT; /* :592 */
-    cprune_t pq = (cprune_t)(prune + colg);
-    const float E1o = pq->E1o, E2 = pq->E2;
-    const float E1gs = __builtin_fmaxf(pq->E1g, pq->E1s);
-    const unsigned long long dead = ~__builtin_amdgcn_ballot_w64(live);
-    const unsigned long long gdead = dead | __builtin_amdgcn_ballot_w64(my.G == IS_INF);
-    const bool nog = IS_SKIP_GROUND_ABOVE_HORIZON && tile_lo >= vhor;
-    __syncthreads();
-
-    if (active) {
-        int slot = 0;
-        for (int vB = vB_top; vB >= 0; vB -= nw) {
-            wait_vmcnt<NV * (K - 1)>();
-            float* sl = my_ring + slot * SLOT;
-            const RowRec rb = lds_rec(sl + ROWF);
-            const float* lrow = sl;
-            const int h = vTc + 1 - vB;
-            const SegTerms t = eval_segment<true, HAS_INVALID>(my, rb, (float)h, s_rcp[h], D, P.iw);
-            const float od = my_tile[t.fni] - lrow[t.fni];
-            bool done = false;
-            if (vB == 0) { /* first segment, :481-594 (its bounds are part of q_o / q_gs) */
-                const bool below = vT <= vhor;
-                const float cost_g = P.dw * t.gd + P.pw * P.first_g + P.sw * t.seg_g;
-                const bool ug = live && below && (cost_g <= b.g);
-                b.g = ug ? cost_g : b.g;
-                b.ig = ug ? IS_GROUND : b.ig;
-                const float prior = below ? P.first_o_below : P.first_o_above;
-                const float cost = P.dw * od + P.pw * prior + P.sw * t.seg_o;
-                const bool uo = live && (cost <= b.o);
-                b.o = uo ? cost : b.o;
-                b.io = uo ? IS_OBJECT : b.io;
-            } else {
-                const StepVals st = lds_step(sl + ROWF + ISF_REC_F);
-                const float lb_o = (st.q_o - E1o) + P.sw * __builtin_fminf(t.f_on, t.f_oi - E2);
-                if (vB > vhor) { /* sky range: vB - 1 >= vhor */
-                    pairwise_step<true, false, false, true>(P, st, vB, live, od, t, b);
-                    unsigned long long ok = __builtin_amdgcn_ballot_w64(lb_o > b.o) | dead;
-                    const float lb_s = (st.q_gs - E1gs) + P.sw * t.f_sky;
-                    ok &= __builtin_amdgcn_ballot_w64(lb_s > b.s) | dead;
-                    done = ok == ~0ull;
-                } else if (nog) { /* ground range of a tile at / above the horizon: object only */
-                    pairwise_step<false, false, true, true>(P, st, vB, live, od, t, b);
-                    done = (__builtin_amdgcn_ballot_w64(lb_o > b.o) | dead) == ~0ull;
-                } else {
-                    pairwise_step<false, false, false, true>(P, st, vB, live, od, t, b);
-                    unsigned long long ok = __builtin_amdgcn_ballot_w64(lb_o > b.o) | dead;
-                    const float lb_g = (st.q_gs - E1gs) + P.sw * t.f_g;
-                    ok &= __builtin_amdgcn_ballot_w64(lb_g > b.g) | gdead;
-                    done = ok == ~0ull;
-                }
-            }
-            if (IS_PRUNE && done) break;
-            asm volatile("" ::: "memory");
-            p1_ring_prefetch<NVR>(lcol, rcol, scol, max(vB - nw * K, 0), D, sl, lane);
-            slot = (slot + 1 == K) ? 0 : slot + 1;
-        }
-    }
-    /* merge the waves: min cost, ties -> smallest vB; the rings must be quiet before reuse */
-    wait_vmcnt<0>();
-    __syncthreads();
-    float* m_cost = s_ring;                          /* [nwl][3][64] */
-    int* m_idx = (int*)(m_cost + nwl * 3 * 64);      /* [nwl][3][64] */
-    m_cost[(wl * 3 + 0) * 64 + lane] = b.g; m_idx[(wl * 3 + 0) * 64 + lane] = b.ig;
-    m_cost[(wl * 3 + 1) * 64 + lane] = b.o; m_idx[(wl * 3 + 1) * 64 + lane] = b.io;
-    m_cost[(wl * 3 + 2) * 64 + lane] = b.s; m_idx[(wl * 3 + 2) * 64 + lane] = b.is;
-    __syncthreads();
-    if (tid < 3 * 64) {
-        const int type = tid >> 6;
-        float c = m_cost[(0 * 3 + type) * 64 + lane];
-        int ix = m_idx[(0 * 3 + type) * 64 + lane];
-        for (int ww = 1; ww < nwl; ww++) {
-            const float c2 = m_cost[(ww * 3 + type) * 64 + lane];
-            const int ix2 = m_idx[(ww * 3 + type) * 64 + lane];
-            const bool take = (c2 < c) || (c2 == c && c2 < IS_INF && (ix2 / 3) < (ix / 3));
-            if (take) { c = c2; ix = ix2; }
-        }
-        if (!(c < IS_INF)) ix = (type == IS_OBJECT) ? IS_OBJECT : -1;
-        const size_t o = (((size_t)colg * nsplit + split) * 3 + type) * 64 + lane;
-        part_cost[o] = c;
-        part_idx[o] = ix;
-    }
-}
-
-/* ====================================================================================== */
-/* Phase 2 with TWO columns per wavefront                                                  */
-/* ====================================================================================== */
-/* Half of make_step's ~240 VALU instructions per serial step are wave-uniform work that all 64
- * lanes repeat, and the diagonal 64x64 block leaves half the lanes idle.  Here lanes 0..31 walk
- * column A and lanes 32..63 column B over 32-row sub-tiles:
- *     rows lo .. lo+31          32 serial steps (diagonal 32x32 block + StepRec of the next row)
- *     rows lo+32 .. lo+63       32 independent steps for the segments that start in the first
- *                               sub-tile (their StepRecs are kept in LDS), then 32 serial steps
- * i.e. 64 serial + 32 independent wave-steps per tile for TWO columns instead of 2 x 64 serial ones.
- * What was wave-uniform (the vB record, the StepRec, previous_mean, the logarithms) is now uniform
- * per half and lives in VGPRs; both columns belong to the same image (even C), so the ground / sky
- * switch stays a scalar branch.  FAST columns only; other pairs are left to k_pw_phase2. */
-template <bool HAS_INVALID>
-__global__ __launch_bounds__(64) void k_pw_phase2x2(
-    const DevParams P, int col_base, int ncols, int tile, int nsplit,
-    const RowRec* __restrict__ recs, const float* __restrict__ lutT,
-    const PriorRec* __restrict__ priors, const float* __restrict__ odr,
-    const float* __restrict__ rcp, const float* __restrict__ sv_arr,
-    const int* __restrict__ vhor_arr, const int* __restrict__ col_flags,
-    const float* __restrict__ part_cost, const int* __restrict__ part_idx,
-    StepRec* __restrict__ steps, float* __restrict__ cost_table, int32_t* __restrict__ index_table) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int colA = col_base + 2 * (int)blockIdx.x;
-    if (colA + 1 >= ncols) return; /* (ncols is even when this kernel is used) */
-    if ((__builtin_amdgcn_readfirstlane(col_flags[colA]) | __builtin_amdgcn_readfirstlane(col_flags[colA + 1])) != 0)
-        return; /* a generic column: both are walked by k_pw_phase2 */
-    const int H = P.H, D = P.D;
-    const int lane = threadIdx.x, half = lane >> 5, l = lane & 31, hb = lane & 32;
-    const int colg = colA + half;
-    const int vhor = __builtin_amdgcn_readfirstlane(vhor_arr[colA / P.C]);
-
-    double* s_invc = (double*)smem;                    /* [32] */
-    double* s_logc = s_invc + IS_LOG_TABLE_SIZE;       /* [32] */
-    float* s_S2 = (float*)(s_logc + IS_LOG_TABLE_SIZE); /* [2][H+1] */
-    float* s_V2 = s_S2 + 2 * (H + 1);                  /* [2][H+1], only with an invalid value */
-    float* s_odr = s_V2 + (HAS_INVALID ? 2 * (H + 1) : 0); /* [D] */
-    float* s_steps = (float*)(((uintptr_t)(s_odr + D) + 15) & ~(uintptr_t)15); /* [2][32][16] */
-    if (lane == 0) is_log_tables(s_invc, s_logc);
-    for (int i = lane; i < 2 * (H + 1); i += 64) {
-        const int c = i / (H + 1), k = i - c * (H + 1);
-        const float* sv = sv_arr + (size_t)(colA + c) * 2 * (H + 1);
-        s_S2[i] = sv[k];
-        if (HAS_INVALID) s_V2[i] = sv[H + 1 + k];
-    }
-    for (int i = lane; i < D; i += 64) s_odr[i] = odr[i];
-    const float* s_S = s_S2 + half * (H + 1);
-    const float* s_V = s_V2 + half * (H + 1);
-    float* my_steps = s_steps + half * 32 * 16;
-
-    const int tile_lo = tile * IS_TILE;
-    const RowRec* rcol = recs + (size_t)colg * (H + 1);
-    const float* lcol = lutT + (size_t)colg * (H + 1) * D;
-    const PriorRec* pcol = priors + (size_t)(colA / P.C) * H;
-    StepRec* scol = steps + (size_t)colg * H;
-    __syncthreads();
-
-    StepVals st;
-    st.pwmp = IS_INF; st.idx_gs = -1;
-    st.g_hi_thr = st.g_lo_thr = st.p1_hi = st.p1_lo = st.p1_mid = st.o_hi_thr = st.o_lo_thr = 0.0f;
-    st.p2_hi = st.p2_lo = st.p2_mid = st.p3_yes = st.p3_no = 0.0f;
-    float q_o, q_gs; /* running minima of the transition terms, see StepRec */
-    if (tile_lo == 0) {
-        q_o = P.pw * __builtin_fminf(P.first_o_below, P.first_o_above);
-        q_gs = P.pw * P.first_g;
-    } else {
-        q_o = scol[tile_lo].q_o;
-        q_gs = scol[tile_lo].q_gs;
-    }
-    st.q_o = q_o; st.q_gs = q_gs;
-
-    for (int h2 = 0; h2 < 2; h2++) {
-        const int lo = tile_lo + 32 * h2;
-        if (lo >= H) break;
-        const int vT = lo + l;
-        const int vTc = min(vT, H - 1);
-        const bool row_ok = vT < H;
-        const RowRec my = load_rec(rcol + vTc + 1);
-        const float* my_row = lcol + (size_t)(vTc + 1) * D;
-        PairBest b; /* partial minima of phase 1 (its nsplit workgroups merged) */
-        {
-            const size_t o = (size_t)colg * nsplit * 3 * 64 + 32 * h2 + l;
-            b.g = part_cost[o]; b.ig = part_idx[o];
-            b.o = part_cost[o + 64]; b.io = part_idx[o + 64];
-            b.s = part_cost[o + 128]; b.is = part_idx[o + 128];
-            for (int sp = 1; sp < nsplit; sp++) {
-                const size_t q = o + (size_t)sp * 3 * 64;
-                float c2 = part_cost[q]; int i2 = part_idx[q];
-                if ((c2 < b.g) || (c2 == b.g && c2 < IS_INF && (i2 / 3) < (b.ig / 3))) { b.g = c2; b.ig = i2; }
-                c2 = part_cost[q + 64]; i2 = part_idx[q + 64];
-                if ((c2 < b.o) || (c2 == b.o && c2 < IS_INF && (i2 / 3) < (b.io / 3))) { b.o = c2; b.io = i2; }
-                c2 = part_cost[q + 128]; i2 = part_idx[q + 128];
-                if ((c2 < b.s) || (c2 == b.s && c2 < IS_INF && (i2 / 3) < (b.is / 3))) { b.s = c2; b.is = i2; }
-            }
-        }
-        if (h2 == 1) {
-            /* segments of the second sub-tile that start in the first one: vB = tile_lo+1 .. lo,
-             * every lane is at or above them; ascending vB with the strict <, as the reference */
-            for (int j = 0; j < 32; j++) {
-                const int vB = tile_lo + 1 + j;
-                const RowRec rb = load_rec(rcol + vB);
-                const StepVals sj = lds_step(my_steps + j * 16);
-                const int h = vTc + 1 - vB;
-                const SegTerms t = eval_segment<true, HAS_INVALID>(my, rb, (float)h, rcp[h], D, P.iw);
-                const float od = my_row[(unsigned)t.fni] - (lcol + (size_t)vB * D)[(unsigned)t.fni];
-                if (vB - 1 < vhor)
-                    pairwise_step<false>(P, sj, vB, row_ok, od, t, b);
-                else
-                    pairwise_step<true>(P, sj, vB, row_ok, od, t, b);
-            }
-        }
-        const int n_rows = min(32, H - lo);
-        for (int s = 0; s < n_rows; s++) {
-            const int r = lo + s; /* row that becomes final in this step */
-            if (s > 0) { /* segments starting at vB = r: lanes vT >= r */
-                const RowRec rb = load_rec(rcol + r);
-                const int hc = max(vTc + 1 - r, 1);
-                const bool live = row_ok && (vT >= r);
-                const SegTerms t = eval_segment<true, HAS_INVALID>(my, rb, (float)hc, rcp[hc], D, P.iw);
-                const float od = my_row[(unsigned)t.fni] - (lcol + (size_t)r * D)[(unsigned)t.fni];
-                if (r - 1 < vhor)
-                    pairwise_step<false>(P, st, r, live, od, t, b);
-                else
-                    pairwise_step<true>(P, st, r, live, od, t, b);
-            }
-            if (r + 1 < H) { /* lane s of each half holds the final row r of its column */
-                const float cG = __shfl(b.g, hb + s, 64), cO = __shfl(b.o, hb + s, 64);
-                const float cS = __shfl(b.s, hb + s, 64);
-                const int io = __shfl(b.io, hb + s, 64);
-                st = make_step<HAS_INVALID, true>(P, s_S, s_V, s_odr, s_invc, s_logc,
-                                                  (cprior_t)(pcol + r + 1), vhor, r, cG, cO, cS, io / 3);
-                const float m8 = __builtin_fminf(
-                    __builtin_fminf(__builtin_fminf(st.p1_hi, st.p1_lo), __builtin_fminf(st.p1_mid, st.p2_hi)),
-                    __builtin_fminf(__builtin_fminf(st.p2_lo, st.p2_mid), __builtin_fminf(st.p3_yes, st.p3_no)));
-                q_o = __builtin_fminf(q_o, P.pw * m8);
-                q_gs = __builtin_fminf(q_gs, st.pwmp);
-                st.q_o = q_o; st.q_gs = q_gs;
-                if (l == 0) {
-                    store_step(scol + r + 1, st);
-                    if (h2 == 0) store_step(reinterpret_cast<StepRec*>(my_steps + s * 16), st);
-                }
-            }
-        }
-        if (row_ok) {
-            const size_t o = ((size_t)colg * H + vT) * 3;
-            cost_table[o + 0] = b.g; cost_table[o + 1] = b.o; cost_table[o + 2] = b.s;
-            index_table[o + 0] = b.ig; index_table[o + 1] = b.io; index_table[o + 2] = b.is;
-        }
-    }
-}
-
 extern "C" {
 
 size_t isk_pairwise_lds_bytes(const DevParams* P, int nwaves) { return isk_unary_lds_bytes(P); }
-size_t isk_phase1_ring_lds_bytes(const DevParams* P, int nwaves, int nvr) {
-    const size_t DP = (size_t)P->D + 1;
-    const size_t tile = ((size_t)IS_TILE * DP + 3) & ~(size_t)3;
-    const size_t rcp = ((size_t)P->H + 1 + 3) & ~(size_t)3;
-    size_t ring = (size_t)nwaves * ISP_RING * (64 * (size_t)nvr + ISF_REC_F + ISP_STEP_F);
-    const size_t merge = (size_t)nwaves * 3 * 64 * 2;
-    if (ring < merge) ring = merge;
-    return sizeof(float) * (tile + rcp + ring) + 16;
-}
-size_t isk_phase2x2_lds_bytes(const DevParams* P) {
-    const size_t sv = (P->invalid >= 0 ? 4 : 2) * ((size_t)P->H + 1);
-    return sizeof(double) * 2 * IS_LOG_TABLE_SIZE + sizeof(float) * (sv + P->D) + 16 +
-           sizeof(float) * 2 * 32 * 16 + 16;
-}
 size_t isk_phase2_lds_bytes(const DevParams* P) {
     /* the valid-count prefix is staged only when the configuration has an invalid-disparity value:
      * the kernel's occupancy is LDS-bound (one wave per column, 64 serial steps per tile) */
@@ -942,20 +638,6 @@ hipError_t isk_launch_dp_pairwise(const DevParams* P, int ncols, int nwaves, con
                                   hipEvent_t ev_fork, hipEvent_t* ev_join) {
     const size_t lds1 = isk_pairwise_lds_bytes(P, nwaves);
     const size_t lds2 = isk_phase2_lds_bytes(P);
-    const size_t lds2x2 = isk_phase2x2_lds_bytes(P);
-    /* FAST columns: the LDS-DMA ring kernel whenever the shape allows it */
-    int ring_nvr = P->D <= 128 ? 2 : (P->D <= 256 ? 4 : 0);
-    const size_t lds1r = isk_phase1_ring_lds_bytes(P, nwaves, ring_nvr);
-    if (lds1r > 160 * 1024 || nwaves != IS_UNARY_WAVES || getenv("IS_NO_RING_KERNEL")) ring_nvr = 0;
-    const int ring_nvr_all = ring_nvr;
-    int ring_from_tile = 0;
-    if (const char* e = getenv("IS_RING_FROM_TILE")) ring_from_tile = atoi(e);
-    /* two columns per wave: the columns of a pair must share the image (even C) and the groups
-     * below must start at even columns */
-    /* (measured on MI355X, batch 64: 30.8 ms per step against 29.9 ms with one column per wave --
-     * the per-half operands cost 60 more VGPRs, 3 waves per SIMD and a global load on every serial
-     * step; opt-in with IS_P2X2=1 until the vB record is prefetched) */
-    const bool x2 = (P->C % 2) == 0 && lds2x2 <= 64 * 1024 && getenv("IS_P2X2") != nullptr;
     /* Columns are independent: with enough of them the batch is cut into groups whose
      * phase-1 / phase-2 chains (2 x ntiles dependent launches each) run on their own streams, so
      * that the tails and the latency-bound serial phase 2 of one group share the CUs with the
@@ -983,36 +665,19 @@ hipError_t isk_launch_dp_pairwise(const DevParams* P, int ncols, int nwaves, con
 #endif
 #define IS_LAUNCH_P1(INV, c0, c1, st)                                                              \
     do {                                                                                           \
-        if (ring_nvr == 2)                                                                         \
-            hipLaunchKernelGGL((k_pw_phase1_ring<INV, 2>), dim3(((c1) - (c0)) * nsplit),           \
-                               dim3(nwaves * 64), lds1r, st, *P, c0, c1, tile, nsplit, recs, lutT, \
-                               steps, rcp, vhor, col_flags, prune, part_cost, part_idx);           \
-        else if (ring_nvr == 4)                                                                    \
-            hipLaunchKernelGGL((k_pw_phase1_ring<INV, 4>), dim3(((c1) - (c0)) * nsplit),           \
-                               dim3(nwaves * 64), lds1r, st, *P, c0, c1, tile, nsplit, recs, lutT, \
-                               steps, rcp, vhor, col_flags, prune, part_cost, part_idx);           \
         if (IS_PW_PHASE1_ROW_REGS && P->D <= 128)                                                  \
             hipLaunchKernelGGL((k_pw_phase1<INV, 2>), dim3(((c1) - (c0)) * nsplit),                \
                                dim3(nwaves * 64), lds1, st, *P, c0, c1, tile, nsplit, recs, lutT,  \
-                               steps, rcp, vhor, col_flags, prune, part_cost, part_idx,            \
-                               ring_nvr != 0);                                                     \
+                               steps, rcp, vhor, col_flags, prune, part_cost, part_idx);           \
         else                                                                                       \
             hipLaunchKernelGGL((k_pw_phase1<INV, 0>), dim3(((c1) - (c0)) * nsplit),                \
                                dim3(nwaves * 64), lds1, st, *P, c0, c1, tile, nsplit, recs, lutT,  \
-                               steps, rcp, vhor, col_flags, prune, part_cost, part_idx,            \
-                               ring_nvr != 0);                                                     \
+                               steps, rcp, vhor, col_flags, prune, part_cost, part_idx);           \
     } while (0)
 #define IS_LAUNCH_P2(INV, c0, c1, st)                                                              \
-    do {                                                                                           \
-        if (x2)                                                                                    \
-            hipLaunchKernelGGL(k_pw_phase2x2<INV>, dim3(((c1) - (c0)) / 2), dim3(64), lds2x2, st,  \
-                               *P, c0, c1, tile, nsplit, recs, lutT, priors, odr, rcp, sv_arr,     \
-                               vhor, col_flags, part_cost, part_idx, steps, cost_table,            \
-                               index_table);                                                       \
-        hipLaunchKernelGGL(k_pw_phase2<INV>, dim3((c1) - (c0)), dim3(64), lds2, st, *P, c0, c1,    \
-                           tile, nsplit, recs, lutT, priors, odr, rcp, sv_arr, vhor, col_flags,    \
-                           part_cost, part_idx, steps, cost_table, index_table, x2 ? 1 : 0);       \
-    } while (0)
+    hipLaunchKernelGGL(k_pw_phase2<INV>, dim3((c1) - (c0)), dim3(64), lds2, st, *P, c0, c1, tile,  \
+                       nsplit, recs, lutT, priors, odr, rcp, sv_arr, vhor, col_flags, part_cost,   \
+                       part_idx, steps, cost_table, index_table)
     const bool inv = P->invalid >= 0;
     if (groups > 1) {
         if ((e = hipEventRecord(ev_fork, stream)) != hipSuccess) return e;
@@ -1020,10 +685,9 @@ hipError_t isk_launch_dp_pairwise(const DevParams* P, int ncols, int nwaves, con
             if ((e = hipStreamWaitEvent(aux[g - 1], ev_fork, 0)) != hipSuccess) return e;
     }
     for (int tile = 0; tile < P->ntiles; tile++) {
-        ring_nvr = tile >= ring_from_tile ? ring_nvr_all : 0;
         for (int g = 0; g < groups; g++) {
-            const int c0 = (int)((long long)ncols * g / groups) & ~1;
-            const int c1 = g + 1 == groups ? ncols : ((int)((long long)ncols * (g + 1) / groups) & ~1);
+            const int c0 = (int)((long long)ncols * g / groups);
+            const int c1 = (int)((long long)ncols * (g + 1) / groups);
             hipStream_t st = g == 0 ? stream : aux[g - 1];
             if (inv) IS_LAUNCH_P1(true, c0, c1, st); else IS_LAUNCH_P1(false, c0, c1, st);
             if (inv) IS_LAUNCH_P2(true, c0, c1, st); else IS_LAUNCH_P2(false, c0, c1, st);
@@ -1048,17 +712,6 @@ hipError_t isk_set_lds_pairwise(const DevParams* P, int nwaves_pair) {
     e = hipFuncSetAttribute((const void*)k_pw_phase1<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, c);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void*)k_pw_phase1<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, c);
-    if (e != hipSuccess) return e;
-    for (int nvr = 2; nvr <= 4; nvr += 2) {
-        const size_t r = isk_phase1_ring_lds_bytes(P, nwaves_pair, nvr);
-        if (r > 160 * 1024) continue;
-        const void* f1 = nvr == 2 ? (const void*)k_pw_phase1_ring<true, 2> : (const void*)k_pw_phase1_ring<true, 4>;
-        const void* f0 = nvr == 2 ? (const void*)k_pw_phase1_ring<false, 2> : (const void*)k_pw_phase1_ring<false, 4>;
-        e = hipFuncSetAttribute(f1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)r);
-        if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute(f0, hipFuncAttributeMaxDynamicSharedMemorySize, (int)r);
-        if (e != hipSuccess) return e;
-    }
     return e;
 }
 

@@ -47,8 +47,6 @@ size_t isk_prepare_lds_bytes(const DevParams* P);
 size_t isk_unary_lds_bytes(const DevParams* P);
 size_t isk_pairwise_lds_bytes(const DevParams* P, int nwaves);
 size_t isk_phase2_lds_bytes(const DevParams* P);
-size_t isk_phase2x2_lds_bytes(const DevParams* P);
-size_t isk_phase1_ring_lds_bytes(const DevParams* P, int nwaves, int nvr);
 size_t isk_unary_fast_lds_bytes(const DevParams* P, int chunk_rows);
 int isk_unary_fast_chunk_rows(const DevParams* P);
 hipError_t isk_set_lds_unary_fast(const DevParams* P);
