@@ -30,7 +30,7 @@ hipError_t isk_launch_priors(const DevParams*, const float*, PriorRec*, int, hip
 hipError_t isk_launch_dp_unary(const DevParams*, int, int, const RowRec*, const float*, const float*,
                                const int*, const int*, const PruneRec*, float*, int32_t*, hipStream_t);
 hipError_t isk_launch_dp_pairwise(const DevParams*, int, int, const RowRec*, const float*,
-                                  const PriorRec*, const float*, const float*, const float*,
+                                  const float*, const PriorRec*, const float*, const float*, const float*,
                                   const int*, const int*, const PruneRec*, StepRec*, float*, int*,
                                   float*, int32_t*,
                                   hipStream_t, hipStream_t*, int, hipEvent_t, hipEvent_t*);
@@ -495,7 +495,7 @@ int is_compute(is_ctx* c, const float* d_joined, const int32_t* d_seg, const flo
     if (c->timing) HIP_TRY(hipEventRecord(c->ev[1], stream));
     if (pairwise)
         HIP_TRY(isk_launch_dp_pairwise(&P, ncols, c->nwaves_pairwise, c->d_recs, c->d_lutT,
-                                       c->d_priors, c->d_odr, c->d_rcp, c->d_sv, c->d_vhor,
+                                       d_joined, c->d_priors, c->d_odr, c->d_rcp, c->d_sv, c->d_vhor,
                                        c->d_col_flags, c->d_prune, c->d_steps, c->d_part_cost,
                                        c->d_part_idx, ct, it,
                                        stream, c->aux_streams, IS_AUX_STREAMS, c->ev_fork, c->ev_joins));

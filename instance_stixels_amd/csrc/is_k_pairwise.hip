@@ -80,22 +80,23 @@ __device__ __forceinline__ void neg_fastlog_div2(float neg_log_va, float v2a, fl
 }
 
 /* StepRec of vB = r + 1 from the final row r.  All inputs are wave-uniform; every lane computes
- * the same values.  s_S / s_V: the column's disparity / valid-count prefixes in LDS. */
+ * the same values. */
 template <bool HAS_INVALID>
-__device__ __forceinline__ StepVals make_step(const DevParams& P, const float* s_S, const float* s_V,
-                                             const float* s_odr, const double* s_invc,
+__device__ __forceinline__ StepVals make_step(const DevParams& P, float S_r1, float V_r1, float S_ob,
+                                             float V_ob, const float* s_odr, const double* s_invc,
                                              const double* s_logc, cprior_t pr, int vhor, int r,
                                              float cG, float cO, float cS, int obj_vB) {
     const int vB = r + 1;
     const float pw = P.pw;
     StepVals st;
-    /* previous_mean = ComputeMean(previous_object_vB, previous_vT), :47-60, :675-685 */
+    /* previous_mean = ComputeMean(previous_object_vB, previous_vT), :47-60, :675-685; S_r1 / V_r1:
+     * the disparity / valid-count prefixes at r + 1, S_ob / V_ob: at obj_vB */
     float pm;
     if (HAS_INVALID) {
-        const float valid_dif = s_V[r + 1] - s_V[obj_vB];
-        pm = (valid_dif == 0) ? 0 : (s_S[r + 1] - s_S[obj_vB]) / valid_dif;
+        const float valid_dif = V_r1 - V_ob;
+        pm = (valid_dif == 0) ? 0 : (S_r1 - S_ob) / valid_dif;
     } else {
-        pm = (s_S[r + 1] - s_S[obj_vB]) / (float)(r + 1 - obj_vB);
+        pm = (S_r1 - S_ob) / (float)(r + 1 - obj_vB);
     }
     if (pm < 0) pm = 0;
     const float pc = pr->pc;
@@ -480,10 +481,39 @@ __global__ __launch_bounds__(IS_UNARY_WAVES * 64, IS_UNARY_WAVES) void k_pw_phas
                                                nsplit, prune + colg, part_cost, part_idx);
 }
 
+/* ---- phase 2: the fn window --------------------------------------------------------------
+ * Every segment of the diagonal block lies inside the tile, so its mean disparity lies between
+ * the smallest and the largest (valid) disparity of the tile's rows, and floor(mean) -- the lutT
+ * column it reads -- inside [floor(dmin) - 1, floor(dmax) + 1] (the +-1 covers the rounding of the
+ * tree-summed prefixes the mean is computed from).  On real and synthetic scenes that window is a
+ * few columns wide (a road ramp moves by ~12 disparities over 64 rows, an object by ~1), so the
+ * wave stages only lutT[tile_lo .. tile_lo+64][lo .. lo+W) in LDS -- 65 x W floats, W <= 32 --
+ * instead of gathering two values per lane and step from the 33 KB tile in global memory (64 + 4
+ * cache lines per step: that gather throughput, at 5.3 TB/s of L2 misses, bounded the kernel).
+ * Exactness does not rest on the window: a lane whose floor(mean) falls outside reads global
+ * memory as before. */
+#ifndef ISP2_WMAX
+#define ISP2_WMAX 16
+#endif
+#define ISP2_WS (ISP2_WMAX + 1) /* row stride: lanes reading one column of 64 rows hit 32 banks */
+#define ISP2_ROWS (IS_TILE + 1)
+
+__device__ __forceinline__ float wave_min_f(float x) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) x = __builtin_fminf(x, __shfl_xor(x, m, 64));
+    return x;
+}
+__device__ __forceinline__ float wave_max_f(float x) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) x = __builtin_fmaxf(x, __shfl_xor(x, m, 64));
+    return x;
+}
+
 template <bool FAST, bool HAS_INVALID>
 __device__ __forceinline__ void pw_phase2_body(const DevParams& P, char* smem, int colg, int tile,
                                                const RowRec* __restrict__ recs,
                                                const float* __restrict__ lutT,
+                                               const float* __restrict__ joined,
                                                const PriorRec* __restrict__ priors,
                                                const float* __restrict__ odr,
                                                const float* __restrict__ rcp,
@@ -497,25 +527,62 @@ __device__ __forceinline__ void pw_phase2_body(const DevParams& P, char* smem, i
     const int lane = threadIdx.x;
     double* s_invc = (double*)smem;                    /* [32] */
     double* s_logc = s_invc + IS_LOG_TABLE_SIZE;       /* [32] */
-    float* s_S = (float*)(s_logc + IS_LOG_TABLE_SIZE); /* [H+1] */
-    float* s_V = s_S + (H + 1);                        /* [H+1], only with an invalid value */
-    float* s_odr = s_V + (HAS_INVALID ? (H + 1) : 0);  /* [D]   */
+    float* s_odr = (float*)(s_logc + IS_LOG_TABLE_SIZE); /* [D] */
+    float* s_rcp = s_odr + D;                          /* [IS_TILE+1] RN(1/h), h <= 64 */
+    float* s_win = s_rcp + (IS_TILE + 1);              /* [65][ISP2_WS] lutT window */
     const int tile_lo = tile * IS_TILE;
     const RowRec* rcol = recs + (size_t)colg * (H + 1);
     const float* lcol = lutT + (size_t)colg * (H + 1) * D;
     const PriorRec* pcol = priors + (size_t)(colg / P.C) * H;
     StepRec* scol = steps + (size_t)colg * H;
     const float* sv = sv_arr + (size_t)colg * 2 * (H + 1);
-    if (lane == 0) is_log_tables(s_invc, s_logc);
-    for (int i = lane; i <= H; i += 64) {
-        s_S[i] = sv[i];
-        if (HAS_INVALID) s_V[i] = sv[H + 1 + i];
-    }
-    for (int i = lane; i < D; i += 64) s_odr[i] = odr[i];
     const int vT = tile_lo + lane;
     const int vTc = min(vT, H - 1);
+
+    /* the window [lo, lo + W) of lutT columns the tile's segments can select */
+    int lo, W;
+    {
+        const float d = joined[(size_t)colg * H + vTc];
+        const bool ok = (vT < H) && !(HAS_INVALID && d == P.invalid);
+        const float dmin = wave_min_f(ok ? d : IS_INF);
+        const float dmax = wave_max_f(ok ? d : -IS_INF);
+        /* any junk (NaN, no valid row, values outside [0, D)) still yields a window inside the
+         * table; lanes that leave it take the global path */
+        int l = (int)__builtin_fminf(__builtin_fmaxf(dmin, 1.0f), (float)D) - 1;
+        l = min(max(l, 0), D - 1);
+        int h = (int)__builtin_fminf(__builtin_fmaxf(dmax, 0.0f), (float)(D - 1)) + 1;
+        h = min(max(h, l), min(D - 1, l + ISP2_WMAX - 1));
+        lo = __builtin_amdgcn_readfirstlane(l);
+        W = __builtin_amdgcn_readfirstlane(h - l + 1);
+    }
+    /* rows tile_lo .. tile_lo + 64 (vB side: row r, vT side: row vT + 1) x window columns.  A
+     * wave instruction covers 64 / Wp rows of Wp = 2^k >= W columns; every load is issued before
+     * the first LDS store (fully unrolled: one memory round trip for the whole window). */
+    {
+        int lg = 0;
+        while ((1 << lg) < W) lg++;
+        lg = __builtin_amdgcn_readfirstlane(lg);
+        const int f = lane & ((1 << lg) - 1);
+        const int j0 = lane >> lg, dj = 64 >> lg;
+        constexpr int NL = (ISP2_ROWS * ISP2_WMAX + 63) / 64; /* loads per lane at the widest window */
+        float tmp[NL];
+#pragma unroll
+        for (int k = 0; k < NL; k++) {
+            const int j = j0 + k * dj;
+            tmp[k] = (j < ISP2_ROWS && f < W) ? lcol[(size_t)min(tile_lo + j, H) * D + lo + f] : 0.0f;
+        }
+#pragma unroll
+        for (int k = 0; k < NL; k++) {
+            const int j = j0 + k * dj;
+            if (j < ISP2_ROWS && f < W) s_win[j * ISP2_WS + f] = tmp[k];
+        }
+    }
+    if (lane == 0) is_log_tables(s_invc, s_logc);
+    for (int i = lane; i < D; i += 64) s_odr[i] = odr[i];
+    for (int i = lane; i <= IS_TILE; i += 64) s_rcp[i] = rcp[min(i, H)];
     const RowRec my = load_rec(rcol + vTc + 1);
     const float* my_row = lcol + (size_t)(vTc + 1) * D;
+    const float* my_win = s_win + (vTc + 1 - tile_lo) * ISP2_WS;
     PairBest b; /* partial minima of phase 1 (its nsplit workgroups merged: min cost, then smallest vB) */
     {
         const size_t o = (size_t)colg * nsplit * 3 * 64 + lane;
@@ -550,18 +617,23 @@ __device__ __forceinline__ void pw_phase2_body(const DevParams& P, char* smem, i
         q_gs = prev->q_gs;
     }
     st.q_o = q_o; st.q_gs = q_gs;
+    int ob_cached = -1;
+    float S_obc = 0.0f, V_obc = 0.0f;
     for (int s = 0; s < n_rows; s++) {
         const int r = tile_lo + s; /* row that becomes final in this step */
         if (s > 0) { /* segments starting at vB = r: lanes vT >= r */
             const RowRec rb = sload_rec(rcol + r);
             const int hc = max(vTc + 1 - r, 1);
             const bool live = (vT < H) && (vT >= r);
-            const SegTerms t = eval_segment<FAST, HAS_INVALID>(my, rb, (float)hc, rcp[hc], D, P.iw);
-#ifdef IS_ABL_P2_NOGATHER
-            const float od = (float)t.fni;
-#else
-            const float od = my_row[(unsigned)t.fni] - (lcol + (size_t)r * D)[(unsigned)t.fni];
-#endif
+            const SegTerms t = eval_segment<FAST, HAS_INVALID>(my, rb, (float)hc, s_rcp[hc], D, P.iw);
+            const int fo = t.fni - lo;
+            const bool inwin = (unsigned)fo < (unsigned)W;
+            const int foc = inwin ? fo : 0;
+            float od = my_win[foc] - s_win[s * ISP2_WS + foc];
+            if (__builtin_amdgcn_ballot_w64(live && !inwin) != 0ull) { /* outside the window: rare */
+                const float og = my_row[(unsigned)t.fni] - (lcol + (size_t)r * D)[(unsigned)t.fni];
+                od = inwin ? od : og;
+            }
             if (r - 1 < vhor)
                 pairwise_step<false>(P, st, r, live, od, t, b);
             else
@@ -570,9 +642,26 @@ __device__ __forceinline__ void pw_phase2_body(const DevParams& P, char* smem, i
         /* lane s holds the final values of row r: broadcast, derive the StepRec of vB = r+1 */
         if (r + 1 < H) {
             const float cG = readlane_f(b.g, s), cO = readlane_f(b.o, s), cS = readlane_f(b.s, s);
-            const int io = __builtin_amdgcn_readlane(b.io, s);
-            st = make_step<HAS_INVALID>(P, s_S, s_V, s_odr, s_invc, s_logc, (cprior_t)(pcol + r + 1), vhor,
-                                        r, cG, cO, cS, io / 3);
+            const int ob = __builtin_amdgcn_readlane(b.io, s) / 3; /* start of the best object chain */
+            /* the disparity / valid-count prefixes at r + 1 and at ob: lane k holds the record of
+             * prefix index tile_lo + k + 1; an index at or below the tile comes from memory through a
+             * scalar load, repeated only when the chain's start changes (inside an object: never) */
+            const float S_r1 = readlane_f(my.S, s), V_r1 = HAS_INVALID ? readlane_f(my.V, s) : 0.0f;
+            float S_ob, V_ob = 0.0f;
+            if (ob > tile_lo) {
+                S_ob = readlane_f(my.S, ob - 1 - tile_lo);
+                if (HAS_INVALID) V_ob = readlane_f(my.V, ob - 1 - tile_lo);
+            } else {
+                if (ob != ob_cached) {
+                    typedef const __attribute__((address_space(4))) float* cflt_t;
+                    S_obc = *(cflt_t)(sv + ob);
+                    if (HAS_INVALID) V_obc = *(cflt_t)(sv + (H + 1) + ob);
+                    ob_cached = ob;
+                }
+                S_ob = S_obc; V_ob = V_obc;
+            }
+            st = make_step<HAS_INVALID>(P, S_r1, V_r1, S_ob, V_ob, s_odr, s_invc, s_logc,
+                                        (cprior_t)(pcol + r + 1), vhor, r, cG, cO, cS, ob);
             /* fminf skips NaN fields: a candidate that selects one costs NaN and never wins */
             const float m8 = __builtin_fminf(
                 __builtin_fminf(__builtin_fminf(st.p1_hi, st.p1_lo), __builtin_fminf(st.p1_mid, st.p2_hi)),
@@ -590,11 +679,14 @@ __device__ __forceinline__ void pw_phase2_body(const DevParams& P, char* smem, i
     }
 }
 
+#ifndef ISP2_OCC
+#define ISP2_OCC 6 /* waves per SIMD the kernel is compiled for */
+#endif
 template <bool HAS_INVALID>
-__global__ __launch_bounds__(64) void k_pw_phase2(
+__global__ __launch_bounds__(64, ISP2_OCC) void k_pw_phase2(
     const DevParams P, int col_base, int ncols, int tile, int nsplit,
     const RowRec* __restrict__ recs, const float* __restrict__ lutT,
-    const PriorRec* __restrict__ priors,
+    const float* __restrict__ joined, const PriorRec* __restrict__ priors,
     const float* __restrict__ odr, const float* __restrict__ rcp,
     const float* __restrict__ sv_arr, const int* __restrict__ vhor_arr,
     const int* __restrict__ col_flags, const float* __restrict__ part_cost,
@@ -605,10 +697,10 @@ __global__ __launch_bounds__(64) void k_pw_phase2(
     if (colg >= ncols) return;
     const int vhor = __builtin_amdgcn_readfirstlane(vhor_arr[colg / P.C]);
     if (__builtin_amdgcn_readfirstlane(col_flags[colg]) == 0)
-        pw_phase2_body<true, HAS_INVALID>(P, smem, colg, tile, recs, lutT, priors, odr, rcp, sv_arr, vhor,
+        pw_phase2_body<true, HAS_INVALID>(P, smem, colg, tile, recs, lutT, joined, priors, odr, rcp, sv_arr, vhor,
                                           nsplit, part_cost, part_idx, steps, cost_table, index_table);
     else
-        pw_phase2_body<false, HAS_INVALID>(P, smem, colg, tile, recs, lutT, priors, odr, rcp, sv_arr, vhor,
+        pw_phase2_body<false, HAS_INVALID>(P, smem, colg, tile, recs, lutT, joined, priors, odr, rcp, sv_arr, vhor,
                                            nsplit, part_cost, part_idx, steps, cost_table, index_table);
 }
 
@@ -616,20 +708,16 @@ extern "C" {
 
 size_t isk_pairwise_lds_bytes(const DevParams* P, int nwaves) { return isk_unary_lds_bytes(P); }
 size_t isk_phase2_lds_bytes(const DevParams* P) {
-    /* the valid-count prefix is staged only when the configuration has an invalid-disparity value:
-     * the kernel's occupancy is LDS-bound (one wave per column, 64 serial steps per tile) */
-    const size_t sv = (P->invalid >= 0 ? 2 : 1) * ((size_t)P->H + 1);
-    size_t need = sizeof(double) * 2 * IS_LOG_TABLE_SIZE + sizeof(float) * (sv + P->D) + 16;
-    /* occupancy throttle: the kernel is bound by the throughput of its per-lane lutT gathers (64
-     * cache lines per wave and step); more resident waves only thrash the L1 (measured on MI355X at
-     * batch 64: 30 waves / CU 35.3 ms per step, 17 waves / CU 29.9 ms) */
-    size_t floor_bytes = 9 * 1024 + 256;
+    size_t need = sizeof(double) * 2 * IS_LOG_TABLE_SIZE +
+                  sizeof(float) * (P->D + (IS_TILE + 1) + (size_t)ISP2_ROWS * ISP2_WS) + 16;
+    /* IS_P2_LDS: a floor on the allocation = an occupancy throttle for experiments */
+    size_t floor_bytes = 0;
     if (const char* e = getenv("IS_P2_LDS")) floor_bytes = (size_t)atoi(e);
     return need > floor_bytes ? need : floor_bytes;
 }
 
 hipError_t isk_launch_dp_pairwise(const DevParams* P, int ncols, int nwaves, const RowRec* recs,
-                                  const float* lutT, const PriorRec* priors, const float* odr,
+                                  const float* lutT, const float* joined, const PriorRec* priors, const float* odr,
                                   const float* rcp, const float* sv_arr, const int* vhor,
                                   const int* col_flags, const PruneRec* prune, StepRec* steps,
                                   float* part_cost, int* part_idx, float* cost_table,
@@ -676,7 +764,8 @@ hipError_t isk_launch_dp_pairwise(const DevParams* P, int ncols, int nwaves, con
     } while (0)
 #define IS_LAUNCH_P2(INV, c0, c1, st)                                                              \
     hipLaunchKernelGGL(k_pw_phase2<INV>, dim3((c1) - (c0)), dim3(64), lds2, st, *P, c0, c1, tile,  \
-                       nsplit, recs, lutT, priors, odr, rcp, sv_arr, vhor, col_flags, part_cost,   \
+                       nsplit, recs, lutT, joined, priors, odr, rcp, sv_arr, vhor, col_flags,      \
+                       part_cost,                                                                  \
                        part_idx, steps, cost_table, index_table)
     const bool inv = P->invalid >= 0;
     if (groups > 1) {
