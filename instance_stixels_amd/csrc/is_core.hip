@@ -46,6 +46,7 @@ int isk_debug_occupancy(const DevParams*, int);
 hipError_t isk_launch_cluster(int, float, int, const float*, const uint8_t*, const int32_t*,
                               const int32_t*, int32_t*, int32_t*, int32_t*, hipStream_t);
 size_t isk_phase2_lds_bytes(const DevParams* P);
+size_t isk_phase2s_lds_bytes(const DevParams* P);
 hipError_t isk_launch_flip_and_pad(const float*, int32_t*, int, int, int, int, int, hipStream_t);
 hipError_t isk_launch_vdisparity(const float*, int*, int*, uint8_t*, int, int, int, float, hipStream_t);
 }
@@ -269,7 +270,8 @@ static int ctx_init(is_ctx* c, const is_stixel_params* p, const float* obj_cost_
     c->nwaves_pairwise = IS_UNARY_WAVES;
     if (sizeof(int) * (6 * (size_t)d.H + 3 * (size_t)d.S + 4) > 160 * 1024 ||
         isk_unary_lds_bytes(&d) > 160 * 1024 || isk_pairwise_lds_bytes(&d, c->nwaves_pairwise) > 160 * 1024 ||
-        isk_prepare_lds_bytes(&d) > 160 * 1024 || isk_phase2_lds_bytes(&d) > 160 * 1024 ||
+        isk_prepare_lds_bytes(&d) > 160 * 1024 || isk_phase2_lds_bytes(&d) > 64 * 1024 ||
+        isk_phase2s_lds_bytes(&d) > 64 * 1024 || /* (both far below: no attribute is set for them) */
         sizeof(int) * (size_t)d.C * IS_INSTANCE_CLASSES + 16 > 160 * 1024)
         return fail_arg("shape needs more than 160 KiB of LDS per workgroup");
 

@@ -232,8 +232,12 @@ hipError_t isk_launch_compact(const DevParams* P, const is_section* sections_img
 }
 
 hipError_t isk_set_lds_backtrace(const DevParams* P) {
-    return hipFuncSetAttribute((const void*)k_backtrace, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)(sizeof(int) * (6 * (size_t)P->H + 3 * (size_t)P->S + 4)));
+    hipError_t e = hipFuncSetAttribute((const void*)k_backtrace, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)(sizeof(int) * (6 * (size_t)P->H + 3 * (size_t)P->S + 4)));
+    if (e != hipSuccess) return e;
+    /* more than 2047 stixel columns: the per-column counters exceed the 64 KiB default */
+    return hipFuncSetAttribute((const void*)k_compact_instances, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)(sizeof(int) * (size_t)P->C * IS_INSTANCE_CLASSES + 16));
 }
 
 } /* extern "C" */

@@ -61,6 +61,20 @@ __device__ __forceinline__ StepVals sload_step(const StepRec* p) {
     return r;
 }
 
+/* sload_rec with every field pinned into its SGPR right here: the compiler otherwise sinks the
+ * loads of the fields towards their first uses and the serial chain of phase 2 waits for scalar
+ * memory twice per step (mean first, the class prefixes later) instead of once */
+__device__ __forceinline__ RowRec sload_rec_pinned(const RowRec* p) {
+    RowRec r = sload_rec(p);
+    asm volatile("" : "+s"(r.Fg0), "+s"(r.Fg1), "+s"(r.Fon[0]), "+s"(r.Fon[1]), "+s"(r.Fon[2]),
+                      "+s"(r.Fon[3]), "+s"(r.Fon[4]), "+s"(r.Fon[5]), "+s"(r.Fon[6]), "+s"(r.Fon[7]));
+    asm volatile("" : "+s"(r.Foi[0]), "+s"(r.Foi[1]), "+s"(r.Foi[2]), "+s"(r.Foi[3]), "+s"(r.Foi[4]),
+                      "+s"(r.Foi[5]), "+s"(r.Foi[6]), "+s"(r.Foi[7]), "+s"(r.Fsky), "+s"(r.Fnic));
+    asm volatile("" : "+s"(r.G), "+s"(r.K), "+s"(r.S), "+s"(r.V), "+s"(r.MX), "+s"(r.MY),
+                      "+s"(r.MX2h), "+s"(r.MX2l), "+s"(r.MY2h), "+s"(r.MY2l));
+    return r;
+}
+
 __device__ __forceinline__ float readlane_f(float x, int l) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), l));
 }
@@ -81,10 +95,23 @@ __device__ __forceinline__ void neg_fastlog_div2(float neg_log_va, float v2a, fl
 
 /* StepRec of vB = r + 1 from the final row r.  All inputs are wave-uniform; every lane computes
  * the same values. */
+/* register (SGPR) copy of a PriorRec: loaded at the top of a step together with the step's RowRec,
+ * so that the serial chain waits for scalar memory once per step, not twice */
+struct PriorVals {
+    float pc, g_from, s_from_g, o_from_s, og_hi, og_lo, og_mid, g_prev;
+};
+__device__ __forceinline__ PriorVals sload_prior(const PriorRec* p) {
+    cprior_t q = (cprior_t)p;
+    PriorVals v;
+    v.pc = q->pc; v.g_from = q->g_from; v.s_from_g = q->s_from_g; v.o_from_s = q->o_from_s;
+    v.og_hi = q->og_hi; v.og_lo = q->og_lo; v.og_mid = q->og_mid; v.g_prev = q->g_prev;
+    return v;
+}
+
 template <bool HAS_INVALID>
 __device__ __forceinline__ StepVals make_step(const DevParams& P, float S_r1, float V_r1, float S_ob,
                                              float V_ob, const float* s_odr, const double* s_invc,
-                                             const double* s_logc, cprior_t pr, int vhor, int r,
+                                             const double* s_logc, const PriorVals* pr, int vhor, int r,
                                              float cG, float cO, float cS, int obj_vB) {
     const int vB = r + 1;
     const float pw = P.pw;
@@ -498,6 +525,28 @@ __global__ __launch_bounds__(IS_UNARY_WAVES * 64, IS_UNARY_WAVES) void k_pw_phas
 #define ISP2_WS (ISP2_WMAX + 1) /* row stride: lanes reading one column of 64 rows hit 32 banks */
 #define ISP2_ROWS (IS_TILE + 1)
 
+#ifdef IS_ABL_P2PHASES
+/* debug build only: s_memtime cycles of the sections of a phase-2 step, summed over all waves */
+__device__ unsigned long long g_p2phase[8];
+#define ISP2_MARK_INIT() unsigned long long t_p2 = __builtin_readcyclecounter()
+#define ISP2_MARK(k)                                                              \
+    do {                                                                          \
+        const unsigned long long now__ = __builtin_readcyclecounter();            \
+        acc_p2[k] += now__ - t_p2;                                                \
+        t_p2 = now__;                                                             \
+    } while (0)
+extern "C" void isk_debug_p2phases(unsigned long long* out, int reset) {
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_p2phase), sizeof(g_p2phase));
+    if (reset) {
+        unsigned long long z[8] = {0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_p2phase), z, sizeof(z));
+    }
+}
+#else
+#define ISP2_MARK_INIT()
+#define ISP2_MARK(k)
+#endif
+
 __device__ __forceinline__ float wave_min_f(float x) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) x = __builtin_fminf(x, __shfl_xor(x, m, 64));
@@ -619,13 +668,22 @@ __device__ __forceinline__ void pw_phase2_body(const DevParams& P, char* smem, i
     st.q_o = q_o; st.q_gs = q_gs;
     int ob_cached = -1;
     float S_obc = 0.0f, V_obc = 0.0f;
+#ifdef IS_ABL_P2PHASES
+    unsigned long long acc_p2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    ISP2_MARK_INIT();
+    ISP2_MARK(0); /* prologue */
     for (int s = 0; s < n_rows; s++) {
         const int r = tile_lo + s; /* row that becomes final in this step */
+        PriorVals pv = sload_prior(pcol + min(r + 1, H - 1));
         if (s > 0) { /* segments starting at vB = r: lanes vT >= r */
-            const RowRec rb = sload_rec(rcol + r);
+            const RowRec rb = sload_rec_pinned(rcol + r);
+            pv.pc = opaque_s(pv.pc); /* the record and the priors arrive behind one wait */
             const int hc = max(vTc + 1 - r, 1);
             const bool live = (vT < H) && (vT >= r);
+            ISP2_MARK(1); /* scalar loads */
             const SegTerms t = eval_segment<FAST, HAS_INVALID>(my, rb, (float)hc, s_rcp[hc], D, P.iw);
+            ISP2_MARK(2); /* eval_segment */
             const int fo = t.fni - lo;
             const bool inwin = (unsigned)fo < (unsigned)W;
             const int foc = inwin ? fo : 0;
@@ -634,10 +692,12 @@ __device__ __forceinline__ void pw_phase2_body(const DevParams& P, char* smem, i
                 const float og = my_row[(unsigned)t.fni] - (lcol + (size_t)r * D)[(unsigned)t.fni];
                 od = inwin ? od : og;
             }
+            ISP2_MARK(3); /* LUT values */
             if (r - 1 < vhor)
                 pairwise_step<false>(P, st, r, live, od, t, b);
             else
                 pairwise_step<true>(P, st, r, live, od, t, b);
+            ISP2_MARK(4); /* pairwise_step */
         }
         /* lane s holds the final values of row r: broadcast, derive the StepRec of vB = r+1 */
         if (r + 1 < H) {
@@ -660,8 +720,10 @@ __device__ __forceinline__ void pw_phase2_body(const DevParams& P, char* smem, i
                 }
                 S_ob = S_obc; V_ob = V_obc;
             }
-            st = make_step<HAS_INVALID>(P, S_r1, V_r1, S_ob, V_ob, s_odr, s_invc, s_logc,
-                                        (cprior_t)(pcol + r + 1), vhor, r, cG, cO, cS, ob);
+            ISP2_MARK(5); /* broadcasts */
+            st = make_step<HAS_INVALID>(P, S_r1, V_r1, S_ob, V_ob, s_odr, s_invc, s_logc, &pv, vhor, r,
+                                        cG, cO, cS, ob);
+            ISP2_MARK(6); /* make_step */
             /* fminf skips NaN fields: a candidate that selects one costs NaN and never wins */
             const float m8 = __builtin_fminf(
                 __builtin_fminf(__builtin_fminf(st.p1_hi, st.p1_lo), __builtin_fminf(st.p1_mid, st.p2_hi)),
@@ -670,8 +732,13 @@ __device__ __forceinline__ void pw_phase2_body(const DevParams& P, char* smem, i
             q_gs = __builtin_fminf(q_gs, st.pwmp);
             st.q_o = q_o; st.q_gs = q_gs;
             if (lane == 0) store_step(scol + r + 1, st);
+            ISP2_MARK(7); /* running minima + store */
         }
     }
+#ifdef IS_ABL_P2PHASES
+    if (lane == 0)
+        for (int k = 0; k < 8; k++) atomicAdd(&g_p2phase[k], acc_p2[k]);
+#endif
     if (vT < H) {
         const size_t o = ((size_t)colg * H + vT) * 3;
         cost_table[o + 0] = b.g; cost_table[o + 1] = b.o; cost_table[o + 2] = b.s;
@@ -704,6 +771,299 @@ __global__ __launch_bounds__(64, ISP2_OCC) void k_pw_phase2(
                                            nsplit, part_cost, part_idx, steps, cost_table, index_table);
 }
 
+/* ====================================================================================== */
+/* phase 2, split over the waves of a workgroup (k_pw_phase2s)                              */
+/* ====================================================================================== */
+/* A lone wavefront retires a dependent instruction every ~8 cycles, and a step of k_pw_phase2 is
+ * ~420 instructions of which only the chain
+ *     final row r-1 -> StepRec(r) -> candidate (r, r) -> final row r
+ * is inherently serial (~1.3 us per step, 82 us per tile at one frame).  Here the work of a
+ * (column, tile) is split over ISP2S_WAVES wavefronts:
+ *
+ *   wave 0 (chain)      per step: reads the state-independent terms of the step from an LDS slot,
+ *                       applies the StepRec (two adds and the three threshold selects per
+ *                       candidate), updates the running minima, broadcasts the finished row,
+ *                       builds and publishes the next StepRec;
+ *   waves 1.. (evaluators) everything of a step that does not depend on the DP state -- the
+ *                       scalar loads of the vB record and the priors, eval_segment, the two lutT
+ *                       values, the weights -- for steps s = e, e + NE, ..., several steps ahead,
+ *                       into a ring of ISP2S_SLOTS LDS slots.
+ *
+ * Hand-over through LDS sequence numbers (seq[slot] = step it holds, cons = last step consumed);
+ * both sides poll with s_sleep.  Dead lanes (vT < r, vT >= H) get +inf data terms: their costs are
+ * +inf or NaN and never pass a `<`, so the chain needs no lane mask.  Arithmetic and operand order
+ * are those of pairwise_step / make_step: cost = (dw * data + pw-term) + sw * seg. */
+#define ISP2S_WAVES 4
+#define ISP2S_NE (ISP2S_WAVES - 1)
+#define ISP2S_SLOTS 8
+#define ISP2S_SLOT_F (5 * 64 + 16) /* A_gs, B_gs, A_o, B_o, fn per lane + the PriorVals of vB = r + 1 */
+#define ISP2S_SPIN_LIMIT (1 << 26)
+
+/* wave-uniform wait until *p >= want; a bound that a correct run never reaches turns a would-be
+ * hang into an abort */
+__device__ __forceinline__ void isp2s_wait_ge(volatile int* p, int want) {
+    int spins = 0;
+    while (__builtin_amdgcn_readfirstlane(*p) < want) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > ISP2S_SPIN_LIMIT) __builtin_trap();
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+template <bool SKY>
+__device__ __forceinline__ void pairwise_step_pre(const DevParams& P, const StepVals st, int vB, float a_gs,
+                                                  float b_gs, float a_o, float b_o, float fn,
+                                                  PairBest& b) {
+    const float cost_gs = a_gs + st.pwmp + b_gs; /* :716-719 / :762-765 */
+    if (SKY) take_if_less(b.s, b.is, cost_gs, st.idx_gs);
+    else take_if_less(b.g, b.ig, cost_gs, st.idx_gs);
+    /* object, :777-837 */
+    const float p1 = (fn > st.g_hi_thr) ? st.p1_hi : ((fn < st.g_lo_thr) ? st.p1_lo : st.p1_mid);
+    const float p2 = (fn > st.o_hi_thr) ? st.p2_hi : ((fn < st.o_lo_thr) ? st.p2_lo : st.p2_mid);
+    const float p3 = (fn > P.epsilon) ? st.p3_yes : st.p3_no;
+    const float m12 = __builtin_fminf(p1, p2);
+    const float mp = __builtin_fminf(m12, p3);
+    const float cost = a_o + P.pw * mp + b_o;
+    const int base_o = vB * 3 + IS_OBJECT;
+    int idx = (p1 < p2) ? (base_o - 1) : base_o;
+    idx = (p3 < m12) ? (base_o + 1) : idx;
+    take_if_less_v(b.o, b.io, cost, idx);
+}
+
+template <bool FAST, bool HAS_INVALID>
+__device__ __forceinline__ void pw_phase2s_body(const DevParams& P, char* smem, int colg, int tile,
+                                                const RowRec* __restrict__ recs,
+                                                const float* __restrict__ lutT,
+                                                const float* __restrict__ joined,
+                                                const PriorRec* __restrict__ priors,
+                                                const float* __restrict__ odr,
+                                                const float* __restrict__ rcp,
+                                                const float* __restrict__ sv_arr, int vhor,
+                                                int nsplit, const float* __restrict__ part_cost,
+                                                const int* __restrict__ part_idx,
+                                                StepRec* __restrict__ steps,
+                                                float* __restrict__ cost_table,
+                                                int32_t* __restrict__ index_table) {
+    const int H = P.H, D = P.D;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    double* s_invc = (double*)smem;                      /* [32] */
+    double* s_logc = s_invc + IS_LOG_TABLE_SIZE;         /* [32] */
+    float* s_odr = (float*)(s_logc + IS_LOG_TABLE_SIZE); /* [D -> x4] */
+    float* s_rcp = s_odr + ((D + 3) & ~3);               /* [IS_TILE+1 -> x4] */
+    float* s_win = s_rcp + ((IS_TILE + 1 + 3) & ~3);     /* [65][ISP2_WS] lutT window */
+    float* s_ring = s_win + ((ISP2_ROWS * ISP2_WS + 3) & ~3); /* [ISP2S_SLOTS][ISP2S_SLOT_F] */
+    volatile int* s_seq = (volatile int*)(s_ring + ISP2S_SLOTS * ISP2S_SLOT_F); /* [SLOTS] + cons */
+    volatile int* s_cons = s_seq + ISP2S_SLOTS;
+    const int tile_lo = tile * IS_TILE;
+    const RowRec* rcol = recs + (size_t)colg * (H + 1);
+    const float* lcol = lutT + (size_t)colg * (H + 1) * D;
+    const PriorRec* pcol = priors + (size_t)(colg / P.C) * H;
+    StepRec* scol = steps + (size_t)colg * H;
+    const float* sv = sv_arr + (size_t)colg * 2 * (H + 1);
+    const int vT = tile_lo + lane;
+    const int vTc = min(vT, H - 1);
+    const int n_rows = min(IS_TILE, H - tile_lo);
+
+    /* ---- prologue, all waves: the fn window (every wave computes it), tables, flags */
+    int lo, W;
+    {
+        const float d = joined[(size_t)colg * H + vTc];
+        const bool ok = (vT < H) && !(HAS_INVALID && d == P.invalid);
+        const float dmin = wave_min_f(ok ? d : IS_INF);
+        const float dmax = wave_max_f(ok ? d : -IS_INF);
+        int l = (int)__builtin_fminf(__builtin_fmaxf(dmin, 1.0f), (float)D) - 1;
+        l = min(max(l, 0), D - 1);
+        int h = (int)__builtin_fminf(__builtin_fmaxf(dmax, 0.0f), (float)(D - 1)) + 1;
+        h = min(max(h, l), min(D - 1, l + ISP2_WMAX - 1));
+        lo = __builtin_amdgcn_readfirstlane(l);
+        W = __builtin_amdgcn_readfirstlane(h - l + 1);
+    }
+    { /* window rows: every load issued before the first LDS store (see pw_phase2_body) */
+        int lg = 0;
+        while ((1 << lg) < W) lg++;
+        lg = __builtin_amdgcn_readfirstlane(lg);
+        const int f = tid & ((1 << lg) - 1);
+        const int j0 = tid >> lg, dj = (ISP2S_WAVES * 64) >> lg;
+        constexpr int NL = (ISP2_ROWS * ISP2_WMAX + ISP2S_WAVES * 64 - 1) / (ISP2S_WAVES * 64);
+        float tmp[NL];
+#pragma unroll
+        for (int k = 0; k < NL; k++) {
+            const int j = j0 + k * dj;
+            tmp[k] = (j < ISP2_ROWS && f < W) ? lcol[(size_t)min(tile_lo + j, H) * D + lo + f] : 0.0f;
+        }
+#pragma unroll
+        for (int k = 0; k < NL; k++) {
+            const int j = j0 + k * dj;
+            if (j < ISP2_ROWS && f < W) s_win[j * ISP2_WS + f] = tmp[k];
+        }
+    }
+    if (tid == 0) is_log_tables(s_invc, s_logc);
+    for (int i = tid; i < D; i += ISP2S_WAVES * 64) s_odr[i] = odr[i];
+    for (int i = tid; i <= IS_TILE; i += ISP2S_WAVES * 64) s_rcp[i] = rcp[min(i, H)];
+    if (tid < ISP2S_SLOTS) s_seq[tid] = -1;
+    if (tid == ISP2S_SLOTS) *s_cons = 0;
+    __syncthreads();
+
+    if (w == 0) {
+        /* ================================ chain wave ================================ */
+        float myS, myV = 0.0f; /* prefixes at vT + 1 (lane k: prefix index tile_lo + k + 1) */
+        {
+            const RowRec* mr = rcol + vTc + 1;
+            myS = mr->S;
+            if (HAS_INVALID) myV = mr->V;
+        }
+        PairBest b;
+        {
+            const size_t o = (size_t)colg * nsplit * 3 * 64 + lane;
+            b.g = part_cost[o]; b.ig = part_idx[o];
+            b.o = part_cost[o + 64]; b.io = part_idx[o + 64];
+            b.s = part_cost[o + 128]; b.is = part_idx[o + 128];
+            for (int sp = 1; sp < nsplit; sp++) {
+                const size_t q = o + (size_t)sp * 3 * 64;
+                float c2 = part_cost[q]; int i2 = part_idx[q];
+                if ((c2 < b.g) || (c2 == b.g && c2 < IS_INF && (i2 / 3) < (b.ig / 3))) { b.g = c2; b.ig = i2; }
+                c2 = part_cost[q + 64]; i2 = part_idx[q + 64];
+                if ((c2 < b.o) || (c2 == b.o && c2 < IS_INF && (i2 / 3) < (b.io / 3))) { b.o = c2; b.io = i2; }
+                c2 = part_cost[q + 128]; i2 = part_idx[q + 128];
+                if ((c2 < b.s) || (c2 == b.s && c2 < IS_INF && (i2 / 3) < (b.is / 3))) { b.s = c2; b.is = i2; }
+            }
+        }
+        StepVals st;
+        st.pwmp = IS_INF; st.idx_gs = -1;
+        st.g_hi_thr = st.g_lo_thr = st.p1_hi = st.p1_lo = st.p1_mid = st.o_hi_thr = st.o_lo_thr = 0.0f;
+        st.p2_hi = st.p2_lo = st.p2_mid = st.p3_yes = st.p3_no = 0.0f;
+        float q_o, q_gs;
+        if (tile_lo == 0) {
+            q_o = P.pw * __builtin_fminf(P.first_o_below, P.first_o_above);
+            q_gs = P.pw * P.first_g;
+        } else {
+            cstep_t prev = (cstep_t)(scol + tile_lo);
+            q_o = prev->q_o;
+            q_gs = prev->q_gs;
+        }
+        st.q_o = q_o; st.q_gs = q_gs;
+        int ob_cached = -1;
+        float S_obc = 0.0f, V_obc = 0.0f;
+        for (int s = 0; s < n_rows; s++) {
+            const int r = tile_lo + s;
+            PriorVals pv;
+            if (s > 0) {
+                const int q = s % ISP2S_SLOTS;
+                const float* slot = s_ring + q * ISP2S_SLOT_F;
+                isp2s_wait_ge(s_seq + q, s);
+                const float a_gs = slot[lane], b_gs = slot[64 + lane], a_o = slot[128 + lane],
+                            b_o = slot[192 + lane], fn = slot[256 + lane];
+                const float4 p0 = *reinterpret_cast<const float4*>(slot + 320);
+                const float4 p1 = *reinterpret_cast<const float4*>(slot + 324);
+                pv.pc = p0.x; pv.g_from = p0.y; pv.s_from_g = p0.z; pv.o_from_s = p0.w;
+                pv.og_hi = p1.x; pv.og_lo = p1.y; pv.og_mid = p1.z; pv.g_prev = p1.w;
+                /* the slot is free again once these reads have executed (LDS operations of a wave
+                 * execute in order) */
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (lane == 0) *s_cons = s;
+                if (r - 1 < vhor)
+                    pairwise_step_pre<false>(P, st, r, a_gs, b_gs, a_o, b_o, fn, b);
+                else
+                    pairwise_step_pre<true>(P, st, r, a_gs, b_gs, a_o, b_o, fn, b);
+            } else {
+                pv = sload_prior(pcol + min(r + 1, H - 1));
+            }
+            if (r + 1 < H) {
+                const float cG = readlane_f(b.g, s), cO = readlane_f(b.o, s), cS = readlane_f(b.s, s);
+                const int ob = __builtin_amdgcn_readlane(b.io, s) / 3;
+                const float S_r1 = readlane_f(myS, s), V_r1 = HAS_INVALID ? readlane_f(myV, s) : 0.0f;
+                float S_ob, V_ob = 0.0f;
+                if (ob > tile_lo) {
+                    S_ob = readlane_f(myS, ob - 1 - tile_lo);
+                    if (HAS_INVALID) V_ob = readlane_f(myV, ob - 1 - tile_lo);
+                } else {
+                    if (ob != ob_cached) {
+                        typedef const __attribute__((address_space(4))) float* cflt_t;
+                        S_obc = *(cflt_t)(sv + ob);
+                        if (HAS_INVALID) V_obc = *(cflt_t)(sv + (H + 1) + ob);
+                        ob_cached = ob;
+                    }
+                    S_ob = S_obc; V_ob = V_obc;
+                }
+                st = make_step<HAS_INVALID>(P, S_r1, V_r1, S_ob, V_ob, s_odr, s_invc, s_logc, &pv, vhor, r,
+                                            cG, cO, cS, ob);
+                const float m8 = __builtin_fminf(
+                    __builtin_fminf(__builtin_fminf(st.p1_hi, st.p1_lo), __builtin_fminf(st.p1_mid, st.p2_hi)),
+                    __builtin_fminf(__builtin_fminf(st.p2_lo, st.p2_mid), __builtin_fminf(st.p3_yes, st.p3_no)));
+                q_o = __builtin_fminf(q_o, P.pw * m8);
+                q_gs = __builtin_fminf(q_gs, st.pwmp);
+                st.q_o = q_o; st.q_gs = q_gs;
+                if (lane == 0) store_step(scol + r + 1, st);
+            }
+        }
+        if (vT < H) {
+            const size_t o = ((size_t)colg * H + vT) * 3;
+            cost_table[o + 0] = b.g; cost_table[o + 1] = b.o; cost_table[o + 2] = b.s;
+            index_table[o + 0] = b.ig; index_table[o + 1] = b.io; index_table[o + 2] = b.is;
+        }
+    } else {
+        /* ================================ evaluator waves ================================ */
+        const RowRec my = load_rec(rcol + vTc + 1);
+        const float* my_row = lcol + (size_t)(vTc + 1) * D;
+        const float* my_win = s_win + (vTc + 1 - tile_lo) * ISP2_WS;
+        for (int s = w; s < n_rows; s += ISP2S_NE) { /* s >= 1 */
+            const int r = tile_lo + s;
+            const PriorVals pv = sload_prior(pcol + min(r + 1, H - 1));
+            const RowRec rb = sload_rec_pinned(rcol + r);
+            const int hc = max(vTc + 1 - r, 1);
+            const bool live = (vT < H) && (vT >= r);
+            const SegTerms t = eval_segment<FAST, HAS_INVALID>(my, rb, (float)hc, s_rcp[hc], D, P.iw);
+            const int fo = t.fni - lo;
+            const bool inwin = (unsigned)fo < (unsigned)W;
+            const int foc = inwin ? fo : 0;
+            float od = my_win[foc] - s_win[s * ISP2_WS + foc];
+            if (__builtin_amdgcn_ballot_w64(live && !inwin) != 0ull) { /* outside the window: rare */
+                const float og = my_row[(unsigned)t.fni] - (lcol + (size_t)r * D)[(unsigned)t.fni];
+                od = inwin ? od : og;
+            }
+            const bool ground = r - 1 < vhor; /* :687 / :729 */
+            const float a_gs = live ? P.dw * (ground ? t.gd : t.sd) : IS_INF;
+            const float b_gs = P.sw * (ground ? t.seg_g : t.seg_s);
+            const float a_o = live ? P.dw * od : IS_INF;
+            const float b_o = P.sw * t.seg_o;
+            const int q = s % ISP2S_SLOTS;
+            float* slot = s_ring + q * ISP2S_SLOT_F;
+            if (s >= ISP2S_SLOTS) isp2s_wait_ge(s_cons, s - ISP2S_SLOTS); /* the slot's last tenant is consumed */
+            slot[lane] = a_gs; slot[64 + lane] = b_gs; slot[128 + lane] = a_o; slot[192 + lane] = b_o;
+            slot[256 + lane] = t.mean;
+            if (lane == 0) {
+                *reinterpret_cast<float4*>(slot + 320) = make_float4(pv.pc, pv.g_from, pv.s_from_g, pv.o_from_s);
+                *reinterpret_cast<float4*>(slot + 324) = make_float4(pv.og_hi, pv.og_lo, pv.og_mid, pv.g_prev);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) s_seq[q] = s;
+        }
+    }
+}
+
+template <bool HAS_INVALID>
+__global__ __launch_bounds__(ISP2S_WAVES * 64, 5) void k_pw_phase2s(
+    const DevParams P, int col_base, int ncols, int tile, int nsplit,
+    const RowRec* __restrict__ recs, const float* __restrict__ lutT,
+    const float* __restrict__ joined, const PriorRec* __restrict__ priors,
+    const float* __restrict__ odr, const float* __restrict__ rcp,
+    const float* __restrict__ sv_arr, const int* __restrict__ vhor_arr,
+    const int* __restrict__ col_flags, const float* __restrict__ part_cost,
+    const int* __restrict__ part_idx, StepRec* __restrict__ steps, float* __restrict__ cost_table,
+    int32_t* __restrict__ index_table) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int colg = col_base + blockIdx.x;
+    if (colg >= ncols) return;
+    const int vhor = __builtin_amdgcn_readfirstlane(vhor_arr[colg / P.C]);
+    if (__builtin_amdgcn_readfirstlane(col_flags[colg]) == 0)
+        pw_phase2s_body<true, HAS_INVALID>(P, smem, colg, tile, recs, lutT, joined, priors, odr, rcp, sv_arr,
+                                           vhor, nsplit, part_cost, part_idx, steps, cost_table, index_table);
+    else
+        pw_phase2s_body<false, HAS_INVALID>(P, smem, colg, tile, recs, lutT, joined, priors, odr, rcp, sv_arr,
+                                            vhor, nsplit, part_cost, part_idx, steps, cost_table, index_table);
+}
+
 extern "C" {
 
 size_t isk_pairwise_lds_bytes(const DevParams* P, int nwaves) { return isk_unary_lds_bytes(P); }
@@ -714,6 +1074,14 @@ size_t isk_phase2_lds_bytes(const DevParams* P) {
     size_t floor_bytes = 0;
     if (const char* e = getenv("IS_P2_LDS")) floor_bytes = (size_t)atoi(e);
     return need > floor_bytes ? need : floor_bytes;
+}
+
+size_t isk_phase2s_lds_bytes(const DevParams* P) {
+    return sizeof(double) * 2 * IS_LOG_TABLE_SIZE +
+           sizeof(float) * (((P->D + 3) & ~3) + ((IS_TILE + 1 + 3) & ~3) +
+                            (((size_t)ISP2_ROWS * ISP2_WS + 3) & ~(size_t)3) +
+                            (size_t)ISP2S_SLOTS * ISP2S_SLOT_F) +
+           sizeof(int) * (ISP2S_SLOTS + 1 + 2 * ISP2S_WAVES) + 32;
 }
 
 hipError_t isk_launch_dp_pairwise(const DevParams* P, int ncols, int nwaves, const RowRec* recs,
@@ -767,7 +1135,18 @@ hipError_t isk_launch_dp_pairwise(const DevParams* P, int ncols, int nwaves, con
                        nsplit, recs, lutT, joined, priors, odr, rcp, sv_arr, vhor, col_flags,      \
                        part_cost,                                                                  \
                        part_idx, steps, cost_table, index_table)
+#define IS_LAUNCH_P2S(INV, c0, c1, st)                                                             \
+    hipLaunchKernelGGL(k_pw_phase2s<INV>, dim3((c1) - (c0)), dim3(ISP2S_WAVES * 64), lds2s, st, *P, \
+                       c0, c1, tile, nsplit, recs, lutT, joined, priors, odr, rcp, sv_arr, vhor,   \
+                       col_flags, part_cost, part_idx, steps, cost_table, index_table)
     const bool inv = P->invalid >= 0;
+    /* phase 2 split over four waves per column (k_pw_phase2s) while the columns are too few to fill
+     * the chip with one wave each: it shortens the serial chain of a column (one frame: 82 -> 74 us
+     * per tile) but spends four wave slots per column, which costs throughput at large batches
+     * (batch 64: 32.7 vs 25.4 ms per step).  IS_P2_SPLIT=0/1 overrides. */
+    bool split2 = ncols <= IS_P2_SPLIT_MAX_COLS;
+    if (const char* e = getenv("IS_P2_SPLIT")) split2 = atoi(e) != 0;
+    const size_t lds2s = isk_phase2s_lds_bytes(P);
     if (groups > 1) {
         if ((e = hipEventRecord(ev_fork, stream)) != hipSuccess) return e;
         for (int g = 1; g < groups; g++)
@@ -779,11 +1158,16 @@ hipError_t isk_launch_dp_pairwise(const DevParams* P, int ncols, int nwaves, con
             const int c1 = (int)((long long)ncols * (g + 1) / groups);
             hipStream_t st = g == 0 ? stream : aux[g - 1];
             if (inv) IS_LAUNCH_P1(true, c0, c1, st); else IS_LAUNCH_P1(false, c0, c1, st);
-            if (inv) IS_LAUNCH_P2(true, c0, c1, st); else IS_LAUNCH_P2(false, c0, c1, st);
+            if (split2) {
+                if (inv) IS_LAUNCH_P2S(true, c0, c1, st); else IS_LAUNCH_P2S(false, c0, c1, st);
+            } else {
+                if (inv) IS_LAUNCH_P2(true, c0, c1, st); else IS_LAUNCH_P2(false, c0, c1, st);
+            }
         }
     }
 #undef IS_LAUNCH_P1
 #undef IS_LAUNCH_P2
+#undef IS_LAUNCH_P2S
     for (int g = 1; g < groups; g++) {
         if ((e = hipEventRecord(ev_join[g - 1], aux[g - 1])) != hipSuccess) return e;
         if ((e = hipStreamWaitEvent(stream, ev_join[g - 1], 0)) != hipSuccess) return e;
