@@ -229,6 +229,34 @@ __device__ __forceinline__ void pairwise_step(const DevParams& P, const StepVals
     }
 }
 
+/* ---- phase 1: warming the L2 for the scalar loads ---------------------------------------------
+ * A step takes the record and the StepRec of its vB through scalar loads (SGPR operands), and a
+ * wave cannot keep two such record sets in SGPRs, so those loads cannot be issued a step ahead:
+ * they were HBM misses on the critical path of every step (~1.5 us under load).  Instead a step
+ * now TOUCHES the two lines of the vB that comes IS_P1_TOUCH_AHEAD steps later with one LDS-DMA
+ * instruction (two lanes, no VGPR, destination a scratch word nobody reads), issued just before
+ * the step's own row prefetch so that it never lengthens a vmcnt wait; when the scalar loads come
+ * they hit the L2. */
+#ifndef IS_P1_TOUCH_AHEAD
+#define IS_P1_TOUCH_AHEAD 2
+#endif
+/* (measured on MI355X, batch 64, ms per step of the pairwise DP: no touch 25.35, 1 step ahead
+ * 24.2, 2 steps 22.96, 3 steps 24.3, 4 steps 23.2, 8 steps 24.2; touching the lutT row of the step
+ * after next as well +0.35; the same trick on the record / priors of phase 2 +0.6: both removed) */
+__device__ __forceinline__ void touch_step(const RowRec* rcol, const StepRec* scol, int vB, int lane,
+                                           unsigned lds_scratch) {
+    if (lane < 2)
+        dma_dword(lane == 0 ? (const float*)(rcol + vB) : (const float*)(scol + vB), lds_scratch);
+}
+/* the four vB of the next ground / sky round: records in lanes 0..3, StepRecs in lanes 4..7 */
+__device__ __forceinline__ void touch_round(const RowRec* rcol, const StepRec* scol, int vB0, int nw,
+                                            int lo, int lane, unsigned lds_scratch) {
+    if (lane < 8) {
+        const int v = max(vB0 - (lane & 3) * nw, lo);
+        dma_dword(lane < 4 ? (const float*)(rcol + v) : (const float*)(scol + v), lds_scratch);
+    }
+}
+
 /* The pairwise DP of one 64-row tile is split over two launches (per tile, bottom-up):
  *
  *  phase 1  k_pw_phase1: segments that START in earlier tiles (vB <= tile_lo).  Their
@@ -255,6 +283,7 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
     const int DP = D + 1;
     float* s_tile = (float*)smem;             /* [64][D+1] */
     float* s_rcp = s_tile + IS_TILE * DP;     /* [H+1]     */
+    float* s_scr = s_rcp + ((H + 1 + 3) & ~3); /* [8 per wave] landing area of the L2-warming DMAs */
     const int tid = threadIdx.x, lane = tid & 63;
     /* `nsplit` workgroups share the vB range of one (column, tile): together they behave like
      * one workgroup of nsplit * nwl waves (few columns = small batches: more of the chip works
@@ -285,6 +314,7 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
     const __amdgpu_buffer_rsrc_t lrsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void*)lcol, 0, (H + 1) * D * (int)sizeof(float), 0x00020000);
     const int lane4 = lane * 4;
+    const unsigned scr = lds_addr(s_scr + 8 * wl);
     if (FAST && IS_PRUNE) {
         /* FAST columns: vB downwards with the exact branch-and-bound of DESIGN.md "Pruning".  A
          * candidate vB' <= vB of lane vT costs at least
@@ -316,6 +346,8 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
             const RowRec rb = sload_rec(rcol + vB);                                                \
             const StepVals st = sload_step(scol + vB);                                             \
             const LutRow<NR> row = next_row;                                                       \
+            if (IS_P1_TOUCH_AHEAD > 0)                                                             \
+                touch_step(rcol, scol, max(vB - IS_P1_TOUCH_AHEAD * nw, 0), lane, scr);            \
             load_lut_row<NR>(next_row, lrsrc, lcol, max(vB - nw, 0), D, lane4);                    \
             const int h = vTc + 1 - vB;                                                            \
             const SegTerms t = eval_segment<true, HAS_INVALID>(my, rb, (float)h, s_rcp[h], D, P.iw); \
@@ -328,6 +360,7 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
 #define IS_P1_GS4(SKY, lo, x_dead, x_closed)                                                       \
             {                                                                                      \
                 const int n_here = min(4, (vB - (lo)) / nw + 1);                                   \
+                if (IS_P1_TOUCH_AHEAD > 0) touch_round(rcol, scol, vB - 4 * nw, nw, (lo), lane, scr); \
                 float c_f[4], c_cost[4];                                                           \
                 int c_idx[4];                                                                      \
                 float c_q[4];                                                                      \
@@ -461,7 +494,10 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
             pairwise_step<true, true>(P, st, vB, live, od, t, b);
         }
     }
-    /* merge the waves: min cost, ties -> smallest vB (a finite cost always has a real index) */
+    /* merge the waves: min cost, ties -> smallest vB (a finite cost always has a real index).
+     * Every L2-warming DMA must have landed before this wave can end: its LDS target would
+     * otherwise be written after the workgroup's LDS has been handed to another one. */
+    wait_vmcnt<0>();
     __syncthreads();
     float* m_cost = (float*)smem;               /* [nwl][3][64] (aliases the tile) */
     int* m_idx = (int*)(m_cost + nwl * 3 * 64); /* [nwl][3][64] */
@@ -488,8 +524,11 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
     }
 }
 
+#ifndef ISP1_OCC
+#define ISP1_OCC IS_UNARY_WAVES /* waves per SIMD phase 1 is compiled for (6 and 4 measured slower) */
+#endif
 template <bool HAS_INVALID, int NR>
-__global__ __launch_bounds__(IS_UNARY_WAVES * 64, IS_UNARY_WAVES) void k_pw_phase1(
+__global__ __launch_bounds__(IS_UNARY_WAVES * 64, ISP1_OCC) void k_pw_phase1(
     const DevParams P, int col_base, int ncols, int tile, int nsplit,
     const RowRec* __restrict__ recs, const float* __restrict__ lutT,
     const StepRec* __restrict__ steps, const float* __restrict__ rcp,
@@ -1066,7 +1105,12 @@ __global__ __launch_bounds__(ISP2S_WAVES * 64, 5) void k_pw_phase2s(
 
 extern "C" {
 
-size_t isk_pairwise_lds_bytes(const DevParams* P, int nwaves) { return isk_unary_lds_bytes(P); }
+size_t isk_pairwise_lds_bytes(const DevParams* P, int nwaves) {
+    const size_t rcp = sizeof(float) * (((size_t)P->H + 1 + 3) & ~(size_t)3);
+    const size_t tile = sizeof(float) * (size_t)IS_TILE * (P->D + 1);
+    const size_t merge = (size_t)nwaves * 3 * 64 * 8; /* aliases the tile after the loop */
+    return (tile > merge ? tile : merge) + rcp + sizeof(float) * 8 * (size_t)nwaves + 16;
+}
 size_t isk_phase2_lds_bytes(const DevParams* P) {
     size_t need = sizeof(double) * 2 * IS_LOG_TABLE_SIZE +
                   sizeof(float) * (P->D + (IS_TILE + 1) + (size_t)ISP2_ROWS * ISP2_WS) + 16;

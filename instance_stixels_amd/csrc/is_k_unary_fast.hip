@@ -23,7 +23,12 @@
  */
 #include "is_kernels.h"
 
+#ifndef ISF_WAVES
 #define ISF_WAVES 8
+#endif
+#ifndef ISF_OCC
+#define ISF_OCC 4 /* waves per SIMD the kernel is compiled for */
+#endif
 #define ISF_THREADS (ISF_WAVES * 64)
 
 struct UnaryBestF {
@@ -138,7 +143,7 @@ __device__ __forceinline__ void ring_prefetch(const float* __restrict__ lcol,
 }
 
 template <bool HAS_INVALID, int NVR>
-__global__ __launch_bounds__(ISF_THREADS, 4) void k_dp_unary_fast(
+__global__ __launch_bounds__(ISF_THREADS, ISF_OCC) void k_dp_unary_fast(
     const DevParams P, int ncols, const RowRec* __restrict__ recs, const float* __restrict__ lutT,
     const float* __restrict__ rcp, const int* __restrict__ vhor_arr,
     const int* __restrict__ col_flags, const PruneRec* __restrict__ prune,

@@ -319,7 +319,9 @@ __device__ __forceinline__ void take_if_less_v(float& best, int& best_v, float c
 /* ====================================================================================== */
 /* Wave-private LDS rings filled by LDS-DMA (is_k_unary_fast.hip, k_pw_phase1_ring)         */
 /* ====================================================================================== */
+#ifndef ISF_RING
 #define ISF_RING 8     /* slots per wave: prefetch distance in steps (unary) */
+#endif
 #define ISF_REC_F 32   /* floats of a record slot */
 
 typedef __attribute__((address_space(3))) void* isf_lds_t;
