@@ -5,7 +5,7 @@ set -u
 TAG=${1:-r01}; shift || true
 ARGS=${@:---batch 8 --steps 2 --warmup 1 --no-cpu-baseline}
 OUT=gpurun_out/prof_$TAG
-mkdir -p $OUT
+rm -rf $OUT; mkdir -p $OUT
 echo "python3 bench.py $ARGS" > $OUT/command.txt
 export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py $ARGS > $OUT/bench_trace.log 2>&1
