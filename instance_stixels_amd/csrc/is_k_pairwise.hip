@@ -298,7 +298,7 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
     const StepRec* scol = steps + (size_t)colg * H;
 
     stage_lut_tile<true>(s_tile, lcol, tile_lo, H, D, tid, (int)blockDim.x);
-    for (int i = tid; i <= H; i += blockDim.x) s_rcp[i] = rcp[i];
+    stage_rcp(s_rcp, rcp, H, tid, (int)blockDim.x);
     const int vT = tile_lo + lane;
     const int vTc = min(vT, H - 1);
     const RowRec my = load_rec(rcol + vTc + 1);

@@ -348,7 +348,7 @@ __global__ __launch_bounds__(IS_UNARY_WAVES * 64, IS_UNARY_OCC) void k_dp_unary(
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const RowRec* rcol = recs + (size_t)colg * (H + 1);
     const float* lcol = lutT + (size_t)colg * (H + 1) * D;
-    for (int i = tid; i <= H; i += blockDim.x) s_rcp[i] = rcp[i];
+    stage_rcp(s_rcp, rcp, H, tid, (int)blockDim.x);
     const __amdgpu_buffer_rsrc_t lrsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void*)lcol, 0, (H + 1) * D * (int)sizeof(float), 0x00020000 /* raw, 32-bit data */);
 

@@ -189,7 +189,7 @@ __global__ __launch_bounds__(ISF_THREADS, ISF_OCC) void k_dp_unary_fast(
         ring_prefetch<NVR>(lcol, rcol, max(vB_top - ISF_WAVES * i, 0), D, my_ring + i * SLOT,
                            my_ring + i * SLOT + ROWF, lane);
     const RowRec my = load_rec(rcol + vTc + 1);
-    for (int i = tid; i <= H; i += ISF_THREADS) s_rcp[i] = rcp[i];
+    stage_rcp(s_rcp, rcp, H, tid, ISF_THREADS);
     stage_lut_tile<true>(s_tile, lcol, tile_lo, H, D, tid, ISF_THREADS);
 
     PruneValsF pv;

@@ -203,18 +203,41 @@ __device__ __forceinline__ void stage_lut_tile(float* s_tile, const float* __res
         const int quads = D >> 2;            /* 16-byte chunks per row */
         const int r0 = tid / quads, f = (tid - r0 * quads) * 4;
         const int dr = nthreads / quads;     /* rows per sweep of the workgroup */
-        for (int r = r0; r < IS_TILE; r += dr) {
-            const int v = min(tile_lo + 1 + r, H);
-            const float4 x = *reinterpret_cast<const float4*>(lcol + (size_t)v * D + f);
-            float* d = s_tile + r * DP + f;
-            d[0] = x.x; d[1] = x.y; d[2] = x.z; d[3] = x.w;
+        /* four sweeps per round trip: all four loads are issued before the first LDS store (a
+         * load -> wait -> store loop costs one full memory latency per sweep, and its vmcnt(0)
+         * also waits for every prefetch the caller has in flight) */
+        for (int rb = r0; rb < IS_TILE; rb += 4 * dr) {
+            float4 x[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int r = rb + k * dr;
+                const int v = min(tile_lo + 1 + min(r, IS_TILE - 1), H);
+                x[k] = *reinterpret_cast<const float4*>(lcol + (size_t)v * D + f);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int r = rb + k * dr;
+                if (r < IS_TILE) {
+                    float* d = s_tile + r * DP + f;
+                    d[0] = x[k].x; d[1] = x[k].y; d[2] = x[k].z; d[3] = x[k].w;
+                }
+            }
         }
     } else if ((nthreads % D) == 0) {
         const int r0 = tid / D, f = tid - r0 * D;
         const int dr = nthreads / D;
-        for (int r = r0; r < IS_TILE; r += dr) {
-            const int v = min(tile_lo + 1 + r, H);
-            s_tile[r * DP + f] = lcol[(size_t)v * D + f];
+        for (int rb = r0; rb < IS_TILE; rb += 8 * dr) {
+            float x[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int r = rb + k * dr;
+                x[k] = lcol[(size_t)min(tile_lo + 1 + min(r, IS_TILE - 1), H) * D + f];
+            }
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int r = rb + k * dr;
+                if (r < IS_TILE) s_tile[r * DP + f] = x[k];
+            }
         }
     } else {
         for (int i = tid; i < IS_TILE * D; i += nthreads) {
@@ -222,6 +245,19 @@ __device__ __forceinline__ void stage_lut_tile(float* s_tile, const float* __res
             const int v = min(tile_lo + 1 + r, H);
             s_tile[r * DP + f] = lcol[(size_t)v * D + f];
         }
+    }
+}
+
+/* s_rcp[0..H] <- rcp[0..H], four elements per thread and round trip (see stage_lut_tile) */
+__device__ __forceinline__ void stage_rcp(float* s_rcp, const float* __restrict__ rcp, int H, int tid,
+                                          int nthreads) {
+    for (int ib = tid; ib <= H; ib += 4 * nthreads) {
+        float x[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) x[k] = rcp[min(ib + k * nthreads, H)];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (ib + k * nthreads <= H) s_rcp[ib + k * nthreads] = x[k];
     }
 }
 

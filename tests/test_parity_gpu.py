@@ -268,6 +268,25 @@ def test_pairwise_two_stream_split_matches_oracle():
         assert helpers.sections_equal(alone["sections"][0], got["sections"][img])
 
 
+@pytest.mark.parametrize("n_images,inv", [(1, -1.0), (3, -1.0), (1, 0.0), (3, 0.0)])
+def test_pairwise_phase2_window_and_fallback(n_images, inv):
+    """Phase 2 of the pairwise DP stages a <= 16-column window of the tile's lutT rows in LDS and
+    reads global memory for lanes outside it.  Columns whose rows alternate between two far-apart
+    disparities put every segment mean of a tile far outside any 16-column window (fallback on
+    every step); smooth columns stay inside it.  One image = 192 columns -> k_pw_phase2s (chain +
+    evaluator waves), three images = 576 columns -> k_pw_phase2 (one wave per column)."""
+    ov = dict(invalid_disparity=inv) if inv >= 0 else {}
+    case = helpers.build_case("drn_d_38_pairwise", 256, 1536, 64, seed=77, n_images=n_images, **ov)
+    d = case["disparity"]
+    rows, width = d.shape[1], d.shape[2]
+    pattern = np.where((np.arange(rows) // 3) % 2 == 0, 3.25, 50.5).astype(np.float32)
+    d[:, :, : width // 2] = pattern[None, :, None]
+    if inv >= 0:  # holes in the alternating columns too: the valid-count prefix path
+        d[:, ::5, : width // 4] = inv
+    got = helpers.run_core(case)
+    _assert_parity(case, got)
+
+
 @pytest.mark.parametrize("preset", ["drn_d_22_unary", "drn_d_38_pairwise"])
 def test_one_context_many_call_sizes_back_to_back(preset):
     """One context, calls of very different sizes queued back to back on one stream WITHOUT
