@@ -237,6 +237,9 @@ __device__ __forceinline__ void pairwise_step(const DevParams& P, const StepVals
  * instruction (two lanes, no VGPR, destination a scratch word nobody reads), issued just before
  * the step's own row prefetch so that it never lengthens a vmcnt wait; when the scalar loads come
  * they hit the L2. */
+#ifndef IS_P1_ROW_AHEAD
+#define IS_P1_ROW_AHEAD 1 /* steps the vB-side lutT row is fetched ahead of its use (1 or 2) */
+#endif
 #ifndef IS_P1_TOUCH_AHEAD
 #define IS_P1_TOUCH_AHEAD 2
 #endif
@@ -269,6 +272,127 @@ __device__ __forceinline__ void touch_round(const RowRec* rcol, const StepRec* s
  *
  * The serial chain of the reference (rows x __syncthreads, StixelsKernels.cu:600-603) is thus
  * confined to phase 2, 1/16 of the pair evaluations at 1024 rows. */
+/* ---- phase 1, FAST columns: the vB record as DPP operands ---------------------------------------
+ * The record of vB is wave-uniform.  Through scalar loads its 32 dwords are free SGPR operands,
+ * but the loads cannot be issued ahead (a wave cannot hold two records in SGPRs) and every step
+ * waits for scalar memory.  Here the record is fetched by two ordinary vector loads instead --
+ * lane l of every 16-lane row holds dwords (l & 15) and 16 + (l & 15) -- TWO steps ahead
+ * (vmcnt-tracked, six VGPRs in flight), and a subtraction takes dword k as a DPP operand:
+ *     v_subrev_f32_dpp d, R, mine row_newbcast:k        d = mine - R[lane k of my row]
+ * A DPP instruction issues in 4 cycles instead of 2 (tools/ubench/dpp_rate.hip), ~60 cycles more
+ * per step, and frees 32 SGPRs (the kernel had 72 SGPR spills).  The StepRec stays in SGPRs and is
+ * double buffered (16 + 16), loaded one step ahead.  `asm volatile`: a DPP read of a lane that
+ * EXEC has switched off returns 0, so these instructions must never sink into divergent code. */
+#ifndef IS_P1_DPP
+#define IS_P1_DPP 1
+#endif
+template <int K>
+__device__ __forceinline__ float dpp_sub(float mine, float R) {
+    float d;
+    asm volatile("v_subrev_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+                 : "=v"(d) : "v"(R), "v"(mine), "n"(K));
+    return d;
+}
+/* The first DPP read of a record register in a step: gfx9 needs two wait states between a VALU
+ * write of a VGPR (the register rotation's v_mov) and a DPP read of it; the compiler's hazard
+ * recogniser does not look inside inline assembly, so the s_nop travels with the instruction. */
+template <int K>
+__device__ __forceinline__ float dpp_sub_first(float mine, float R) {
+    float d;
+    asm volatile("s_nop 1\n\tv_subrev_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+                 : "=v"(d) : "v"(R), "v"(mine), "n"(K));
+    return d;
+}
+/* integer dword (Fnic): fetched with v_mov_b32_dpp and subtracted by an ordinary instruction --
+ * v_subrev_u32_dpp returns a wrong operand on gfx950 (tools/ubench/dpp_sub_check.hip) */
+template <int K>
+__device__ __forceinline__ int dpp_sub_i_first(int mine, float R) {
+    int d;
+    asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf"
+                 : "=v"(d) : "v"(R), "n"(K));
+    return mine - d;
+}
+/* eval_segment<true, HAS_INVALID> (is_kernels.h) with the vB record in (R0, R1): identical
+ * operations in identical order, only the source of the vB operand differs */
+template <bool HAS_INVALID>
+__device__ __forceinline__ SegTerms eval_segment_dpp(const RowRec& my, float R0, float R1, float height,
+                                                     float r, int D, float iw) {
+    SegTerms t;
+    const float nic = iw * (float)dpp_sub_i_first<3>(my.Fnic, R1);
+    const float d_g0 = dpp_sub_first<0>(my.Fg0, R0); /* (explicit statements: asm order = source order) */
+    const float d_g1 = dpp_sub<1>(my.Fg1, R0);
+    float f_g = __builtin_fminf(d_g0, d_g1);
+    float f_on = dpp_sub<2>(my.Fon[0], R0);
+    f_on = __builtin_fminf(f_on, dpp_sub<3>(my.Fon[1], R0));
+    f_on = __builtin_fminf(f_on, dpp_sub<4>(my.Fon[2], R0));
+    f_on = __builtin_fminf(f_on, dpp_sub<5>(my.Fon[3], R0));
+    f_on = __builtin_fminf(f_on, dpp_sub<6>(my.Fon[4], R0));
+    f_on = __builtin_fminf(f_on, dpp_sub<7>(my.Fon[5], R0));
+    f_on = __builtin_fminf(f_on, dpp_sub<8>(my.Fon[6], R0));
+    f_on = __builtin_fminf(f_on, dpp_sub<9>(my.Fon[7], R0));
+    float f_oi = dpp_sub<10>(my.Foi[0], R0);
+    f_oi = __builtin_fminf(f_oi, dpp_sub<11>(my.Foi[1], R0));
+    f_oi = __builtin_fminf(f_oi, dpp_sub<12>(my.Foi[2], R0));
+    f_oi = __builtin_fminf(f_oi, dpp_sub<13>(my.Foi[3], R0));
+    f_oi = __builtin_fminf(f_oi, dpp_sub<14>(my.Foi[4], R0));
+    f_oi = __builtin_fminf(f_oi, dpp_sub<15>(my.Foi[5], R0));
+    f_oi = __builtin_fminf(f_oi, dpp_sub<0>(my.Foi[6], R1));
+    f_oi = __builtin_fminf(f_oi, dpp_sub<1>(my.Foi[7], R1));
+    const float f_sky = dpp_sub<2>(my.Fsky, R1);
+    const float meanx = dpp_sub<8>(my.MX, R1);
+    const float meany = dpp_sub<9>(my.MY, R1);
+    const float d_x2h = dpp_sub<10>(my.MX2h, R1);
+    const float d_x2l = dpp_sub<11>(my.MX2l, R1);
+    const float d_y2h = dpp_sub<12>(my.MY2h, R1);
+    const float d_y2l = dpp_sub<13>(my.MY2l, R1);
+    const float meanx2 = d_x2h + d_x2l;
+    const float meany2 = d_y2h + d_y2l;
+    const float ic = iw * (meanx2 - fast_div(meanx * meanx, height, r) + meany2 -
+                           fast_div(meany * meany, height, r));
+    t.f_g = f_g; t.f_on = f_on; t.f_oi = f_oi; t.f_sky = f_sky;
+    t.seg_g = f_g + nic;
+    const float on = nic + f_on;
+    const float oi = ic + f_oi;
+    t.seg_o = __builtin_fminf(oi, on);
+    t.seg_s = f_sky + nic;
+    t.gd = dpp_sub<4>(my.G, R1);
+    t.sd = dpp_sub<5>(my.K, R1);
+    float mean;
+    if (HAS_INVALID) {
+        const float valid_dif = dpp_sub<7>(my.V, R1);
+        const float sdif = dpp_sub<6>(my.S, R1);
+        mean = (valid_dif == 0) ? 0 : sdif / valid_dif;
+    } else {
+        mean = fast_div(dpp_sub<6>(my.S, R1), height, r);
+    }
+    t.fni = (int)min(cvt_u32_sat(mean), (unsigned)(D - 1));
+    t.mean = __builtin_fmaxf(mean, 0.0f);
+    return t;
+}
+
+#ifdef IS_ABL_P1PHASES
+/* debug build only: s_memtime cycles of wave 0 of every phase-1 workgroup in prologue / walk /
+ * waiting for the other waves / merge, plus the number of full and ground-sky rounds of wave 0 */
+__device__ unsigned long long g_p1phase[8];
+#define ISP1_MARK(k)                                                              \
+    do {                                                                          \
+        const unsigned long long now__ = __builtin_readcyclecounter();            \
+        if (threadIdx.x == 0) atomicAdd(&g_p1phase[k], now__ - t_p1);             \
+        t_p1 = now__;                                                             \
+    } while (0)
+#define ISP1_COUNT(k) do { if (threadIdx.x == 0) atomicAdd(&g_p1phase[k], 1ull); } while (0)
+extern "C" void isk_debug_p1phases(unsigned long long* out, int reset) {
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_p1phase), sizeof(g_p1phase));
+    if (reset) {
+        unsigned long long z[8] = {0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_p1phase), z, sizeof(z));
+    }
+}
+#else
+#define ISP1_MARK(k)
+#define ISP1_COUNT(k)
+#endif
+
 template <bool FAST, bool HAS_INVALID, int NR>
 __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, int colg, int tile,
                                                const RowRec* __restrict__ recs,
@@ -297,6 +421,10 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
     const float* lcol = lutT + (size_t)colg * (H + 1) * D;
     const StepRec* scol = steps + (size_t)colg * H;
 
+#ifdef IS_ABL_P1PHASES
+    unsigned long long t_p1 = __builtin_readcyclecounter();
+#endif
+    const int vB_last = min(tile_lo, H - 1);
     stage_lut_tile<true>(s_tile, lcol, tile_lo, H, D, tid, (int)blockDim.x);
     stage_rcp(s_rcp, rcp, H, tid, (int)blockDim.x);
     const int vT = tile_lo + lane;
@@ -305,12 +433,12 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
     const float* my_tile = s_tile + lane * DP;
     const bool live = vT < H;
     __syncthreads();
+    ISP1_MARK(0);
 
     PairBest b;
     b.g = b.o = b.s = IS_INF;
     b.ig = b.is = -1;
     b.io = IS_OBJECT; /* :592 */
-    const int vB_last = min(tile_lo, H - 1);
     const __amdgpu_buffer_rsrc_t lrsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void*)lcol, 0, (H + 1) * D * (int)sizeof(float), 0x00020000);
     const int lane4 = lane * 4;
@@ -332,6 +460,10 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
             int vB = vB_last - (vB_last - w) % nw; /* the wave's largest vB */
             LutRow<NR> next_row;
             load_lut_row<NR>(next_row, lrsrc, lcol, vB, D, lane4);
+#if IS_P1_ROW_AHEAD == 2
+            LutRow<NR> next2_row; /* the row of the step after next: two rows in flight */
+            load_lut_row<NR>(next2_row, lrsrc, lcol, max(vB - nw, 0), D, lane4);
+#endif
             /* The bounds are sticky per type (a bound that holds at vB holds at every smaller vB:
              * the class minima only grow, the running minima q only grow, the best cost cannot
              * change any more).  The OBJECT bound -- minimum over the object classes only --
@@ -342,24 +474,72 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
              * no LUT access -- a fifth of the instructions of a full step; they are evaluated FOUR
              * vB at a time so that one scalar-load latency covers four steps. */
             bool done = false, o_closed = false;
+#if IS_P1_ROW_AHEAD == 2
+#define IS_P1_NEXT_ROW()                                                                           \
+            next_row = next2_row;                                                                  \
+            load_lut_row<NR>(next2_row, lrsrc, lcol, max(vB - 2 * nw, 0), D, lane4)
+#else
+#define IS_P1_NEXT_ROW() load_lut_row<NR>(next_row, lrsrc, lcol, max(vB - nw, 0), D, lane4)
+#endif
+#if IS_P1_DPP
+            /* record of vB (c_*), of vB - nw (n_*): vector loads, two steps ahead; StepRec one step
+             * ahead in a second set of SGPRs */
+            const int l15 = lane & 15;
+            float c_r0, c_r1, n_r0, n_r1;
+            { /* (requesting these before the tile staging of the prologue measured 2.5 % slower) */
+                const float* q0 = (const float*)(rcol + vB);
+                const float* q1 = (const float*)(rcol + max(vB - nw, 0));
+                c_r0 = q0[l15]; c_r1 = q0[16 + l15];
+                n_r0 = q1[l15]; n_r1 = q1[16 + l15];
+            }
+            StepVals st_next = sload_step(scol + vB);
 #define IS_P1_STEP(SKY, NOG)                                                                       \
+            ISP1_COUNT(4);                                                                         \
+            const float r0 = c_r0, r1 = c_r1;                                                      \
+            const StepVals st = st_next;                                                           \
+            const LutRow<NR> row = next_row;                                                       \
+            if (IS_P1_TOUCH_AHEAD > 0)                                                             \
+                touch_step(rcol, scol, max(vB - IS_P1_TOUCH_AHEAD * nw, 0), lane, scr);            \
+            IS_P1_NEXT_ROW();                                                                      \
+            c_r0 = n_r0; c_r1 = n_r1;                                                              \
+            {                                                                                      \
+                const float* q2 = (const float*)(rcol + max(vB - 2 * nw, 0));                      \
+                n_r0 = q2[l15]; n_r1 = q2[16 + l15];                                               \
+            }                                                                                      \
+            const int h = vTc + 1 - vB;                                                            \
+            const SegTerms t = eval_segment_dpp<HAS_INVALID>(my, r0, r1, (float)h, s_rcp[h], D, P.iw); \
+            const float od = my_tile[t.fni] - pick_lut<NR>(row, t.fni);                            \
+            {   /* the next StepRec: requested only now -- every LDS wait is an lgkmcnt(0) wait and \
+                 * would wait for this scalar load too (SMEM returns out of order) */              \
+                const StepRec* sn = scol + max(vB - nw, 0);                                        \
+                asm volatile("" : "+s"(sn) : "v"(od));                                             \
+                st_next = sload_step(sn);                                                          \
+            }                                                                                      \
+            pairwise_step<SKY, true, NOG, true>(P, st, vB, live, od, t, b);                        \
+            const float lb_o = (st.q_o - E1o) + P.sw * __builtin_fminf(t.f_on, t.f_oi - E2);       \
+            const bool ok_o = (__builtin_amdgcn_ballot_w64(lb_o > b.o) | dead) == ~0ull
+#else
+#define IS_P1_STEP(SKY, NOG)                                                                       \
+            ISP1_COUNT(4);                                                                         \
             const RowRec rb = sload_rec(rcol + vB);                                                \
             const StepVals st = sload_step(scol + vB);                                             \
             const LutRow<NR> row = next_row;                                                       \
             if (IS_P1_TOUCH_AHEAD > 0)                                                             \
                 touch_step(rcol, scol, max(vB - IS_P1_TOUCH_AHEAD * nw, 0), lane, scr);            \
-            load_lut_row<NR>(next_row, lrsrc, lcol, max(vB - nw, 0), D, lane4);                    \
+            IS_P1_NEXT_ROW();                                                                      \
             const int h = vTc + 1 - vB;                                                            \
             const SegTerms t = eval_segment<true, HAS_INVALID>(my, rb, (float)h, s_rcp[h], D, P.iw); \
             const float od = my_tile[t.fni] - pick_lut<NR>(row, t.fni);                            \
             pairwise_step<SKY, true, NOG, true>(P, st, vB, live, od, t, b);                        \
             const float lb_o = (st.q_o - E1o) + P.sw * __builtin_fminf(t.f_on, t.f_oi - E2);       \
             const bool ok_o = (__builtin_amdgcn_ballot_w64(lb_o > b.o) | dead) == ~0ull
+#endif
             /* ground / sky candidates of up to four vB (vB, vB - nw, ...) >= lo; closes `x_closed`
              * when the bound of the last one holds; leaves vB at the next unvisited value */
 #define IS_P1_GS4(SKY, lo, x_dead, x_closed)                                                       \
             {                                                                                      \
                 const int n_here = min(4, (vB - (lo)) / nw + 1);                                   \
+                ISP1_COUNT(5);                                                                     \
                 if (IS_P1_TOUCH_AHEAD > 0) touch_round(rcol, scol, vB - 4 * nw, nw, (lo), lane, scr); \
                 float c_f[4], c_cost[4];                                                           \
                 int c_idx[4];                                                                      \
@@ -424,6 +604,7 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
                 }
             }
 #undef IS_P1_STEP
+#undef IS_P1_NEXT_ROW
 #undef IS_P1_GS4
             if (!done && vB == 0) { /* first segment, :481-594 */
                 const RowRec rb = sload_rec(rcol);
@@ -498,7 +679,9 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
      * Every L2-warming DMA must have landed before this wave can end: its LDS target would
      * otherwise be written after the workgroup's LDS has been handed to another one. */
     wait_vmcnt<0>();
+    ISP1_MARK(1);
     __syncthreads();
+    ISP1_MARK(2);
     float* m_cost = (float*)smem;               /* [nwl][3][64] (aliases the tile) */
     int* m_idx = (int*)(m_cost + nwl * 3 * 64); /* [nwl][3][64] */
     m_cost[(wl * 3 + 0) * 64 + lane] = b.g; m_idx[(wl * 3 + 0) * 64 + lane] = b.ig;
@@ -522,10 +705,11 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
         part_cost[o] = c;
         part_idx[o] = ix;
     }
+    ISP1_MARK(3);
 }
 
 #ifndef ISP1_OCC
-#define ISP1_OCC IS_UNARY_WAVES /* waves per SIMD phase 1 is compiled for (6 and 4 measured slower) */
+#define ISP1_OCC 6 /* waves per SIMD phase 1 is compiled for: 80 VGPRs, no spills (8: 64 VGPRs + spills) */
 #endif
 template <bool HAS_INVALID, int NR>
 __global__ __launch_bounds__(IS_UNARY_WAVES * 64, ISP1_OCC) void k_pw_phase1(
