@@ -286,90 +286,6 @@ __device__ __forceinline__ void touch_round(const RowRec* rcol, const StepRec* s
 #ifndef IS_P1_DPP
 #define IS_P1_DPP 1
 #endif
-template <int K>
-__device__ __forceinline__ float dpp_sub(float mine, float R) {
-    float d;
-    asm volatile("v_subrev_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
-                 : "=v"(d) : "v"(R), "v"(mine), "n"(K));
-    return d;
-}
-/* The first DPP read of a record register in a step: gfx9 needs two wait states between a VALU
- * write of a VGPR (the register rotation's v_mov) and a DPP read of it; the compiler's hazard
- * recogniser does not look inside inline assembly, so the s_nop travels with the instruction. */
-template <int K>
-__device__ __forceinline__ float dpp_sub_first(float mine, float R) {
-    float d;
-    asm volatile("s_nop 1\n\tv_subrev_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
-                 : "=v"(d) : "v"(R), "v"(mine), "n"(K));
-    return d;
-}
-/* integer dword (Fnic): fetched with v_mov_b32_dpp and subtracted by an ordinary instruction --
- * v_subrev_u32_dpp returns a wrong operand on gfx950 (tools/ubench/dpp_sub_check.hip) */
-template <int K>
-__device__ __forceinline__ int dpp_sub_i_first(int mine, float R) {
-    int d;
-    asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf"
-                 : "=v"(d) : "v"(R), "n"(K));
-    return mine - d;
-}
-/* eval_segment<true, HAS_INVALID> (is_kernels.h) with the vB record in (R0, R1): identical
- * operations in identical order, only the source of the vB operand differs */
-template <bool HAS_INVALID>
-__device__ __forceinline__ SegTerms eval_segment_dpp(const RowRec& my, float R0, float R1, float height,
-                                                     float r, int D, float iw) {
-    SegTerms t;
-    const float nic = iw * (float)dpp_sub_i_first<3>(my.Fnic, R1);
-    const float d_g0 = dpp_sub_first<0>(my.Fg0, R0); /* (explicit statements: asm order = source order) */
-    const float d_g1 = dpp_sub<1>(my.Fg1, R0);
-    float f_g = __builtin_fminf(d_g0, d_g1);
-    float f_on = dpp_sub<2>(my.Fon[0], R0);
-    f_on = __builtin_fminf(f_on, dpp_sub<3>(my.Fon[1], R0));
-    f_on = __builtin_fminf(f_on, dpp_sub<4>(my.Fon[2], R0));
-    f_on = __builtin_fminf(f_on, dpp_sub<5>(my.Fon[3], R0));
-    f_on = __builtin_fminf(f_on, dpp_sub<6>(my.Fon[4], R0));
-    f_on = __builtin_fminf(f_on, dpp_sub<7>(my.Fon[5], R0));
-    f_on = __builtin_fminf(f_on, dpp_sub<8>(my.Fon[6], R0));
-    f_on = __builtin_fminf(f_on, dpp_sub<9>(my.Fon[7], R0));
-    float f_oi = dpp_sub<10>(my.Foi[0], R0);
-    f_oi = __builtin_fminf(f_oi, dpp_sub<11>(my.Foi[1], R0));
-    f_oi = __builtin_fminf(f_oi, dpp_sub<12>(my.Foi[2], R0));
-    f_oi = __builtin_fminf(f_oi, dpp_sub<13>(my.Foi[3], R0));
-    f_oi = __builtin_fminf(f_oi, dpp_sub<14>(my.Foi[4], R0));
-    f_oi = __builtin_fminf(f_oi, dpp_sub<15>(my.Foi[5], R0));
-    f_oi = __builtin_fminf(f_oi, dpp_sub<0>(my.Foi[6], R1));
-    f_oi = __builtin_fminf(f_oi, dpp_sub<1>(my.Foi[7], R1));
-    const float f_sky = dpp_sub<2>(my.Fsky, R1);
-    const float meanx = dpp_sub<8>(my.MX, R1);
-    const float meany = dpp_sub<9>(my.MY, R1);
-    const float d_x2h = dpp_sub<10>(my.MX2h, R1);
-    const float d_x2l = dpp_sub<11>(my.MX2l, R1);
-    const float d_y2h = dpp_sub<12>(my.MY2h, R1);
-    const float d_y2l = dpp_sub<13>(my.MY2l, R1);
-    const float meanx2 = d_x2h + d_x2l;
-    const float meany2 = d_y2h + d_y2l;
-    const float ic = iw * (meanx2 - fast_div(meanx * meanx, height, r) + meany2 -
-                           fast_div(meany * meany, height, r));
-    t.f_g = f_g; t.f_on = f_on; t.f_oi = f_oi; t.f_sky = f_sky;
-    t.seg_g = f_g + nic;
-    const float on = nic + f_on;
-    const float oi = ic + f_oi;
-    t.seg_o = __builtin_fminf(oi, on);
-    t.seg_s = f_sky + nic;
-    t.gd = dpp_sub<4>(my.G, R1);
-    t.sd = dpp_sub<5>(my.K, R1);
-    float mean;
-    if (HAS_INVALID) {
-        const float valid_dif = dpp_sub<7>(my.V, R1);
-        const float sdif = dpp_sub<6>(my.S, R1);
-        mean = (valid_dif == 0) ? 0 : sdif / valid_dif;
-    } else {
-        mean = fast_div(dpp_sub<6>(my.S, R1), height, r);
-    }
-    t.fni = (int)min(cvt_u32_sat(mean), (unsigned)(D - 1));
-    t.mean = __builtin_fmaxf(mean, 0.0f);
-    return t;
-}
-
 #ifdef IS_ABL_P1PHASES
 /* debug build only: s_memtime cycles of wave 0 of every phase-1 workgroup in prologue / walk /
  * waiting for the other waves / merge, plus the number of full and ground-sky rounds of wave 0 */

@@ -26,8 +26,11 @@
 #ifndef ISF_WAVES
 #define ISF_WAVES 8
 #endif
+#ifndef ISF_DPP
+#define ISF_DPP 1 /* the record of vB as two dwords per lane + DPP operands instead of 32 VGPRs */
+#endif
 #ifndef ISF_OCC
-#define ISF_OCC 4 /* waves per SIMD the kernel is compiled for */
+#define ISF_OCC 6 /* waves per SIMD the kernel is compiled for */
 #endif
 #define ISF_THREADS (ISF_WAVES * 64)
 
@@ -39,7 +42,7 @@ struct UnaryBestF {
 /* One (vB, vT) evaluation; semantics of unary_step (is_k_unary.hip) with the `<=` update of a
  * descending walk.  lrow: the lutT row of vB in LDS. */
 template <bool HAS_INVALID, bool SKY, bool DIAG, bool FIRST, bool NOGROUND>
-__device__ __forceinline__ SegTerms fast_step(const DevParams& P, const RowRec& my, const RowRec& rb,
+__device__ __forceinline__ SegTerms fast_step(const DevParams& P, const RowRec& my, const float* srec,
                                               const float* lrow, const float* my_tile,
                                               const float* s_rcp, int vT, int vTc, int vhor, int vB,
                                               bool row_ok, UnaryBestF& b) {
@@ -47,7 +50,13 @@ __device__ __forceinline__ SegTerms fast_step(const DevParams& P, const RowRec& 
     const bool live = DIAG ? ((h > 0) && row_ok) : row_ok;
     const int hc = DIAG ? max(h, 1) : h;
     const float r = s_rcp[hc]; /* RN(1/h) = (float)(1./h) = inverse_height, :485, :608 */
+#if ISF_DPP
+    const int l15 = threadIdx.x & 15;
+    const SegTerms t = eval_segment_dpp<HAS_INVALID>(my, srec[l15], srec[16 + l15], (float)hc, r, P.D, P.iw);
+#else
+    const RowRec rb = lds_rec(srec);
     const SegTerms t = eval_segment<true, HAS_INVALID>(my, rb, (float)hc, r, P.D, P.iw);
+#endif
     const float od = my_tile[t.fni] - lrow[t.fni];
     const float pwih = P.pw * r;
     /* cost = dw*data + pw*(1/h) + sw*seg, left to right (:716-719, 762-765, 820-823) */
@@ -213,7 +222,7 @@ __global__ __launch_bounds__(ISF_THREADS, ISF_OCC) void k_dp_unary_fast(
     for (int vB = vB_top; vB >= 0; vB -= ISF_WAVES) {
         wait_vmcnt<(NVR + 1) * (K - 1)>(); /* this step's slot has landed; K - 1 prefetches in flight */
         float* s_row = my_ring + slot * SLOT;
-        const RowRec rb = lds_rec(s_row + ROWF);
+        const float* rb = s_row + ROWF; /* the record of vB in the ring slot */
         const float* lrow = s_row;
         const bool diag = vB > tile_lo;
         bool done = false;
