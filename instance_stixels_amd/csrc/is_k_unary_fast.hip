@@ -29,6 +29,9 @@
 #ifndef ISF_DPP
 #define ISF_DPP 1 /* the record of vB as two dwords per lane + DPP operands instead of 32 VGPRs */
 #endif
+#ifndef ISF_GS_STEPS
+#define ISF_GS_STEPS 1 /* ground / sky-only steps once the object bound holds for the wave */
+#endif
 #ifndef ISF_OCC
 #define ISF_OCC 6 /* waves per SIMD the kernel is compiled for */
 #endif
@@ -97,20 +100,53 @@ struct PruneValsF {
     unsigned long long gdead; /* dead, or the ground data term of the lane is +inf for good   */
 };
 
-/* see the proof sketch at unary_step_desc (is_k_unary.hip) and DESIGN.md "Pruning" */
+/* see the proof sketch at unary_step_desc (is_k_unary.hip) and DESIGN.md "Pruning".  Bit 0: the
+ * object bound holds in every lane, bit 1: the ground / sky bound does. */
 template <bool SKY, bool NOGROUND>
-__device__ __forceinline__ bool fast_nothing_below(const DevParams& P, const PruneValsF& pv,
-                                                   const SegTerms& t, const UnaryBestF& b) {
+__device__ __forceinline__ int fast_bounds(const DevParams& P, const PruneValsF& pv, const SegTerms& t,
+                                           const UnaryBestF& b) {
     const float lb_o = P.sw * __builtin_fminf(t.f_on, t.f_oi - pv.E2) - pv.E1o;
-    unsigned long long ok = __builtin_amdgcn_ballot_w64(lb_o > b.o) | pv.dead;
+    const bool ok_o = (__builtin_amdgcn_ballot_w64(lb_o > b.o) | pv.dead) == ~0ull;
+    bool ok_x = true;
     if (SKY) {
         const float lb_s = P.sw * t.f_sky - pv.E1s;
-        ok &= __builtin_amdgcn_ballot_w64(lb_s > b.s) | pv.dead;
+        ok_x = (__builtin_amdgcn_ballot_w64(lb_s > b.s) | pv.dead) == ~0ull;
     } else if (!NOGROUND) {
         const float lb_g = P.sw * t.f_g - pv.E1g;
-        ok &= __builtin_amdgcn_ballot_w64(lb_g > b.g) | pv.gdead;
+        ok_x = (__builtin_amdgcn_ballot_w64(lb_g > b.g) | pv.gdead) == ~0ull;
     }
-    return ok == ~0ull;
+    return (ok_o ? 1 : 0) | (ok_x ? 2 : 0);
+}
+
+/* A step after the object type has been closed for the wave (its bound is sticky: the class
+ * minima only grow and the best cost cannot change any more): only the ground or the sky
+ * candidate of vB is left -- two class differences, no instance term, no mean, no LUT value; a
+ * fifth of the instructions of fast_step, same operand order (cost = dw * data + pw / h +
+ * sw * (f + nic)).  rec: the record of vB in the ring slot.  Returns true when the bound of the
+ * type holds too: the wave is done. */
+template <bool SKY>
+__device__ __forceinline__ bool fast_step_gs(const DevParams& P, const PruneValsF& pv, const RowRec& my,
+                                             const float* rec, const float* s_rcp, int vTc, int vB,
+                                             UnaryBestF& b) {
+    const float r = s_rcp[vTc + 1 - vB];
+    const float4 q = *reinterpret_cast<const float4*>(rec + 16); /* Foi[6], Foi[7], Fsky, Fnic */
+    const float2 gk = *reinterpret_cast<const float2*>(rec + 20); /* G, K */
+    const float nic = P.iw * (float)(my.Fnic - __float_as_int(q.w));
+    const float pwih = P.pw * r;
+    if (SKY) {
+        const float f = my.Fsky - q.z;
+        const float cost = P.dw * (my.K - gk.y) + pwih + P.sw * (f + nic);
+        take_if_le(b.s, b.vs, cost, vB);
+        const float lb = P.sw * f - pv.E1s;
+        return (__builtin_amdgcn_ballot_w64(lb > b.s) | pv.dead) == ~0ull;
+    } else {
+        const float2 g01 = *reinterpret_cast<const float2*>(rec);
+        const float f = __builtin_fminf(my.Fg0 - g01.x, my.Fg1 - g01.y);
+        const float cost = P.dw * (my.G - gk.x) + pwih + P.sw * (f + nic);
+        take_if_le(b.g, b.vg, cost, vB);
+        const float lb = P.sw * f - pv.E1g;
+        return (__builtin_amdgcn_ballot_w64(lb > b.g) | pv.gdead) == ~0ull;
+    }
 }
 
 #ifdef IS_ABL_PHASES
@@ -219,6 +255,7 @@ __global__ __launch_bounds__(ISF_THREADS, ISF_OCC) void k_dp_unary_fast(
 
     /* ---- the wave's walk, vB downwards; slot i % K holds step i */
     int slot = 0;
+    bool o_closed = false;
     for (int vB = vB_top; vB >= 0; vB -= ISF_WAVES) {
         wait_vmcnt<(NVR + 1) * (K - 1)>(); /* this step's slot has landed; K - 1 prefetches in flight */
         float* s_row = my_ring + slot * SLOT;
@@ -226,6 +263,15 @@ __global__ __launch_bounds__(ISF_THREADS, ISF_OCC) void k_dp_unary_fast(
         const float* lrow = s_row;
         const bool diag = vB > tile_lo;
         bool done = false;
+        int ok = 0;
+        if (ISF_GS_STEPS && o_closed && vB != 0) { /* (closed in a full step: the diagonal is over) */
+            if (vB > vhor)
+                done = fast_step_gs<true>(P, pv, my, rb, s_rcp, vTc, vB, b);
+            else if (nog)
+                done = true; /* only +inf ground candidates are left */
+            else
+                done = fast_step_gs<false>(P, pv, my, rb, s_rcp, vTc, vB, b);
+        } else {
         if (vB == 0) { /* first segment (:481-594): ground + object */
             if (diag)
                 fast_step<HAS_INVALID, false, true, true, false>(P, my, rb, lrow, my_tile, s_rcp, vT, vTc, vhor,
@@ -240,7 +286,7 @@ __global__ __launch_bounds__(ISF_THREADS, ISF_OCC) void k_dp_unary_fast(
             } else {
                 const SegTerms t = fast_step<HAS_INVALID, true, false, false, false>(
                     P, my, rb, lrow, my_tile, s_rcp, vT, vTc, vhor, vB, row_ok, b);
-                done = IS_PRUNE && fast_nothing_below<true, false>(P, pv, t, b);
+                if (IS_PRUNE) ok = fast_bounds<true, false>(P, pv, t, b);
             }
         } else { /* ground + object (:687) */
             if (diag) {
@@ -249,12 +295,16 @@ __global__ __launch_bounds__(ISF_THREADS, ISF_OCC) void k_dp_unary_fast(
             } else if (nog) {
                 const SegTerms t = fast_step<HAS_INVALID, false, false, false, true>(
                     P, my, rb, lrow, my_tile, s_rcp, vT, vTc, vhor, vB, row_ok, b);
-                done = IS_PRUNE && fast_nothing_below<false, true>(P, pv, t, b);
+                if (IS_PRUNE) ok = fast_bounds<false, true>(P, pv, t, b);
             } else {
                 const SegTerms t = fast_step<HAS_INVALID, false, false, false, false>(
                     P, my, rb, lrow, my_tile, s_rcp, vT, vTc, vhor, vB, row_ok, b);
-                done = IS_PRUNE && fast_nothing_below<false, false>(P, pv, t, b);
+                if (IS_PRUNE) ok = fast_bounds<false, false>(P, pv, t, b);
             }
+        }
+        done = ok == 3;
+        o_closed = (ok & 1) != 0; /* sticky; the ground / sky bound is re-tested in its own steps
+                                   * (it does not carry over from the sky range to the ground range) */
         }
         if (done) break; /* nothing below can win any more */
         /* refill the slot just consumed (its reads have returned: their values were used) */
