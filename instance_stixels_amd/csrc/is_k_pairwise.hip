@@ -397,59 +397,56 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
 #else
 #define IS_P1_NEXT_ROW() load_lut_row<NR>(next_row, lrsrc, lcol, max(vB - nw, 0), D, lane4)
 #endif
-#if IS_P1_DPP
+            /* DPP record operands without an invalid-disparity value; with one (valid-count operands
+             * and an IEEE division per step: 90+ VGPRs) the scalar-load form at 8 waves per SIMD is
+             * the faster one (2375 vs 2250 frames/s with 5 % holes) */
+            constexpr bool USE_DPP = IS_P1_DPP && !HAS_INVALID;
             /* record of vB (c_*), of vB - nw (n_*): vector loads, two steps ahead; StepRec one step
              * ahead in a second set of SGPRs */
             const int l15 = lane & 15;
-            float c_r0, c_r1, n_r0, n_r1;
-            { /* (requesting these before the tile staging of the prologue measured 2.5 % slower) */
+            float c_r0 = 0.0f, c_r1 = 0.0f, n_r0 = 0.0f, n_r1 = 0.0f;
+            StepVals st_next;
+            if (USE_DPP) { /* (requesting these before the tile staging of the prologue measured 2.5 % slower) */
                 const float* q0 = (const float*)(rcol + vB);
                 const float* q1 = (const float*)(rcol + max(vB - nw, 0));
                 c_r0 = q0[l15]; c_r1 = q0[16 + l15];
                 n_r0 = q1[l15]; n_r1 = q1[16 + l15];
+                st_next = sload_step(scol + vB);
             }
-            StepVals st_next = sload_step(scol + vB);
 #define IS_P1_STEP(SKY, NOG)                                                                       \
             ISP1_COUNT(4);                                                                         \
-            const float r0 = c_r0, r1 = c_r1;                                                      \
-            const StepVals st = st_next;                                                           \
             const LutRow<NR> row = next_row;                                                       \
             if (IS_P1_TOUCH_AHEAD > 0)                                                             \
                 touch_step(rcol, scol, max(vB - IS_P1_TOUCH_AHEAD * nw, 0), lane, scr);            \
             IS_P1_NEXT_ROW();                                                                      \
-            c_r0 = n_r0; c_r1 = n_r1;                                                              \
-            {                                                                                      \
-                const float* q2 = (const float*)(rcol + max(vB - 2 * nw, 0));                      \
-                n_r0 = q2[l15]; n_r1 = q2[16 + l15];                                               \
-            }                                                                                      \
             const int h = vTc + 1 - vB;                                                            \
-            const SegTerms t = eval_segment_dpp<HAS_INVALID>(my, r0, r1, (float)h, s_rcp[h], D, P.iw); \
-            const float od = my_tile[t.fni] - pick_lut<NR>(row, t.fni);                            \
-            {   /* the next StepRec: requested only now -- every LDS wait is an lgkmcnt(0) wait and \
-                 * would wait for this scalar load too (SMEM returns out of order) */              \
+            SegTerms t;                                                                            \
+            StepVals st;                                                                           \
+            float od;                                                                              \
+            if (USE_DPP) {                                                                         \
+                const float r0 = c_r0, r1 = c_r1;                                                  \
+                st = st_next;                                                                      \
+                c_r0 = n_r0; c_r1 = n_r1;                                                          \
+                {                                                                                  \
+                    const float* q2 = (const float*)(rcol + max(vB - 2 * nw, 0));                  \
+                    n_r0 = q2[l15]; n_r1 = q2[16 + l15];                                           \
+                }                                                                                  \
+                t = eval_segment_dpp<HAS_INVALID>(my, r0, r1, (float)h, s_rcp[h], D, P.iw);        \
+                od = my_tile[t.fni] - pick_lut<NR>(row, t.fni);                                    \
+                /* the next StepRec: requested only now -- every LDS wait is an lgkmcnt(0) wait    \
+                 * and would wait for this scalar load too (SMEM returns out of order) */          \
                 const StepRec* sn = scol + max(vB - nw, 0);                                        \
                 asm volatile("" : "+s"(sn) : "v"(od));                                             \
                 st_next = sload_step(sn);                                                          \
+            } else {                                                                               \
+                const RowRec rb = sload_rec(rcol + vB);                                            \
+                st = sload_step(scol + vB);                                                        \
+                t = eval_segment<true, HAS_INVALID>(my, rb, (float)h, s_rcp[h], D, P.iw);          \
+                od = my_tile[t.fni] - pick_lut<NR>(row, t.fni);                                    \
             }                                                                                      \
             pairwise_step<SKY, true, NOG, true>(P, st, vB, live, od, t, b);                        \
             const float lb_o = (st.q_o - E1o) + P.sw * __builtin_fminf(t.f_on, t.f_oi - E2);       \
             const bool ok_o = (__builtin_amdgcn_ballot_w64(lb_o > b.o) | dead) == ~0ull
-#else
-#define IS_P1_STEP(SKY, NOG)                                                                       \
-            ISP1_COUNT(4);                                                                         \
-            const RowRec rb = sload_rec(rcol + vB);                                                \
-            const StepVals st = sload_step(scol + vB);                                             \
-            const LutRow<NR> row = next_row;                                                       \
-            if (IS_P1_TOUCH_AHEAD > 0)                                                             \
-                touch_step(rcol, scol, max(vB - IS_P1_TOUCH_AHEAD * nw, 0), lane, scr);            \
-            IS_P1_NEXT_ROW();                                                                      \
-            const int h = vTc + 1 - vB;                                                            \
-            const SegTerms t = eval_segment<true, HAS_INVALID>(my, rb, (float)h, s_rcp[h], D, P.iw); \
-            const float od = my_tile[t.fni] - pick_lut<NR>(row, t.fni);                            \
-            pairwise_step<SKY, true, NOG, true>(P, st, vB, live, od, t, b);                        \
-            const float lb_o = (st.q_o - E1o) + P.sw * __builtin_fminf(t.f_on, t.f_oi - E2);       \
-            const bool ok_o = (__builtin_amdgcn_ballot_w64(lb_o > b.o) | dead) == ~0ull
-#endif
             /* ground / sky candidates of up to four vB (vB, vB - nw, ...) >= lo; closes `x_closed`
              * when the bound of the last one holds; leaves vB at the next unvisited value */
 #define IS_P1_GS4(SKY, lo, x_dead, x_closed)                                                       \
@@ -624,11 +621,14 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
     ISP1_MARK(3);
 }
 
+#ifndef ISP1_OCC_INV
+#define ISP1_OCC_INV 8 /* with an invalid-disparity value: the scalar-load form of the step, 64 VGPRs */
+#endif
 #ifndef ISP1_OCC
 #define ISP1_OCC 6 /* waves per SIMD phase 1 is compiled for: 80 VGPRs, no spills (8: 64 VGPRs + spills) */
 #endif
 template <bool HAS_INVALID, int NR>
-__global__ __launch_bounds__(IS_UNARY_WAVES * 64, ISP1_OCC) void k_pw_phase1(
+__global__ __launch_bounds__(IS_UNARY_WAVES * 64, HAS_INVALID ? ISP1_OCC_INV : ISP1_OCC) void k_pw_phase1(
     const DevParams P, int col_base, int ncols, int tile, int nsplit,
     const RowRec* __restrict__ recs, const float* __restrict__ lutT,
     const StepRec* __restrict__ steps, const float* __restrict__ rcp,

@@ -32,6 +32,9 @@
 #ifndef ISF_GS_STEPS
 #define ISF_GS_STEPS 1 /* ground / sky-only steps once the object bound holds for the wave */
 #endif
+#ifndef ISF_OCC_INV
+#define ISF_OCC_INV 5 /* with an invalid-disparity value: 9 spilled VGPRs at 6 */
+#endif
 #ifndef ISF_OCC
 #define ISF_OCC 6 /* waves per SIMD the kernel is compiled for */
 #endif
@@ -188,7 +191,7 @@ __device__ __forceinline__ void ring_prefetch(const float* __restrict__ lcol,
 }
 
 template <bool HAS_INVALID, int NVR>
-__global__ __launch_bounds__(ISF_THREADS, ISF_OCC) void k_dp_unary_fast(
+__global__ __launch_bounds__(ISF_THREADS, HAS_INVALID ? ISF_OCC_INV : ISF_OCC) void k_dp_unary_fast(
     const DevParams P, int ncols, const RowRec* __restrict__ recs, const float* __restrict__ lutT,
     const float* __restrict__ rcp, const int* __restrict__ vhor_arr,
     const int* __restrict__ col_flags, const PruneRec* __restrict__ prune,
