@@ -53,6 +53,7 @@ void RoadEstimation::Finish() { /* RE.cu:84-92 */
 
 bool RoadEstimation::Compute(const std::vector<pixel_t>& im) { /* RE.cu:94-102 */
     IS_CHECK_RETURN(is_memcpy_h2d(d_disparity, im.data(), im.size() * sizeof(pixel_t), nullptr));
+    IS_CHECK_RETURN(is_stream_synchronize(nullptr)); /* the caller's vector may be a temporary */
     return Compute(d_disparity);
 }
 
