@@ -474,10 +474,11 @@ def main():
                                    if cfg.pairwise else "k_dp_unary",
                          "kernel_ms": kt["dp_ms"],
                          "algorithmic_bytes_per_image": alg_bytes_img,
-                         "note": "the column DP is bound by VALU issue, not by HBM (SURVEY.md "
-                                 "H1, DESIGN.md section 5): see the valu fields; traffic = "
-                                 "(2*FETCH_SIZE + WRITE_SIZE) per launch from the committed "
-                                 "rocprofv3 PMC passes (profiles/r02_traffic.json)"},
+                         "note": "the column DP is bound by VALU issue and per-step latency, "
+                                 "not by HBM (SURVEY.md H1, DESIGN.md sections 6-7): see the valu "
+                                 "fields; traffic = (2*FETCH_SIZE + WRITE_SIZE) of the DP kernels "
+                                 "per step from the committed rocprofv3 PMC passes "
+                                 "(profiles/r02_traffic.json)"},
             "valu": {"pair_evals_per_s": pairs_img * B / dp_s,
                      "pair_evals_per_image": pairs_img,
                      "lane_ops_peak_per_s": VALU_PEAK_LANEOPS},
