@@ -838,8 +838,10 @@ __device__ __forceinline__ void pw_phase2_body(const DevParams& P, char* smem, i
                 pairwise_step<true>(P, st, r, live, od, t, b);
             ISP2_MARK(4); /* pairwise_step */
         }
-        /* lane s holds the final values of row r: broadcast, derive the StepRec of vB = r+1 */
-        if (r + 1 < H) {
+        /* lane s holds the final values of row r: broadcast, derive the StepRec of vB = r+1.
+         * (Also for the last row of the image, whose StepRec nobody reads: an unconditional
+         * assignment keeps `st` in place -- a guarded one costs 16 register moves per step.) */
+        {
             const float cG = readlane_f(b.g, s), cO = readlane_f(b.o, s), cS = readlane_f(b.s, s);
             const int ob = __builtin_amdgcn_readlane(b.io, s) / 3; /* start of the best object chain */
             /* the disparity / valid-count prefixes at r + 1 and at ob: lane k holds the record of
@@ -870,7 +872,7 @@ __device__ __forceinline__ void pw_phase2_body(const DevParams& P, char* smem, i
             q_o = __builtin_fminf(q_o, P.pw * m8);
             q_gs = __builtin_fminf(q_gs, st.pwmp);
             st.q_o = q_o; st.q_gs = q_gs;
-            if (lane == 0) store_step(scol + r + 1, st);
+            if (lane == 0 && r + 1 < H) store_step(scol + r + 1, st);
             ISP2_MARK(7); /* running minima + store */
         }
     }
@@ -1108,7 +1110,7 @@ __device__ __forceinline__ void pw_phase2s_body(const DevParams& P, char* smem, 
             } else {
                 pv = sload_prior(pcol + min(r + 1, H - 1));
             }
-            if (r + 1 < H) {
+            { /* (unconditional: see pw_phase2_body) */
                 const float cG = readlane_f(b.g, s), cO = readlane_f(b.o, s), cS = readlane_f(b.s, s);
                 const int ob = __builtin_amdgcn_readlane(b.io, s) / 3;
                 const float S_r1 = readlane_f(myS, s), V_r1 = HAS_INVALID ? readlane_f(myV, s) : 0.0f;
@@ -1133,7 +1135,7 @@ __device__ __forceinline__ void pw_phase2s_body(const DevParams& P, char* smem, 
                 q_o = __builtin_fminf(q_o, P.pw * m8);
                 q_gs = __builtin_fminf(q_gs, st.pwmp);
                 st.q_o = q_o; st.q_gs = q_gs;
-                if (lane == 0) store_step(scol + r + 1, st);
+                if (lane == 0 && r + 1 < H) store_step(scol + r + 1, st);
             }
         }
         if (vT < H) {
