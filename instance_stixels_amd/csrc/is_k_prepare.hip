@@ -201,8 +201,11 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_columns(
         uint64_t total = 0;
         int negative = 0;
         for (int k = 0; k < P2S; k++) {
-            negative |= (ch[k] < 0);
-            total += (uint64_t)(uint32_t)ch[k];
+            /* (rotated start: the 19 threads would otherwise read the same LDS bank every time --
+             * the channels are P2S = 2^k dwords apart) */
+            const int32_t x = ch[(k + tid) & (P2S - 1)];
+            negative |= (x < 0);
+            total += (uint64_t)(uint32_t)x;
         }
         slow |= negative | (total * IS_DOWNSAMPLE_FACTOR >= (uint64_t)IS_FAST_CLASS_LIMIT);
     }
