@@ -32,7 +32,8 @@
 #endif
 #define IS_TILE 64
 #define IS_PW_MAX_SPLIT 4            /* phase-1 workgroups per (column, tile) at small batches */
-#define IS_PW_SPLIT_TARGET_WGS 1024 /* = 4 workgroups per CU */
+#define IS_PW_SPLIT_TARGET_WGS 1024 /* partial-minima slots reserved for the split phase 1 */
+#define IS_PW_SPLIT_MAX_COLS 512     /* up to that many columns: two phase-1 workgroups per (column, tile) */
 #define IS_PREPARE_OVERLAP_MAX_COLS 1024 /* below: the two prepare kernels run on two streams */
 #define IS_PAIRWISE_SPLIT_MIN_COLS 1024 /* columns per group before the pairwise DP uses one more stream */
 #define IS_PAIRWISE_MAX_GROUPS 1       /* column groups (streams) of the pairwise DP */

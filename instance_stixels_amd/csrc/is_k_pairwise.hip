@@ -1244,9 +1244,11 @@ hipError_t isk_launch_dp_pairwise(const DevParams* P, int ncols, int nwaves, con
      * phase-1 / phase-2 chains (2 x ntiles dependent launches each) run on their own streams, so
      * that the tails and the latency-bound serial phase 2 of one group share the CUs with the
      * other groups' launches. */
-    /* few columns: nsplit workgroups per (column, tile) in phase 1, up to ~one workgroup per CU x4 */
-    int nsplit = IS_PW_SPLIT_TARGET_WGS / (ncols > 0 ? ncols : 1);
-    nsplit = nsplit < 1 ? 1 : (nsplit > IS_PW_MAX_SPLIT ? IS_PW_MAX_SPLIT : nsplit);
+    /* few columns: two workgroups per (column, tile) in phase 1 */
+    /* (measured on MI355X, frames/s of one / two 256-column frames per call: 1 workgroup per
+     * (column, tile) 540 / 903, 2: 587 / 931, 3: 584 / -, 4: 561 / -) */
+    int nsplit = ncols <= IS_PW_SPLIT_MAX_COLS ? 2 : 1;
+    if (nsplit > IS_PW_MAX_SPLIT) nsplit = IS_PW_MAX_SPLIT;
     int groups = ncols / IS_PAIRWISE_SPLIT_MIN_COLS;
     groups = groups < 1 ? 1 : groups;
     /* measured on MI355X at batch 64 after the pruning of phase 1: 1 group 29.8 ms, 2 groups 30.2,
