@@ -33,11 +33,13 @@
 #define IS_TILE 64
 #define IS_PW_MAX_SPLIT 4            /* phase-1 workgroups per (column, tile) at small batches */
 #define IS_PW_SPLIT_TARGET_WGS 1024 /* partial-minima slots reserved for the split phase 1 */
+#ifndef IS_PW_SPLIT_MAX_COLS
 #define IS_PW_SPLIT_MAX_COLS 512     /* up to that many columns: two phase-1 workgroups per (column, tile) */
+#endif
 #define IS_PREPARE_OVERLAP_MAX_COLS 1024 /* below: the two prepare kernels run on two streams */
 #define IS_PAIRWISE_SPLIT_MIN_COLS 1024 /* columns per group before the pairwise DP uses one more stream */
 #define IS_PAIRWISE_MAX_GROUPS 1       /* column groups (streams) of the pairwise DP */
-#define IS_P2_SPLIT_MAX_COLS 512      /* up to two 2048-px frames: phase 2 of the pairwise DP on four waves per column */
+#define IS_P2_SPLIT_MAX_COLS 2048     /* up to eight 2048-px frames: phase 2 of the pairwise DP as chain + evaluator wave per column */
 #define IS_AUX_STREAMS 7               /* auxiliary streams a context owns */
 #define IS_N_ON 8           /* non-instance object classes 2..9   (Cityscapes.h:69) */
 #define IS_N_OI 8           /* instance object classes     11..18 (Cityscapes.h:75) */

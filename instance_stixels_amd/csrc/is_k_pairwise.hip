@@ -934,9 +934,13 @@ __global__ __launch_bounds__(64, ISP2_OCC) void k_pw_phase2(
  * both sides poll with s_sleep.  Dead lanes (vT < r, vT >= H) get +inf data terms: their costs are
  * +inf or NaN and never pass a `<`, so the chain needs no lane mask.  Arithmetic and operand order
  * are those of pairwise_step / make_step: cost = (dw * data + pw-term) + sw * seg. */
-#define ISP2S_WAVES 4
+#ifndef ISP2S_WAVES
+#define ISP2S_WAVES 2
+#endif
 #define ISP2S_NE (ISP2S_WAVES - 1)
-#define ISP2S_SLOTS 8
+#ifndef ISP2S_SLOTS
+#define ISP2S_SLOTS 4
+#endif
 #define ISP2S_SLOT_F (5 * 64 + 16) /* A_gs, B_gs, A_o, B_o, fn per lane + the PriorVals of vB = r + 1 */
 #define ISP2S_SPIN_LIMIT (1 << 26)
 
@@ -1247,6 +1251,8 @@ hipError_t isk_launch_dp_pairwise(const DevParams* P, int ncols, int nwaves, con
     /* few columns: two workgroups per (column, tile) in phase 1 */
     /* (measured on MI355X, frames/s of one / two 256-column frames per call: 1 workgroup per
      * (column, tile) 540 / 903, 2: 587 / 931, 3: 584 / -, 4: 561 / -) */
+    static_assert(2 * IS_PW_SPLIT_MAX_COLS <= IS_PW_SPLIT_TARGET_WGS,
+                  "the context reserves IS_PW_SPLIT_TARGET_WGS partial-minima slots for the split phase 1");
     int nsplit = ncols <= IS_PW_SPLIT_MAX_COLS ? 2 : 1;
     if (nsplit > IS_PW_MAX_SPLIT) nsplit = IS_PW_MAX_SPLIT;
     int groups = ncols / IS_PAIRWISE_SPLIT_MIN_COLS;
