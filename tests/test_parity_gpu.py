@@ -55,6 +55,16 @@ def test_small_cases_bit_exact(preset, rows, cols, D, ov):
     _assert_parity(case, got)
 
 
+@pytest.mark.parametrize("preset,rows,cols,D,ov", [c for c in SMALL if "pairwise" in c[0]])
+def test_small_pairwise_cases_one_wave_phase2(preset, rows, cols, D, ov, monkeypatch):
+    """The library walks phase 2 of small calls (<= 2048 columns) with k_pw_phase2s; the one-wave
+    kernel k_pw_phase2 of large batches must give the same bits on the same cases."""
+    monkeypatch.setenv("IS_P2_SPLIT", "0")
+    case = helpers.build_case(preset, rows, cols, D, seed=7, n_images=2, **ov)
+    got = helpers.run_core(case)
+    _assert_parity(case, got)
+
+
 def _random_case(k):
     """Seeded random shape / weights / model parameters around the presets."""
     rng = np.random.default_rng(9000 + k)
@@ -268,13 +278,15 @@ def test_pairwise_two_stream_split_matches_oracle():
         assert helpers.sections_equal(alone["sections"][0], got["sections"][img])
 
 
-@pytest.mark.parametrize("n_images,inv", [(1, -1.0), (3, -1.0), (1, 0.0), (3, 0.0)])
-def test_pairwise_phase2_window_and_fallback(n_images, inv):
+@pytest.mark.parametrize("split,inv", [(1, -1.0), (0, -1.0), (1, 0.0), (0, 0.0)])
+def test_pairwise_phase2_window_and_fallback(split, inv, monkeypatch):
     """Phase 2 of the pairwise DP stages a <= 16-column window of the tile's lutT rows in LDS and
     reads global memory for lanes outside it.  Columns whose rows alternate between two far-apart
     disparities put every segment mean of a tile far outside any 16-column window (fallback on
-    every step); smooth columns stay inside it.  One image = 192 columns -> k_pw_phase2s (chain +
-    evaluator waves), three images = 576 columns -> k_pw_phase2 (one wave per column)."""
+    every step); smooth columns stay inside it.  IS_P2_SPLIT selects the kernel (the library picks
+    by column count): 1 = k_pw_phase2s (chain + evaluator wave), 0 = k_pw_phase2 (one wave)."""
+    monkeypatch.setenv("IS_P2_SPLIT", str(split))
+    n_images = 2
     ov = dict(invalid_disparity=inv) if inv >= 0 else {}
     case = helpers.build_case("drn_d_38_pairwise", 256, 1536, 64, seed=77, n_images=n_images, **ov)
     d = case["disparity"]
