@@ -341,8 +341,7 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
     unsigned long long t_p1 = __builtin_readcyclecounter();
 #endif
     const int vB_last = min(tile_lo, H - 1);
-    stage_lut_tile<true>(s_tile, lcol, tile_lo, H, D, tid, (int)blockDim.x);
-    stage_rcp(s_rcp, rcp, H, tid, (int)blockDim.x);
+    stage_tile_and_rcp(s_tile, s_rcp, lcol, rcp, tile_lo, H, D, tid, (int)blockDim.x);
     const int vT = tile_lo + lane;
     const int vTc = min(vT, H - 1);
     const RowRec my = load_rec(rcol + vTc + 1);

@@ -236,9 +236,11 @@ __global__ __launch_bounds__(ISF_THREADS, HAS_INVALID ? ISF_OCC_INV : ISF_OCC) v
     for (int i = 0; i < K; i++)
         ring_prefetch<NVR>(lcol, rcol, max(vB_top - ISF_WAVES * i, 0), D, my_ring + i * SLOT,
                            my_ring + i * SLOT + ROWF, lane);
+    ISF_MARK(4); /* (debug build: ring requests issued) */
     const RowRec my = load_rec(rcol + vTc + 1);
-    stage_rcp(s_rcp, rcp, H, tid, ISF_THREADS);
-    stage_lut_tile<true>(s_tile, lcol, tile_lo, H, D, tid, ISF_THREADS);
+    ISF_MARK(5); /* (debug build: record requested) */
+    stage_tile_and_rcp(s_tile, s_rcp, lcol, rcp, tile_lo, H, D, tid, ISF_THREADS);
+    ISF_MARK(6); /* (debug build: tile + 1/h table staged; mark 0 then = the barrier) */
 
     PruneValsF pv;
     {

@@ -261,6 +261,47 @@ __device__ __forceinline__ void stage_rcp(float* s_rcp, const float* __restrict_
     }
 }
 
+/* The tile and the 1/h table behind ONE memory round trip: staged one after the other, the
+ * second one's loads are only issued after the first one's vmcnt(0) wait (measured in the unary
+ * ring kernel: 19 % + 15 % of a workgroup's life for the two).  Common shapes (16-byte path of
+ * stage_lut_tile in one batch, H + 1 <= 4 * nthreads) take the fused path. */
+__device__ __forceinline__ void stage_tile_and_rcp(float* s_tile, float* s_rcp,
+                                                   const float* __restrict__ lcol,
+                                                   const float* __restrict__ rcp, int tile_lo, int H,
+                                                   int D, int tid, int nthreads) {
+    const int quads = D >> 2;
+    const bool fused = (D & 3) == 0 && ((4 * nthreads) % D) == 0 && (nthreads / quads) * 4 >= IS_TILE &&
+                       H + 1 <= 4 * nthreads;
+    if (!fused) {
+        stage_rcp(s_rcp, rcp, H, tid, nthreads);
+        stage_lut_tile<true>(s_tile, lcol, tile_lo, H, D, tid, nthreads);
+        return;
+    }
+    const int DP = D + 1;
+    const int r0 = tid / quads, f = (tid - r0 * quads) * 4;
+    const int dr = nthreads / quads;
+    float rc[4];
+    float4 x[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) rc[k] = rcp[min(tid + k * nthreads, H)];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int r = min(r0 + k * dr, IS_TILE - 1);
+        x[k] = *reinterpret_cast<const float4*>(lcol + (size_t)min(tile_lo + 1 + r, H) * D + f);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        if (tid + k * nthreads <= H) s_rcp[tid + k * nthreads] = rc[k];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int r = r0 + k * dr;
+        if (r < IS_TILE) {
+            float* d = s_tile + r * DP + f;
+            d[0] = x[k].x; d[1] = x[k].y; d[2] = x[k].z; d[3] = x[k].w;
+        }
+    }
+}
+
 /* vB-side row of lutT.  NR > 0: the wave holds the whole row in NR registers per lane (element
  * j*64 + lane), fetched with coalesced loads one step AHEAD of its use -- the address does not
  * depend on the segment -- and a lane picks its element fni with ds_bpermute (no memory access on

@@ -13,5 +13,9 @@ finally:
     L.isk_debug_phases(out, 1)
     v = list(out)
     tot = sum(v[:4]) or 1
-    print("phases (cycles of wave 0 per WG, summed): prologue %.3g loop %.3g wait-for-waves %.3g merge %.3g  -> %s; (%d)" % (
-        v[0], v[1], v[2], v[3], ["%.1f%%" % (100.0 * x / tot) for x in v[:4]], v[5]))
+    tot = (v[0] + v[4] + v[5] + v[6] + v[1] + v[2] + v[3]) or 1
+    names = ["ring requests", "record + 1/h table", "tile staging", "barrier", "walk", "wait for waves", "merge"]
+    vals = [v[4], v[5], v[6], v[0], v[1], v[2], v[3]]
+    print("wave 0 of every workgroup, s_memtime ticks summed:")
+    for n, x in zip(names, vals):
+        print("  %-20s %12.4g  %5.1f%%" % (n, x, 100.0 * x / tot))
