@@ -204,7 +204,10 @@ __global__ __launch_bounds__(ISF_THREADS, HAS_INVALID ? ISF_OCC_INV : ISF_OCC) v
     constexpr int SLOT = ROWF + ISF_REC_F;     /* floats of a ring slot */
     float* s_rcp = (float*)smem;                        /* [H+1 -> x4]                       */
     float* s_tile = s_rcp + ((H + 1 + 3) & ~3);         /* [64][D+1] lutT rows tile_lo+1 ..   */
-    float* s_ring = s_tile + ((IS_TILE * DP + 3) & ~3); /* [8 waves][K][SLOT]                */
+    /* (the tile's space also holds the merge area after the walk: at least ISF_MERGE_F floats) */
+    constexpr int ISF_MERGE_F = 2 * ISF_WAVES * 3 * 64 + 2 * 3 * 64;
+    const int tile_f = max((IS_TILE * DP + 3) & ~3, ISF_MERGE_F);
+    float* s_ring = s_tile + tile_f;                    /* [8 waves][K][SLOT]                */
 
     /* XCD-aware order: blocks b, b+8, ... share an XCD/L2; the tiles of a column stay on one XCD
      * (they fetch the same lutT rows) and the tallest tiles start first */
@@ -319,13 +322,17 @@ __global__ __launch_bounds__(ISF_THREADS, HAS_INVALID ? ISF_OCC_INV : ISF_OCC) v
     }
     ISF_MARK(1);
 
-    /* ---- merge the waves' partial minima: min cost, ties -> smallest vB.  The rings may still
-     * receive prefetched slots: everything has to land before the merge area reuses them. */
-    wait_vmcnt<0>();
+    /* ---- merge the waves' partial minima: min cost, ties -> smallest vB.  After the barrier no
+     * wave reads the lutT tile any more, so the merge runs in ITS space; the rings may still
+     * receive prefetched slots (a wave that left early has up to K fills in flight), and nothing
+     * has to wait for them until the very end: the drain hides behind the barrier and the merge
+     * (it used to sit in front of them: an HBM latency per workgroup). */
     __syncthreads();
     ISF_MARK(2);
-    float* m_cost = s_ring;                              /* [8][3][64] */
+    float* m_cost = s_tile;                              /* [8][3][64] */
     int* m_vb = (int*)(m_cost + ISF_WAVES * 3 * 64);     /* [8][3][64] */
+    float* f_cost = m_cost + 2 * ISF_WAVES * 3 * 64;     /* [3][64] final values */
+    int* f_vb = (int*)(f_cost + 3 * 64);                 /* [3][64] */
     m_cost[(w * 3 + 0) * 64 + lane] = b.g; m_vb[(w * 3 + 0) * 64 + lane] = b.vg;
     m_cost[(w * 3 + 1) * 64 + lane] = b.o; m_vb[(w * 3 + 1) * 64 + lane] = b.vo;
     m_cost[(w * 3 + 2) * 64 + lane] = b.s; m_vb[(w * 3 + 2) * 64 + lane] = b.vs;
@@ -343,18 +350,18 @@ __global__ __launch_bounds__(ISF_THREADS, HAS_INVALID ? ISF_OCC_INV : ISF_OCC) v
         /* a row without a finite candidate keeps the initial index (the descending walk records
          * +inf candidates, the reference's strict < never does; :592 for the object type) */
         if (!(c < IS_INF)) vb = (type == IS_OBJECT) ? 0 : -1;
-        s_tile[type * 64 + lane] = c; /* the tile is no longer needed */
-        ((int*)s_tile)[3 * 64 + type * 64 + lane] = vb;
+        f_cost[type * 64 + lane] = c;
+        f_vb[type * 64 + lane] = vb;
     }
     __syncthreads();
     if (w == 0 && row_ok) {
         const size_t o = ((size_t)colg * H + vT) * 3;
         float* cd = cost_table + o;
         int32_t* id = index_table + o;
-        const int* f_vb = (const int*)s_tile + 3 * 64;
-        cd[0] = s_tile[0 * 64 + lane]; cd[1] = s_tile[1 * 64 + lane]; cd[2] = s_tile[2 * 64 + lane];
+        cd[0] = f_cost[0 * 64 + lane]; cd[1] = f_cost[1 * 64 + lane]; cd[2] = f_cost[2 * 64 + lane];
         id[0] = f_vb[0 * 64 + lane]; id[1] = f_vb[1 * 64 + lane]; id[2] = f_vb[2 * 64 + lane];
     }
+    wait_vmcnt<0>(); /* no LDS-DMA may land after the workgroup has gone (its LDS is reassigned) */
     ISF_MARK(3);
 }
 
@@ -370,10 +377,10 @@ static int isf_nvr(const DevParams* P) {
 size_t isk_unary_fast_lds_bytes(const DevParams* P, int nvr) {
     const size_t DP = (size_t)P->D + 1;
     const size_t rcp = ((size_t)P->H + 1 + 3) & ~(size_t)3;
-    const size_t tile = ((size_t)IS_TILE * DP + 3) & ~(size_t)3;
-    size_t ring = (size_t)ISF_WAVES * ISF_RING * (64 * (size_t)nvr + ISF_REC_F);
-    const size_t merge = (size_t)ISF_WAVES * 3 * 64 * 2;
-    if (ring < merge) ring = merge;
+    size_t tile = ((size_t)IS_TILE * DP + 3) & ~(size_t)3;
+    const size_t ring = (size_t)ISF_WAVES * ISF_RING * (64 * (size_t)nvr + ISF_REC_F);
+    const size_t merge = (size_t)ISF_WAVES * 3 * 64 * 2 + 2 * 3 * 64; /* lives in the tile's space */
+    if (tile < merge) tile = merge;
     return sizeof(float) * (rcp + tile + ring) + 16;
 }
 
