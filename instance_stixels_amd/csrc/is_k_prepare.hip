@@ -7,6 +7,9 @@
 /* ====================================================================================== */
 #define PREP_THREADS 256
 
+/* LDS stride of a segmentation channel: H/8 + 1 prefix entries, rounded up to 16 bytes */
+__host__ __device__ static inline int prep_seg_stride(int H) { return (((H >> 3) + 1) + 3) & ~3; }
+
 /* Exclusive prefix of index i (0 <= i < n) with the association of the reference's
  * work-efficient block scan ComputePrefixSum (StixelsKernels.h:73-103): the up-sweep builds a
  * pairwise tree, the down-sweep gives a right child `parent + left subtree sum`, i.e. the
@@ -124,10 +127,14 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_columns(
     PruneRec* __restrict__ prune) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int H = P.H, P2 = P.P2, P2S = P.P2S, CH = P.CH, K = P.K;
+    /* LDS stride of a segmentation channel: only its first H/8 + 1 entries matter (an exclusive
+     * prefix at index <= H/8 never sees the zero padding up to P2S), and 21 channels of P2S = 256
+     * entries were 21.5 of the kernel's 46 KB of LDS: with 132 the CU holds four workgroups, not three */
+    const int SS = prep_seg_stride(H);
     float* s_d = (float*)smem;                          /* [P2]   disparity column        */
     float* s_pyr = s_d + P2;                            /* [2*P2] scan tree                */
-    int32_t* s_seg = (int32_t*)(s_pyr + 2 * P2);        /* [CH][P2S]                       */
-    int64_t* s_wave = (int64_t*)(s_seg + CH * P2S);     /* [4]                             */
+    int32_t* s_seg = (int32_t*)(s_pyr + 2 * P2);        /* [CH][SS]                        */
+    int64_t* s_wave = (int64_t*)(s_seg + CH * SS);      /* [4]                             */
     float* s_red = (float*)(s_wave + 4);                /* [8] block reductions            */
     float* s_tot = s_red + 8;                           /* [2] sum mx^2 + my^2 of the column */
 
@@ -149,13 +156,20 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_columns(
         float4* sd4 = reinterpret_cast<float4*>(s_d);
         for (int i = tid; i < (H >> 2); i += PREP_THREADS) sd4[i] = d4[i];
         for (int i = H + tid; i < P2; i += PREP_THREADS) s_d[i] = 0.0f;
-        if ((P2S & 3) == 0) {
+        if ((P2S & 3) == 0 && SS <= P2S) {
             const int4* g4 = reinterpret_cast<const int4*>(scol);
             int4* s4 = reinterpret_cast<int4*>(s_seg);
-#pragma unroll 6
-            for (int i = tid; i < ((CH * P2S) >> 2); i += PREP_THREADS) s4[i] = g4[i];
+            const int sq = SS >> 2, gq = P2S >> 2;
+#pragma unroll 4
+            for (int i = tid; i < CH * sq; i += PREP_THREADS) {
+                const int c = i / sq, q = i - c * sq;
+                s4[i] = g4[c * gq + q];
+            }
         } else {
-            for (int i = tid; i < CH * P2S; i += PREP_THREADS) s_seg[i] = scol[i];
+            for (int i = tid; i < CH * SS; i += PREP_THREADS) {
+                const int c = i / SS, k = i - c * SS;
+                s_seg[i] = k < P2S ? scol[c * P2S + k] : 0;
+            }
         }
     }
     __syncthreads();
@@ -165,8 +179,8 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_columns(
      * my = trunc(row - offy + 0.5): n for n >= 0, n + 1 for n < 0 (truncation toward zero). */
     const int R = (H + PREP_THREADS - 1) / PREP_THREADS;
     const int r_lo = tid * R;
-    const int32_t* offy = s_seg + K * P2S;
-    const int32_t* offx = s_seg + (K + 1) * P2S;
+    const int32_t* offy = s_seg + K * SS;
+    const int32_t* offx = s_seg + (K + 1) * SS;
     int64_t sum_mx = 0, sum_my = 0, sum_mx2 = 0, sum_my2 = 0;
     uint64_t abs_mx = 0, abs_my = 0;
     int slow = 0; /* column needs the generic (int64 / IEEE-division) DP path, see RowRec */
@@ -197,13 +211,13 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_columns(
         __syncthreads(); /* s_wave is reused by the scans below */
     }
     if (tid < K) { /* class channels of a FAST column: values >= 0, full-resolution total < 2^24 */
-        const int32_t* ch = s_seg + tid * P2S;
+        const int32_t* ch = s_seg + tid * SS;
         uint64_t total = 0;
         int negative = 0;
-        for (int k = 0; k < P2S; k++) {
-            /* (rotated start: the 19 threads would otherwise read the same LDS bank every time --
-             * the channels are P2S = 2^k dwords apart) */
-            const int32_t x = ch[(k + tid) & (P2S - 1)];
+        for (int k = 0; k < SS; k++) {
+            /* (rotated start: spreads the 19 threads over the LDS banks) */
+            const int kk = (k + tid < SS) ? k + tid : k + tid - SS;
+            const int32_t x = ch[kk % SS];
             negative |= (x < 0);
             total += (uint64_t)(uint32_t)x;
         }
@@ -237,9 +251,9 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_columns(
 
     /* ---- square the offset channels in place (StixelsKernels.cu:411-416), then exclusive
      * prefix of every channel at 1/8 resolution (:462-469); integer, so any order is exact */
-    for (int i = tid; i < 2 * P2S; i += PREP_THREADS) {
-        const uint32_t x = (uint32_t)s_seg[K * P2S + i];
-        s_seg[K * P2S + i] = (int32_t)(x * x);
+    for (int i = tid; i < 2 * SS; i += PREP_THREADS) {
+        const uint32_t x = (uint32_t)s_seg[K * SS + i];
+        s_seg[K * SS + i] = (int32_t)(x * x);
     }
     __syncthreads();
     /* branch-and-bound precondition: the non-instance offset term is >= 0 and monotone when no
@@ -248,8 +262,8 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_columns(
     int nic_bad = 0;
     {
         unsigned long long sq_sum = 0;
-        for (int i = tid; i < 2 * P2S; i += PREP_THREADS) {
-            const int32_t v = s_seg[K * P2S + i];
+        for (int i = tid; i < 2 * SS; i += PREP_THREADS) {
+            const int32_t v = s_seg[K * SS + i];
             nic_bad |= v < 0;
             sq_sum += (unsigned long long)(uint32_t)v;
         }
@@ -262,31 +276,28 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_columns(
         __syncthreads();
     }
     nic_bad = __syncthreads_or(nic_bad);
-    /* one wave per channel (round robin): lane l owns P2S/64 consecutive entries */
+    /* one wave per channel (round robin): lane l owns `per` consecutive entries of the SS */
     {
-        const int lane = tid & 63, wv = tid >> 6, per = P2S >> 6;
+        const int lane = tid & 63, wv = tid >> 6, per = (SS + 63) >> 6;
         for (int c = wv; c < CH; c += PREP_THREADS / 64) {
-            int32_t* ch = s_seg + c * P2S;
-            if (per >= 1) {
-                uint32_t local = 0;
-                for (int k = 0; k < per; k++) local += (uint32_t)ch[lane * per + k];
-                uint32_t inc = local; /* inclusive wave scan of the lane totals */
+            int32_t* ch = s_seg + c * SS;
+            uint32_t local = 0;
+            for (int k = 0; k < per; k++) {
+                const int idx = lane * per + k;
+                if (idx < SS) local += (uint32_t)ch[idx];
+            }
+            uint32_t inc = local; /* inclusive wave scan of the lane totals */
 #pragma unroll
-                for (int j = 1; j < 64; j <<= 1) {
-                    const uint32_t n = (uint32_t)__shfl_up((int)inc, j, 64);
-                    if (lane >= j) inc += n;
-                }
-                uint32_t run = inc - local;
-                for (int k = 0; k < per; k++) {
-                    const uint32_t x = (uint32_t)ch[lane * per + k];
-                    ch[lane * per + k] = (int32_t)run;
-                    run += x;
-                }
-            } else if (lane == 0) { /* P2S < 64: tiny columns */
-                uint32_t run = 0;
-                for (int k = 0; k < P2S; k++) {
-                    const uint32_t x = (uint32_t)ch[k];
-                    ch[k] = (int32_t)run;
+            for (int j = 1; j < 64; j <<= 1) {
+                const uint32_t n = (uint32_t)__shfl_up((int)inc, j, 64);
+                if (lane >= j) inc += n;
+            }
+            uint32_t run = inc - local;
+            for (int k = 0; k < per; k++) {
+                const int idx = lane * per + k;
+                if (idx < SS) {
+                    const uint32_t x = (uint32_t)ch[idx];
+                    ch[idx] = (int32_t)run;
                     run += x;
                 }
             }
@@ -302,11 +313,11 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_columns(
         for (int j = 0; j < 4; j++) {
             const int dw = q * 4 + j; /* dword of RowRec: Fg0 Fg1 Fon[8] Foi[8] Fsky Fnic */
             if (dw == 19) {
-                x[j] = (int32_t)((uint32_t)full_prefix(s_seg + (K + 1) * P2S, v) +
-                                 (uint32_t)full_prefix(s_seg + K * P2S, v));
+                x[j] = (int32_t)((uint32_t)full_prefix(s_seg + (K + 1) * SS, v) +
+                                 (uint32_t)full_prefix(s_seg + K * SS, v));
             } else {
                 const int chn = dw < 10 ? dw : (dw < 18 ? dw + 1 : 10);
-                const int32_t f = full_prefix(s_seg + chn * P2S, v);
+                const int32_t f = full_prefix(s_seg + chn * SS, v);
                 x[j] = slow ? f : __float_as_int((float)f);
             }
         }
@@ -541,7 +552,7 @@ __global__ void k_prior_tables(const DevParams P, const float* __restrict__ grou
 extern "C" {
 
 size_t isk_prepare_lds_bytes(const DevParams* P) {
-    return sizeof(float) * (size_t)P->P2 * 3 + sizeof(int32_t) * (size_t)P->CH * P->P2S + 192;
+    return sizeof(float) * (size_t)P->P2 * 3 + sizeof(int32_t) * (size_t)P->CH * prep_seg_stride(P->H) + 192;
 }
 
 hipError_t isk_launch_prepare(const DevParams* P, int ncols, const float* joined,
