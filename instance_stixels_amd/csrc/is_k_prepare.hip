@@ -9,6 +9,10 @@
 
 /* LDS stride of a segmentation channel: H/8 + 1 prefix entries, rounded up to 16 bytes */
 __host__ __device__ static inline int prep_seg_stride(int H) { return (((H >> 3) + 1) + 3) & ~3; }
+/* leaves of the fp32 scan trees: H when H is a power of two (then P2 = 2H), else P2 */
+__host__ __device__ static inline int prep_scan_leaves(int H, int P2) {
+    return ((H & (H - 1)) == 0 && P2 == 2 * H && H >= 16) ? H : P2;
+}
 
 /* Exclusive prefix of index i (0 <= i < n) with the association of the reference's
  * work-efficient block scan ComputePrefixSum (StixelsKernels.h:73-103): the up-sweep builds a
@@ -131,9 +135,19 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_columns(
      * prefix at index <= H/8 never sees the zero padding up to P2S), and 21 channels of P2S = 256
      * entries were 21.5 of the kernel's 46 KB of LDS: with 132 the CU holds four workgroups, not three */
     const int SS = prep_seg_stride(H);
-    float* s_d = (float*)smem;                          /* [P2]   disparity column        */
-    float* s_pyr = s_d + P2;                            /* [2*P2] scan tree                */
-    int32_t* s_seg = (int32_t*)(s_pyr + 2 * P2);        /* [CH][SS]                        */
+    /* The scans run over P2 >= H + 1 zero-padded elements (StixelsKernels.h:73-103).  When H is a
+     * power of two (P2 = 2H) everything a prefix at index <= H needs lies in the LEFT half of that
+     * tree: indices < H walk the same nodes as in a tree over H leaves, and index H is the left
+     * child of the root = the root of the H-leaf tree.  The tree is then built over NP = H leaves:
+     * identical sums, half the LDS (12 instead of 24 KB at H = 1024). */
+    const int NP = prep_scan_leaves(H, P2);
+    const int LNP = (NP == P2) ? P.log2P2 : P.log2P2 - 1;
+    float* s_d = (float*)smem;                          /* [NP]   disparity column        */
+    float* s_pyr = s_d + NP;                            /* [2*NP] scan tree                */
+    int32_t* s_seg = (int32_t*)(s_pyr + 2 * NP);        /* [CH][SS]                        */
+    auto prefix_at = [&](int v) -> float { /* exclusive prefix at v <= H */
+        return (v == NP) ? s_pyr[2 * NP - 2] : blelloch_prefix(s_pyr, NP, LNP, v);
+    };
     int64_t* s_wave = (int64_t*)(s_seg + CH * SS);      /* [4]                             */
     float* s_red = (float*)(s_wave + 4);                /* [8] block reductions            */
     float* s_tot = s_red + 8;                           /* [2] sum mx^2 + my^2 of the column */
@@ -155,7 +169,7 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_columns(
         const float4* d4 = reinterpret_cast<const float4*>(dcol);
         float4* sd4 = reinterpret_cast<float4*>(s_d);
         for (int i = tid; i < (H >> 2); i += PREP_THREADS) sd4[i] = d4[i];
-        for (int i = H + tid; i < P2; i += PREP_THREADS) s_d[i] = 0.0f;
+        for (int i = H + tid; i < NP; i += PREP_THREADS) s_d[i] = 0.0f;
         if ((P2S & 3) == 0 && SS <= P2S) {
             const int4* g4 = reinterpret_cast<const int4*>(scol);
             int4* s4 = reinterpret_cast<int4*>(s_seg);
@@ -334,7 +348,7 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_columns(
     for (int k = 0; k < MAXR; k++) pS[k] = pV[k] = pG[k] = pK[k] = 0.0f;
     float* svcol = sv_arr + (size_t)colg * 2 * (H + 1); /* compact copies for the pairwise phase 2 */
     /* S: disparity (valid-masked when invalid >= 0, :382-389) */
-    for (int i = tid; i < P2; i += PREP_THREADS) {
+    for (int i = tid; i < NP; i += PREP_THREADS) {
         float x = 0.0f;
         if (i < H) {
             const float d = s_d[i];
@@ -348,16 +362,16 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_columns(
         s_pyr[i] = x;
     }
     __syncthreads();
-    blelloch_build(s_pyr, P2, P.log2P2);
+    blelloch_build(s_pyr, NP, LNP);
     if (regs) {
 #pragma unroll
         for (int k = 0; k < MAXR; k++) {
             const int v = tid + k * PREP_THREADS;
-            if (v <= H) { pS[k] = blelloch_prefix(s_pyr, P2, P.log2P2, v); svcol[v] = pS[k]; }
+            if (v <= H) { pS[k] = prefix_at(v); svcol[v] = pS[k]; }
         }
     } else {
         for (int v = tid; v <= H; v += PREP_THREADS) {
-            const float x = blelloch_prefix(s_pyr, P2, P.log2P2, v);
+            const float x = prefix_at(v);
             rcol[v].S = x;
             svcol[v] = x;
         }
@@ -365,19 +379,19 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_columns(
     __syncthreads();
     /* V: valid count (all zero without an invalid-disparity value: no scan needed) */
     if (P.invalid >= 0) {
-        for (int i = tid; i < P2; i += PREP_THREADS)
+        for (int i = tid; i < NP; i += PREP_THREADS)
             s_pyr[i] = (i < H) ? (float)(s_d[i] != P.invalid) : 0.0f;
         __syncthreads();
-        blelloch_build(s_pyr, P2, P.log2P2);
+        blelloch_build(s_pyr, NP, LNP);
         if (regs) {
 #pragma unroll
             for (int k = 0; k < MAXR; k++) {
                 const int v = tid + k * PREP_THREADS;
-                if (v <= H) { pV[k] = blelloch_prefix(s_pyr, P2, P.log2P2, v); svcol[H + 1 + v] = pV[k]; }
+                if (v <= H) { pV[k] = prefix_at(v); svcol[H + 1 + v] = pV[k]; }
             }
         } else {
             for (int v = tid; v <= H; v += PREP_THREADS) {
-                const float x = blelloch_prefix(s_pyr, P2, P.log2P2, v);
+                const float x = prefix_at(v);
                 rcol[v].V = x;
                 svcol[H + 1 + v] = x;
             }
@@ -391,7 +405,7 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_columns(
     }
     /* G: ground data cost, +inf at / above the horizon (:435-446) */
     float g_abs = 0.0f, g_min = 0.0f; /* over the finite rows: slack of the ground data term */
-    for (int i = tid; i < P2; i += PREP_THREADS) {
+    for (int i = tid; i < NP; i += PREP_THREADS) {
         float x = 0.0f;
         if (i < H) {
             x = (i >= vhor) ? IS_INF : data_cost_ground(gfun[i], s_d[i], gnorm[i], gis2[i], P);
@@ -401,20 +415,20 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_columns(
     }
     const float2 g_red = block_sum_min(g_abs, g_min, s_red);
     __syncthreads();
-    blelloch_build(s_pyr, P2, P.log2P2);
+    blelloch_build(s_pyr, NP, LNP);
     if (regs) {
 #pragma unroll
         for (int k = 0; k < MAXR; k++) {
             const int v = tid + k * PREP_THREADS;
-            if (v <= H) pG[k] = blelloch_prefix(s_pyr, P2, P.log2P2, v);
+            if (v <= H) pG[k] = prefix_at(v);
         }
     } else {
-        for (int v = tid; v <= H; v += PREP_THREADS) rcol[v].G = blelloch_prefix(s_pyr, P2, P.log2P2, v);
+        for (int v = tid; v <= H; v += PREP_THREADS) rcol[v].G = prefix_at(v);
     }
     __syncthreads();
     /* K: sky data cost, 0 below the horizon (:424-433) */
     float k_abs = 0.0f, k_min = 0.0f;
-    for (int i = tid; i < P2; i += PREP_THREADS) {
+    for (int i = tid; i < NP; i += PREP_THREADS) {
         float x = 0.0f;
         if (i < H) x = (i < vhor) ? 0.0f : data_cost_sky(s_d[i], P);
         k_abs += __builtin_fabsf(x);
@@ -443,18 +457,18 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_columns(
         prune[colg] = pr;
     }
     __syncthreads();
-    blelloch_build(s_pyr, P2, P.log2P2);
+    blelloch_build(s_pyr, NP, LNP);
     if (regs) {
 #pragma unroll
         for (int k = 0; k < MAXR; k++) {
             const int v = tid + k * PREP_THREADS;
             if (v <= H) {
-                pK[k] = blelloch_prefix(s_pyr, P2, P.log2P2, v);
+                pK[k] = prefix_at(v);
                 reinterpret_cast<float4*>(rcol + v)[5] = make_float4(pG[k], pK[k], pS[k], pV[k]);
             }
         }
     } else {
-        for (int v = tid; v <= H; v += PREP_THREADS) rcol[v].K = blelloch_prefix(s_pyr, P2, P.log2P2, v);
+        for (int v = tid; v <= H; v += PREP_THREADS) rcol[v].K = prefix_at(v);
     }
 }
 
@@ -552,7 +566,8 @@ __global__ void k_prior_tables(const DevParams P, const float* __restrict__ grou
 extern "C" {
 
 size_t isk_prepare_lds_bytes(const DevParams* P) {
-    return sizeof(float) * (size_t)P->P2 * 3 + sizeof(int32_t) * (size_t)P->CH * prep_seg_stride(P->H) + 192;
+    return sizeof(float) * (size_t)prep_scan_leaves(P->H, P->P2) * 3 +
+           sizeof(int32_t) * (size_t)P->CH * prep_seg_stride(P->H) + 192;
 }
 
 hipError_t isk_launch_prepare(const DevParams* P, int ncols, const float* joined,
