@@ -68,9 +68,10 @@ __device__ __forceinline__ is_section make_section(const DevParams& P, const Row
 }
 
 /* One wavefront per column.  The reference lets thread 0 do everything serially
- * (StixelsKernels.cu:843-955); only the index chase is inherently serial, so: the column's
- * tables are staged in LDS (coalesced), lane 0 walks the chain in LDS and records the cuts,
- * then the lanes build the Sections in parallel (one per lane). */
+ * (StixelsKernels.cu:843-955); only the index chase is inherently serial, so: lane 0 walks the
+ * chain and records the cuts, then the lanes build the Sections in parallel (one per lane).  The
+ * chase reads the tables where they lie (two dependent loads per section, a few dozen sections):
+ * staging the column's 24 KB of tables in LDS first (round 1) limited a CU to five waves. */
 __global__ __launch_bounds__(64) void k_backtrace(const DevParams P, int ncols, int pairwise,
                                                   const RowRec* __restrict__ recs,
                                                   const float* __restrict__ cost_table,
@@ -82,20 +83,15 @@ __global__ __launch_bounds__(64) void k_backtrace(const DevParams P, int ncols, 
     if (colg >= ncols) return;
     const int lane = threadIdx.x;
     const int H = P.H, S = P.S;
-    float* s_cost = (float*)smem;           /* [3H] */
-    int* s_idx = (int*)(s_cost + 3 * H);    /* [3H] */
-    int* s_cut = s_idx + 3 * H;             /* [S][3]: vT, vB, type */
+    int* s_cut = (int*)smem;                /* [S][3]: vT, vB, type */
     int* s_n = s_cut + 3 * S;               /* [1] */
     const bool wide = col_flags[colg] != 0; /* generic record encoding, see RowRec */
     const RowRec* rcol = recs + (size_t)colg * (H + 1);
     const float* ct = cost_table + (size_t)colg * H * 3;
     const int32_t* it = index_table + (size_t)colg * H * 3;
     is_section* out = sections + (size_t)colg * S;
-    for (int i = lane; i < 3 * H; i += 64) {
-        s_cost[i] = ct[i];
-        s_idx[i] = it[i];
-    }
-    __syncthreads();
+    const float* s_cost = ct; /* (names kept: the walk below reads global memory) */
+    const int32_t* s_idx = it;
     if (lane == 0) {
         int vT = H - 1;
         const float last_ground = s_cost[vT * 3 + IS_GROUND];
@@ -216,7 +212,7 @@ extern "C" {
 hipError_t isk_launch_backtrace(const DevParams* P, int ncols, int pairwise, const RowRec* recs,
                                 const float* cost_table, const int32_t* index_table,
                                 const int* col_flags, is_section* sections, hipStream_t stream) {
-    const size_t lds = sizeof(int) * (6 * (size_t)P->H + 3 * (size_t)P->S + 4);
+    const size_t lds = sizeof(int) * (3 * (size_t)P->S + 4);
     hipLaunchKernelGGL(k_backtrace, dim3(ncols), dim3(64), lds, stream, *P, ncols, pairwise, recs,
                        cost_table, index_table, col_flags, sections);
     return hipGetLastError();
@@ -233,7 +229,7 @@ hipError_t isk_launch_compact(const DevParams* P, const is_section* sections_img
 
 hipError_t isk_set_lds_backtrace(const DevParams* P) {
     hipError_t e = hipFuncSetAttribute((const void*)k_backtrace, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)(sizeof(int) * (6 * (size_t)P->H + 3 * (size_t)P->S + 4)));
+                                       (int)(sizeof(int) * (3 * (size_t)P->S + 4)));
     if (e != hipSuccess) return e;
     /* more than 2047 stixel columns: the per-column counters exceed the 64 KiB default */
     return hipFuncSetAttribute((const void*)k_compact_instances, hipFuncAttributeMaxDynamicSharedMemorySize,
