@@ -102,12 +102,18 @@ __global__ __launch_bounds__(64) void k_backtrace(const DevParams P, int ncols, 
         if (last_sky < __builtin_fminf(last_ground, last_object)) type = IS_SKY;
         int n = 0;
         int prev_vT;
+        /* the three index entries of the current row travel with the walk: a hop then costs ONE
+         * dependent memory round trip (the costs and the indices of row vB - 1 together), not two */
+        int i0 = s_idx[vT * 3 + 0], i1 = s_idx[vT * 3 + 1], i2 = s_idx[vT * 3 + 2];
         do {
-            const int raw = s_idx[vT * 3 + type];
+            const int raw = type == 0 ? i0 : (type == 1 ? i1 : i2);
             int vB, prev_type;
             if (pairwise) {
                 vB = raw / 3;
                 prev_type = raw % 3;
+                if (vB > 0) {
+                    i0 = s_idx[(vB - 1) * 3 + 0]; i1 = s_idx[(vB - 1) * 3 + 1]; i2 = s_idx[(vB - 1) * 3 + 2];
+                }
             } else {
                 /* unary: index_table holds the winning vB; the predecessor type is the arg-min
                  * of the FINAL cost_table[vB-1], tie rules of :723-727, 769-773, 828-835 */
@@ -116,11 +122,10 @@ __global__ __launch_bounds__(64) void k_backtrace(const DevParams P, int ncols, 
                 if (vB > 0) {
                     const float cG = s_cost[(vB - 1) * 3 + IS_GROUND];
                     const float cO = s_cost[(vB - 1) * 3 + IS_OBJECT];
+                    const float cS = s_cost[(vB - 1) * 3 + IS_SKY];
+                    i0 = s_idx[(vB - 1) * 3 + 0]; i1 = s_idx[(vB - 1) * 3 + 1]; i2 = s_idx[(vB - 1) * 3 + 2];
                     if (cG < cO) prev_type = IS_GROUND;
-                    if (type == IS_OBJECT) {
-                        const float cS = s_cost[(vB - 1) * 3 + IS_SKY];
-                        if (cS < __builtin_fminf(cG, cO)) prev_type = IS_SKY;
-                    }
+                    if (type == IS_OBJECT && cS < __builtin_fminf(cG, cO)) prev_type = IS_SKY;
                 }
             }
             s_cut[n * 3 + 0] = vT; s_cut[n * 3 + 1] = vB; s_cut[n * 3 + 2] = type;
