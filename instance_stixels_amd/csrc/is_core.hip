@@ -23,12 +23,13 @@ size_t isk_unary_lds_bytes(const DevParams* P);
 size_t isk_pairwise_lds_bytes(const DevParams* P, int nwaves);
 hipError_t isk_launch_join(const float*, float*, int, int, int, int, int, int, float, int, hipStream_t);
 hipError_t isk_launch_prepare(const DevParams*, int, const float*, const int32_t*, const float*,
-                              const int*, const float*, RowRec*, float*, int*, float*, PruneRec*,
+                              const int*, const float*, RowRec*, float*, int*, float*, PruneRec*, int*,
                               hipStream_t, hipStream_t, hipEvent_t, hipEvent_t);
 struct StepRec;
 hipError_t isk_launch_priors(const DevParams*, const float*, PriorRec*, int, hipStream_t);
 hipError_t isk_launch_dp_unary(const DevParams*, int, int, const RowRec*, const float*, const float*,
-                               const int*, const int*, const PruneRec*, float*, int32_t*, hipStream_t);
+                               const int*, const int*, const PruneRec*, float*, int32_t*, const int*,
+                               hipStream_t);
 hipError_t isk_launch_dp_pairwise(const DevParams*, int, int, const RowRec*, const float*,
                                   const float*, const PriorRec*, const float*, const float*, const float*,
                                   const int*, const int*, const PruneRec*, StepRec*, float*, int*,
@@ -83,6 +84,7 @@ struct is_ctx {
     float* d_rcp;            /* [H+1]   RN(1/h) = (float)(1./h), the reference's inverse_height */
     int* d_col_flags;        /* [max_batch*C] 0 = FAST column, see RowRec */
     PruneRec* d_prune;       /* [max_batch*C] branch-and-bound slacks of the column */
+    int* d_n_generic;        /* [1] generic-encoding columns of the current call */
     /* per-call device inputs */
     float* d_ground;         /* [max_batch][3][H] */
     int* d_vhor;             /* [max_batch] */
@@ -287,6 +289,7 @@ static int ctx_init(is_ctx* c, const is_stixel_params* p, const float* obj_cost_
     ALLOC(c->d_rcp, sizeof(float) * (H + 1));
     ALLOC(c->d_col_flags, sizeof(int) * B * C);
     ALLOC(c->d_prune, sizeof(PruneRec) * B * C);
+    ALLOC(c->d_n_generic, sizeof(int));
     ALLOC(c->d_ground, sizeof(float) * B * 3 * H);
     ALLOC(c->d_vhor, sizeof(int) * B);
     ALLOC(c->d_recs, sizeof(RowRec) * B * C * (H + 1));
@@ -358,7 +361,7 @@ int is_ctx_destroy(is_ctx* c) {
     if (!c) return IS_OK;
     DeviceScope scope(c->device);
     (void)hipDeviceSynchronize();
-    (void)hipFree(c->d_obj_cost_lut); (void)hipFree(c->d_odr); (void)hipFree(c->d_rcp); (void)hipFree(c->d_col_flags); (void)hipFree(c->d_prune); (void)hipFree(c->d_ground);
+    (void)hipFree(c->d_obj_cost_lut); (void)hipFree(c->d_odr); (void)hipFree(c->d_rcp); (void)hipFree(c->d_col_flags); (void)hipFree(c->d_prune); (void)hipFree(c->d_n_generic); (void)hipFree(c->d_ground);
     (void)hipFree(c->d_vhor); (void)hipFree(c->d_recs); (void)hipFree(c->d_lutT); (void)hipFree(c->d_priors); (void)hipFree(c->d_steps); (void)hipFree(c->d_part_cost); (void)hipFree(c->d_part_idx); (void)hipFree(c->d_sv);
     (void)hipFree(c->d_cost_table); (void)hipFree(c->d_index_table); (void)hipFree(c->d_cluster_scratch);
     for (int i = 0; i < IS_STAGE_SLOTS; i++) {
@@ -490,9 +493,10 @@ int is_compute(is_ctx* c, const float* d_joined, const int32_t* d_seg, const flo
     int32_t* it = d_index_table ? d_index_table : c->d_index_table;
 
     if (c->timing) HIP_TRY(hipEventRecord(c->ev[0], stream));
+    HIP_TRY(hipMemsetAsync(c->d_n_generic, 0, sizeof(int), stream));
     HIP_TRY(isk_launch_prepare(&P, ncols, d_joined, d_seg, c->d_ground, c->d_vhor,
                                c->d_obj_cost_lut, c->d_recs, c->d_lutT, c->d_col_flags, c->d_sv,
-                               c->d_prune, stream, c->aux_stream, c->ev_fork, c->ev_join));
+                               c->d_prune, c->d_n_generic, stream, c->aux_stream, c->ev_fork, c->ev_join));
     if (pairwise) HIP_TRY(isk_launch_priors(&P, c->d_ground, c->d_priors, n_images, stream));
     if (c->timing) HIP_TRY(hipEventRecord(c->ev[1], stream));
     if (pairwise)
@@ -503,7 +507,8 @@ int is_compute(is_ctx* c, const float* d_joined, const int32_t* d_seg, const flo
                                        stream, c->aux_streams, IS_AUX_STREAMS, c->ev_fork, c->ev_joins));
     else
         HIP_TRY(isk_launch_dp_unary(&P, ncols, c->nwaves_unary, c->d_recs, c->d_lutT, c->d_rcp,
-                                    c->d_vhor, c->d_col_flags, c->d_prune, ct, it, stream));
+                                    c->d_vhor, c->d_col_flags, c->d_prune, ct, it, c->d_n_generic,
+                                    stream));
     if (c->timing) HIP_TRY(hipEventRecord(c->ev[2], stream));
     HIP_TRY(isk_launch_backtrace(&P, ncols, pairwise ? 1 : 0, c->d_recs, ct, it, c->d_col_flags,
                                  d_sections, stream));

@@ -128,7 +128,7 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_columns(
     const DevParams P, const float* __restrict__ joined, const int32_t* __restrict__ seg,
     const float* __restrict__ ground /*[img][3][H]*/, const int* __restrict__ vhor_arr,
     RowRec* __restrict__ recs, int* __restrict__ col_flags, float* __restrict__ sv_arr,
-    PruneRec* __restrict__ prune) {
+    PruneRec* __restrict__ prune, int* __restrict__ n_generic) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int H = P.H, P2 = P.P2, P2S = P.P2S, CH = P.CH, K = P.K;
     /* LDS stride of a segmentation channel: only its first H/8 + 1 entries matter (an exclusive
@@ -238,7 +238,10 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_columns(
         slow |= negative | (total * IS_DOWNSAMPLE_FACTOR >= (uint64_t)IS_FAST_CLASS_LIMIT);
     }
     slow = __syncthreads_or(slow);
-    if (tid == 0) col_flags[colg] = slow;
+    if (tid == 0) {
+        col_flags[colg] = slow;
+        if (slow) atomicAdd(n_generic, 1); /* (zeroed by the caller before the launch) */
+    }
     int64_t base_mx = block_excl_scan_i64(sum_mx, s_wave);
     int64_t base_my = block_excl_scan_i64(sum_my, s_wave);
     int64_t base_mx2 = block_excl_scan_i64(sum_mx2, s_wave);
@@ -573,7 +576,8 @@ size_t isk_prepare_lds_bytes(const DevParams* P) {
 hipError_t isk_launch_prepare(const DevParams* P, int ncols, const float* joined,
                               const int32_t* seg, const float* ground, const int* vhor,
                               const float* cost_T, RowRec* recs, float* lutT,
-                              int* col_flags, float* sv_arr, PruneRec* prune, hipStream_t stream,
+                              int* col_flags, float* sv_arr, PruneRec* prune, int* n_generic,
+                              hipStream_t stream,
                               hipStream_t aux, hipEvent_t ev_fork, hipEvent_t ev_join) {
     /* The two prepare kernels are independent.  With few columns (a single frame = 256) neither
      * fills the chip and both are latency chains, so they run side by side on two streams; with
@@ -591,7 +595,7 @@ hipError_t isk_launch_prepare(const DevParams* P, int ncols, const float* joined
                        joined, cost_T, lutT);
     hipLaunchKernelGGL(k_prepare_columns, dim3(ncols), dim3(PREP_THREADS),
                        isk_prepare_lds_bytes(P), stream, *P, joined, seg, ground, vhor, recs,
-                       col_flags, sv_arr, prune);
+                       col_flags, sv_arr, prune, n_generic);
     if (side_by_side) {
         if ((e = hipEventRecord(ev_join, aux)) != hipSuccess) return e;
         if ((e = hipStreamWaitEvent(stream, ev_join, 0)) != hipSuccess) return e;

@@ -322,6 +322,7 @@ __global__ __launch_bounds__(IS_UNARY_WAVES * 64, IS_UNARY_OCC) void k_dp_unary(
                                                   const PruneRec* __restrict__ prune,
                                                   float* __restrict__ cost_table,
                                                   int32_t* __restrict__ index_table,
+                                                  const int* __restrict__ n_generic,
                                                   int pairs_per_wg) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int H = P.H, D = P.D;
@@ -334,12 +335,20 @@ __global__ __launch_bounds__(IS_UNARY_WAVES * 64, IS_UNARY_OCC) void k_dp_unary(
     const int nxcd = 8;
     const int npairs = (P.ntiles + 1) / 2;
     const int wg_per_col = (npairs + pairs_per_wg - 1) / pairs_per_wg;
+    /* The launch of the generic columns is a small grid that walks all (column, tile pair) items
+     * and leaves at once when the batch has no generic column (k_prepare_columns counts them):
+     * a full grid of workgroups that each only read their column's flag cost 0.13 ms per 64
+     * frames in dispatch alone. */
+    if (!FASTCOLS && __builtin_amdgcn_readfirstlane(*n_generic) == 0) return;
+    const int n_items = ((ncols + nxcd - 1) / nxcd) * nxcd * wg_per_col;
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+    __syncthreads(); /* the previous item's merge area aliases this item's LUT tile */
     /* (integer division runs on the VALU: pin the uniform results back into SGPRs) */
-    const int xcd = blockIdx.x % nxcd, q = blockIdx.x / nxcd;
+    const int xcd = item % nxcd, q = item / nxcd;
     const int wg_in_col = __builtin_amdgcn_readfirstlane(q % wg_per_col);
     const int colg = __builtin_amdgcn_readfirstlane((q / wg_per_col) * nxcd + xcd);
-    if (colg >= ncols) return;
-    if ((__builtin_amdgcn_readfirstlane(col_flags[colg]) == 0) != FASTCOLS) return;
+    if (colg >= ncols) continue;
+    if ((__builtin_amdgcn_readfirstlane(col_flags[colg]) == 0) != FASTCOLS) continue;
     const int img = __builtin_amdgcn_readfirstlane(colg / P.C);
     const int vhor = __builtin_amdgcn_readfirstlane(vhor_arr[img]);
 
@@ -430,6 +439,7 @@ __global__ __launch_bounds__(IS_UNARY_WAVES * 64, IS_UNARY_OCC) void k_dp_unary(
     IS_PHASE_MARK(3);
     } /* pass */
     } /* pair */
+    } /* item */
 }
 
 extern "C" hipError_t isk_launch_dp_unary_fast(const DevParams*, int, const RowRec*, const float*,
@@ -448,7 +458,7 @@ size_t isk_unary_lds_bytes(const DevParams* P) {
 hipError_t isk_launch_dp_unary(const DevParams* P, int ncols, int nwaves, const RowRec* recs,
                                const float* lutT, const float* rcp, const int* vhor,
                                const int* col_flags, const PruneRec* prune, float* cost_table,
-                               int32_t* index_table, hipStream_t stream) {
+                               int32_t* index_table, const int* n_generic, hipStream_t stream) {
     /* FAST columns: the chunk-staged kernel of is_k_unary_fast.hip whenever the shape allows it;
      * then only the generic columns are left for this file's kernel */
     /* (measured on MI355X, batch 64: 8.7 ms against 9.3 ms of the tile-pair kernel below, and no
@@ -466,6 +476,7 @@ hipError_t isk_launch_dp_unary(const DevParams* P, int ncols, int nwaves, const 
     const int pairs_per_wg = 1;
     const int wg_per_col = (npairs + pairs_per_wg - 1) / pairs_per_wg;
     const dim3 grid(groups * 8 * wg_per_col);
+    const dim3 grid_generic(grid.x < 16384u ? grid.x : 16384u); /* walks the items, see the kernel */
     const size_t lds = isk_unary_lds_bytes(P);
     /* D <= 128: the vB-side lutT row travels in two registers per lane (LutRow<2>); wider
      * tables gather per lane */
@@ -474,10 +485,10 @@ hipError_t isk_launch_dp_unary(const DevParams* P, int ncols, int nwaves, const 
         if (!fast_kernel)                                                                          \
             hipLaunchKernelGGL((k_dp_unary<INV, NR, true>), grid, dim3(nwaves * 64), lds, stream,  \
                                *P, ncols, recs, lutT, rcp, vhor, col_flags, prune, cost_table,     \
-                               index_table, pairs_per_wg);                                         \
-        hipLaunchKernelGGL((k_dp_unary<INV, NR, false>), grid, dim3(nwaves * 64), lds, stream, *P, \
-                           ncols, recs, lutT, rcp, vhor, col_flags, prune, cost_table,             \
-                           index_table, pairs_per_wg);                                             \
+                               index_table, n_generic, pairs_per_wg);                              \
+        hipLaunchKernelGGL((k_dp_unary<INV, NR, false>), grid_generic, dim3(nwaves * 64), lds,     \
+                           stream, *P, ncols, recs, lutT, rcp, vhor, col_flags, prune, cost_table, \
+                           index_table, n_generic, pairs_per_wg);                                  \
     } while (0)
     if (P->D <= 128) {
         if (P->invalid >= 0) IS_LAUNCH_UNARY(true, 2); else IS_LAUNCH_UNARY(false, 2);
