@@ -142,6 +142,31 @@ def test_config3_batch_of_full_frames(preset):
 
 
 @pytest.mark.parametrize("preset", ["drn_d_22_unary", "drn_d_38_pairwise"])
+def test_pruning_changes_nothing_at_full_size(preset, monkeypatch):
+    """Size-independent property at BASELINE's sizes (no oracle needed): the exact branch-and-bound
+    only skips candidates that cannot win, so with IS_NO_PRUNE=1 (every (vB, vT) pair evaluated,
+    the reference's O(H^2) walk) the complete DP tables and all Sections of 12 full 1024x2048x128
+    frames are bit-identical to the pruned run.  12 frames = 3072 columns: the one-wave phase 2 and
+    the unsplit phase 1 of the pairwise mode, the geometry of large batches."""
+    case4 = helpers.build_case(preset, 1024, 2048, 128, seed=91, n_images=4)
+    pick = [i % 4 for i in range(12)]
+    case = dict(case4)
+    case["frames"] = [case4["frames"][k] for k in pick]
+    for k in ("gf", "ng", "ig", "vhor", "disparity", "segmentation"):
+        case[k] = case4[k][pick]
+    pruned = helpers.run_core(case, want_tables=True)
+    monkeypatch.setenv("IS_NO_PRUNE", "1")
+    full = helpers.run_core(case, want_tables=True)
+    assert np.array_equal(pruned["cost_table"].view(np.uint32), full["cost_table"].view(np.uint32))
+    assert np.array_equal(pruned["index_table"], full["index_table"])
+    for img in range(12):
+        assert helpers.sections_equal(pruned["sections"][img], full["sections"][img])
+    # and the frames that repeat inside the batch agree with each other
+    for img in range(4, 12):
+        assert helpers.sections_equal(pruned["sections"][img], pruned["sections"][img % 4])
+
+
+@pytest.mark.parametrize("preset", ["drn_d_22_unary", "drn_d_38_pairwise"])
 def test_batch64_launch_geometry(preset):
     """BASELINE configs[2] / the per-GPU share of configs[3]: 64 full 1024x2048x128 frames in ONE
     call -- 16 384 columns, the launch geometry bench.py times (12 GB of scratch, the two-stream
