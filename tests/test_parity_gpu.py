@@ -164,6 +164,19 @@ def test_pruning_changes_nothing_at_full_size(preset, monkeypatch):
     # and the frames that repeat inside the batch agree with each other
     for img in range(4, 12):
         assert helpers.sections_equal(pruned["sections"][img], pruned["sections"][img % 4])
+    # the Sections of every column tile it exactly, top of the image first (R10), and carry the
+    # clipped table cost of their last row (StixelsKernels.cu:868-944)
+    H = int(case["cfg"].rows)
+    for img in range(4):
+        secs, ct = pruned["sections"][img], pruned["cost_table"][img]
+        for c in range(secs.shape[0]):
+            n = helpers.n_sections(secs[c])
+            col = secs[c][:n]
+            assert n >= 1 and col["vT"][0] == H - 1 and col["vB"][-1] == 0
+            assert np.array_equal(col["vT"][1:], col["vB"][:-1] - 1)
+            assert np.all(col["vB"] <= col["vT"])
+            best = np.minimum(ct[c][col["vT"]].min(axis=1), np.float32(1e4))
+            assert np.all(col["cost"] <= np.float32(1e4)) and np.all(col["cost"] >= best)
 
 
 @pytest.mark.parametrize("preset", ["drn_d_22_unary", "drn_d_38_pairwise"])
