@@ -77,17 +77,26 @@ public:
      * with the reference's CUDA code).  Every later call runs on that device whatever the
      * caller's current device is. */
     void SetDevice(int device) { m_device = device; }
+    /* the device requested with SetDevice() (-1 = current device at Initialize() time) */
     int GetDevice() const { return m_device; }
+    /* the device the buffers of the last Initialize() live on (-1 before) */
+    int GetActiveDevice() const { return m_ctx_device; }
     /* Host half of Initialize() (tables + parameter block); needs no device. */
     void PrecomputeHost();
     /* Like Initialize(), with device scratch for up to max_batch frames per ComputeBatch(). */
     void InitializeBatch(int max_batch);
     /* Batched Compute on device-resident inputs:
      *   d_disparity_big [n][rows][cols] float, d_segmentation [n][realcols][channels][P2S] int32.
-     * Fills `out[i]` like Compute() fills its StixelsData.  `stream` is a hipStream_t. */
+     * Fills `out[i]` like Compute() fills its StixelsData.  `stream` is a hipStream_t.
+     * `instance_stixels` (optional): filled with what GetInstanceStixels() returns after a
+     * Compute() of frame i -- the instance candidates of every frame are compacted and clustered
+     * on the device in two launches for the whole batch (the reference does both inside
+     * Compute(), StixelsKernels.cu:926-942, Stixels.cu:613). */
+    typedef std::map<std::pair<int, int>, int> InstanceMapping;
     void ComputeBatch(bool pairwise, int n_images, const pixel_t* d_disparity_big,
                       const int32_t* d_segmentation, const RoadParameters* road,
-                      std::vector<StixelsData>& out, void* stream = nullptr);
+                      std::vector<StixelsData>& out, void* stream = nullptr,
+                      std::vector<InstanceMapping>* instance_stixels = nullptr);
     /* Introspection for tests / bench. */
     const StixelParameters& GetParameters() const { return m_params; }
     const std::vector<float>& GetObjectCostLUT() const { return m_obj_cost_lut; }
@@ -109,7 +118,7 @@ private:
     float ComputeObjectDisparityRange(const float previous_mean) const;
     float FastLog(float v) const;
     void FillHeader(StixelsData& d, float alpha_ground, int vhor_lib) const;
-    is_instance_buffers InstanceBuffers() const;
+    is_instance_buffers InstanceBuffers(int image = 0) const;
     GroundModel m_ground; /* per-frame ground model, storage reused between frames */
 
     /* device (owned between Initialize and Finish, Stixels.cu:53-74, 136-163) */
@@ -122,14 +131,16 @@ private:
     int32_t* d_instance_indices = nullptr;
     uint8_t* d_instance_core_candidates = nullptr;
     int32_t* d_instances_per_class = nullptr;
+    /* (every instance array: one slice per frame of the batch) */
     int32_t* d_instance_labels = nullptr;  /* the reference's d_instance_labels, Stixels.cu:66-68 */
     int32_t* d_instance_packed = nullptr;  /* [1 + 3*classes*realcols*max_sections], see is_instance_buffers */
     /* pinned host mirrors: Compute() ends with ONE stream synchronisation */
     Section* h_stixels = nullptr;
-    int32_t* h_instance_head = nullptr;    /* [8 per-class counts] */
+    int32_t* h_instance_head = nullptr;    /* [max_batch][8 per-class counts] */
     int32_t* h_instance_packed = nullptr;
     int m_max_batch = 1;
-    int m_device = -1;
+    int m_device = -1;      /* requested (SetDevice) */
+    int m_ctx_device = -1;  /* resolved at Initialize(): where the buffers live */
     bool m_labels_on_host = false; /* h_instance_packed holds the triples of the last frame */
 
     StixelParameters m_params{};

@@ -36,16 +36,16 @@ hipError_t isk_launch_dp_pairwise(const DevParams*, int, int, const RowRec*, con
                                   float*, int32_t*,
                                   hipStream_t, hipStream_t*, int, hipEvent_t, hipEvent_t*);
 hipError_t isk_launch_backtrace(const DevParams*, int, int, const RowRec*, const float*,
-                                const int32_t*, const int*, is_section*, hipStream_t);
-hipError_t isk_launch_compact(const DevParams*, const is_section*, float*, int32_t*, uint8_t*,
-                              int32_t*, hipStream_t);
+                                const int32_t*, const int*, is_section*, int*, hipStream_t);
+hipError_t isk_launch_compact(const DevParams*, int, const is_section*, const int*,
+                              const is_instance_buffers*, hipStream_t);
 hipError_t isk_set_lds_prepare(const DevParams*);
 hipError_t isk_set_lds_unary(const DevParams*);
 hipError_t isk_set_lds_pairwise(const DevParams*, int);
 hipError_t isk_set_lds_backtrace(const DevParams*);
 int isk_debug_occupancy(const DevParams*, int);
-hipError_t isk_launch_cluster(int, float, int, const float*, const uint8_t*, const int32_t*,
-                              const int32_t*, int32_t*, int32_t*, int32_t*, hipStream_t);
+hipError_t isk_launch_cluster(int, float, int, int, const is_instance_buffers*,
+                              const is_instance_buffers*, int32_t*, hipStream_t);
 size_t isk_phase2_lds_bytes(const DevParams* P);
 size_t isk_phase2s_lds_bytes(const DevParams* P);
 hipError_t isk_launch_flip_and_pad(const float*, int32_t*, int, int, int, int, int, hipStream_t);
@@ -92,6 +92,7 @@ struct is_ctx {
      * being read by the H2D copy of the call IS_STAGE_SLOTS calls ago */
     float* h_ground_pinned[IS_STAGE_SLOTS];
     int* h_vhor_pinned[IS_STAGE_SLOTS];
+    is_instance_buffers* h_inst_pinned[IS_STAGE_SLOTS]; /* [max_batch] per-image output arrays */
     hipEvent_t staging_free[IS_STAGE_SLOTS]; /* recorded after the H2D copies of the slot's call */
     bool staging_pending[IS_STAGE_SLOTS];
     int stage_next;
@@ -99,7 +100,9 @@ struct is_ctx {
     hipStream_t aux_streams[IS_AUX_STREAMS]; /* column groups of the pairwise DP in flight */
     hipEvent_t ev_fork, ev_join;
     hipEvent_t ev_joins[IS_AUX_STREAMS];
-    int32_t* d_cluster_scratch; /* [8][2][C*S] work arrays of k_cluster_instances */
+    int32_t* d_cluster_scratch; /* [max_batch][8][2][C*S] work arrays of k_cluster_instances */
+    is_instance_buffers* d_inst_tbl; /* [max_batch] device copy of the caller's per-image arrays */
+    int* d_inst_cnt;            /* [max_batch*C][8] instance candidates per column and class */
     /* scratch */
     RowRec* d_recs;          /* [max_batch*C][H+1] */
     float* d_lutT;           /* [max_batch*C][H+1][D] */
@@ -145,7 +148,7 @@ struct DeviceScope {
         return fail_hip(dev_scope__.err, "hipSetDevice(ctx->device)", __FILE__, __LINE__)
 
 const char* is_last_error(void) { return g_err; }
-const char* is_version(void) { return "instance_stixels_amd-core 0.1 (gfx950)"; }
+const char* is_version(void) { return "instance_stixels_amd-core 0.3 (gfx950)"; }
 
 int is_device_malloc(void** ptr, size_t bytes) { HIP_TRY(hipMalloc(ptr, bytes)); return IS_OK; }
 int is_device_free(void* ptr) { HIP_TRY(hipFree(ptr)); return IS_OK; }
@@ -244,6 +247,17 @@ static int ctx_init(is_ctx* c, const is_stixel_params* p, const float* obj_cost_
     d.first_o_above = d.rows_log + 0.0f + d.max_dis_log;
     d.size_filter = p->clustering_size_filter;
     d.column_step = p->column_step;
+    /* the IS_* knobs (experiments, A/B tests) are read here, once per context, never per call */
+    const bool no_prune = getenv("IS_NO_PRUNE") != nullptr;
+    const bool debug = getenv("IS_DEBUG") != nullptr;
+    {
+        auto knob = [](const char* name) { const char* e = getenv(name); return e ? atoi(e) : -1; };
+        d.knob_ring_kernel = getenv("IS_NO_RING_KERNEL") ? 0 : -1;
+        d.knob_prepare_overlap = knob("IS_PREPARE_OVERLAP");
+        d.knob_p2_lds_floor = knob("IS_P2_LDS");
+        d.knob_pw_groups = knob("IS_PW_GROUPS");
+        d.knob_p2_split = knob("IS_P2_SPLIT");
+    }
     {
         /* branch-and-bound constants (PruneRec, is_device.h).  gamma_d bounds the relative error of
          * a prefix computed by a summation tree of depth d: Blelloch needs <= 2 log2(P2) additions
@@ -261,7 +275,7 @@ static int ctx_init(is_ctx* c, const is_stixel_params* p, const float* obj_cost_
         }
         const bool weights_ok = d.dw >= 0.0f && d.sw >= 0.0f && d.iw >= 0.0f && d.pw >= 0.0f &&
                                 d.dw < IS_FLT_HUGE && d.sw < IS_FLT_HUGE && d.iw < IS_FLT_HUGE;
-        if (finite && weights_ok && !getenv("IS_NO_PRUNE"))
+        if (finite && weights_ok && !no_prune)
             d.sigma_od = (float)(((0.0 - min_v) * d.H + 2.0 * gamma * d.H * max_abs) * 1.001);
         else
             d.sigma_od = __builtin_inff(); /* pruning off */
@@ -304,12 +318,15 @@ static int ctx_init(is_ctx* c, const is_stixel_params* p, const float* obj_cost_
     ALLOC(c->d_sv, sizeof(float) * B * C * 2 * (H + 1));
     ALLOC(c->d_cost_table, sizeof(float) * B * C * H * 3);
     ALLOC(c->d_index_table, sizeof(int32_t) * B * C * H * 3);
-    ALLOC(c->d_cluster_scratch, sizeof(int32_t) * IS_INSTANCE_CLASSES * 2 * C * (size_t)d.S);
+    ALLOC(c->d_cluster_scratch, sizeof(int32_t) * B * IS_INSTANCE_CLASSES * 2 * C * (size_t)d.S);
+    ALLOC(c->d_inst_tbl, sizeof(is_instance_buffers) * B);
+    ALLOC(c->d_inst_cnt, sizeof(int) * B * C * IS_INSTANCE_CLASSES);
 #undef ALLOC
     c->scratch_bytes = total;
     for (int i = 0; i < IS_STAGE_SLOTS; i++) {
         HIP_TRY(hipHostMalloc((void**)&c->h_ground_pinned[i], sizeof(float) * B * 3 * H));
         HIP_TRY(hipHostMalloc((void**)&c->h_vhor_pinned[i], sizeof(int) * B));
+        HIP_TRY(hipHostMalloc((void**)&c->h_inst_pinned[i], sizeof(is_instance_buffers) * B));
         HIP_TRY(hipEventCreateWithFlags(&c->staging_free[i], hipEventDisableTiming));
     }
     for (int i = 0; i < IS_AUX_STREAMS; i++) {
@@ -351,7 +368,7 @@ static int ctx_init(is_ctx* c, const is_stixel_params* p, const float* obj_cost_
     HIP_TRY(isk_set_lds_unary(&d));
     HIP_TRY(isk_set_lds_pairwise(&d, c->nwaves_pairwise));
     HIP_TRY(isk_set_lds_backtrace(&d));
-    if (getenv("IS_DEBUG"))
+    if (debug)
         fprintf(stderr, "[is_core] unary DP: %d waves/WG, %zu B LDS/WG, occupancy API: %d WG/CU\n",
                 c->nwaves_unary, isk_unary_lds_bytes(&d), isk_debug_occupancy(&d, c->nwaves_unary));
     return IS_OK;
@@ -364,9 +381,11 @@ int is_ctx_destroy(is_ctx* c) {
     (void)hipFree(c->d_obj_cost_lut); (void)hipFree(c->d_odr); (void)hipFree(c->d_rcp); (void)hipFree(c->d_col_flags); (void)hipFree(c->d_prune); (void)hipFree(c->d_n_generic); (void)hipFree(c->d_ground);
     (void)hipFree(c->d_vhor); (void)hipFree(c->d_recs); (void)hipFree(c->d_lutT); (void)hipFree(c->d_priors); (void)hipFree(c->d_steps); (void)hipFree(c->d_part_cost); (void)hipFree(c->d_part_idx); (void)hipFree(c->d_sv);
     (void)hipFree(c->d_cost_table); (void)hipFree(c->d_index_table); (void)hipFree(c->d_cluster_scratch);
+    (void)hipFree(c->d_inst_tbl); (void)hipFree(c->d_inst_cnt);
     for (int i = 0; i < IS_STAGE_SLOTS; i++) {
         if (c->h_ground_pinned[i]) (void)hipHostFree(c->h_ground_pinned[i]);
         if (c->h_vhor_pinned[i]) (void)hipHostFree(c->h_vhor_pinned[i]);
+        if (c->h_inst_pinned[i]) (void)hipHostFree(c->h_inst_pinned[i]);
         if (c->staging_free[i]) (void)hipEventDestroy(c->staging_free[i]);
     }
     for (int i = 0; i < IS_AUX_STREAMS; i++) {
@@ -401,10 +420,9 @@ int is_cluster_instances(is_ctx* c, const is_instance_buffers* ib, void* stream)
     if (!ib->d_labels || !ib->d_centerofmass || !ib->d_core_candidates || !ib->d_instances_per_class)
         return fail_arg("d_labels, d_centerofmass, d_core_candidates and d_instances_per_class are required");
     ON_CTX_DEVICE(c);
+    /* (the scratch of image slot 0: calls on one context must be stream-ordered, see the header) */
     HIP_TRY(isk_launch_cluster(c->dp.C * c->dp.S, c->params.clustering_eps, c->params.clustering_min_pts,
-                               ib->d_centerofmass, ib->d_core_candidates, ib->d_instances_per_class,
-                               ib->d_indices, ib->d_labels, c->d_cluster_scratch, ib->d_packed,
-                               (hipStream_t)stream));
+                               1, nullptr, ib, c->d_cluster_scratch, (hipStream_t)stream));
     return IS_OK;
 }
 
@@ -510,22 +528,28 @@ int is_compute(is_ctx* c, const float* d_joined, const int32_t* d_seg, const flo
                                     c->d_vhor, c->d_col_flags, c->d_prune, ct, it, c->d_n_generic,
                                     stream));
     if (c->timing) HIP_TRY(hipEventRecord(c->ev[2], stream));
-    HIP_TRY(isk_launch_backtrace(&P, ncols, pairwise ? 1 : 0, c->d_recs, ct, it, c->d_col_flags,
-                                 d_sections, stream));
-    if (instances) {
+    bool want_inst = false, want_labels = false;
+    if (instances)
         for (int i = 0; i < n_images; i++) {
             const is_instance_buffers& ib = instances[i];
-            if (!ib.d_centerofmass && !ib.d_indices && !ib.d_core_candidates && !ib.d_instances_per_class)
-                continue;
-            HIP_TRY(isk_launch_compact(&P, d_sections + (size_t)i * P.C * P.S, ib.d_centerofmass,
-                                       ib.d_indices, ib.d_core_candidates, ib.d_instances_per_class,
-                                       stream));
-            if (ib.d_labels) /* Stixels::ClusterInstances, Stixels.cu:613 */
-                HIP_TRY(isk_launch_cluster(P.C * P.S, c->params.clustering_eps,
-                                           c->params.clustering_min_pts, ib.d_centerofmass,
-                                           ib.d_core_candidates, ib.d_instances_per_class, ib.d_indices,
-                                           ib.d_labels, c->d_cluster_scratch, ib.d_packed, stream));
+            want_inst = want_inst || ib.d_centerofmass || ib.d_indices || ib.d_core_candidates ||
+                        ib.d_instances_per_class;
+            want_labels = want_labels || ib.d_labels;
         }
+    HIP_TRY(isk_launch_backtrace(&P, ncols, pairwise ? 1 : 0, c->d_recs, ct, it, c->d_col_flags,
+                                 d_sections, want_inst ? c->d_inst_cnt : nullptr, stream));
+    if (want_inst) {
+        /* the instance candidates (StixelsKernels.cu:926-942) and their clustering
+         * (Stixels::ClusterInstances, Stixels.cu:613) of the WHOLE batch: two launches; the
+         * per-image output pointers travel through the pinned staging slot of this call */
+        memcpy(c->h_inst_pinned[slot], instances, sizeof(is_instance_buffers) * n_images);
+        HIP_TRY(hipMemcpyAsync(c->d_inst_tbl, c->h_inst_pinned[slot], sizeof(is_instance_buffers) * n_images,
+                               hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipEventRecord(c->staging_free[slot], stream)); /* (re-recorded behind this copy) */
+        HIP_TRY(isk_launch_compact(&P, n_images, d_sections, c->d_inst_cnt, c->d_inst_tbl, stream));
+        if (want_labels)
+            HIP_TRY(isk_launch_cluster(P.C * P.S, c->params.clustering_eps, c->params.clustering_min_pts,
+                                       n_images, c->d_inst_tbl, nullptr, c->d_cluster_scratch, stream));
     }
     if (c->timing) {
         HIP_TRY(hipEventRecord(c->ev[3], stream));

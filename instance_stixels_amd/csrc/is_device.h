@@ -146,6 +146,13 @@ struct DevParams {
      * 2 * gamma_d, the relative error bound of the tree-summed prefixes */
     float sigma_od;
     float gamma2;
+    /* host-side launch knobs: the IS_* environment variables, read ONCE in is_ctx_create (never
+     * per call); -1 = automatic.  The kernels ignore them. */
+    int knob_ring_kernel;     /* IS_NO_RING_KERNEL=1 -> 0: unary FAST columns through k_dp_unary */
+    int knob_prepare_overlap; /* IS_PREPARE_OVERLAP: the two prepare kernels on two streams */
+    int knob_p2_lds_floor;    /* IS_P2_LDS: floor on phase 2's LDS allocation (occupancy throttle) */
+    int knob_pw_groups;       /* IS_PW_GROUPS: column groups (streams) of the pairwise DP */
+    int knob_p2_split;        /* IS_P2_SPLIT: 1 = k_pw_phase2s, 0 = k_pw_phase2 */
 };
 
 #endif /* IS_DEVICE_H_ */

@@ -77,7 +77,8 @@ __global__ __launch_bounds__(64) void k_backtrace(const DevParams P, int ncols, 
                                                   const float* __restrict__ cost_table,
                                                   const int32_t* __restrict__ index_table,
                                                   const int* __restrict__ col_flags,
-                                                  is_section* __restrict__ sections) {
+                                                  is_section* __restrict__ sections,
+                                                  int* __restrict__ inst_cnt /* [ncols][8] or null */) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int colg = blockIdx.x;
     if (colg >= ncols) return;
@@ -138,76 +139,110 @@ __global__ __launch_bounds__(64) void k_backtrace(const DevParams P, int ncols, 
     }
     __syncthreads();
     const int n = *s_n;
-    for (int i = lane; i <= n; i += 64) {
+    int my_cnt = 0; /* lane k < 8: instance candidates of class 11 + k in this column */
+    for (int i0 = 0; i0 <= n; i0 += 64) { /* (wave-uniform trip count: ballots inside) */
+        const int i = i0 + lane;
         is_section sec;
+        sec.type = -1; sec.vB = 0; sec.vT = 0; sec.disparity = 0.0f; /* terminator, :952-954 */
+        sec.semantic_class = 0; sec.cost = 0.0f; sec.instance_meanx = 0.0f; sec.instance_meany = 0.0f;
         if (i < n) {
             const int vT = s_cut[i * 3 + 0], vB = s_cut[i * 3 + 1], type = s_cut[i * 3 + 2];
             sec = make_section(P, rcol, wide, vT, vB, type, s_cost[vT * 3 + type]);
-        } else { /* terminator, :952-954 */
-            sec.type = -1; sec.vB = 0; sec.vT = 0; sec.disparity = 0.0f;
-            sec.semantic_class = 0; sec.cost = 0.0f; sec.instance_meanx = 0.0f; sec.instance_meany = 0.0f;
         }
-        out[i] = sec;
+        if (i <= n) out[i] = sec;
+        if (inst_cnt) { /* candidates per instance class, :926-942 (the scatter: k_compact_instances) */
+            const bool cand = i < n && sec.type == IS_OBJECT && sec.semantic_class >= IS_FIRST_INSTANCE_CLASS;
+            const int k = sec.semantic_class - IS_FIRST_INSTANCE_CLASS;
+#pragma unroll
+            for (int kk = 0; kk < IS_INSTANCE_CLASSES; kk++) {
+                const int c = __builtin_popcountll(__builtin_amdgcn_ballot_w64(cand && k == kk));
+                if (lane == kk) my_cnt += c;
+            }
+        }
     }
+    if (inst_cnt && lane < IS_INSTANCE_CLASSES) inst_cnt[(size_t)colg * IS_INSTANCE_CLASSES + lane] = my_cnt;
 }
 
 /* ====================================================================================== */
 /* Instance candidates in canonical (column, section) order, reference layout              */
-/* (StixelsKernels.cu:926-942; one workgroup per image)                                    */
+/* (StixelsKernels.cu:926-942), the whole batch in ONE launch                              */
 /* ====================================================================================== */
-__global__ __launch_bounds__(256) void k_compact_instances(
-    const DevParams P, const is_section* __restrict__ sections, float* __restrict__ com,
-    int32_t* __restrict__ indices, uint8_t* __restrict__ core, int32_t* __restrict__ per_class) {
+/* grid = (ISC_CHUNKS, n_images).  k_backtrace has left the per-column, per-class candidate counts
+ * in inst_cnt; every workgroup turns its image's C x 8 counts into exclusive offsets (a few
+ * thousand integers: cheaper to repeat per chunk than to hand over through memory), then its
+ * waves scatter the candidates of the chunk's columns, one wave per column at a time: lane i
+ * reads Section i, its slot is offset[column][class] + the number of same-class candidates in
+ * the lanes below it (ballot + mbcnt).  `tbl[image]`: the caller's per-image output arrays. */
+#define ISC_THREADS 256
+#define ISC_CHUNKS 4
+__global__ __launch_bounds__(ISC_THREADS) void k_compact_instances(
+    const DevParams P, const is_section* __restrict__ sections, const int* __restrict__ inst_cnt,
+    const is_instance_buffers* __restrict__ tbl) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    int* s_cnt = (int*)smem; /* [C][8] counts, then exclusive offsets */
+    int* s_off = (int*)smem;                    /* [C][8] exclusive offsets */
+    int* s_part = s_off + (size_t)P.C * IS_INSTANCE_CLASSES; /* [ISC_THREADS / 8][8] */
     const int C = P.C, S = P.S;
-    const is_section* sec = sections; /* already offset to the image by the host */
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        int cnt[IS_INSTANCE_CLASSES];
-#pragma unroll
-        for (int k = 0; k < IS_INSTANCE_CLASSES; k++) cnt[k] = 0;
-        for (int i = 0; i < S; i++) {
-            const is_section s = sec[(size_t)c * S + i];
-            if (s.type == -1) break;
-            if (s.type == IS_OBJECT && s.semantic_class >= IS_FIRST_INSTANCE_CLASS) {
-                const int k = s.semantic_class - IS_FIRST_INSTANCE_CLASS;
-#pragma unroll
-                for (int kk = 0; kk < IS_INSTANCE_CLASSES; kk++)
-                    if (kk == k) cnt[kk]++;
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < IS_INSTANCE_CLASSES; k++) s_cnt[c * IS_INSTANCE_CLASSES + k] = cnt[k];
+    const int img = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const is_instance_buffers ib = tbl[img];
+    if (!ib.d_centerofmass && !ib.d_indices && !ib.d_core_candidates && !ib.d_instances_per_class)
+        return; /* nothing wanted for this image */
+    const is_section* sec = sections + (size_t)img * C * S;
+    const int* cnt = inst_cnt + (size_t)img * C * IS_INSTANCE_CLASSES;
+    /* exclusive scan over the columns, per class: thread (g, k) sums the columns of group g,
+     * a serial pass over the ISC_THREADS / 8 group totals, then the groups are written out */
+    constexpr int NG = ISC_THREADS / IS_INSTANCE_CLASSES;
+    const int k = tid & (IS_INSTANCE_CLASSES - 1), g = tid / IS_INSTANCE_CLASSES;
+    const int per = (C + NG - 1) / NG;
+    const int c_lo = min(g * per, C), c_hi = min(c_lo + per, C);
+    int sum = 0;
+    for (int c = c_lo; c < c_hi; c++) sum += cnt[c * IS_INSTANCE_CLASSES + k];
+    s_part[g * IS_INSTANCE_CLASSES + k] = sum;
+    __syncthreads();
+    int base = 0;
+    for (int gg = 0; gg < g; gg++) base += s_part[gg * IS_INSTANCE_CLASSES + k];
+    if (g == NG - 1 && blockIdx.x == 0 && ib.d_instances_per_class) ib.d_instances_per_class[k] = base + sum;
+    for (int c = c_lo; c < c_hi; c++) {
+        s_off[c * IS_INSTANCE_CLASSES + k] = base;
+        base += cnt[c * IS_INSTANCE_CLASSES + k];
     }
     __syncthreads();
-    if (threadIdx.x < IS_INSTANCE_CLASSES) {
-        int run = 0;
-        for (int c = 0; c < C; c++) {
-            const int n = s_cnt[c * IS_INSTANCE_CLASSES + threadIdx.x];
-            s_cnt[c * IS_INSTANCE_CLASSES + threadIdx.x] = run;
-            run += n;
-        }
-        if (per_class) per_class[threadIdx.x] = run;
-    }
-    __syncthreads();
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        int off[IS_INSTANCE_CLASSES];
+    /* scatter: the chunk's columns, one wave per column */
+    const int cols_per_chunk = (C + ISC_CHUNKS - 1) / ISC_CHUNKS;
+    const int cc_lo = blockIdx.x * cols_per_chunk, cc_hi = min(cc_lo + cols_per_chunk, C);
+    for (int c = cc_lo + w; c < cc_hi; c += ISC_THREADS / 64) {
+        int run[IS_INSTANCE_CLASSES];
 #pragma unroll
-        for (int k = 0; k < IS_INSTANCE_CLASSES; k++) off[k] = s_cnt[c * IS_INSTANCE_CLASSES + k];
-        for (int i = 0; i < S; i++) {
-            const is_section s = sec[(size_t)c * S + i];
-            if (s.type == -1) break;
-            if (s.type == IS_OBJECT && s.semantic_class >= IS_FIRST_INSTANCE_CLASS) {
-                const int k = s.semantic_class - IS_FIRST_INSTANCE_CLASS;
-                int idx = 0;
+        for (int kk = 0; kk < IS_INSTANCE_CLASSES; kk++) run[kk] = s_off[c * IS_INSTANCE_CLASSES + kk];
+        for (int i0 = 0; i0 < S; i0 += 64) { /* wave-uniform trip count */
+            const int i = i0 + lane;
+            is_section s;
+            s.type = -1;
+            if (i < S) s = sec[(size_t)c * S + i];
+            /* everything behind the terminator is unspecified: cut at the first -1 */
+            const unsigned long long term = __builtin_amdgcn_ballot_w64(s.type == -1);
+            const unsigned long long below_term = term ? ((term & (0 - term)) - 1ull) : ~0ull;
+            const bool valid = (below_term >> lane) & 1ull;
+            const bool cand = valid && s.type == IS_OBJECT && s.semantic_class >= IS_FIRST_INSTANCE_CLASS;
+            const int kc = s.semantic_class - IS_FIRST_INSTANCE_CLASS;
+            int slot = -1;
 #pragma unroll
-                for (int kk = 0; kk < IS_INSTANCE_CLASSES; kk++)
-                    if (kk == k) idx = off[kk]++;
-                const size_t slot = (size_t)k * C * S + idx;
-                if (com) { com[slot * 2] = s.instance_meanx; com[slot * 2 + 1] = s.instance_meany; }
-                if (indices) { indices[slot * 2] = c; indices[slot * 2 + 1] = i; }
-                if (core) core[slot] = (s.vT + 1 - s.vB) >= P.size_filter;
+            for (int kk = 0; kk < IS_INSTANCE_CLASSES; kk++) {
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(cand && kc == kk);
+                const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32),
+                                                           __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+                if (cand && kc == kk) slot = run[kk] + rank;
+                run[kk] += __builtin_popcountll(m);
             }
+            if (cand) {
+                const size_t o = (size_t)kc * C * S + slot;
+                if (ib.d_centerofmass) {
+                    ib.d_centerofmass[o * 2] = s.instance_meanx;
+                    ib.d_centerofmass[o * 2 + 1] = s.instance_meany;
+                }
+                if (ib.d_indices) { ib.d_indices[o * 2] = c; ib.d_indices[o * 2 + 1] = i; }
+                if (ib.d_core_candidates) ib.d_core_candidates[o] = (s.vT + 1 - s.vB) >= P.size_filter;
+            }
+            if (term) break;
         }
     }
 }
@@ -216,19 +251,24 @@ extern "C" {
 
 hipError_t isk_launch_backtrace(const DevParams* P, int ncols, int pairwise, const RowRec* recs,
                                 const float* cost_table, const int32_t* index_table,
-                                const int* col_flags, is_section* sections, hipStream_t stream) {
+                                const int* col_flags, is_section* sections, int* inst_cnt,
+                                hipStream_t stream) {
     const size_t lds = sizeof(int) * (3 * (size_t)P->S + 4);
     hipLaunchKernelGGL(k_backtrace, dim3(ncols), dim3(64), lds, stream, *P, ncols, pairwise, recs,
-                       cost_table, index_table, col_flags, sections);
+                       cost_table, index_table, col_flags, sections, inst_cnt);
     return hipGetLastError();
 }
 
-hipError_t isk_launch_compact(const DevParams* P, const is_section* sections_img, float* com,
-                              int32_t* indices, uint8_t* core, int32_t* per_class,
+static size_t compact_lds_bytes(const DevParams* P) {
+    return sizeof(int) * ((size_t)P->C * IS_INSTANCE_CLASSES + ISC_THREADS) + 16;
+}
+
+/* the instance candidates of `n_images` images: one launch */
+hipError_t isk_launch_compact(const DevParams* P, int n_images, const is_section* sections,
+                              const int* inst_cnt, const is_instance_buffers* d_tbl,
                               hipStream_t stream) {
-    const size_t lds = sizeof(int) * (size_t)P->C * IS_INSTANCE_CLASSES + 16;
-    hipLaunchKernelGGL(k_compact_instances, dim3(1), dim3(256), lds, stream, *P, sections_img, com,
-                       indices, core, per_class);
+    hipLaunchKernelGGL(k_compact_instances, dim3(ISC_CHUNKS, n_images), dim3(ISC_THREADS),
+                       compact_lds_bytes(P), stream, *P, sections, inst_cnt, d_tbl);
     return hipGetLastError();
 }
 
@@ -236,9 +276,9 @@ hipError_t isk_set_lds_backtrace(const DevParams* P) {
     hipError_t e = hipFuncSetAttribute((const void*)k_backtrace, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)(sizeof(int) * (3 * (size_t)P->S + 4)));
     if (e != hipSuccess) return e;
-    /* more than 2047 stixel columns: the per-column counters exceed the 64 KiB default */
+    /* more than ~2000 stixel columns: the per-column offsets exceed the 64 KiB default */
     return hipFuncSetAttribute((const void*)k_compact_instances, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)(sizeof(int) * (size_t)P->C * IS_INSTANCE_CLASSES + 16));
+                               (int)compact_lds_bytes(P));
 }
 
 } /* extern "C" */

@@ -20,6 +20,7 @@
  * input.  One workgroup per (image, instance class); N <= realcols * max_sections, in practice a
  * few hundred, so the O(N^2) neighbour sweeps are a few microseconds and nothing leaves the
  * device: Stixels::Compute no longer copies candidates to the host to cluster them.
+ * A batch is ONE launch: grid = (8 classes, n_images).
  */
 #include "is_kernels.h"
 
@@ -137,23 +138,27 @@ __device__ __forceinline__ void cluster_class(int n, float eps2, int min_pts, co
     for (int i = tid; i < n; i += CLU_THREADS) labels[i] = out[i];
 }
 
-/* One workgroup per instance class.  `packed` (optional): packed[0] = number of candidates of
- * all classes, then one (column, section index, label) triple per candidate, classes in
- * ascending order -- everything Stixels::GetInstanceStixels needs in one small copy. */
+/* One workgroup per (instance class, image): grid = (8, n_images).  `tbl[image]` holds the
+ * image's candidate arrays (NULL: the single image `one`); images without d_labels are skipped.
+ * `packed` (optional, per image): packed[0] = number of candidates of all classes, then one
+ * (column, section index, label) triple per candidate, classes in ascending order -- everything
+ * Stixels::GetInstanceStixels needs in one small copy.  scratch: [n_images][classes][2][n_slots]. */
 __global__ __launch_bounds__(CLU_THREADS) void k_cluster_instances(
-    int n_slots, float eps2, int min_pts, const float* __restrict__ com_all,
-    const uint8_t* __restrict__ cand_all, const int32_t* __restrict__ per_class,
-    const int32_t* __restrict__ indices_all, int32_t* __restrict__ labels_all,
-    int32_t* __restrict__ scratch /* [classes][2][n_slots] */, int32_t* __restrict__ packed) {
+    int n_slots, float eps2, int min_pts, const is_instance_buffers* __restrict__ tbl,
+    const is_instance_buffers one, int32_t* __restrict__ scratch) {
     __shared__ int s_red[CLU_THREADS];
-    const int cls = blockIdx.x, tid = threadIdx.x;
+    const int cls = blockIdx.x, img = blockIdx.y, tid = threadIdx.x;
+    const is_instance_buffers ib = tbl ? tbl[img] : one;
+    if (!ib.d_labels) return;
+    const int32_t* per_class = ib.d_instances_per_class;
     const int n = min(max(per_class[cls], 0), n_slots);
-    const float2* com = reinterpret_cast<const float2*>(com_all) + (size_t)cls * n_slots;
-    const uint8_t* cand = cand_all + (size_t)cls * n_slots;
-    int32_t* labels = labels_all + (size_t)cls * n_slots;
-    int32_t* rank = scratch + (size_t)cls * 2 * n_slots;
+    const float2* com = reinterpret_cast<const float2*>(ib.d_centerofmass) + (size_t)cls * n_slots;
+    const uint8_t* cand = ib.d_core_candidates + (size_t)cls * n_slots;
+    int32_t* labels = ib.d_labels + (size_t)cls * n_slots;
+    int32_t* rank = scratch + ((size_t)img * IS_INSTANCE_CLASSES + cls) * 2 * n_slots;
     cluster_class(n, eps2, min_pts, com, cand, labels, rank, rank + n_slots, s_red);
-    if (packed && indices_all) {
+    int32_t* packed = ib.d_packed;
+    if (packed && ib.d_indices) {
         __syncthreads();
         int base = 0, total = 0;
         for (int k = 0; k < IS_INSTANCE_CLASSES; k++) {
@@ -162,7 +167,7 @@ __global__ __launch_bounds__(CLU_THREADS) void k_cluster_instances(
             total += m;
         }
         if (cls == 0 && tid == 0) packed[0] = total;
-        const int32_t* idx = indices_all + (size_t)cls * n_slots * 2;
+        const int32_t* idx = ib.d_indices + (size_t)cls * n_slots * 2;
         for (int i = tid; i < n; i += CLU_THREADS) {
             int32_t* t = packed + 1 + (size_t)(base + i) * 3;
             t[0] = idx[2 * i]; t[1] = idx[2 * i + 1]; t[2] = labels[i];
@@ -170,12 +175,13 @@ __global__ __launch_bounds__(CLU_THREADS) void k_cluster_instances(
     }
 }
 
-extern "C" hipError_t isk_launch_cluster(int n_slots, float eps, int min_pts, const float* com,
-                                         const uint8_t* cand, const int32_t* per_class,
-                                         const int32_t* indices, int32_t* labels, int32_t* scratch,
-                                         int32_t* packed, hipStream_t stream) {
-    hipLaunchKernelGGL(k_cluster_instances, dim3(IS_INSTANCE_CLASSES), dim3(CLU_THREADS), 0, stream,
-                       n_slots, eps * eps, min_pts, com, cand, per_class, indices, labels, scratch,
-                       packed);
+extern "C" hipError_t isk_launch_cluster(int n_slots, float eps, int min_pts, int n_images,
+                                         const is_instance_buffers* d_tbl,
+                                         const is_instance_buffers* one, int32_t* scratch,
+                                         hipStream_t stream) {
+    is_instance_buffers o;
+    if (one) o = *one; else o = is_instance_buffers{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipLaunchKernelGGL(k_cluster_instances, dim3(IS_INSTANCE_CLASSES, n_images), dim3(CLU_THREADS), 0,
+                       stream, n_slots, eps * eps, min_pts, d_tbl, o, scratch);
     return hipGetLastError();
 }

@@ -1220,8 +1220,7 @@ size_t isk_phase2_lds_bytes(const DevParams* P) {
     size_t need = sizeof(double) * 2 * IS_LOG_TABLE_SIZE +
                   sizeof(float) * (P->D + (IS_TILE + 1) + (size_t)ISP2_ROWS * ISP2_WS) + 16;
     /* IS_P2_LDS: a floor on the allocation = an occupancy throttle for experiments */
-    size_t floor_bytes = 0;
-    if (const char* e = getenv("IS_P2_LDS")) floor_bytes = (size_t)atoi(e);
+    const size_t floor_bytes = P->knob_p2_lds_floor > 0 ? (size_t)P->knob_p2_lds_floor : 0;
     return need > floor_bytes ? need : floor_bytes;
 }
 
@@ -1261,10 +1260,7 @@ hipError_t isk_launch_dp_pairwise(const DevParams* P, int ncols, int nwaves, con
      * default is one group; IS_PW_GROUPS overrides */
     if (groups > IS_PAIRWISE_MAX_GROUPS) groups = IS_PAIRWISE_MAX_GROUPS;
     if (groups > n_aux + 1) groups = n_aux + 1;
-    if (const char* gs = getenv("IS_PW_GROUPS")) {
-        const int g = atoi(gs);
-        if (g >= 1 && g <= n_aux + 1) groups = g;
-    }
+    if (P->knob_pw_groups >= 1 && P->knob_pw_groups <= n_aux + 1) groups = P->knob_pw_groups;
     hipError_t e;
 /* the vB-side lutT row in registers (LutRow<2>, D <= 128): slower than the per-lane gather while
  * phase 1 was issue-bound (41.4 vs 38.0 ms per 64 frames, round 1), faster now that the pruned
@@ -1298,7 +1294,7 @@ hipError_t isk_launch_dp_pairwise(const DevParams* P, int ncols, int nwaves, con
      * per tile) but spends four wave slots per column, which costs throughput at large batches
      * (batch 64: 32.7 vs 25.4 ms per step).  IS_P2_SPLIT=0/1 overrides. */
     bool split2 = ncols <= IS_P2_SPLIT_MAX_COLS;
-    if (const char* e = getenv("IS_P2_SPLIT")) split2 = atoi(e) != 0;
+    if (P->knob_p2_split >= 0) split2 = P->knob_p2_split != 0;
     const size_t lds2s = isk_phase2s_lds_bytes(P);
     if (groups > 1) {
         if ((e = hipEventRecord(ev_fork, stream)) != hipSuccess) return e;

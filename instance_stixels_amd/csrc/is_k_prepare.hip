@@ -583,7 +583,7 @@ hipError_t isk_launch_prepare(const DevParams* P, int ncols, const float* joined
      * fills the chip and both are latency chains, so they run side by side on two streams; with
      * many columns they are throughput-bound (HBM writes) and stay in order on one stream. */
     bool side_by_side = aux != nullptr && ncols < IS_PREPARE_OVERLAP_MAX_COLS;
-    if (const char* e = getenv("IS_PREPARE_OVERLAP")) side_by_side = aux != nullptr && atoi(e) != 0;
+    if (P->knob_prepare_overlap >= 0) side_by_side = aux != nullptr && P->knob_prepare_overlap != 0;
     hipError_t e;
     hipStream_t lut_stream = stream;
     if (side_by_side) {

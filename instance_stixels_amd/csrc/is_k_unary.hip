@@ -463,7 +463,7 @@ hipError_t isk_launch_dp_unary(const DevParams* P, int ncols, int nwaves, const 
      * then only the generic columns are left for this file's kernel */
     /* (measured on MI355X, batch 64: 8.7 ms against 9.3 ms of the tile-pair kernel below, and no
      * scratch; IS_NO_RING_KERNEL=1 selects the old kernel for comparisons) */
-    const bool fast_kernel = isk_unary_fast_chunk_rows(P) > 0 && getenv("IS_NO_RING_KERNEL") == nullptr;
+    const bool fast_kernel = isk_unary_fast_chunk_rows(P) > 0 && P->knob_ring_kernel != 0;
     if (fast_kernel) {
         const hipError_t e = isk_launch_dp_unary_fast(P, ncols, recs, lutT, rcp, vhor, col_flags, prune,
                                                       cost_table, index_table, stream);

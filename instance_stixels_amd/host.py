@@ -25,7 +25,7 @@ EXPORTS = [
     "ish_get_parameters", "ish_get_luts", "ish_core_context", "ish_set_disparity_image",
     "ish_set_segmentation", "ish_set_road_parameters", "ish_get_ground_model", "ish_compute",
     "ish_get_instance_stixels", "ish_get_3d_vertices", "ish_save_stixels", "ish_time_compute",
-    "ish_set_device",
+    "ish_set_device", "ish_compute_batch", "ish_time_compute_batch",
     "ire_create", "ire_destroy", "ire_initialize", "ire_finish", "ire_compute", "ire_get_binary",
     "ire_hough_lines",
 ]
@@ -78,6 +78,9 @@ def lib():
         L.ish_get_instance_stixels.argtypes = [vp, vp, ci]
         L.ish_time_compute.argtypes = [vp, ci, ci, ci, ctypes.POINTER(ctypes.c_double)]
         L.ish_set_device.argtypes = [vp, ci]
+        L.ish_compute_batch.argtypes = [vp, ci, ci, vp, vp, vp, vp, vp, vp, ci, vp, vp]
+        L.ish_time_compute_batch.argtypes = [vp, ci, ci, vp, vp, vp, ci, ci,
+                                             ctypes.POINTER(ctypes.c_double)]
         L.ish_get_3d_vertices.argtypes = [vp, vp, cf, ci, vp, ci]
         L.ish_save_stixels.argtypes = [vp, vp, vp, ci, cf, ci, ctypes.c_char_p]
         L.ire_create.restype = vp
@@ -191,6 +194,44 @@ class Stixels:
                                       hdr.ctypes.data, ctypes.byref(alpha), ctypes.byref(ret)),
                     "Compute")
         return StixelsData(sec, *[int(x) for x in hdr[:7]], float(alpha.value), int(hdr[7]))
+
+    def ComputeBatch(self, pairwise, d_disparity_big, d_segmentation, road, with_instances=True,
+                     stream=0):
+        """Stixels::ComputeBatch on device-resident inputs (device pointers as ints):
+        d_disparity_big [n][rows][cols] f32, d_segmentation [n][realcols][channels][P2S] i32,
+        road: n tuples (vhor_image, camera_tilt, camera_height, alpha_ground).
+        Returns (list of StixelsData, list of instance mappings or None)."""
+        n = len(road)
+        C, S = self.GetRealCols(), self.GetMaxSections()
+        rp = np.ascontiguousarray(road, np.float32).reshape(n, 4)
+        sec = np.zeros((n, C, S), SECTION_DTYPE)
+        vh = np.zeros(n, np.int32)
+        cap = C * S
+        tri = np.zeros((n, cap, 3), np.int32) if with_instances else None
+        cnt = np.zeros(n, np.int32)
+        self._check(lib().ish_compute_batch(self._h, int(bool(pairwise)), n, d_disparity_big,
+                                            d_segmentation, rp.ctypes.data, sec.ctypes.data,
+                                            vh.ctypes.data, tri.ctypes.data if with_instances else None,
+                                            cap, cnt.ctypes.data, stream), "ComputeBatch")
+        cfg = self._cfg
+        data = [StixelsData(sec[i], int(cfg.rows), int(cfg.cols), C, S, int(cfg.max_dis),
+                            int(cfg.column_step), int(cfg.n_semantic_classes), float(rp[i, 3]),
+                            int(vh[i])) for i in range(n)]
+        maps = None
+        if with_instances:
+            maps = [{(int(u), int(v)): int(l) for u, v, l in tri[i, :cnt[i]]} for i in range(n)]
+        return data, maps
+
+    def time_compute_batch(self, pairwise, d_disparity_big, d_segmentation, road, n_iter=5,
+                           with_instances=False):
+        """Seconds per ComputeBatch() call, timed inside the C++ library."""
+        rp = np.ascontiguousarray(road, np.float32).reshape(len(road), 4)
+        t = ctypes.c_double()
+        self._check(lib().ish_time_compute_batch(self._h, int(bool(pairwise)), len(road),
+                                                 d_disparity_big, d_segmentation, rp.ctypes.data,
+                                                 int(n_iter), int(bool(with_instances)),
+                                                 ctypes.byref(t)), "time_compute_batch")
+        return t.value
 
     def GetInstanceStixels(self):
         cap = self.GetRealCols() * self.GetMaxSections()

@@ -16,6 +16,32 @@
 #include <iostream>
 #include <stdexcept>
 
+namespace {
+/* Runs a public method on the device of the object's buffers and puts the caller's current
+ * device back on every exit path (SetDevice() contract in Stixels.hpp): the copies and
+ * synchronisations below use the NULL stream, which belongs to the CURRENT device. */
+class DeviceGuard {
+public:
+    explicit DeviceGuard(int device) {
+        if (device < 0) return;
+        IS_CHECK_RETURN(is_get_device(&m_prev));
+        if (m_prev != device) {
+            IS_CHECK_RETURN(is_set_device(device));
+            m_switched = true;
+        }
+    }
+    ~DeviceGuard() {
+        if (m_switched) (void)is_set_device(m_prev);
+    }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+
+private:
+    int m_prev = -1;
+    bool m_switched = false;
+};
+}  // namespace
+
 Stixels::Stixels() {}
 Stixels::~Stixels() {} /* like the reference, buffers are released by Finish(), Stixels.cu:36-37 */
 
@@ -315,13 +341,12 @@ void Stixels::InitializeBatch(int max_batch) { /* Stixels.cu:43-248 */
 
     /* device side: LUT upload + all buffers (Stixels.cu:53-74, 136-210) on the caller's current
      * device unless SetDevice() chose one */
-    int caller_device = 0;
-    IS_CHECK_RETURN(is_get_device(&caller_device));
-    const int device = m_device >= 0 ? m_device : caller_device;
-    m_device = device;
+    int device = m_device;
+    if (device < 0) IS_CHECK_RETURN(is_get_device(&device));
+    m_ctx_device = device; /* (m_device keeps the REQUEST: -1 resolves again at the next Initialize) */
+    const DeviceGuard guard(device);
     IS_CHECK_RETURN(is_ctx_create(&m_params, m_obj_cost_lut.data(),
                                   m_object_disparity_range.data(), m_max_batch, device, &m_ctx));
-    if (caller_device != device) IS_CHECK_RETURN(is_set_device(device));
     const size_t B = m_max_batch;
     IS_CHECK_RETURN(is_device_malloc((void**)&d_stixels,
                                      B * m_realcols * m_max_sections * sizeof(Section)));
@@ -339,18 +364,18 @@ void Stixels::InitializeBatch(int max_batch) { /* Stixels.cu:43-248 */
                                      (size_t)m_rows * m_cols * sizeof(float)));
     IS_CHECK_RETURN(is_device_malloc((void**)&d_disparity,
                                      B * m_rows * m_realcols * sizeof(float)));
-    IS_CHECK_RETURN(is_device_malloc((void**)&d_instance_labels, inst_n * sizeof(int32_t)));
-    IS_CHECK_RETURN(is_device_malloc((void**)&d_instance_packed, (1 + 3 * inst_n) * sizeof(int32_t)));
+    IS_CHECK_RETURN(is_device_malloc((void**)&d_instance_labels, B * inst_n * sizeof(int32_t)));
+    IS_CHECK_RETURN(is_device_malloc((void**)&d_instance_packed, B * (1 + 3 * inst_n) * sizeof(int32_t)));
     IS_CHECK_RETURN(is_host_malloc((void**)&h_stixels,
                                    (size_t)m_realcols * m_max_sections * sizeof(Section)));
-    IS_CHECK_RETURN(is_host_malloc((void**)&h_instance_head, 16 * sizeof(int32_t)));
+    IS_CHECK_RETURN(is_host_malloc((void**)&h_instance_head, B * 16 * sizeof(int32_t)));
     IS_CHECK_RETURN(is_host_malloc((void**)&h_instance_packed, (1 + 3 * inst_n) * sizeof(int32_t)));
     h_instance_packed[0] = 0;
-    if (caller_device != device) IS_CHECK_RETURN(is_set_device(caller_device));
     m_is_initialized = true;
 }
 
 void Stixels::Finish() { /* Stixels.cu:250-283 */
+    const DeviceGuard guard(m_ctx_device);
     IS_CHECK_RETURN(is_device_free(d_segmentation));
     IS_CHECK_RETURN(is_device_free(d_disparity_big));
     IS_CHECK_RETURN(is_device_free(d_disparity));
@@ -374,17 +399,20 @@ void Stixels::Finish() { /* Stixels.cu:250-283 */
     m_log_lut.clear(); m_obj_cost_lut.clear(); m_object_disparity_range.clear();
     m_normalization_object.clear(); m_inv_sigma2_object.clear();
     m_is_initialized = false;
+    m_ctx_device = -1;
 }
 
 /* ---------------------------------------------------------------- per-frame inputs */
 
 void Stixels::SetSegmentation(const std::vector<int32_t>& segmentation) { /* :340-346 */
+    const DeviceGuard guard(m_ctx_device);
     IS_CHECK_RETURN(is_memcpy_h2d(d_segmentation, segmentation.data(),
                                   sizeof(int32_t) * segmentation.size(), nullptr));
     IS_CHECK_RETURN(is_stream_synchronize(nullptr));
 }
 
 void Stixels::SetDisparityImage(const std::vector<pixel_t>& disp_im) { /* :348-355 */
+    const DeviceGuard guard(m_ctx_device);
     /* the reference queues a cudaMemcpyAsync from the caller's pageable vector; the copy is
      * finished here before returning, so the vector may be a temporary */
     IS_CHECK_RETURN(is_memcpy_h2d(d_disparity_big, disp_im.data(),
@@ -414,6 +442,7 @@ void Stixels::FillHeader(StixelsData& d, float alpha_ground, int vhor_lib) const
 float Stixels::Compute(const bool pairwise, StixelsData& stixels_data,
                        int32_t* d_segmentation_local) { /* Stixels.cu:449-637 */
     if (d_segmentation_local == nullptr) d_segmentation_local = d_segmentation;
+    const DeviceGuard guard(m_ctx_device);
 
     GroundModel& g = m_ground;
     PrecomputeGround(m_vhor, m_camera_tilt, m_camera_height, m_alpha_ground, g); /* :463 */
@@ -423,7 +452,7 @@ float Stixels::Compute(const bool pairwise, StixelsData& stixels_data,
                                     d_disparity, 1, nullptr)); /* :509-511 */
     /* the DP, the instance candidates and their clustering (ClusterInstances, :613) are queued
      * back to back on the device; nothing returns to the host in between */
-    const is_instance_buffers ib = InstanceBuffers();
+    const is_instance_buffers ib = InstanceBuffers(0);
     IS_CHECK_RETURN(is_compute(m_ctx, d_disparity, d_segmentation_local, g.function.data(),
                                g.normalization.data(), g.inv_sigma2.data(), &m_vhor,
                                pairwise ? 1 : 0, 1, d_stixels, &ib, nullptr, nullptr,
@@ -450,22 +479,26 @@ float Stixels::Compute(const bool pairwise, StixelsData& stixels_data,
     return -1; /* the reference's timers are commented out, Stixels.cu:636 */
 }
 
-is_instance_buffers Stixels::InstanceBuffers() const {
-    is_instance_buffers ib;
-    ib.d_centerofmass = d_instance_centerofmass;
-    ib.d_indices = d_instance_indices;
-    ib.d_core_candidates = d_instance_core_candidates;
-    ib.d_instances_per_class = d_instances_per_class;
-    ib.d_labels = d_instance_labels;
-    ib.d_packed = d_instance_packed;
+is_instance_buffers Stixels::InstanceBuffers(int image) const {
+    const size_t inst_n = (size_t)m_instance_classes * m_realcols * m_max_sections;
+    const size_t i = (size_t)image;
+    is_instance_buffers ib = {}; /* (zero-initialised: fields added by later versions stay NULL) */
+    ib.d_centerofmass = d_instance_centerofmass + i * inst_n * 2;
+    ib.d_indices = d_instance_indices + i * inst_n * 2;
+    ib.d_core_candidates = d_instance_core_candidates + i * inst_n;
+    ib.d_instances_per_class = d_instances_per_class + i * m_instance_classes;
+    ib.d_labels = d_instance_labels + i * inst_n;
+    ib.d_packed = d_instance_packed + i * (1 + 3 * inst_n);
     return ib;
 }
 
 void Stixels::ComputeBatch(bool pairwise, int n_images, const pixel_t* d_big,
                            const int32_t* d_seg, const RoadParameters* road,
-                           std::vector<StixelsData>& out, void* stream) {
+                           std::vector<StixelsData>& out, void* stream,
+                           std::vector<InstanceMapping>* instance_stixels) {
     if (n_images < 1 || n_images > m_max_batch)
         throw std::invalid_argument("n_images outside [1, max_batch] of InitializeBatch().");
+    const DeviceGuard guard(m_ctx_device);
     std::vector<float> gf((size_t)n_images * m_rows), ng(gf.size()), ig(gf.size());
     std::vector<int> vh(n_images);
     for (int i = 0; i < n_images; i++) {
@@ -479,9 +512,13 @@ void Stixels::ComputeBatch(bool pairwise, int n_images, const pixel_t* d_big,
     }
     IS_CHECK_RETURN(is_join_columns(m_ctx, d_big, m_cols, m_median_join ? 1 : 0, d_disparity,
                                     n_images, stream));
+    /* instance candidates + clustering of every frame: two more launches for the whole batch */
+    std::vector<is_instance_buffers> ibs;
+    if (instance_stixels)
+        for (int i = 0; i < n_images; i++) ibs.push_back(InstanceBuffers(i));
     IS_CHECK_RETURN(is_compute(m_ctx, d_disparity, d_seg, gf.data(), ng.data(), ig.data(),
-                               vh.data(), pairwise ? 1 : 0, n_images, d_stixels, nullptr, nullptr,
-                               nullptr, stream));
+                               vh.data(), pairwise ? 1 : 0, n_images, d_stixels,
+                               instance_stixels ? ibs.data() : nullptr, nullptr, nullptr, stream));
     out.resize(n_images);
     const size_t per = (size_t)m_realcols * m_max_sections;
     for (int i = 0; i < n_images; i++) {
@@ -489,7 +526,32 @@ void Stixels::ComputeBatch(bool pairwise, int n_images, const pixel_t* d_big,
         IS_CHECK_RETURN(is_memcpy_d2h(out[i].sections.data(), d_stixels + per * i,
                                       per * sizeof(Section), stream));
     }
+    if (instance_stixels) /* the per-class counts of all frames: one small copy */
+        IS_CHECK_RETURN(is_memcpy_d2h(h_instance_head, d_instances_per_class,
+                                      (size_t)n_images * m_instance_classes * sizeof(int32_t), stream));
     IS_CHECK_RETURN(is_stream_synchronize(stream));
+    if (!instance_stixels) return;
+    /* (column, section, label) triples of every frame, sized by the counts just read */
+    const size_t inst_n = (size_t)m_instance_classes * m_realcols * m_max_sections;
+    std::vector<int> totals(n_images, 0);
+    std::vector<std::vector<int32_t>> triples(n_images);
+    for (int i = 0; i < n_images; i++) {
+        for (int k = 0; k < m_instance_classes; k++) totals[i] += h_instance_head[i * m_instance_classes + k];
+        triples[i].resize(3 * (size_t)totals[i] + 1);
+        if (totals[i] > 0)
+            IS_CHECK_RETURN(is_memcpy_d2h(triples[i].data(), d_instance_packed + (size_t)i * (1 + 3 * inst_n),
+                                          (1 + 3 * (size_t)totals[i]) * sizeof(int32_t), stream));
+    }
+    IS_CHECK_RETURN(is_stream_synchronize(stream));
+    instance_stixels->assign(n_images, InstanceMapping());
+    for (int i = 0; i < n_images; i++) {
+        const int32_t* t = triples[i].data() + 1;
+        for (int j = 0; j < totals[i]; j++)
+            (*instance_stixels)[i][std::make_pair(t[3 * j], t[3 * j + 1])] = t[3 * j + 2];
+    }
+    /* a following GetInstanceStixels() returns the mapping of frame 0 (slice 0 of the arrays) */
+    for (int k = 0; k < m_instance_classes; k++) m_instances_per_class[k] = h_instance_head[k];
+    m_labels_on_host = false;
 }
 
 /* ---------------------------------------------------------------- instances */
@@ -501,6 +563,7 @@ void Stixels::ComputeBatch(bool pairwise, int n_images, const pixel_t* d_big,
  * Compute() already runs it; calling it again re-clusters the candidates of the last frame with
  * the eps / min_pts of Initialize() (m_params, like the reference). */
 float Stixels::ClusterInstances() {
+    const DeviceGuard guard(m_ctx_device);
     const is_instance_buffers ib = InstanceBuffers();
     IS_CHECK_RETURN(is_cluster_instances(m_ctx, &ib, nullptr));
     m_labels_on_host = false;
@@ -511,6 +574,7 @@ std::map<std::pair<int, int>, int> Stixels::GetInstanceStixels() { /* Stixels.cu
     /* the reference copies the complete label and index arrays (4.8 MB, "~0.8 milliseconds",
      * :745); here the device has packed (column, section, label) triples of the candidates */
     if (!m_labels_on_host) {
+        const DeviceGuard guard(m_ctx_device);
         int total = 0;
         for (int k = 0; k < m_instance_classes; k++) total += m_instances_per_class[k];
         if (total > 0) {

@@ -9,6 +9,7 @@
 #include <ctime>
 #include <exception>
 #include <string>
+#include <vector>
 
 #include "InstanceStixels/RoadEstimation.h"
 #include "InstanceStixels/Stixels.hpp"
@@ -163,6 +164,62 @@ int ish_time_compute(void* h, int pairwise, int n_iter, int with_instances, doub
         clock_gettime(CLOCK_MONOTONIC, &t1);
         (void)sink;
         *s_per_frame = ((t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec)) / n_iter;
+    });
+}
+
+/* ComputeBatch() on device-resident inputs.  road: [n][4] = (vhor_image, camera_tilt,
+ * camera_height, alpha_ground); sections: [n][realcols*max_sections]; vhor_lib: [n].
+ * triples (optional): [n][cap][3] (column, section, label) of every frame, counts: [n]. */
+int ish_compute_batch(void* h, int pairwise, int n_images, const float* d_big, const int32_t* d_seg,
+                      const float* road, Section* sections, int* vhor_lib, int* triples, int cap,
+                      int* counts, void* stream) {
+    return guard([&] {
+        Stixels* s = (Stixels*)h;
+        std::vector<Stixels::RoadParameters> rp(n_images);
+        for (int i = 0; i < n_images; i++)
+            rp[i] = Stixels::RoadParameters{(int)road[4 * i], road[4 * i + 1], road[4 * i + 2], road[4 * i + 3]};
+        std::vector<StixelsData> out;
+        std::vector<Stixels::InstanceMapping> maps;
+        s->ComputeBatch(pairwise != 0, n_images, d_big, d_seg, rp.data(), out, stream,
+                        triples ? &maps : nullptr);
+        for (int i = 0; i < n_images; i++) {
+            std::memcpy(sections + (size_t)i * out[i].sections.size(), out[i].sections.data(),
+                        out[i].sections.size() * sizeof(Section));
+            vhor_lib[i] = out[i].vhor;
+            if (triples) {
+                int n = 0;
+                for (const auto& kv : maps[i]) {
+                    if (n >= cap) break;
+                    int* t = triples + ((size_t)i * cap + n) * 3;
+                    t[0] = kv.first.first; t[1] = kv.first.second; t[2] = kv.second;
+                    n++;
+                }
+                counts[i] = (int)maps[i].size();
+            }
+        }
+    });
+}
+
+/* Times n_iter ComputeBatch() calls of n_images frames (inputs resident on the device), with or
+ * without the per-frame instance mappings.  -> seconds per call. */
+int ish_time_compute_batch(void* h, int pairwise, int n_images, const float* d_big, const int32_t* d_seg,
+                           const float* road, int n_iter, int with_instances, double* s_per_call) {
+    return guard([&] {
+        Stixels* s = (Stixels*)h;
+        std::vector<Stixels::RoadParameters> rp(n_images);
+        for (int i = 0; i < n_images; i++)
+            rp[i] = Stixels::RoadParameters{(int)road[4 * i], road[4 * i + 1], road[4 * i + 2], road[4 * i + 3]};
+        std::vector<StixelsData> out;
+        std::vector<Stixels::InstanceMapping> maps;
+        s->ComputeBatch(pairwise != 0, n_images, d_big, d_seg, rp.data(), out, nullptr,
+                        with_instances ? &maps : nullptr);
+        timespec t0, t1;
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        for (int i = 0; i < n_iter; i++)
+            s->ComputeBatch(pairwise != 0, n_images, d_big, d_seg, rp.data(), out, nullptr,
+                            with_instances ? &maps : nullptr);
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        *s_per_call = ((t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec)) / n_iter;
     });
 }
 

@@ -368,3 +368,79 @@ def test_compute_labels_and_file_through_host_class(preset, seed, tmp_path):
     assert n_labelled >= 50 and max(want.values()) >= 2
     assert open(f, "rb").read() == format_stixels(ref["sections"], want, frame.alpha_ground,
                                                   int(case["vhor"][0]))
+
+
+def _twin_mapping(cfg, ref):
+    """(column, section) -> label of every instance candidate of an oracle result, through the twin."""
+    want = {}
+    for cls in range(8):
+        n = int(ref["inst_per_class"][cls])
+        lab = oracle.cluster_instances(ref["inst_centerofmass"][cls][:n], ref["inst_core"][cls][:n],
+                                       cfg.eps, cfg.min_pts)
+        for (u, v), l in zip(ref["inst_indices"][cls][:n].tolist(), lab.tolist()):
+            want[(u, v)] = l
+    return want
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("preset", ["drn_d_22_unary", "drn_d_38_pairwise"])
+def test_batched_instance_path_eight_frames(preset):
+    """The batched instance path (the reference emits candidates and clusters inside Compute for
+    every frame: StixelsKernels.cu:926-942, Stixels.cu:613): eight distinct frames in ONE
+    is_compute call -- candidates of the whole batch in one launch, clustering in one launch
+    (grid 8 classes x 8 images) -- candidates in canonical order and labels against the oracle and
+    its twin of the reference's assign_instances; then the same batch through
+    Stixels::ComputeBatch, whose per-frame mappings must equal what Compute + GetInstanceStixels
+    give frame by frame."""
+    import torch
+    ov = dict(size_filter=10) if preset.endswith("unary") else dict(size_filter=8)
+    n = 8
+    case = helpers.build_case(preset, 256, 1024, 64, seed=21, n_images=n, **ov)
+    cfg = case["cfg"]
+    frames = [synthetic.make_frame(cfg, seed=500 + i, n_slabs=10 + 2 * i, offset_scale=1.0) for i in range(n)]
+    case["frames"] = frames
+    case["disparity"] = np.stack([f.disparity for f in frames])
+    case["segmentation"] = np.stack([f.segmentation for f in frames])
+    got = helpers.run_core(case, want_tables=False)
+    refs, wants = [], []
+    n_labelled = 0
+    for img in range(n):
+        ref = helpers.run_oracle(case, image=img)
+        errs = helpers.compare(ref, got, img, cfg, check_tables=False)   # incl. the candidate arrays
+        assert not errs, "image %d:\n" % img + "\n".join(errs[:10])
+        want = _twin_mapping(cfg, ref)
+        for cls in range(8):
+            m = int(ref["inst_per_class"][cls])
+            lab = got["inst_labels"][img][cls][:m]
+            idx = ref["inst_indices"][cls][:m]
+            assert [want[(int(u), int(v))] for u, v in idx] == lab.tolist(), (img, cls)
+        n_labelled += sum(1 for l in want.values() if l >= 0)
+        refs.append(ref); wants.append(want)
+    assert n_labelled >= 100
+
+    st = host.Stixels()
+    st.SetConfig(cfg)
+    st.Initialize(max_batch=n)
+    dev = torch.device("cuda", 0)
+    big = torch.from_numpy(case["disparity"]).to(dev)
+    seg = torch.from_numpy(case["segmentation"]).to(dev)
+    road = [(f.vhor_image, f.camera_tilt, f.camera_height, f.alpha_ground) for f in frames]
+    data, maps = st.ComputeBatch(cfg.pairwise, big.data_ptr(), seg.data_ptr(), road)
+    for img in range(n):
+        assert helpers.sections_equal(refs[img]["sections"], data[img].sections), img
+        assert maps[img] == wants[img], img
+        assert data[img].vhor == int(case["vhor"][img])
+    # a smaller call on the same object, without mappings, then frame by frame
+    data3, none = st.ComputeBatch(cfg.pairwise, big[2:5].data_ptr(), seg[2:5].data_ptr(), road[2:5],
+                                  with_instances=False)
+    assert none is None
+    for k in range(3):
+        assert helpers.sections_equal(refs[2 + k]["sections"], data3[k].sections)
+    f = frames[5]
+    st.SetDisparityImage(f.disparity)
+    st.SetSegmentation(f.segmentation)
+    st.SetRoadParameters(*road[5])
+    d5 = st.Compute(cfg.pairwise)
+    assert helpers.sections_equal(refs[5]["sections"], d5.sections)
+    assert st.GetInstanceStixels() == wants[5]
+    st.close()
