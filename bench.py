@@ -9,6 +9,15 @@ communication is the final gather of the stixel outputs to rank 0 over RCCL, ins
 region.  Rank 0 prints ONE JSON line.
 
     python bench.py [--gpus N --steps K --warmup W] [--batch B] [--preset drn_d_22_unary]
+
+The default run (N = 1) also reports, outside `value`:
+  verify      frames of the TIMED output against the CPU oracle (bit-exact Section arrays)
+  prune       what the exact branch-and-bound evaluated (device counters, separate untimed pass)
+  variants    pruning off, three more input families, the OTHER model (pairwise when the preset
+              is unary) at the same batch with its own roofline / pruning-off / verify,
+              BASELINE configs[4] (1024x4096x256) in both modes, configs[0] (512x1024x64,
+              disparity only) on the CPU and the GPU, invalid-disparity kernels, generic
+              column encoding, the C++ host class.
 """
 import argparse
 import json
@@ -23,6 +32,8 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
 VALU_PEAK_LANEOPS = 78.6e12    # 157.3 TFLOP/s fp32 vector = 78.6 T lane-FMA/s
+OTHER_PRESET = {"drn_d_22_unary": "drn_d_38_pairwise", "drn_d_38_unary": "drn_d_38_pairwise",
+                "drn_d_22_pairwise": "drn_d_22_unary", "drn_d_38_pairwise": "drn_d_22_unary"}
 
 
 def parse():
@@ -35,9 +46,12 @@ def parse():
     ap.add_argument("--rows", type=int, default=1024)
     ap.add_argument("--cols", type=int, default=2048)
     ap.add_argument("--max-dis", type=int, default=128)
+    ap.add_argument("--family", default="scene", help="synthetic input family (synthetic.FAMILIES)")
     ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic frames per rank")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise RCCL and run the gather pipeline even with one rank (plumbing test)")
+    ap.add_argument("--gather", choices=("fixed", "compact"), default="compact",
+                    help="N > 1: gather fixed-stride Section tensors, or per-column counts + packed sections")
     ap.add_argument("--pcie", action="store_true",
                     help="also measure value_incl_h2d_d2h (inputs from pinned host memory each step)")
     ap.add_argument("--no-single", action="store_true",
@@ -47,11 +61,11 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=6.0)
     ap.add_argument("--no-gather", action="store_true")
-    ap.add_argument("--verify", action="store_true",
-                    help="after the timed region: check frames of the timed output against the oracle")
+    ap.add_argument("--no-verify", action="store_true",
+                    help="skip the oracle check of the timed output (about one CPU-second per frame)")
+    ap.add_argument("--verify", action="store_true", help="(default since round 3; kept for old command lines)")
     ap.add_argument("--no-variants", action="store_true",
-                    help="skip the extra figures (pruning off, invalid-disparity kernels, generic "
-                         "column encoding, the C++ host class)")
+                    help="skip the extra figures (see the module docstring)")
     ap.add_argument("--min-seconds", type=float, default=2.0,
                     help="repeat the timed K-step block until this much time has been measured; "
                          "the MEDIAN block is reported")
@@ -84,7 +98,7 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(cfg, frame, target_seconds):
+def cpu_baseline(cfg, frame, target_seconds, single_thread=True):
     """The oracle (kind "port": the reference has no CPU path) on a bounded sample of the same
     workload: whole frames, all host cores (OpenMP over stixel columns), repeated until about
     `target_seconds` of wall time have been spent."""
@@ -104,158 +118,359 @@ def cpu_baseline(cfg, frame, target_seconds):
         dt = time.perf_counter() - t0
         if dt >= target_seconds or n >= 64:
             break
-    # single-thread figure on a few columns of the same frame, scaled to the frame
-    ncol1 = min(4, cfg.realcols)
-    t1 = time.perf_counter()
-    oracle.compute(params, lut, odr, joined, frame.segmentation, gf, ng, ig, vhor, cfg.pairwise,
-                   nthreads=1, want_tables=False, col_range=(0, ncol1))
-    dt1 = time.perf_counter() - t1
-    return dict(value=n / dt, unit="images/s", cores=cores, kind="port",
-                sample=f"{n} x one {cfg.rows}x{cfg.cols}x{cfg.max_dis} frame "
-                       f"({cfg.realcols} stixel columns) in {dt:.2f} s wall, OpenMP over columns "
-                       f"on {cores} threads = {dt * cores:.0f} core-seconds",
-                single_thread_value=ncol1 / dt1 / cfg.realcols,
-                single_thread_sample=f"{ncol1} of {cfg.realcols} columns of that frame on one "
-                                     f"thread in {dt1:.2f} s, scaled to the frame")
+    out = dict(value=n / dt, unit="images/s", cores=cores, kind="port",
+               sample=f"{n} x one {cfg.rows}x{cfg.cols}x{cfg.max_dis} frame "
+                      f"({cfg.realcols} stixel columns) in {dt:.2f} s wall, OpenMP over columns "
+                      f"on {cores} threads = {dt * cores:.0f} core-seconds")
+    if single_thread:   # single-thread figure on a few columns of the same frame, scaled to the frame
+        ncol1 = min(4, cfg.realcols)
+        t1 = time.perf_counter()
+        oracle.compute(params, lut, odr, joined, frame.segmentation, gf, ng, ig, vhor, cfg.pairwise,
+                       nthreads=1, want_tables=False, col_range=(0, ncol1))
+        dt1 = time.perf_counter() - t1
+        out["single_thread_value"] = ncol1 / dt1 / cfg.realcols
+        out["single_thread_sample"] = (f"{ncol1} of {cfg.realcols} columns of that frame on one "
+                                       f"thread in {dt1:.2f} s, scaled to the frame")
+    return out
 
 
 def committed_traffic(cfg, B, H, W, D):
-    """HBM bytes per launch of the dominant DP kernel from the committed PMC passes
-    (profiles/r02_traffic.json; counters cannot be read from inside the timed run), or None when
-    that profile was taken on another mode / shape / batch."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_traffic.json")
-    try:
-        with open(path) as fh:
-            t = json.load(fh).get("pairwise" if cfg.pairwise else "unary")
-    except (OSError, ValueError):
-        return None
-    if not t or (t["batch"], t["rows"], t["cols"], t["max_dis"]) != (B, H, W, D):
-        return None
-    return (2.0 * t["fetch_size_kb"] + t["write_size_kb"]) * 1024.0
-
-
-
-def verify_frames(cfg, frames, pick, d_sections, B, C, S):
-    """Oracle check of the first, the middle (where a two-stream split would cut the batch) and
-    the last frame of the batch that was just timed.  Returns a dict for the JSON line; raises
-    SystemExit when a frame differs."""
-    import torch
-    from oracle import oracle
-    from instance_stixels_amd.config import SECTION_DTYPE
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import helpers
-    params, lut, odr = oracle.host_initialize(cfg)
-    checked = []
-    for i in sorted({0, B // 2 - 1 if B > 1 else 0, B // 2, B - 1}):
-        if i < 0 or i >= B:
+    """HBM bytes per step of the DP kernels from the committed PMC passes (profiles/rNN_traffic.json,
+    newest round first; counters cannot be read from inside the timed run), or None when no profile
+    was taken on this mode / shape / batch.  Returns (bytes, file name)."""
+    prof = os.path.join(ROOT, "profiles")
+    for name in ("r03_traffic.json", "r02_traffic.json"):
+        try:
+            with open(os.path.join(prof, name)) as fh:
+                t = json.load(fh).get("pairwise" if cfg.pairwise else "unary")
+        except (OSError, ValueError):
             continue
-        f = frames[pick[i]]
-        gf, ng, ig, vh = oracle.host_ground(cfg, f.vhor_image, f.camera_tilt, f.camera_height,
-                                            f.alpha_ground)
-        joined = oracle.join_columns(cfg, f.disparity)
-        ref = oracle.compute(params, lut, odr, joined, f.segmentation, gf, ng, ig, vh, cfg.pairwise,
-                             want_tables=False)
-        got = d_sections[i].cpu().numpy().view(SECTION_DTYPE).reshape(C, S)
-        if not helpers.sections_equal(ref["sections"], got):
-            raise SystemExit(f"bench.py --verify: frame {i} of the timed batch differs from the oracle")
-        checked.append(i)
-    return {"frames_checked": checked, "against": "oracle (bit-exact Section arrays)", "ok": True}
+        if not t or (t["batch"], t["rows"], t["cols"], t["max_dis"]) != (B, H, W, D):
+            continue
+        return (2.0 * t["fetch_size_kb"] + t["write_size_kb"]) * 1024.0, name
+    return None, None
 
 
-def measure_variants(args, cfg, frames, pick, dev, local_rank):
-    """Throughput of the same step on the other kernel variants the library contains: pruning
-    switched off (the worst case of the branch-and-bound: every (vB, vT) pair is evaluated), an
-    invalid-disparity value with 5 % holes (HAS_INVALID kernels), all columns in the generic
-    int32/int64 encoding, and a single frame through the C++ `Stixels::Compute` host class."""
-    import torch
-    from instance_stixels_amd import make_config, host
-    from instance_stixels_amd.core import Core
-    B = args.batch
-    H, W, D = int(cfg.rows), int(cfg.cols), int(cfg.max_dis)
-    stream = torch.cuda.current_stream(dev).cuda_stream
-    out = {}
+class Workload:
+    """One configuration's batch, resident in HBM: host tables through the C++ Stixels class,
+    `distinct` synthetic frames repeated to `batch`, device inputs and output buffers."""
 
-    def run(tag, vcfg, disp, seg, env=None, steps=3):
+    def __init__(self, preset, H, W, D, batch, distinct, dev, local_rank, seed0=17, family="scene",
+                 **overrides):
+        import torch
+        from instance_stixels_amd import make_config, synthetic, host
+        self.torch = torch
+        self.dev, self.local_rank, self.B = dev, local_rank, batch
+        self.cfg = cfg = make_config(preset, H, W, D, **overrides)
+        self.H, self.W, self.D, self.C = int(cfg.rows), int(cfg.cols), int(cfg.max_dis), cfg.realcols
         st = host.Stixels()
-        st.SetConfig(vcfg)
+        st.SetConfig(cfg)
         st.PrecomputeHost()
-        params = st.GetParameters()
-        lut, odr = st.GetLUTs()
-        gfs, ngs, igs, vhs = [], [], [], []
-        for f in frames:
+        self.params = st.GetParameters()
+        self.lut, self.odr = st.GetLUTs()
+        zero_seg = preset.startswith("disparity_only")
+        self.frames = [synthetic.make_frame(cfg, seed=seed0 + i, family=family, zero_segmentation=zero_seg)
+                       for i in range(distinct)]
+        g = []
+        for f in self.frames:
             st.SetRoadParameters(f.vhor_image, f.camera_tilt, f.camera_height, f.alpha_ground)
-            gf, ng, ig, vh = st.GetGroundModel()
-            gfs.append(gf); ngs.append(ng); igs.append(ig); vhs.append(vh)
+            g.append(st.GetGroundModel())
         st.close()
-        gf = np.stack([gfs[i] for i in pick]); ng = np.stack([ngs[i] for i in pick])
-        ig = np.stack([igs[i] for i in pick]); vh = np.array([vhs[i] for i in pick], np.int32)
+        self.pick = pick = [i % distinct for i in range(batch)]
+        self.gf = np.stack([g[i][0] for i in pick]); self.ng = np.stack([g[i][1] for i in pick])
+        self.ig = np.stack([g[i][2] for i in pick]); self.vh = np.array([g[i][3] for i in pick], np.int32)
+        idx = torch.tensor(pick, device=dev)
+        self.d_big = torch.from_numpy(np.stack([f.disparity for f in self.frames])).to(dev)[idx].contiguous()
+        self.d_seg = torch.from_numpy(np.stack([f.segmentation for f in self.frames])).to(dev)[idx].contiguous()
+        self.S = self.params.max_sections
+        self.d_joined = torch.empty((batch, self.C, self.H), dtype=torch.float32, device=dev)
+        self.d_sections = torch.empty((batch, self.C, self.S, 8), dtype=torch.int32, device=dev)
+        self.stream = torch.cuda.current_stream(dev).cuda_stream
+
+    def make_core(self, env=None, max_batch=None):
+        """A context; `env`: IS_* knobs, which the library reads once, when a context is created."""
+        from instance_stixels_amd.core import Core
         old = {k: os.environ.get(k) for k in (env or {})}
         os.environ.update(env or {})
         try:
-            core = Core(params, lut, odr, max_batch=B, device=local_rank)
+            return Core(self.params, self.lut, self.odr, max_batch=max_batch or self.B,
+                        device=self.local_rank)
         finally:
             for k, v in old.items():
                 if v is None:
                     os.environ.pop(k, None)
                 else:
                     os.environ[k] = v
-        C, S = params.cols, params.max_sections
-        d_joined = torch.empty((B, C, H), dtype=torch.float32, device=dev)
-        d_sections = torch.empty((B, C, S, 8), dtype=torch.int32, device=dev)
 
-        def step():
-            core.join_columns_ptr(disp.data_ptr(), W, vcfg.median_join, d_joined.data_ptr(), B, stream)
-            core.compute_ptr(d_joined.data_ptr(), seg.data_ptr(), gf, ng, ig, vh, vcfg.pairwise, B,
-                             d_sections.data_ptr(), None, None, None, stream)
-        step()
-        torch.cuda.synchronize(dev)
+    def step(self, core, out=None, n=None, instances=None):
+        n = n or self.B
+        out = self.d_sections if out is None else out
+        core.join_columns_ptr(self.d_big.data_ptr(), self.W, self.cfg.median_join,
+                              self.d_joined.data_ptr(), n, self.stream)
+        core.compute_ptr(self.d_joined.data_ptr(), self.d_seg.data_ptr(), self.gf[:n], self.ng[:n],
+                         self.ig[:n], self.vh[:n], self.cfg.pairwise, n, out.data_ptr(), instances,
+                         None, None, self.stream)
+
+    def time_steps(self, core, steps, **kw):
+        self.step(core, **kw)
+        self.torch.cuda.synchronize(self.dev)
         t0 = time.perf_counter()
         for _ in range(steps):
-            step()
-        torch.cuda.synchronize(dev)
-        out[tag] = {"images_per_s": B * steps / (time.perf_counter() - t0), "steps": steps}
-        core.close()
-        del d_joined, d_sections
+            self.step(core, **kw)
+        self.torch.cuda.synchronize(self.dev)
+        return (time.perf_counter() - t0) / steps
 
-    idx = torch.tensor(pick, device=dev)
-    disp = torch.from_numpy(np.stack([f.disparity for f in frames])).to(dev)[idx].contiguous()
-    seg = torch.from_numpy(np.stack([f.segmentation for f in frames])).to(dev)[idx].contiguous()
-    run("pruning_off", cfg, disp, seg, env={"IS_NO_PRUNE": "1"})
-    out["pruning_off"]["what"] = ("IS_NO_PRUNE=1: the exact branch-and-bound never fires, every "
-                                  "(vB, vT) pair is evaluated (data-independent worst case)")
-    # invalid-disparity value 0 with 5 % holes: the HAS_INVALID kernel variants
-    icfg = make_config(args.preset, H, W, D, invalid_disparity=0.0)
-    g = torch.Generator(device=dev); g.manual_seed(5)
-    holes = torch.rand(disp.shape, device=dev, generator=g) < 0.05
-    run("invalid_disparity_0", icfg, torch.where(holes, torch.zeros_like(disp), disp), seg)
-    out["invalid_disparity_0"]["what"] = "invalid_disparity = 0, 5 % of the pixels invalid (HAS_INVALID kernels)"
-    del holes
-    # every column in the generic encoding: one negative class value per column
-    gseg = seg.clone()
-    gseg[:, :, 0, 0] = -1
-    run("generic_encoding", cfg, disp, gseg, steps=2)
-    out["generic_encoding"]["what"] = ("one negative class value per column: int32 / int64 records, "
-                                       "IEEE division, no pruning (the hostile-input path)")
-    del gseg, disp, seg
-    # BASELINE configs[1] through the C++ host class: Stixels::Compute() incl. the device-side
+    def instance_buffers(self):
+        """Per-image candidate / label arrays for the batched instance path."""
+        from instance_stixels_amd.core import InstanceBuffers
+        from instance_stixels_amd.config import INSTANCE_CLASSES
+        torch, n, slots = self.torch, self.B, self.C * self.S
+        com = torch.zeros((n, INSTANCE_CLASSES, slots, 2), dtype=torch.float32, device=self.dev)
+        idx = torch.zeros((n, INSTANCE_CLASSES, slots, 2), dtype=torch.int32, device=self.dev)
+        cand = torch.zeros((n, INSTANCE_CLASSES, slots), dtype=torch.uint8, device=self.dev)
+        per = torch.zeros((n, INSTANCE_CLASSES), dtype=torch.int32, device=self.dev)
+        lab = torch.zeros((n, INSTANCE_CLASSES, slots), dtype=torch.int32, device=self.dev)
+        pk = torch.zeros((n, 1 + 3 * INSTANCE_CLASSES * slots), dtype=torch.int32, device=self.dev)
+        keep = (com, idx, cand, per, lab, pk)
+        return keep, [InstanceBuffers(com[i].data_ptr(), idx[i].data_ptr(), cand[i].data_ptr(),
+                                      per[i].data_ptr(), lab[i].data_ptr(), pk[i].data_ptr())
+                      for i in range(n)]
+
+    def prune_stats(self, core):
+        """Device counters of one untimed step: what the branch-and-bound evaluated.  All columns
+        of the synthetic families are FAST columns (class values >= 0), whose walks are counted."""
+        core.set_eval_counters(True)
+        self.step(core)
+        c = core.eval_counters()
+        core.set_eval_counters(False)
+        H, ncols = self.H, self.B * self.C
+        tiles = [min(64, H - lo) for lo in range(0, H, 64)]
+        diag = sum(n * (n - 1) // 2 for n in tiles)        # vB inside the tile: always evaluated
+        nominal = ncols * H * (H + 1) // 2
+        if self.cfg.pairwise:
+            full, gs = c["p1_full"], c["p1_gs"]
+        else:
+            full, gs = c["unary_full"], c["unary_gs"]
+        ev = ncols * diag + 64 * (full + gs)
+        return {"evaluated_frac": ev / nominal, "full_eval_frac": (ncols * diag + 64 * full) / nominal,
+                "ground_sky_only_frac": 64 * gs / nominal, "pairs_nominal": nominal,
+                "pairs_evaluated": ev,
+                "how": "device counters of one untimed step (is_set_eval_counters): 64-pair wave-steps "
+                       "below the diagonal blocks + the always-evaluated diagonal blocks, over the "
+                       "nominal C*H*(H+1)/2 pairs; full = all three candidates, ground_sky_only = the "
+                       "cheap steps after the object bound has closed"}
+
+    def verify(self, d_sections, images=None):
+        """Oracle check of frames of a finished step (first, either side of the middle, last)."""
+        from oracle import oracle
+        from instance_stixels_amd.config import SECTION_DTYPE
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import helpers
+        cfg, B = self.cfg, self.B
+        params, lut, odr = oracle.host_initialize(cfg)
+        checked = []
+        for i in (sorted({0, B // 2 - 1 if B > 1 else 0, B // 2, B - 1}) if images is None else images):
+            if i < 0 or i >= B:
+                continue
+            f = self.frames[self.pick[i]]
+            gf, ng, ig, vh = oracle.host_ground(cfg, f.vhor_image, f.camera_tilt, f.camera_height,
+                                                f.alpha_ground)
+            joined = oracle.join_columns(cfg, f.disparity)
+            ref = oracle.compute(params, lut, odr, joined, f.segmentation, gf, ng, ig, vh, cfg.pairwise,
+                                 want_tables=False)
+            got = d_sections[i].cpu().numpy().view(SECTION_DTYPE).reshape(self.C, self.S)
+            if not helpers.sections_equal(ref["sections"], got):
+                raise SystemExit(f"bench.py verify: frame {i} of the timed batch "
+                                 f"({cfg.rows}x{cfg.cols}, pairwise={cfg.pairwise}) differs from the oracle")
+            checked.append(i)
+        return {"frames_checked": checked, "against": "oracle (bit-exact Section arrays)", "ok": True}
+
+    def roofline(self, dp_ms, kernel, traffic=None, traffic_file=None):
+        from instance_stixels_amd import synthetic
+        alg = synthetic.algorithmic_bytes_per_image(self.cfg)
+        achieved = alg * self.B / (dp_ms * 1e-3) / 1e9
+        r = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": kernel, "kernel_ms": dp_ms,
+             "algorithmic_bytes_per_image": alg}
+        if traffic is not None:
+            r["measured_hbm_gbps"] = traffic / (dp_ms * 1e-3) / 1e9
+            r["measured_hbm_frac"] = r["measured_hbm_gbps"] / HBM_PEAK_GBS
+            r["traffic_source"] = f"profiles/{traffic_file}"
+        return r
+
+    def free(self):
+        del self.d_big, self.d_seg, self.d_joined, self.d_sections
+
+
+def dp_kernel_name(cfg):
+    return ("k_pw_phase1 + k_pw_phase2, all 64-row tiles of the step" if cfg.pairwise
+            else "k_dp_unary_fast (FAST columns; k_dp_unary takes generic columns: none here)")
+
+
+def measure_mode(wl, steps=3, with_pruning_off=True, with_verify=True, with_prune=True):
+    """images/s, DP time, roofline, pruning statistics, pruning-off figure and oracle check of one
+    workload -- the fields a non-default mode / shape reports under `variants`."""
+    core = wl.make_core()
+    core.set_kernel_timing(True)
+    dt = wl.time_steps(core, steps)
+    kt = core.kernel_times_ms()
+    traffic, tfile = committed_traffic(wl.cfg, wl.B, wl.H, wl.W, wl.D)
+    out = {"preset_pairwise": bool(wl.cfg.pairwise), "batch": wl.B, "images_per_s": wl.B / dt,
+           "ms_per_step": dt * 1e3, "dp_ms": kt["dp_ms"], "kernel_ms": kt, "steps": steps,
+           "roofline": wl.roofline(kt["dp_ms"], dp_kernel_name(wl.cfg), traffic, tfile)}
+    if with_verify:
+        out["verify"] = wl.verify(wl.d_sections, images=[0, wl.B - 1] if wl.B > 1 else [0])
+    if with_prune:
+        out["prune"] = wl.prune_stats(core)
+    core.close()
+    if with_pruning_off:
+        core = wl.make_core(env={"IS_NO_PRUNE": "1"})
+        core.set_kernel_timing(True)
+        dt0 = wl.time_steps(core, max(2, steps - 1))
+        out["pruning_off"] = {"images_per_s": wl.B / dt0, "dp_ms": core.kernel_times_ms()["dp_ms"]}
+        core.close()
+    return out
+
+
+def measure_variants(args, wl, dev, local_rank):
+    """Figures of the same step on the other kernel variants, input families, the other model and
+    the other BASELINE shapes.  Never part of `value`."""
+    import torch
+    from instance_stixels_amd import host
+    B, H, W, D = wl.B, wl.H, wl.W, wl.D
+    out = {}
+
+    # ---- pruning off on the headline workload
+    core = wl.make_core(env={"IS_NO_PRUNE": "1"})
+    core.set_kernel_timing(True)
+    dt = wl.time_steps(core, 3)
+    out["pruning_off"] = {
+        "images_per_s": B / dt, "dp_ms": core.kernel_times_ms()["dp_ms"], "steps": 3,
+        "evaluated_frac": wl.prune_stats(core)["evaluated_frac"],
+        "what": "IS_NO_PRUNE=1: the exact branch-and-bound never fires, every (vB, vT) pair is "
+                "evaluated (data-independent worst case)"}
+    core.close()
+
+    # ---- the batched instance path inside the step (candidates + clustering of all frames)
+    core = wl.make_core()
+    keep, ibs = wl.instance_buffers()
+    dt_i = wl.time_steps(core, 3, instances=ibs)
+    dt_p = wl.time_steps(core, 3)
+    out["with_instances"] = {
+        "images_per_s": B / dt_i, "images_per_s_without": B / dt_p, "ratio": dt_p / dt_i,
+        "candidates_per_image": float(keep[3].sum().item()) / B,
+        "what": "the same step with the instance candidates (StixelsKernels.cu:926-942) and their "
+                "size-filtered DBSCAN (Stixels.cu:613) for every frame: two more launches per batch"}
+    del keep, ibs
+
+    # ---- invalid-disparity value 0 with 5 % holes: the HAS_INVALID kernel variants
+    wl.free()
+    torch.cuda.empty_cache()
+    wi = Workload(args.preset, H, W, D, B, args.distinct, dev, local_rank, invalid_disparity=0.0)
+    core = wi.make_core()
+    out["invalid_disparity_0"] = {"images_per_s": B / wi.time_steps(core, 3), "steps": 3,
+                                  "what": "invalid_disparity = 0, 5 % of the pixels invalid (HAS_INVALID kernels)"}
+    core.close(); wi.free(); del wi
+    torch.cuda.empty_cache()
+
+    # ---- other input families (SURVEY.md 8d generator + three harder ones)
+    fam = {}
+    for name in ("iid_noise", "low_confidence", "flat_disparity"):
+        wf = Workload(args.preset, H, W, D, B, 2, dev, local_rank, family=name)
+        core = wf.make_core()
+        dtf = wf.time_steps(core, 3)
+        ps = wf.prune_stats(core)
+        fam[name] = {"images_per_s": B / dtf, "evaluated_frac": ps["evaluated_frac"],
+                     "full_eval_frac": ps["full_eval_frac"]}
+        core.close(); wf.free(); del wf
+        torch.cuda.empty_cache()
+    fam["what"] = ("synthetic.make_frame(family=...): iid_noise = every class logit N(0,1), no scene in "
+                   "the segmentation; low_confidence = true-class logit +1..2 instead of +4..5; "
+                   "flat_disparity = the scene's segmentation over constant + U(0,1) disparity; "
+                   "2 distinct frames repeated to the batch")
+    out["families"] = fam
+
+    # ---- every column in the generic encoding: one negative class value per column
+    wg = Workload(args.preset, H, W, D, B, args.distinct, dev, local_rank)
+    wg.d_seg[:, :, 0, 0] = -1
+    core = wg.make_core()
+    out["generic_encoding"] = {"images_per_s": B / wg.time_steps(core, 2), "steps": 2,
+                               "what": "one negative class value per column: int32 / int64 records, "
+                                       "IEEE division, no pruning (the hostile-input path)"}
+    core.close(); wg.free(); del wg
+    torch.cuda.empty_cache()
+
+    # ---- the OTHER model at the same shape and batch (BASELINE configs[3]'s per-GPU share when
+    # the headline is the unary preset): own roofline, pruning statistics, pruning off, verify
+    other = OTHER_PRESET.get(args.preset)
+    if other:
+        wo = Workload(other, H, W, D, B, args.distinct, dev, local_rank)
+        key = ("pairwise" if wo.cfg.pairwise else "unary") + f"_batch{B}"
+        out[key] = measure_mode(wo, steps=3)
+        out[key]["preset"] = other
+        wo.free(); del wo
+        torch.cuda.empty_cache()
+
+    # ---- BASELINE configs[4]: 1024x4096 frames, 256 disparity bins, both models
+    c5 = {}
+    for preset in (args.preset, other):
+        if not preset:
+            continue
+        w5 = Workload(preset, 1024, 4096, 256, 32, 2, dev, local_rank, seed0=91)
+        m = measure_mode(w5, steps=2, with_verify=False)
+        m["preset"] = preset
+        c5["pairwise" if w5.cfg.pairwise else "unary"] = m
+        w5.free(); del w5
+        torch.cuda.empty_cache()
+    c5["what"] = ("BASELINE configs[4]: 32 frames of 1024x4096, 256 disparity bins per call (512 stixel "
+                  "columns per frame, 2.2 GB of lutT per frame); parity: tests/test_parity_gpu.py "
+                  "test_config5_*")
+    out["c5_1024x4096x256"] = c5
+
+    # ---- BASELINE configs[0]: one 512x1024 frame, 64 bins, disparity only -- CPU path + GPU
+    c1 = {}
+    for preset in ("disparity_only_unary", "disparity_only_pairwise"):
+        w1 = Workload(preset, 512, 1024, 64, 1, 1, dev, local_rank, seed0=12)
+        core = w1.make_core()
+        dt1 = w1.time_steps(core, 50)
+        v = w1.verify(w1.d_sections, images=[0])
+        core.close()
+        c1[preset] = {"gpu_images_per_s": 1.0 / dt1, "gpu_ms_per_frame": dt1 * 1e3, "verify_ok": v["ok"],
+                      "cpu": cpu_baseline(w1.cfg, w1.frames[0], 1.5, single_thread=True)}
+        w1.free(); del w1
+    c1["what"] = ("BASELINE configs[0]: single 512x1024 frame, 64 disparity bins, segmentation weight 0; "
+                  "cpu = the oracle (kind port) on the GPU box's host cores, gpu = one frame per call")
+    out["c1_cpu_512x1024x64"] = c1
+
+    # ---- BASELINE configs[1] through the C++ host class: Stixels::Compute() incl. the device-side
     # clustering, the D2H copy of the sections and one synchronisation per frame
+    wh = Workload(args.preset, H, W, D, 8, args.distinct, dev, local_rank)
     st = host.Stixels()
-    st.SetConfig(cfg)
+    st.SetConfig(wh.cfg)
     st.SetDevice(local_rank)
-    st.Initialize()
-    f = frames[0]
+    st.Initialize(max_batch=8)
+    f = wh.frames[0]
     st.SetDisparityImage(f.disparity)
     st.SetSegmentation(f.segmentation)
     st.SetRoadParameters(f.vhor_image, f.camera_tilt, f.camera_height, f.alpha_ground)
-    t_plain = st.time_compute(cfg.pairwise, 200, False)
-    t_inst = st.time_compute(cfg.pairwise, 200, True)
+    t_plain = st.time_compute(wh.cfg.pairwise, 200, False)
+    t_inst = st.time_compute(wh.cfg.pairwise, 200, True)
+    road = [(wh.frames[i].vhor_image, wh.frames[i].camera_tilt, wh.frames[i].camera_height,
+             wh.frames[i].alpha_ground) for i in wh.pick]
+    t_b = st.time_compute_batch(wh.cfg.pairwise, wh.d_big.data_ptr(), wh.d_seg.data_ptr(), road, 5, False)
+    t_bi = st.time_compute_batch(wh.cfg.pairwise, wh.d_big.data_ptr(), wh.d_seg.data_ptr(), road, 5, True)
     st.close()
+    wh.free(); del wh
     out["stixels_compute_host_class"] = {
         "images_per_s": 1.0 / t_plain, "ms_per_frame": t_plain * 1e3,
         "images_per_s_with_GetInstanceStixels": 1.0 / t_inst,
+        "compute_batch8_images_per_s": 8 / t_b,
+        "compute_batch8_with_instance_mappings_images_per_s": 8 / t_bi,
         "what": "one frame per Stixels::Compute() call, timed inside the C++ library "
                 "(ish_time_compute): ground model on the host, JoinColumns + DP + back-trace + "
-                "instance candidates + clustering on the device, sections copied to the host"}
+                "instance candidates + clustering on the device, sections copied to the host; "
+                "compute_batch8: Stixels::ComputeBatch of 8 frames incl. the D2H copy of all "
+                "sections (and of the per-frame instance mappings)"}
     return out
 
 
@@ -275,9 +490,8 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from instance_stixels_amd import make_config, synthetic, host
-    from instance_stixels_amd.core import Core, InstanceBuffers
-    from instance_stixels_amd.parallel import PipelinedGather
+    from instance_stixels_amd import synthetic
+    from instance_stixels_amd.parallel import PipelinedGather, PipelinedCompactGather
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
@@ -292,49 +506,24 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
 
-    cfg = make_config(args.preset, args.rows, args.cols, args.max_dis)
-    B = args.batch
-    H, W, C, D = int(cfg.rows), int(cfg.cols), cfg.realcols, int(cfg.max_dis)
-
-    # ---- host side: the C++ Stixels class computes the parameter block, LUTs, ground model
-    st = host.Stixels()
-    st.SetConfig(cfg)
-    st.PrecomputeHost()
-    params = st.GetParameters()
-    lut, odr = st.GetLUTs()
-    frames = [synthetic.make_frame(cfg, seed=17 + 101 * rank + i) for i in range(args.distinct)]
-    gfs, ngs, igs, vhs = [], [], [], []
-    for f in frames:
-        st.SetRoadParameters(f.vhor_image, f.camera_tilt, f.camera_height, f.alpha_ground)
-        gf, ng, ig, vh = st.GetGroundModel()
-        gfs.append(gf); ngs.append(ng); igs.append(ig); vhs.append(vh)
-    pick = [i % args.distinct for i in range(B)]
-    gf = np.stack([gfs[i] for i in pick]); ng = np.stack([ngs[i] for i in pick])
-    ig = np.stack([igs[i] for i in pick]); vh = np.array([vhs[i] for i in pick], np.int32)
-
-    # ---- inputs resident in HBM before the timed region
-    d_frames = torch.from_numpy(np.stack([f.disparity for f in frames])).to(dev)
-    s_frames = torch.from_numpy(np.stack([f.segmentation for f in frames])).to(dev)
-    idx = torch.tensor(pick, device=dev)
-    d_big = d_frames[idx].contiguous()                    # [B][H][W] f32
-    d_seg = s_frames[idx].contiguous()                    # [B][C][21][P2S] i32
-    d_joined = torch.empty((B, C, H), dtype=torch.float32, device=dev)
-    S = params.max_sections
-    d_sections = torch.empty((B, C, S, 8), dtype=torch.int32, device=dev)
-    del d_frames, s_frames
-
-    core = Core(params, lut, odr, max_batch=B, device=local_rank)
+    # ---- host side (C++ Stixels class) + inputs resident in HBM before the timed region
+    wl = Workload(args.preset, args.rows, args.cols, args.max_dis, args.batch, args.distinct, dev,
+                  local_rank, seed0=17 + 101 * rank, family=args.family)
+    cfg, B, H, W, C, D, S = wl.cfg, wl.B, wl.H, wl.W, wl.C, wl.D, wl.S
+    core = wl.make_core()
     core.set_kernel_timing(True)
-    stream = torch.cuda.current_stream(dev).cuda_stream
     # N > 1: the stixel outputs of every step are gathered on rank 0 (RCCL over xGMI); the gather
     # of step k overlaps the compute of step k+1 (double-buffered outputs)
-    pipe = PipelinedGather(d_sections, depth=2, dst=0) if (use_dist and not args.no_gather) else None
+    pipe = None
+    if use_dist and not args.no_gather:
+        if args.gather == "compact":
+            pipe = PipelinedCompactGather(wl.d_sections, core, depth=2, dst=0)
+        else:
+            pipe = PipelinedGather(wl.d_sections, depth=2, dst=0)
 
     def step():
-        out = pipe.next_buffer() if pipe is not None else d_sections
-        core.join_columns_ptr(d_big.data_ptr(), W, cfg.median_join, d_joined.data_ptr(), B, stream)
-        core.compute_ptr(d_joined.data_ptr(), d_seg.data_ptr(), gf, ng, ig, vh, cfg.pairwise, B,
-                         out.data_ptr(), None, None, None, stream)
+        out = pipe.next_buffer() if pipe is not None else wl.d_sections
+        wl.step(core, out=out)
         if pipe is not None:
             pipe.submit()
 
@@ -372,22 +561,31 @@ def main():
     dt = float(np.median(blocks))
     # per-kernel durations of the LAST timed step, measured with HIP events on the launch stream
     kt = core.kernel_times_ms()
+    timed_out = wl.d_sections if pipe is None else pipe.last_local()
+
+    # ---- verify (default): frames of the TIMED output (the batch geometry the value is measured on)
+    verify = None
+    if not args.no_verify and rank == 0:
+        verify = wl.verify(timed_out)
+        if pipe is not None:  # what the RCCL gather delivered to rank 0 is what the ranks computed
+            verify["rccl_gather"] = pipe.check_last(S)
+            if not verify["rccl_gather"]["rank0_copy_equals_local"]:
+                raise SystemExit("bench.py verify: gathered copy of rank 0 differs from its output")
+
+    # ---- what the branch-and-bound evaluated (device counters, separate untimed step)
+    prune = wl.prune_stats(core) if rank == 0 else None
 
     # BASELINE.json configs[1] (ONE 1024x2048 frame per call) next to the batched headline value:
     # the same entry points with n_images = 1, i.e. the latency a per-frame caller sees
     single = None
     if world == 1 and not args.no_single:
-        def step1():
-            core.join_columns_ptr(d_big.data_ptr(), W, cfg.median_join, d_joined.data_ptr(), 1, stream)
-            core.compute_ptr(d_joined.data_ptr(), d_seg.data_ptr(), gf[:1], ng[:1], ig[:1], vh[:1],
-                             cfg.pairwise, 1, d_sections.data_ptr(), None, None, None, stream)
         for _ in range(10):
-            step1()
+            wl.step(core, n=1)
         torch.cuda.synchronize(dev)
         n1 = 100
         t1 = time.perf_counter()
         for _ in range(n1):
-            step1()
+            wl.step(core, n=1)
         torch.cuda.synchronize(dev)
         single = (time.perf_counter() - t1) / n1
 
@@ -396,27 +594,28 @@ def main():
     # Stixels::Compute does, Stixels.cu:629-633)
     d2h_value = None
     if world == 1 and not args.no_d2h:
-        h_sections = torch.empty(d_sections.shape, dtype=d_sections.dtype, pin_memory=True)
+        h_sections = torch.empty(wl.d_sections.shape, dtype=wl.d_sections.dtype, pin_memory=True)
         for _ in range(2):
-            step(); h_sections.copy_(d_sections, non_blocking=True)
+            wl.step(core); h_sections.copy_(wl.d_sections, non_blocking=True)
         torch.cuda.synchronize(dev)
         k = max(2, min(args.steps, 5))
         t1 = time.perf_counter()
         for _ in range(k):
-            step(); h_sections.copy_(d_sections, non_blocking=True)
+            wl.step(core); h_sections.copy_(wl.d_sections, non_blocking=True)
         torch.cuda.synchronize(dev)
         d2h_value = B * k / (time.perf_counter() - t1)
+        del h_sections
 
     # PCIe-inclusive figure for DESIGN.md (--pcie): inputs come from pinned host memory every step
     # and the sections go back, all on the compute stream, nothing overlapped
     pcie_value = None
     if world == 1 and args.pcie:
-        h_big = torch.empty(d_big.shape, dtype=d_big.dtype, pin_memory=True).copy_(d_big)
-        h_seg = torch.empty(d_seg.shape, dtype=d_seg.dtype, pin_memory=True).copy_(d_seg)
-        h_out = torch.empty(d_sections.shape, dtype=d_sections.dtype, pin_memory=True)
+        h_big = torch.empty(wl.d_big.shape, dtype=wl.d_big.dtype, pin_memory=True).copy_(wl.d_big)
+        h_seg = torch.empty(wl.d_seg.shape, dtype=wl.d_seg.dtype, pin_memory=True).copy_(wl.d_seg)
+        h_out = torch.empty(wl.d_sections.shape, dtype=wl.d_sections.dtype, pin_memory=True)
         def step_pcie():
-            d_big.copy_(h_big, non_blocking=True); d_seg.copy_(h_seg, non_blocking=True)
-            step(); h_out.copy_(d_sections, non_blocking=True)
+            wl.d_big.copy_(h_big, non_blocking=True); wl.d_seg.copy_(h_seg, non_blocking=True)
+            wl.step(core); h_out.copy_(wl.d_sections, non_blocking=True)
         step_pcie(); torch.cuda.synchronize(dev)
         k = 3
         t1 = time.perf_counter()
@@ -424,35 +623,29 @@ def main():
             step_pcie()
         torch.cuda.synchronize(dev)
         pcie_value = B * k / (time.perf_counter() - t1)
+        del h_big, h_seg, h_out
 
-    # ---- --verify: frames of the TIMED output (the batch geometry the value is measured on)
-    verify = None
-    if args.verify and rank == 0:
-        verify = verify_frames(cfg, frames, pick, d_sections if pipe is None else pipe.last_local(),
-                               B, C, S)
-        if pipe is not None:  # what the RCCL gather delivered to rank 0 is what the ranks computed
-            got = pipe.last_gathered()
-            same = bool(torch.equal(got[0], pipe.last_local()))
-            verify["rccl_gather"] = {"tensors": len(got), "bytes_per_rank": got[0].numel() * 4,
-                                     "rank0_copy_equals_local": same}
-            if not same:
-                raise SystemExit("bench.py --verify: gathered copy of rank 0 differs from its output")
+    cpu = None
+    if not args.no_cpu_baseline and world == 1 and rank == 0:
+        cpu = cpu_baseline(cfg, wl.frames[0], args.cpu_seconds)
 
-    # ---- extra figures (N = 1): other kernel variants of the same step, never part of `value`
+    # ---- extra figures (N = 1): other kernel variants / families / models / shapes
     variants = None
+    core.close()
     if world == 1 and not args.no_variants:
-        core.close()
-        variants = measure_variants(args, cfg, frames, pick, dev, local_rank)
-        core = Core(params, lut, odr, max_batch=1, device=local_rank)  # closed again below
+        variants = measure_variants(args, wl, dev, local_rank)   # (frees wl's device buffers)
 
     if rank == 0:
         images = B * world * args.steps
         value = images / dt
-        alg_bytes_img = synthetic.algorithmic_bytes_per_image(cfg)
         pairs_img = synthetic.pair_evaluations_per_image(cfg)
         dp_s = kt["dp_ms"] * 1e-3
-        achieved = alg_bytes_img * B / dp_s / 1e9
-        traffic = committed_traffic(cfg, B, H, W, D)
+        traffic, tfile = committed_traffic(cfg, B, H, W, D)
+        roof = wl.roofline(kt["dp_ms"], dp_kernel_name(cfg), traffic, tfile)
+        roof["note"] = ("the column DP is bound by VALU issue and per-step latency, not by HBM "
+                        "(SURVEY.md H1, DESIGN.md sections 6-7): see the valu fields; traffic = "
+                        "(2*FETCH_SIZE + WRITE_SIZE) of the DP kernels per step from the committed "
+                        "rocprofv3 PMC passes")
         out = {
             "metric": "images/s on 1024x2048x128-disp column DP",
             "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps,
@@ -461,27 +654,22 @@ def main():
             "dtype": "f32+i32", "data": "synthetic",
             "config": {"workload": f"C2/C3: {B} frames/GPU of {H}x{W}, {D} disparity bins, "
                                    f"19 classes + 2 offset channels, preset {args.preset} "
-                                   f"({'pairwise' if cfg.pairwise else 'unary'}), JoinColumns + "
-                                   "prepare + DP + back-trace, device-resident in/out",
+                                   f"({'pairwise' if cfg.pairwise else 'unary'}), input family "
+                                   f"{args.family}, JoinColumns + prepare + DP + back-trace, "
+                                   "device-resident in/out",
                        "batch_per_gpu": B, "rows": H, "cols": W, "max_dis": D,
-                       "preset": args.preset,
-                       "parallelism": f"batch shards x{world}, RCCL gather of sections to rank 0 "
-                                      "(overlapped with the next step)"
+                       "preset": args.preset, "family": args.family,
+                       "parallelism": (f"batch shards x{world}, RCCL gather ({args.gather}) of the "
+                                       "sections to rank 0, overlapped with the next step")
                                       if world > 1 else "single GPU"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "k_pw_phase1 + k_pw_phase2, all tiles of the step"
-                                   if cfg.pairwise else "k_dp_unary",
-                         "kernel_ms": kt["dp_ms"],
-                         "algorithmic_bytes_per_image": alg_bytes_img,
-                         "note": "the column DP is bound by VALU issue and per-step latency, "
-                                 "not by HBM (SURVEY.md H1, DESIGN.md sections 6-7): see the valu "
-                                 "fields; traffic = (2*FETCH_SIZE + WRITE_SIZE) of the DP kernels "
-                                 "per step from the committed rocprofv3 PMC passes "
-                                 "(profiles/r02_traffic.json)"},
-            "valu": {"pair_evals_per_s": pairs_img * B / dp_s,
-                     "pair_evals_per_image": pairs_img,
-                     "lane_ops_peak_per_s": VALU_PEAK_LANEOPS},
+            "roofline": roof,
+            "valu": {"pair_evals_per_s": pairs_img * B * prune["evaluated_frac"] / dp_s,
+                     "pair_evals_per_s_nominal": pairs_img * B / dp_s,
+                     "pair_evals_per_image_nominal": pairs_img,
+                     "lane_ops_peak_per_s": VALU_PEAK_LANEOPS,
+                     "note": "pair_evals_per_s counts the pairs the branch-and-bound actually "
+                             "evaluated (prune.evaluated_frac), _nominal all C*H*(H+1)/2"},
+            "prune": prune,
             "kernel_ms": kt,
         }
         if d2h_value is not None:
@@ -494,19 +682,17 @@ def main():
                                    "images_per_s": 1.0 / single, "ms_per_frame": single * 1e3}
         out["timed_blocks"] = {"count": len(blocks), "steps_per_block": args.steps,
                                "seconds": [round(x, 5) for x in blocks], "reported": "median"}
-        if traffic is not None:
-            out["roofline"]["measured_hbm_gbps"] = traffic / dp_s / 1e9
-            out["roofline"]["measured_hbm_frac"] = traffic / dp_s / 1e9 / HBM_PEAK_GBS
+        if pipe is not None:
+            out["gather"] = pipe.stats()
         if verify is not None:
             out["verify"] = verify
         if variants is not None:
             out["variants"] = variants
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(cfg, frames[0], args.cpu_seconds)
+            out["value_incl_instances"] = variants["with_instances"]["images_per_s"]
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
     else:
         out = None
-
-    core.close()
 
     def flush_c_stdio():
         sys.stdout.flush()

@@ -96,6 +96,10 @@ typedef struct is_section {
  * class_offset = class_id * realcols * max_sections.  Any pointer may be NULL to skip it.
  * Order inside a class is canonical (column ascending, then section index ascending)
  * instead of the reference's atomic arrival order. */
+/* ABI 0.3: the struct MUST be zero-initialised (memset / `= {}`) before its fields are set --
+ * is_compute dereferences every non-NULL member, and members added by later versions then stay
+ * NULL.  All calls on one context must be stream-ordered (the context owns scratch that
+ * is_compute and is_cluster_instances share). */
 typedef struct is_instance_buffers {
     float* d_centerofmass;     /* [8][realcols*max_sections][2]  (meanx, meany) */
     int32_t* d_indices;        /* [8][realcols*max_sections][2]  (column, section index) */
@@ -143,7 +147,9 @@ int is_join_columns(is_ctx* ctx, const float* d_disparity_big, int full_cols, in
  *                       host, [n_images][rows]  (Stixels::PrecomputeGround, Stixels.cu:790-817)
  *   h_vhor              host, [n_images], library convention rows-vhor_image-1 (Stixels.cu:377)
  *   d_sections          device, [n_images][realcols][max_sections] is_section
- *   instances           per image (array of n_images) or NULL
+ *   instances           per image (array of n_images) or NULL.  The candidates of the whole
+ *                       batch are compacted by ONE launch and clustered by ONE launch
+ *                       (grid = 8 classes x n_images), whatever n_images is.
  *   d_cost_table        optional device out, [n_images][realcols][rows][3] final DP costs
  *   d_index_table       optional device out, [n_images][realcols][rows][3] int32.  PAIRWISE:
  *                       vB*3 + predecessor type, the reference's encoding
@@ -164,12 +170,27 @@ int is_compute(is_ctx* ctx, const float* d_joined, const int32_t* d_segmentation
                float* d_cost_table, int32_t* d_index_table, void* stream);
 
 /* Replaces Stixels::ClusterInstances (Stixels.cu:639-681: one ML::dbscanFit per instance class
- * with the size filter of the cuML fork) for the candidates of ONE image: size-filtered DBSCAN
+ * with the size filter of the cuML fork) for the candidates of ONE image (is_compute clusters a
+ * whole batch in one launch): size-filtered DBSCAN
  * with the semantics of the reference's Python twin
  * (tools/visualization/clustering_visualization.py:894-960) on the device, no host round trip.
  * Reads d_centerofmass / d_core_candidates / d_instances_per_class, writes d_labels.
  * is_compute() runs it by itself for every image whose d_labels is set. */
 int is_cluster_instances(is_ctx* ctx, const is_instance_buffers* instances, void* stream);
+
+/* Compaction of the fixed-stride Section output for the final gather of a multi-GPU batch
+ * (the reference copies all max_sections = 200 slots of every column to the host,
+ * Stixels.cu:629-633, of which 10-40 are used).  On the current device, on `stream`:
+ *   d_sections  [n_columns][max_sections] (n_columns = n_images * realcols), terminator type -1
+ *   d_counts    [n_columns]      sections in front of each column's terminator
+ *   d_offsets   [n_columns + 1]  exclusive prefix of the counts; d_offsets[n_columns] = total
+ *   d_packed    [>= total]       the sections in (image, column, section) order
+ * is_unpack_sections is the inverse (it recomputes d_offsets from d_counts and writes the
+ * terminators); entries behind a terminator are unspecified on both sides. */
+int is_pack_sections(const is_section* d_sections, int n_columns, int max_sections,
+                     int32_t* d_counts, int32_t* d_offsets, is_section* d_packed, void* stream);
+int is_unpack_sections(const int32_t* d_counts, int32_t* d_offsets, const is_section* d_packed,
+                       int n_columns, int max_sections, is_section* d_sections, void* stream);
 
 /* Replaces the output wrapper of the reference's CNN export ("FlipAndPad",
  * tools/CNN_training/models/wrappers.py:35-61), i.e. the producer of d_segmentation:
@@ -211,6 +232,14 @@ const char* is_version(void);
 int is_set_kernel_timing(is_ctx* ctx, int enabled);
 int is_get_kernel_times_ms(is_ctx* ctx, float* prepare_ms, float* dp_ms, float* backtrace_ms);
 size_t is_scratch_bytes(const is_ctx* ctx);
+/* Evaluation counters of the exact branch-and-bound, for measurements
+ * OUTSIDE a timed region: while enabled, the DP kernels of FAST columns add the number of 64-pair
+ * wave-steps they evaluated below the diagonal blocks to a device array (enabling resets it).
+ *   out[0] unary full steps, out[1] unary ground/sky-only steps,
+ *   out[2] pairwise phase-1 full steps, out[3] pairwise phase-1 ground/sky-only candidates.
+ * Both calls synchronise the device. */
+int is_set_eval_counters(is_ctx* ctx, int enabled);
+int is_get_eval_counters(is_ctx* ctx, unsigned long long* out, int n);
 
 #ifdef __cplusplus
 }

@@ -21,7 +21,8 @@ EXPORTS = [
     "is_device_synchronize", "is_last_error", "is_version", "is_set_kernel_timing",
     "is_get_kernel_times_ms", "is_scratch_bytes", "is_flip_and_pad", "is_road_vdisparity",
     "is_cluster_instances", "is_host_malloc", "is_host_free", "is_get_device", "is_set_device",
-    "is_ctx_device",
+    "is_ctx_device", "is_set_eval_counters", "is_get_eval_counters",
+    "is_pack_sections", "is_unpack_sections",
 ]
 
 
@@ -76,6 +77,10 @@ def lib():
         L.is_get_device.argtypes = [ctypes.POINTER(ci)]
         L.is_set_device.argtypes = [ci]
         L.is_ctx_device.argtypes = [vp]
+        L.is_set_eval_counters.argtypes = [vp, ci]
+        L.is_get_eval_counters.argtypes = [vp, vp, ci]
+        L.is_pack_sections.argtypes = [vp, ci, ci, vp, vp, vp, vp]
+        L.is_unpack_sections.argtypes = [vp, vp, vp, ci, ci, vp, vp]
         L.is_scratch_bytes.argtypes = [vp]
         L.is_scratch_bytes.restype = ctypes.c_size_t
         _LIB = L
@@ -124,6 +129,15 @@ class Core:
 
     def set_kernel_timing(self, enabled=True):
         _check(lib().is_set_kernel_timing(self._ctx, int(enabled)), "is_set_kernel_timing")
+
+    def set_eval_counters(self, enabled=True):
+        """Evaluation counters of the branch-and-bound (never inside a timed region)."""
+        _check(lib().is_set_eval_counters(self._ctx, int(enabled)), "is_set_eval_counters")
+
+    def eval_counters(self):
+        out = np.zeros(8, np.uint64)
+        _check(lib().is_get_eval_counters(self._ctx, _hp(out), 8), "is_get_eval_counters")
+        return dict(unary_full=int(out[0]), unary_gs=int(out[1]), p1_full=int(out[2]), p1_gs=int(out[3]))
 
     def kernel_times_ms(self):
         a, b, c = ctypes.c_float(), ctypes.c_float(), ctypes.c_float()
@@ -232,6 +246,17 @@ class Core:
         torch.cuda.synchronize(dev)
         pk = packed.cpu().numpy()
         return lab.cpu().numpy(), pk[1:1 + 3 * int(pk[0])].reshape(-1, 3)
+
+
+def pack_sections_ptr(d_sections, n_columns, max_sections, d_counts, d_offsets, d_packed, stream=0):
+    """is_pack_sections on raw device pointers (ints)."""
+    _check(lib().is_pack_sections(d_sections, int(n_columns), int(max_sections), d_counts, d_offsets,
+                                  d_packed, stream), "is_pack_sections")
+
+
+def unpack_sections_ptr(d_counts, d_offsets, d_packed, n_columns, max_sections, d_sections, stream=0):
+    _check(lib().is_unpack_sections(d_counts, d_offsets, d_packed, int(n_columns), int(max_sections),
+                                    d_sections, stream), "is_unpack_sections")
 
 
 def flip_and_pad(cnn_out, rows_power2_segmentation, device=0):

@@ -29,11 +29,11 @@ struct StepRec;
 hipError_t isk_launch_priors(const DevParams*, const float*, PriorRec*, int, hipStream_t);
 hipError_t isk_launch_dp_unary(const DevParams*, int, int, const RowRec*, const float*, const float*,
                                const int*, const int*, const PruneRec*, float*, int32_t*, const int*,
-                               hipStream_t);
+                               unsigned long long*, hipStream_t);
 hipError_t isk_launch_dp_pairwise(const DevParams*, int, int, const RowRec*, const float*,
                                   const float*, const PriorRec*, const float*, const float*, const float*,
                                   const int*, const int*, const PruneRec*, StepRec*, float*, int*,
-                                  float*, int32_t*,
+                                  float*, int32_t*, unsigned long long*,
                                   hipStream_t, hipStream_t*, int, hipEvent_t, hipEvent_t*);
 hipError_t isk_launch_backtrace(const DevParams*, int, int, const RowRec*, const float*,
                                 const int32_t*, const int*, is_section*, int*, hipStream_t);
@@ -48,6 +48,8 @@ hipError_t isk_launch_cluster(int, float, int, int, const is_instance_buffers*,
                               const is_instance_buffers*, int32_t*, hipStream_t);
 size_t isk_phase2_lds_bytes(const DevParams* P);
 size_t isk_phase2s_lds_bytes(const DevParams* P);
+hipError_t isk_launch_pack(const is_section*, int, int, int32_t*, int32_t*, is_section*, hipStream_t);
+hipError_t isk_launch_unpack(const int32_t*, int32_t*, const is_section*, int, int, is_section*, hipStream_t);
 hipError_t isk_launch_flip_and_pad(const float*, int32_t*, int, int, int, int, int, hipStream_t);
 hipError_t isk_launch_vdisparity(const float*, int*, int*, uint8_t*, int, int, int, float, hipStream_t);
 }
@@ -103,6 +105,8 @@ struct is_ctx {
     int32_t* d_cluster_scratch; /* [max_batch][8][2][C*S] work arrays of k_cluster_instances */
     is_instance_buffers* d_inst_tbl; /* [max_batch] device copy of the caller's per-image arrays */
     int* d_inst_cnt;            /* [max_batch*C][8] instance candidates per column and class */
+    unsigned long long* d_counters; /* [IS_CNT_N] evaluation counters (is_set_eval_counters) */
+    bool counting;
     /* scratch */
     RowRec* d_recs;          /* [max_batch*C][H+1] */
     float* d_lutT;           /* [max_batch*C][H+1][D] */
@@ -321,6 +325,7 @@ static int ctx_init(is_ctx* c, const is_stixel_params* p, const float* obj_cost_
     ALLOC(c->d_cluster_scratch, sizeof(int32_t) * B * IS_INSTANCE_CLASSES * 2 * C * (size_t)d.S);
     ALLOC(c->d_inst_tbl, sizeof(is_instance_buffers) * B);
     ALLOC(c->d_inst_cnt, sizeof(int) * B * C * IS_INSTANCE_CLASSES);
+    ALLOC(c->d_counters, sizeof(unsigned long long) * IS_CNT_N);
 #undef ALLOC
     c->scratch_bytes = total;
     for (int i = 0; i < IS_STAGE_SLOTS; i++) {
@@ -381,7 +386,7 @@ int is_ctx_destroy(is_ctx* c) {
     (void)hipFree(c->d_obj_cost_lut); (void)hipFree(c->d_odr); (void)hipFree(c->d_rcp); (void)hipFree(c->d_col_flags); (void)hipFree(c->d_prune); (void)hipFree(c->d_n_generic); (void)hipFree(c->d_ground);
     (void)hipFree(c->d_vhor); (void)hipFree(c->d_recs); (void)hipFree(c->d_lutT); (void)hipFree(c->d_priors); (void)hipFree(c->d_steps); (void)hipFree(c->d_part_cost); (void)hipFree(c->d_part_idx); (void)hipFree(c->d_sv);
     (void)hipFree(c->d_cost_table); (void)hipFree(c->d_index_table); (void)hipFree(c->d_cluster_scratch);
-    (void)hipFree(c->d_inst_tbl); (void)hipFree(c->d_inst_cnt);
+    (void)hipFree(c->d_inst_tbl); (void)hipFree(c->d_inst_cnt); (void)hipFree(c->d_counters);
     for (int i = 0; i < IS_STAGE_SLOTS; i++) {
         if (c->h_ground_pinned[i]) (void)hipHostFree(c->h_ground_pinned[i]);
         if (c->h_vhor_pinned[i]) (void)hipHostFree(c->h_vhor_pinned[i]);
@@ -426,6 +431,26 @@ int is_cluster_instances(is_ctx* c, const is_instance_buffers* ib, void* stream)
     return IS_OK;
 }
 
+int is_pack_sections(const is_section* d_sections, int n_columns, int max_sections, int32_t* d_counts,
+                     int32_t* d_offsets, is_section* d_packed, void* stream) {
+    if (!d_sections || !d_counts || !d_offsets || !d_packed) return fail_arg("null pointer");
+    if (n_columns < 1 || max_sections < 2) return fail_arg("empty shape");
+    if ((((uintptr_t)d_sections) | ((uintptr_t)d_packed)) & 15) return fail_arg("section arrays must be 16-byte aligned");
+    HIP_TRY(isk_launch_pack(d_sections, n_columns, max_sections, d_counts, d_offsets, d_packed,
+                            (hipStream_t)stream));
+    return IS_OK;
+}
+
+int is_unpack_sections(const int32_t* d_counts, int32_t* d_offsets, const is_section* d_packed,
+                       int n_columns, int max_sections, is_section* d_sections, void* stream) {
+    if (!d_sections || !d_counts || !d_offsets || !d_packed) return fail_arg("null pointer");
+    if (n_columns < 1 || max_sections < 2) return fail_arg("empty shape");
+    if ((((uintptr_t)d_sections) | ((uintptr_t)d_packed)) & 15) return fail_arg("section arrays must be 16-byte aligned");
+    HIP_TRY(isk_launch_unpack(d_counts, d_offsets, d_packed, n_columns, max_sections, d_sections,
+                              (hipStream_t)stream));
+    return IS_OK;
+}
+
 int is_flip_and_pad(const float* d_cnn_out, int32_t* d_segmentation, int n_images, int channels,
                     int rows8, int cols8, int rows_power2_segmentation, void* stream) {
     if (!d_cnn_out || !d_segmentation) return fail_arg("null pointer");
@@ -444,6 +469,24 @@ int is_road_vdisparity(const float* d_disparity, int rows, int cols, int max_dis
     if (rows < 1 || cols < 1 || max_dis < 1 || max_dis > 16384) return fail_arg("bad shape");
     HIP_TRY(isk_launch_vdisparity(d_disparity, d_vdisp, d_maximum, d_binary, rows, cols, max_dis,
                                   threshold, (hipStream_t)stream));
+    return IS_OK;
+}
+
+int is_set_eval_counters(is_ctx* c, int enabled) {
+    if (!c) return fail_arg("null ctx");
+    ON_CTX_DEVICE(c);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemset(c->d_counters, 0, sizeof(unsigned long long) * IS_CNT_N));
+    c->counting = enabled != 0;
+    return IS_OK;
+}
+
+int is_get_eval_counters(is_ctx* c, unsigned long long* out, int n) {
+    if (!c || !out) return fail_arg("null pointer");
+    if (n < 1 || n > IS_CNT_N) return fail_arg("n outside [1, 8]");
+    ON_CTX_DEVICE(c);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, c->d_counters, sizeof(unsigned long long) * n, hipMemcpyDeviceToHost));
     return IS_OK;
 }
 
@@ -521,12 +564,12 @@ int is_compute(is_ctx* c, const float* d_joined, const int32_t* d_seg, const flo
         HIP_TRY(isk_launch_dp_pairwise(&P, ncols, c->nwaves_pairwise, c->d_recs, c->d_lutT,
                                        d_joined, c->d_priors, c->d_odr, c->d_rcp, c->d_sv, c->d_vhor,
                                        c->d_col_flags, c->d_prune, c->d_steps, c->d_part_cost,
-                                       c->d_part_idx, ct, it,
+                                       c->d_part_idx, ct, it, c->counting ? c->d_counters : nullptr,
                                        stream, c->aux_streams, IS_AUX_STREAMS, c->ev_fork, c->ev_joins));
     else
         HIP_TRY(isk_launch_dp_unary(&P, ncols, c->nwaves_unary, c->d_recs, c->d_lutT, c->d_rcp,
                                     c->d_vhor, c->d_col_flags, c->d_prune, ct, it, c->d_n_generic,
-                                    stream));
+                                    c->counting ? c->d_counters : nullptr, stream));
     if (c->timing) HIP_TRY(hipEventRecord(c->ev[2], stream));
     bool want_inst = false, want_labels = false;
     if (instances)

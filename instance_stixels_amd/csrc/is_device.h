@@ -123,6 +123,15 @@ struct __attribute__((aligned(32))) PruneRec {
 };
 static_assert(sizeof(PruneRec) == 32, "PruneRec must be 32 bytes");
 
+/* Evaluation counters (is_set_eval_counters): wave-steps of 64 (vB, vT) pairs the pruned walks of
+ * FAST columns actually evaluated BELOW the diagonal blocks (those are always evaluated in full).
+ * A null pointer in timed runs; bench.py reads them in a separate, untimed pass. */
+#define IS_CNT_UNARY_FULL 0 /* k_dp_unary_fast: full steps (three candidates)          */
+#define IS_CNT_UNARY_GS 1   /* k_dp_unary_fast: ground- / sky-only steps               */
+#define IS_CNT_P1_FULL 2    /* k_pw_phase1: full steps (incl. the first segment vB = 0) */
+#define IS_CNT_P1_GS 3      /* k_pw_phase1: ground- / sky-only candidates               */
+#define IS_CNT_N 8
+
 struct DevParams {
     int H, C, D, P2, P2S, CH, K, S;
     int ntiles;        /* ceil(H / IS_TILE) */

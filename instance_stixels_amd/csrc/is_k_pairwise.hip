@@ -318,7 +318,8 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
                                                int split, int nsplit,
                                                const PruneRec* __restrict__ prec,
                                                float* __restrict__ part_cost,
-                                               int* __restrict__ part_idx) {
+                                               int* __restrict__ part_idx,
+                                               unsigned long long* __restrict__ counters) {
     const int H = P.H, D = P.D;
     const int DP = D + 1;
     float* s_tile = (float*)smem;             /* [64][D+1] */
@@ -389,6 +390,7 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
              * no LUT access -- a fifth of the instructions of a full step; they are evaluated FOUR
              * vB at a time so that one scalar-load latency covers four steps. */
             bool done = false, o_closed = false;
+            int n_full = 0, n_gs = 0; /* evaluation counters (wave-uniform) */
 #if IS_P1_ROW_AHEAD == 2
 #define IS_P1_NEXT_ROW()                                                                           \
             next_row = next2_row;                                                                  \
@@ -414,6 +416,7 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
             }
 #define IS_P1_STEP(SKY, NOG)                                                                       \
             ISP1_COUNT(4);                                                                         \
+            n_full++;                                                                              \
             const LutRow<NR> row = next_row;                                                       \
             if (IS_P1_TOUCH_AHEAD > 0)                                                             \
                 touch_step(rcol, scol, max(vB - IS_P1_TOUCH_AHEAD * nw, 0), lane, scr);            \
@@ -452,6 +455,7 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
             {                                                                                      \
                 const int n_here = min(4, (vB - (lo)) / nw + 1);                                   \
                 ISP1_COUNT(5);                                                                     \
+                n_gs += n_here;                                                                    \
                 if (IS_P1_TOUCH_AHEAD > 0) touch_round(rcol, scol, vB - 4 * nw, nw, (lo), lane, scr); \
                 float c_f[4], c_cost[4];                                                           \
                 int c_idx[4];                                                                      \
@@ -519,6 +523,7 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
 #undef IS_P1_NEXT_ROW
 #undef IS_P1_GS4
             if (!done && vB == 0) { /* first segment, :481-594 */
+                n_full++;
                 const RowRec rb = sload_rec(rcol);
                 const int h = vTc + 1;
                 const SegTerms t = eval_segment<true, HAS_INVALID>(my, rb, (float)h, s_rcp[h], D, P.iw);
@@ -533,6 +538,10 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
                 const bool uo = live && (cost <= b.o);
                 b.o = uo ? cost : b.o;
                 b.io = uo ? IS_OBJECT : b.io;
+            }
+            if (counters != nullptr && lane == 0) {
+                atomicAdd(counters + IS_CNT_P1_FULL, (unsigned long long)n_full);
+                atomicAdd(counters + IS_CNT_P1_GS, (unsigned long long)n_gs);
             }
         }
     } else {
@@ -632,7 +641,8 @@ __global__ __launch_bounds__(IS_UNARY_WAVES * 64, HAS_INVALID ? ISP1_OCC_INV : I
     const RowRec* __restrict__ recs, const float* __restrict__ lutT,
     const StepRec* __restrict__ steps, const float* __restrict__ rcp,
     const int* __restrict__ vhor_arr, const int* __restrict__ col_flags,
-    const PruneRec* __restrict__ prune, float* __restrict__ part_cost, int* __restrict__ part_idx) {
+    const PruneRec* __restrict__ prune, float* __restrict__ part_cost, int* __restrict__ part_idx,
+    unsigned long long* __restrict__ counters) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int colg = col_base + (int)(blockIdx.x / (unsigned)nsplit);
     const int split = __builtin_amdgcn_readfirstlane((int)(blockIdx.x % (unsigned)nsplit));
@@ -640,10 +650,10 @@ __global__ __launch_bounds__(IS_UNARY_WAVES * 64, HAS_INVALID ? ISP1_OCC_INV : I
     const int vhor = __builtin_amdgcn_readfirstlane(vhor_arr[colg / P.C]);
     if (__builtin_amdgcn_readfirstlane(col_flags[colg]) == 0)
         pw_phase1_body<true, HAS_INVALID, NR>(P, smem, colg, tile, recs, lutT, steps, rcp, vhor, split,
-                                              nsplit, prune + colg, part_cost, part_idx);
+                                              nsplit, prune + colg, part_cost, part_idx, counters);
     else
         pw_phase1_body<false, HAS_INVALID, NR>(P, smem, colg, tile, recs, lutT, steps, rcp, vhor, split,
-                                               nsplit, prune + colg, part_cost, part_idx);
+                                               nsplit, prune + colg, part_cost, part_idx, counters);
 }
 
 /* ---- phase 2: the fn window --------------------------------------------------------------
@@ -1237,7 +1247,7 @@ hipError_t isk_launch_dp_pairwise(const DevParams* P, int ncols, int nwaves, con
                                   const float* rcp, const float* sv_arr, const int* vhor,
                                   const int* col_flags, const PruneRec* prune, StepRec* steps,
                                   float* part_cost, int* part_idx, float* cost_table,
-                                  int32_t* index_table,
+                                  int32_t* index_table, unsigned long long* counters,
                                   hipStream_t stream, hipStream_t* aux, int n_aux,
                                   hipEvent_t ev_fork, hipEvent_t* ev_join) {
     const size_t lds1 = isk_pairwise_lds_bytes(P, nwaves);
@@ -1273,11 +1283,11 @@ hipError_t isk_launch_dp_pairwise(const DevParams* P, int ncols, int nwaves, con
         if (IS_PW_PHASE1_ROW_REGS && P->D <= 128)                                                  \
             hipLaunchKernelGGL((k_pw_phase1<INV, 2>), dim3(((c1) - (c0)) * nsplit),                \
                                dim3(nwaves * 64), lds1, st, *P, c0, c1, tile, nsplit, recs, lutT,  \
-                               steps, rcp, vhor, col_flags, prune, part_cost, part_idx);           \
+                               steps, rcp, vhor, col_flags, prune, part_cost, part_idx, counters); \
         else                                                                                       \
             hipLaunchKernelGGL((k_pw_phase1<INV, 0>), dim3(((c1) - (c0)) * nsplit),                \
                                dim3(nwaves * 64), lds1, st, *P, c0, c1, tile, nsplit, recs, lutT,  \
-                               steps, rcp, vhor, col_flags, prune, part_cost, part_idx);           \
+                               steps, rcp, vhor, col_flags, prune, part_cost, part_idx, counters); \
     } while (0)
 #define IS_LAUNCH_P2(INV, c0, c1, st)                                                              \
     hipLaunchKernelGGL(k_pw_phase2<INV>, dim3((c1) - (c0)), dim3(64), lds2, st, *P, c0, c1, tile,  \

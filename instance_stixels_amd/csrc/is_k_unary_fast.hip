@@ -195,7 +195,8 @@ __global__ __launch_bounds__(ISF_THREADS, HAS_INVALID ? ISF_OCC_INV : ISF_OCC) v
     const DevParams P, int ncols, const RowRec* __restrict__ recs, const float* __restrict__ lutT,
     const float* __restrict__ rcp, const int* __restrict__ vhor_arr,
     const int* __restrict__ col_flags, const PruneRec* __restrict__ prune,
-    float* __restrict__ cost_table, int32_t* __restrict__ index_table) {
+    float* __restrict__ cost_table, int32_t* __restrict__ index_table,
+    unsigned long long* __restrict__ counters /* null, or the evaluation counters (is_device.h) */) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int H = P.H, D = P.D;
     const int DP = D + 1;
@@ -264,6 +265,7 @@ __global__ __launch_bounds__(ISF_THREADS, HAS_INVALID ? ISF_OCC_INV : ISF_OCC) v
     /* ---- the wave's walk, vB downwards; slot i % K holds step i */
     int slot = 0;
     bool o_closed = false;
+    int n_full = 0, n_gs = 0; /* steps below the diagonal block (wave-uniform: SALU only) */
     for (int vB = vB_top; vB >= 0; vB -= ISF_WAVES) {
         wait_vmcnt<(NVR + 1) * (K - 1)>(); /* this step's slot has landed; K - 1 prefetches in flight */
         float* s_row = my_ring + slot * SLOT;
@@ -273,6 +275,7 @@ __global__ __launch_bounds__(ISF_THREADS, HAS_INVALID ? ISF_OCC_INV : ISF_OCC) v
         bool done = false;
         int ok = 0;
         if (ISF_GS_STEPS && o_closed && vB != 0) { /* (closed in a full step: the diagonal is over) */
+            n_gs++;
             if (vB > vhor)
                 done = fast_step_gs<true>(P, pv, my, rb, s_rcp, vTc, vB, b);
             else if (nog)
@@ -280,6 +283,7 @@ __global__ __launch_bounds__(ISF_THREADS, HAS_INVALID ? ISF_OCC_INV : ISF_OCC) v
             else
                 done = fast_step_gs<false>(P, pv, my, rb, s_rcp, vTc, vB, b);
         } else {
+        n_full += diag ? 0 : 1;
         if (vB == 0) { /* first segment (:481-594): ground + object */
             if (diag)
                 fast_step<HAS_INVALID, false, true, true, false>(P, my, rb, lrow, my_tile, s_rcp, vT, vTc, vhor,
@@ -321,6 +325,10 @@ __global__ __launch_bounds__(ISF_THREADS, HAS_INVALID ? ISF_OCC_INV : ISF_OCC) v
         slot = (slot + 1 == K) ? 0 : slot + 1;
     }
     ISF_MARK(1);
+    if (counters != nullptr && lane == 0) {
+        atomicAdd(counters + IS_CNT_UNARY_FULL, (unsigned long long)n_full);
+        atomicAdd(counters + IS_CNT_UNARY_GS, (unsigned long long)n_gs);
+    }
 
     /* ---- merge the waves' partial minima: min cost, ties -> smallest vB.  After the barrier no
      * wave reads the lutT tile any more, so the merge runs in ITS space; the rings may still
@@ -410,14 +418,15 @@ hipError_t isk_set_lds_unary_fast(const DevParams* P) {
 hipError_t isk_launch_dp_unary_fast(const DevParams* P, int ncols, const RowRec* recs,
                                     const float* lutT, const float* rcp, const int* vhor,
                                     const int* col_flags, const PruneRec* prune, float* cost_table,
-                                    int32_t* index_table, hipStream_t stream) {
+                                    int32_t* index_table, unsigned long long* counters,
+                                    hipStream_t stream) {
     const int nvr = isk_unary_fast_chunk_rows(P);
     const int groups = (ncols + 7) / 8;
     const dim3 grid(groups * 8 * P->ntiles);
     const size_t lds = isk_unary_fast_lds_bytes(P, nvr);
 #define ISF_LAUNCH(INV, NVR)                                                                      \
     hipLaunchKernelGGL((k_dp_unary_fast<INV, NVR>), grid, dim3(ISF_THREADS), lds, stream, *P, ncols, \
-                       recs, lutT, rcp, vhor, col_flags, prune, cost_table, index_table)
+                       recs, lutT, rcp, vhor, col_flags, prune, cost_table, index_table, counters)
     if (P->invalid >= 0) {
         if (nvr == 2) ISF_LAUNCH(true, 2); else ISF_LAUNCH(true, 4);
     } else {

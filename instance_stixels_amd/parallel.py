@@ -1,6 +1,8 @@
 """Multi-GPU use of the column DP: images are independent, so a batch is sharded over ranks
 (one process per GPU) with no data-path collective; the only exchange is the final gather of the
-stixel outputs to one rank (RCCL over xGMI on GPUs, gloo in the CPU tests)."""
+stixel outputs to one rank (RCCL over xGMI on GPUs, gloo in the CPU tests): fixed-stride Section
+tensors (gather_sections / PipelinedGather) or, ~10 x fewer bytes, per-column counts + the used
+sections only (gather_compact / PipelinedCompactGather)."""
 import torch
 import torch.distributed as dist
 
@@ -93,3 +95,235 @@ class PipelinedGather:
             if w is not None:
                 w.wait()
                 self.inflight[i] = None
+
+    def check_last(self, max_sections=None):
+        """On `dst` after flush(): is rank dst's gathered copy its own output?"""
+        got = self.last_gathered()
+        same = bool(torch.equal(got[self.dst], self.last_local()))
+        return {"kind": "fixed", "tensors": len(got), "bytes_per_rank": got[0].numel() * 4,
+                "rank0_copy_equals_local": same}
+
+    def stats(self):
+        b = self.buffers[0].numel() * 4
+        return {"kind": "fixed", "bytes_per_rank_per_step": b, "fixed_stride_bytes_per_rank_per_step": b}
+
+
+# ---------------------------------------------------------------------------------------------
+# Compacted gather (SURVEY.md 8e): per-column counts + the used sections only
+# ---------------------------------------------------------------------------------------------
+
+def pack_sections(sections: torch.Tensor):
+    """[..., C, S, 8] int32 fixed-stride Section tensor -> (counts [n_columns] int32, packed [N, 8]
+    int32): the sections in front of each column's terminator (type == -1), in (image, column,
+    section) order.  Device tensors go through the HIP kernels of the core (is_pack_sections: no
+    host round trip except the caller's read of N); CPU tensors -- the gloo tests -- through torch."""
+    S = sections.shape[-2]
+    flat = sections.reshape(-1, S, 8)
+    n_columns = flat.shape[0]
+    if flat.is_cuda:
+        from . import core
+        counts = torch.empty(n_columns, dtype=torch.int32, device=flat.device)
+        offsets = torch.empty(n_columns + 1, dtype=torch.int32, device=flat.device)
+        packed = torch.empty((n_columns * (S - 1), 8), dtype=torch.int32, device=flat.device)
+        flat = flat.contiguous()
+        core.pack_sections_ptr(flat.data_ptr(), n_columns, S, counts.data_ptr(), offsets.data_ptr(),
+                               packed.data_ptr(), torch.cuda.current_stream(flat.device).cuda_stream)
+        return counts, packed[: int(offsets[-1].item())]
+    term = flat[:, :, 0] == -1
+    counts = torch.where(term.any(dim=1), term.to(torch.int32).argmax(dim=1),
+                         torch.full((n_columns,), S - 1, dtype=torch.int64)).to(torch.int32)
+    mask = torch.arange(S)[None, :] < counts[:, None]
+    return counts, flat[mask]
+
+
+def unpack_sections(counts: torch.Tensor, packed: torch.Tensor, max_sections: int) -> torch.Tensor:
+    """Inverse of pack_sections: [n_columns][S][8] with a terminator behind each column's sections
+    and zeros behind the terminator."""
+    n_columns, S = counts.numel(), max_sections
+    if counts.is_cuda:
+        from . import core
+        out = torch.zeros((n_columns, S, 8), dtype=torch.int32, device=counts.device)
+        offsets = torch.empty(n_columns + 1, dtype=torch.int32, device=counts.device)
+        buf = packed.contiguous() if packed.numel() else torch.zeros((1, 8), dtype=torch.int32,
+                                                                      device=counts.device)
+        core.unpack_sections_ptr(counts.data_ptr(), offsets.data_ptr(), buf.data_ptr(), n_columns, S,
+                                 out.data_ptr(), torch.cuda.current_stream(counts.device).cuda_stream)
+        return out
+    out = torch.zeros((n_columns, S, 8), dtype=torch.int32)
+    mask = torch.arange(S)[None, :] < counts[:, None]
+    out[mask] = packed
+    out[torch.arange(n_columns), counts.long(), 0] = -1
+    return out
+
+
+def _exchange_compact(counts, packed, dst, group, recv=None):
+    """The collective part: sizes by all_gather, then counts + packed sections of every rank to
+    `dst` with point-to-point transfers sized by what each rank really has.  Returns on `dst` a
+    list of (counts_r, packed_r) per rank (its own: the inputs), None elsewhere; `works`: the
+    asynchronous handles still in flight."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    dev = counts.device
+    mine = torch.tensor([counts.numel(), packed.shape[0]], dtype=torch.int64, device=dev)
+    sizes = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(sizes, mine, group=group)
+    sizes = [(int(s[0].item()), int(s[1].item())) for s in sizes]
+    ops, out = [], None
+    if rank == dst:
+        out = []
+        for r, (nc, n) in enumerate(sizes):
+            if r == dst:
+                out.append((counts, packed))
+                continue
+            if recv is not None:
+                c_r, p_r = recv[r][0][:nc], recv[r][1][:n]
+            else:
+                c_r = torch.empty(nc, dtype=torch.int32, device=dev)
+                p_r = torch.empty((n, 8), dtype=torch.int32, device=dev)
+            ops.append(dist.P2POp(dist.irecv, c_r, r, group))
+            if n > 0:
+                ops.append(dist.P2POp(dist.irecv, p_r, r, group))
+            out.append((c_r, p_r))
+    else:
+        ops.append(dist.P2POp(dist.isend, counts, dst, group))
+        if packed.shape[0] > 0:
+            ops.append(dist.P2POp(dist.isend, packed, dst, group))
+    works = dist.batch_isend_irecv(ops) if ops else []
+    return out, works, sizes
+
+
+def gather_compact(sections: torch.Tensor, dst: int = 0, group=None):
+    """Compacted gather of every rank's Section tensor ([n_r][C][S][8] int32, n_r may differ per
+    rank) on `dst`: returns there the list of per-rank (counts, packed) pairs (see
+    pack_sections), None on the other ranks.  About 10 x fewer bytes than the fixed-stride gather:
+    10-40 of the 200 slots of a column are used."""
+    counts, packed = pack_sections(sections)
+    out, works, _ = _exchange_compact(counts, packed, dst, group)
+    for w in works:
+        w.wait()
+    return out
+
+
+class PipelinedCompactGather:
+    """PipelinedGather with the compacted payload.  Step k computes into buffer k % depth and its
+    pack kernels are queued behind it; the exchange of step k-1 (whose size the host must read:
+    one 4-byte copy) is started right after step k has been queued, on a side stream that waits
+    only for step k-1's pack -- so the transfer overlaps step k's compute and the host never
+    leaves the GPU without queued work.  `flush()` finishes what is still pending."""
+
+    def __init__(self, like: torch.Tensor, core=None, depth: int = 2, dst: int = 0, group=None):
+        self.dst, self.group, self.depth = dst, group, depth
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.S = like.shape[-2]
+        self.n_columns = like.numel() // (self.S * 8)
+        dev = like.device
+        self.dev = dev
+        cap = self.n_columns * (self.S - 1)
+        self.buffers = [torch.empty_like(like) for _ in range(depth)]
+        self.counts = [torch.empty(self.n_columns, dtype=torch.int32, device=dev) for _ in range(depth)]
+        self.offsets = [torch.empty(self.n_columns + 1, dtype=torch.int32, device=dev) for _ in range(depth)]
+        self.packed = [torch.empty((cap, 8), dtype=torch.int32, device=dev) for _ in range(depth)]
+        self.total = [torch.zeros(1, dtype=torch.int32).pin_memory() if dev.type == "cuda"
+                      else torch.zeros(1, dtype=torch.int32) for _ in range(depth)]
+        self.events = [torch.cuda.Event() if dev.type == "cuda" else None for _ in range(depth)]
+        self.comm = torch.cuda.Stream(dev) if dev.type == "cuda" else None
+        self.recv = None
+        if self.rank == dst:   # worst-case landing buffers per slot and rank
+            self.recv = [[(torch.empty(self.n_columns, dtype=torch.int32, device=dev),
+                           torch.empty((cap, 8), dtype=torch.int32, device=dev)) if r != dst else None
+                          for r in range(self.world)] for _ in range(depth)]
+        self.works = [[] for _ in range(depth)]
+        self.result = [None] * depth
+        self.sizes = [None] * depth
+        self.pending = []
+        self.step = 0
+
+    def next_buffer(self) -> torch.Tensor:
+        slot = self.step % self.depth
+        self._finish(slot)   # the slot's packed buffers may still be on the wire
+        return self.buffers[slot]
+
+    def _finish(self, slot):
+        if slot in self.pending:
+            self._exchange(slot)
+        for w in self.works[slot]:
+            w.wait()
+        self.works[slot] = []
+
+    def submit(self):
+        slot = self.step % self.depth
+        if self.dev.type == "cuda":
+            from . import core
+            stream = torch.cuda.current_stream(self.dev)
+            core.pack_sections_ptr(self.buffers[slot].data_ptr(), self.n_columns, self.S,
+                                   self.counts[slot].data_ptr(), self.offsets[slot].data_ptr(),
+                                   self.packed[slot].data_ptr(), stream.cuda_stream)
+            self.total[slot].copy_(self.offsets[slot][-1:], non_blocking=True)
+            self.events[slot].record(stream)
+        else:
+            c, p = pack_sections(self.buffers[slot])
+            self.counts[slot].copy_(c)
+            self.packed[slot][: p.shape[0]].copy_(p)
+            self.total[slot][0] = p.shape[0]
+        older = list(self.pending)
+        self.pending.append(slot)
+        self.step += 1
+        for s in older:      # the exchange of the step before, overlapped with the one just queued
+            self._exchange(s)
+        return slot
+
+    def _exchange(self, slot):
+        self.pending.remove(slot)
+        if self.dev.type == "cuda":
+            self.events[slot].synchronize()
+            n = int(self.total[slot][0])
+            self.comm.wait_event(self.events[slot])
+            with torch.cuda.stream(self.comm):
+                out, works, sizes = _exchange_compact(self.counts[slot], self.packed[slot][:n], self.dst,
+                                                      self.group, None if self.recv is None else self.recv[slot])
+        else:
+            n = int(self.total[slot][0])
+            out, works, sizes = _exchange_compact(self.counts[slot], self.packed[slot][:n], self.dst,
+                                                  self.group, None if self.recv is None else self.recv[slot])
+        self.works[slot], self.result[slot], self.sizes[slot] = works, out, sizes
+
+    def flush(self):
+        for slot in list(self.pending):
+            self._exchange(slot)
+        for slot in range(self.depth):
+            for w in self.works[slot]:
+                w.wait()
+            self.works[slot] = []
+        if self.comm is not None:
+            torch.cuda.current_stream(self.dev).wait_stream(self.comm)
+
+    def last_local(self) -> torch.Tensor:
+        return self.buffers[(self.step - 1) % self.depth]
+
+    def last_gathered(self):
+        """On `dst` after flush(): [(counts_r, packed_r)] of the most recent step."""
+        return self.result[(self.step - 1) % self.depth]
+
+    def check_last(self, max_sections=None):
+        """On `dst` after flush(): every rank's payload is consistent (its counts sum to its
+        packed length) and rank dst's own unpacks to its fixed-stride output."""
+        got = self.last_gathered()
+        ok = all(int(c.sum().item()) == p.shape[0] for c, p in got)
+        c0, p0 = got[self.dst]
+        local = self.last_local().reshape(-1, self.S, 8)
+        back = unpack_sections(c0, p0, self.S)
+        idx = torch.arange(self.S, device=local.device)[None, :]
+        body = idx < c0[:, None]
+        same = bool(torch.equal(back[body], local[body])) and \
+            bool((local[..., 0][idx == c0[:, None]] == -1).all())
+        return {"kind": "compact", "ranks": len(got), "payload_consistent": ok,
+                "rank0_copy_equals_local": bool(ok and same),
+                "sections_per_rank": [int(p.shape[0]) for _, p in got]}
+
+    def stats(self):
+        slot = (self.step - 1) % self.depth
+        sizes = self.sizes[slot] or []
+        fixed = self.buffers[0].numel() * 4
+        per_rank = [4 * nc + 32 * n for nc, n in sizes]
+        return {"kind": "compact", "bytes_per_rank_per_step": per_rank,
+                "fixed_stride_bytes_per_rank_per_step": fixed,
+                "ratio_vs_fixed": (sum(per_rank) / len(per_rank) / fixed) if per_rank else None}

@@ -38,9 +38,21 @@ def rows_power2_segmentation(rows: int) -> int:  # Stixels.cu:132-133
     return int(2 ** math.ceil(math.log2(rows // 8 + 1)))
 
 
+FAMILIES = ("scene", "iid_noise", "low_confidence", "flat_disparity")
+
+
 def make_frame(cfg: StixelConfig, seed: int = 0, n_slabs: int = 6, hole_fraction: float = 0.05,
-               zero_segmentation: bool = False, offset_scale: float = 8.0) -> Frame:
-    """offset_scale: the offset channels hold int(offset_scale * offset in full-resolution
+               zero_segmentation: bool = False, offset_scale: float = 8.0,
+               family: str = "scene") -> Frame:
+    """family (bench.py `variants.families`; the default "scene" is the data of every earlier
+    round, bit for bit): "iid_noise" -- every class logit N(0, 1), the segmentation carries no
+    scene at all; "low_confidence" -- the true class's logit is only 1 .. 2 above the N(0, 1)
+    rest (a hesitant CNN: class sums separate slowly, the branch-and-bound prunes late);
+    "flat_disparity" -- the scene's segmentation over a disparity image without structure
+    (constant + U(0, 1) everywhere).  The value range of the class channels is that of the
+    reference's CNN wrapper, 8 * -log_softmax (wrappers.py:50-60).
+
+    offset_scale: the offset channels hold int(offset_scale * offset in full-resolution
     pixels).  The kernel adds the channel value to the pixel position as it is
     (StixelsKernels.cu:401-405), so 1.0 makes the predicted centres of an object coincide (what a
     trained CNN delivers; used by the clustering tests); the default 8.0 is the bench / parity
@@ -84,6 +96,10 @@ def make_frame(cfg: StixelConfig, seed: int = 0, n_slabs: int = 6, hole_fraction
         has_obj[top:foot, x0:x0 + w] = cls >= 11
         centre_x[top:foot, x0:x0 + w] = x0 + 0.5 * w
         centre_y[top:foot, x0:x0 + w] = 0.5 * (top + foot)
+    if family not in FAMILIES:
+        raise ValueError(f"unknown input family {family!r}")
+    if family == "flat_disparity":   # keep only the U(0, 1) part of every pixel
+        disp = np.float32(D // 3) + (disp - np.floor(disp))
     disp = np.clip(disp, 0.0, D - 1.01).astype(np.float32)
     if cfg.invalid_disparity >= 0 and hole_fraction > 0:
         holes = rng.random((H, W)) < hole_fraction
@@ -98,8 +114,10 @@ def make_frame(cfg: StixelConfig, seed: int = 0, n_slabs: int = 6, hole_fraction
         xs = np.minimum(xs, W - 1)
         lab = label[np.ix_(ys, xs)]                                     # [Hs][C]
         logits = rng.normal(0.0, 1.0, (Hs, C, K)).astype(np.float32)
-        np.put_along_axis(logits, lab[..., None], 4.0 + rng.random((Hs, C, 1), dtype=np.float32),
-                          axis=2)
+        if family != "iid_noise":
+            true_logit = 1.0 if family == "low_confidence" else 4.0
+            np.put_along_axis(logits, lab[..., None],
+                              np.float32(true_logit) + rng.random((Hs, C, 1), dtype=np.float32), axis=2)
         logits -= logits.max(axis=2, keepdims=True)
         nlogp = -(logits - np.log(np.exp(logits).sum(axis=2, keepdims=True)))
         sem = (8.0 * nlogp).astype(np.int32)                            # [Hs][C][K]

@@ -532,3 +532,51 @@ def test_plain_cpp_caller_runs():
         assert "stixels" in out.stdout and "horizon row" in out.stdout
         hor = int(out.stdout.split("horizon row")[1].split()[0])
         assert abs(hor - int(0.45 * 256)) <= 8
+
+
+def test_pack_sections_kernels_match_host_logic():
+    """is_pack_sections / is_unpack_sections (the compacted payload of the multi-GPU gather,
+    SURVEY.md 8e) on the device against the torch restatement the gloo tests use: counts, packed
+    order and the round trip, with emptied columns and a column without terminator."""
+    import torch
+    from instance_stixels_amd.parallel import pack_sections, unpack_sections
+    case = helpers.build_case("drn_d_38_pairwise", 128, 512, 32, seed=3, n_images=3)
+    got = helpers.run_core(case, want_tables=False)
+    sec = torch.from_numpy(got["sections"].view(np.int32).reshape(3, -1, 200, 8).copy())
+    sec[0, 5, 0, 0] = -1                               # empty column
+    sec[2, 63, 0, 0] = -1
+    sec[1, 7, :, 0] = 1                                # no terminator at all: 199 sections
+    c_ref, p_ref = pack_sections(sec)
+    dev = torch.device("cuda", 0)
+    c, p = pack_sections(sec.to(dev))
+    assert torch.equal(c.cpu(), c_ref) and torch.equal(p.cpu(), p_ref)
+    back = unpack_sections(c, p, 200).cpu()
+    assert torch.equal(back, unpack_sections(c_ref, p_ref, 200))
+    c2, p2 = pack_sections(back.to(dev))
+    assert torch.equal(c2.cpu(), c_ref) and torch.equal(p2.cpu(), p_ref)
+
+
+def test_set_device_guard_with_two_gpus():
+    """Stixels::SetDevice(d): every later call runs on d whatever the caller's current device is
+    (needs two GPUs; the one-GPU box skips it)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    from instance_stixels_amd import host
+    case = helpers.build_case("drn_d_22_unary", 128, 256, 32, seed=51)
+    cfg, f = case["cfg"], case["frames"][0]
+    ref = helpers.run_oracle(case)
+    st = host.Stixels()
+    st.SetConfig(cfg)
+    st.SetDevice(1)
+    torch.cuda.set_device(0)
+    st.Initialize()
+    for _ in range(2):
+        st.SetDisparityImage(f.disparity)
+        st.SetSegmentation(f.segmentation)
+        st.SetRoadParameters(f.vhor_image, f.camera_tilt, f.camera_height, f.alpha_ground)
+        data = st.Compute(cfg.pairwise)
+        assert helpers.sections_equal(ref["sections"], data.sections)
+        assert len(st.GetInstanceStixels()) == int(ref["inst_per_class"].sum())
+        assert torch.cuda.current_device() == 0
+    st.close()
