@@ -580,3 +580,136 @@ def test_set_device_guard_with_two_gpus():
         assert len(st.GetInstanceStixels()) == int(ref["inst_per_class"].sum())
         assert torch.cuda.current_device() == 0
     st.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# The exact branch-and-bound: proof-of-exactness tests AT the bounds
+# ---------------------------------------------------------------------------------------------
+ADV_FAMILIES = ["negative_data_costs", "ties", "constant_centres", "weight_cutoffs",
+                "horizon_in_tile", "confident_scene"]
+
+
+def _adversarial_case(family, k):
+    """Small seeded cases built so that the slack terms of the bounds matter (lemmas L1-L6 of
+    DESIGN.md section 5).  Returns a helpers case."""
+    rng = np.random.default_rng(40000 + 97 * ADV_FAMILIES.index(family) + k)
+    pairwise = bool(k % 2)
+    preset = ["drn_d_22_unary", "drn_d_38_pairwise"][pairwise]
+    rows = int(rng.choice([128, 136, 192, 256]))
+    cols = int(rng.choice([64, 96]))
+    D = int(rng.choice([16, 32]))
+    ov = {}
+    if k % 4 >= 2:
+        ov["invalid_disparity"] = 0.0
+    if family == "negative_data_costs":
+        # the narrowest Gaussians the reference's FastLog domain allows ((1 - pout) / (sigma *
+        # sqrt(2 pi)) <= 1, Stixels.cu:79-84, 786-788): where the Gaussian's mass inside [0, D) is
+        # about a half (fn near 0, ground rows near the horizon) the normalisation term is negative
+        # and so are LUT minima and per-row ground costs; the sky term (sigma_sky << 1) is negative
+        # for every d near 0.  sigma_od, sig_g, sig_k of PruneRec then carry the bound (L3).
+        pout = float(rng.uniform(0.01, 0.1))
+        smin = (1.0 - pout) / 2.5066 * 1.002
+        ov.update(sigma_disparity_object=float(rng.uniform(smin, smin + 0.1)),
+                  sigma_disparity_ground=float(rng.uniform(smin, smin + 0.1)),
+                  sigma_sky=float(rng.uniform(0.02, 0.1)), pout=pout,
+                  pout_sky=float(rng.uniform(0.01, 0.1)),
+                  disparity_weight=float(10.0 ** rng.uniform(-3, 0.5)))
+    elif family == "ties":
+        ov.update(disparity_weight=float(rng.choice([0.0, 1e-7, 1e-3])),
+                  prior_weight=float(rng.choice([0.0, 1e-6, 1.0])) if not pairwise else 1.0,
+                  segmentation_weight=float(rng.choice([1.0, 2.0, 0.5])),
+                  instance_weight=float(rng.choice([0.0, 1e-3])))
+    elif family == "weight_cutoffs":
+        # sw at / next to the 1e-5 cut-off below which the host zeroes iw, iw at / next to its own
+        # 1e-8 cut-off (Stixels.cu:408-423); class values x64 (column totals still < 2^24) and small
+        # dw / pw so that sw * f still decides and the bound can fire
+        ov.update(segmentation_weight=float(rng.choice([1e-5, 1.1e-5, 2e-5, 1e-4])),
+                  instance_weight=float(rng.choice([1e-8, 0.9e-8, 1.1e-8, 1e-7, 1e-3])),
+                  disparity_weight=float(rng.choice([1e-6, 1e-4])),
+                  prior_weight=1.0 if pairwise else float(rng.choice([0.0, 1e-2, 1.0])))
+    case = helpers.build_case(preset, rows, cols, D, seed=41000 + k, **ov)
+    seg, disp = case["segmentation"], case["disparity"]
+    cfg = case["cfg"]
+    Hs = rows // 8
+    if family == "ties":
+        # tiny integer class values: the class-group minima, hence the bounds, move in steps of
+        # sw and meet the best costs exactly; whole-column ties between a pruned and a winning vB
+        seg[:, :, :19, :Hs] = rng.integers(0, 3, seg[:, :, :19, :Hs].shape) * \
+            (rng.random(seg[:, :, :19, :Hs].shape) < 0.3)
+        seg[:, 0, :19, :Hs] = 0                       # a column where every class ties everywhere
+        seg[:, 1, :19, :Hs] = 1
+        seg[:, :, 19:, :Hs] = rng.integers(-2, 3, seg[:, :, 19:, :Hs].shape)
+        disp[:] = np.float32(3.5)                      # constant data terms
+    elif family == "weight_cutoffs":
+        seg[:, :, :19, :Hs] *= 64
+    elif family == "constant_centres":
+        # sum(x^2) - (sum x)^2 / h cancels exactly in real arithmetic: the computed instance term
+        # is pure rounding noise of either sign, amplified by large centres (E2, lemma L4)
+        big = int(rng.choice([1000, 4000, 12000]))
+        seg[:, :, 20, :Hs] = big                                   # mx = 8 col + 4 + big: constant
+        seg[:, :, 19, :Hs] = 8 * np.arange(Hs)[None, None, :] - big  # my = big + (v mod 8)
+        seg[:, ::2, 19, :Hs] += rng.integers(-1, 2, seg[:, ::2, 19, :Hs].shape)
+    elif family == "horizon_in_tile":
+        f = case["frames"][0]
+        vhor_image = int(rng.choice([1, 5, 63, 64, 65, rows - 70, rows - 64, rows - 2]))
+        g = oracle_mod().host_ground(cfg, vhor_image, f.camera_tilt, f.camera_height, f.alpha_ground)
+        case["gf"][0], case["ng"][0], case["ig"][0], case["vhor"][0] = g
+    return case
+
+
+def oracle_mod():
+    from oracle import oracle
+    return oracle
+
+
+def _run_counted(case, env, monkeypatch):
+    """One is_compute call with the evaluation counters on; returns (outputs, evaluated steps)."""
+    from instance_stixels_amd.core import Core
+    for k in ("IS_NO_PRUNE",):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    cfg = case["cfg"]
+    core = Core(case["params"], case["lut"], case["odr"], max_batch=len(case["frames"]))
+    try:
+        core.set_eval_counters(True)
+        out = core.run(disparity_big=case["disparity"], segmentation=case["segmentation"],
+                       ground_function=case["gf"], normalization_ground=case["ng"],
+                       inv_sigma2_ground=case["ig"], vhor=case["vhor"], pairwise=bool(cfg.pairwise),
+                       median_join=bool(cfg.median_join), want_tables=True)
+        c = core.eval_counters()
+    finally:
+        core.close()
+    steps = c["p1_full"] + c["p1_gs"] if cfg.pairwise else c["unary_full"] + c["unary_gs"]
+    return out, steps
+
+
+@pytest.mark.parametrize("family", ADV_FAMILIES)
+def test_branch_and_bound_is_exact_at_the_bounds(family, monkeypatch):
+    """36 seeded cases per family (216 in all), each run pruned and with IS_NO_PRUNE=1 (every pair
+    evaluated, the reference's walk, StixelsKernels.cu:600-839): the complete cost_table,
+    index_table and all Sections must agree bit for bit; every sixth case is also compared with
+    the oracle.  The families put the inputs AT the bounds: negative per-row data costs (LUT
+    minima < 0), exact ties between pruned and winning vB, constant instance centres (E2
+    cancellation), sw -> 1e-5 and iw at its cut-off, +inf ground prefixes starting inside a
+    tile.  The counters prove that the pruned runs really skipped work."""
+    pruned_steps = full_steps = 0
+    for k in range(36):
+        case = _adversarial_case(family, k)
+        a, sa = _run_counted(case, {}, monkeypatch)
+        b, sb = _run_counted(case, {"IS_NO_PRUNE": "1"}, monkeypatch)
+        tag = f"{family}[{k}] pairwise={case['cfg'].pairwise}"
+        assert np.array_equal(a["cost_table"].view(np.uint32), b["cost_table"].view(np.uint32)), tag
+        assert np.array_equal(a["index_table"], b["index_table"]), tag
+        assert helpers.sections_equal(a["sections"][0], b["sections"][0]), tag
+        assert sa <= sb, tag
+        pruned_steps += sa
+        full_steps += sb
+        if k % 6 == 0:
+            _assert_parity(case, a)
+    assert full_steps > 0
+    # the bound must fire where it can: confident scenes and tie patterns prune a lot, slack-heavy
+    # families at least something (a family that never prunes would test nothing)
+    assert pruned_steps < full_steps, (family, pruned_steps, full_steps)
+    if family in ("confident_scene", "horizon_in_tile"):
+        assert pruned_steps < 0.8 * full_steps, (family, pruned_steps, full_steps)
