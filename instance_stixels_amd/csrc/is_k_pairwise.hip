@@ -211,13 +211,17 @@ __device__ __forceinline__ void pairwise_step(const DevParams& P, const StepVals
     const float p1 = (fn > st.g_hi_thr) ? st.p1_hi : ((fn < st.g_lo_thr) ? st.p1_lo : st.p1_mid);
     const float p2 = (fn > st.o_hi_thr) ? st.p2_hi : ((fn < st.o_lo_thr) ? st.p2_lo : st.p2_mid);
     const float p3 = (fn > P.epsilon) ? st.p3_yes : st.p3_no;
-    const float m12 = __builtin_fminf(p1, p2);
-    const float mp = __builtin_fminf(m12, p3);
+    /* (min_raw: the p values are computed fp32 values -- quiet NaNs only --, see is_kernels.h) */
+    const float m12 = min_raw(p1, p2);
+    const float mp = min_raw(m12, p3);
     const float cost = P.dw * od + P.pw * mp + P.sw * t.seg_o;
-    /* min_prev: OBJECT (1), GROUND (0) if p1 < p2, SKY (2) if p3 < fminf(p1, p2), :828-835 */
-    const int base_o = vB * 3 + IS_OBJECT;
-    int idx = (p1 < p2) ? (base_o - 1) : base_o;
-    idx = (p3 < m12) ? (base_o + 1) : idx;
+    /* min_prev: OBJECT (1), GROUND (0) if p1 < p2, SKY (2) if p3 < fminf(p1, p2), :828-835;
+     * vB * 3 on the scalar unit (left to itself the compiler folds it into a 64-bit vector mad) */
+    int base3 = vB * 3;
+    asm volatile("" : "+s"(base3));
+    int sel = (p1 < p2) ? IS_GROUND : IS_OBJECT;
+    sel = (p3 < m12) ? IS_SKY : sel;
+    const int idx = base3 + sel;
     if (CMPX && DESC) {
         take_if_le_v(b.o, b.io, cost, idx);
     } else if (CMPX) {
@@ -433,7 +437,8 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
                     const float* q2 = (const float*)(rcol + max(vB - 2 * nw, 0));                  \
                     n_r0 = q2[l15]; n_r1 = q2[16 + l15];                                           \
                 }                                                                                  \
-                t = eval_segment_dpp<HAS_INVALID>(my, r0, r1, (float)h, s_rcp[h], D, P.iw);        \
+                t = eval_segment_dpp<HAS_INVALID, (SKY) ? IS_WANT_SKY : ((NOG) ? 0 : IS_WANT_GROUND)>(  \
+                    my, r0, r1, (float)h, s_rcp[h], D, P.iw);                                      \
                 od = my_tile[t.fni] - pick_lut<NR>(row, t.fni);                                    \
                 /* the next StepRec: requested only now -- every LDS wait is an lgkmcnt(0) wait    \
                  * and would wait for this scalar load too (SMEM returns out of order) */          \
@@ -447,7 +452,7 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
                 od = my_tile[t.fni] - pick_lut<NR>(row, t.fni);                                    \
             }                                                                                      \
             pairwise_step<SKY, true, NOG, true>(P, st, vB, live, od, t, b);                        \
-            const float lb_o = (st.q_o - E1o) + P.sw * __builtin_fminf(t.f_on, t.f_oi - E2);       \
+            const float lb_o = (st.q_o - E1o) + P.sw * min_raw(t.f_on, t.f_oi - E2);              \
             const bool ok_o = (__builtin_amdgcn_ballot_w64(lb_o > b.o) | dead) == ~0ull
             /* ground / sky candidates of up to four vB (vB, vB - nw, ...) >= lo; closes `x_closed`
              * when the bound of the last one holds; leaves vB at the next unvisited value */

@@ -58,7 +58,10 @@ __device__ __forceinline__ SegTerms fast_step(const DevParams& P, const RowRec& 
     const float r = s_rcp[hc]; /* RN(1/h) = (float)(1./h) = inverse_height, :485, :608 */
 #if ISF_DPP
     const int l15 = threadIdx.x & 15;
-    const SegTerms t = eval_segment_dpp<HAS_INVALID>(my, srec[l15], srec[16 + l15], (float)hc, r, P.D, P.iw);
+    /* FIRST (vB = 0): ground + object; otherwise the sky OR the ground candidate, or neither */
+    constexpr int WANT = SKY ? IS_WANT_SKY : (NOGROUND ? 0 : IS_WANT_GROUND);
+    const SegTerms t = eval_segment_dpp<HAS_INVALID, WANT>(my, srec[l15], srec[16 + l15], (float)hc, r, P.D,
+                                                           P.iw);
 #else
     const RowRec rb = lds_rec(srec);
     const SegTerms t = eval_segment<true, HAS_INVALID>(my, rb, (float)hc, r, P.D, P.iw);
@@ -108,7 +111,7 @@ struct PruneValsF {
 template <bool SKY, bool NOGROUND>
 __device__ __forceinline__ int fast_bounds(const DevParams& P, const PruneValsF& pv, const SegTerms& t,
                                            const UnaryBestF& b) {
-    const float lb_o = P.sw * __builtin_fminf(t.f_on, t.f_oi - pv.E2) - pv.E1o;
+    const float lb_o = P.sw * min_raw(t.f_on, t.f_oi - pv.E2) - pv.E1o;
     const bool ok_o = (__builtin_amdgcn_ballot_w64(lb_o > b.o) | pv.dead) == ~0ull;
     bool ok_x = true;
     if (SKY) {

@@ -424,33 +424,68 @@ __device__ __forceinline__ int dpp_sub_i_first(int mine, float R) {
                  : "=v"(d) : "v"(R), "n"(K));
     return mine - d;
 }
+/* v_min_f32 / v_min3_f32 as they are.  `__builtin_fminf` on a value that comes out of inline
+ * assembly (the DPP subtractions) makes the compiler canonicalise both operands first (two extra
+ * 4-cycle v_max_f32 x, x per minimum) because it cannot see that they are no signalling NaNs; the
+ * operands here are differences / sums of computed fp32 values, whose NaNs (if any) are quiet, so
+ * the bare instruction already has fminf's semantics (the other operand wins over a quiet NaN;
+ * kernels run in IEEE mode).  Not volatile: unused results disappear. */
+__device__ __forceinline__ float min_raw(float a, float b) {
+    float d;
+    asm("v_min_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ float min3_raw(float a, float b, float c) {
+    float d;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
+/* what a step needs besides the object terms: the ground candidate's, the sky candidate's, both
+ * (the first segment of the pairwise model, generic callers) or neither (tiles above the horizon) */
+#define IS_WANT_GROUND 1
+#define IS_WANT_SKY 2
+
 /* eval_segment<true, HAS_INVALID> (is_kernels.h) with the vB record in (R0, R1): identical
- * operations in identical order, only the source of the vB operand differs */
-template <bool HAS_INVALID>
+ * operations in identical order, only the source of the vB operand differs.  WANT: which of the
+ * ground / sky terms are computed at all -- the DPP instructions are `asm volatile` and would
+ * otherwise be executed even where their result is never read. */
+template <bool HAS_INVALID, int WANT = IS_WANT_GROUND | IS_WANT_SKY>
 __device__ __forceinline__ SegTerms eval_segment_dpp(const RowRec& my, float R0, float R1, float height,
                                                      float r, int D, float iw) {
     SegTerms t;
     const float nic = iw * (float)dpp_sub_i_first<3>(my.Fnic, R1);
-    const float d_g0 = dpp_sub_first<0>(my.Fg0, R0); /* (explicit statements: asm order = source order) */
-    const float d_g1 = dpp_sub<1>(my.Fg1, R0);
-    float f_g = __builtin_fminf(d_g0, d_g1);
-    float f_on = dpp_sub<2>(my.Fon[0], R0);
-    f_on = __builtin_fminf(f_on, dpp_sub<3>(my.Fon[1], R0));
-    f_on = __builtin_fminf(f_on, dpp_sub<4>(my.Fon[2], R0));
-    f_on = __builtin_fminf(f_on, dpp_sub<5>(my.Fon[3], R0));
-    f_on = __builtin_fminf(f_on, dpp_sub<6>(my.Fon[4], R0));
-    f_on = __builtin_fminf(f_on, dpp_sub<7>(my.Fon[5], R0));
-    f_on = __builtin_fminf(f_on, dpp_sub<8>(my.Fon[6], R0));
-    f_on = __builtin_fminf(f_on, dpp_sub<9>(my.Fon[7], R0));
+    float f_g = 0.0f;
+    float f_on;
+    if (WANT & IS_WANT_GROUND) {
+        const float d_g0 = dpp_sub_first<0>(my.Fg0, R0); /* (explicit statements: asm order = source order) */
+        const float d_g1 = dpp_sub<1>(my.Fg1, R0);
+        f_g = min_raw(d_g0, d_g1);
+        f_on = dpp_sub<2>(my.Fon[0], R0);
+    } else {
+        f_on = dpp_sub_first<2>(my.Fon[0], R0);
+    }
+    {
+        const float a1 = dpp_sub<3>(my.Fon[1], R0), a2 = dpp_sub<4>(my.Fon[2], R0);
+        f_on = min3_raw(f_on, a1, a2);
+        const float a3 = dpp_sub<5>(my.Fon[3], R0), a4 = dpp_sub<6>(my.Fon[4], R0);
+        f_on = min3_raw(f_on, a3, a4);
+        const float a5 = dpp_sub<7>(my.Fon[5], R0), a6 = dpp_sub<8>(my.Fon[6], R0);
+        f_on = min3_raw(f_on, a5, a6);
+        f_on = min_raw(f_on, dpp_sub<9>(my.Fon[7], R0));
+    }
     float f_oi = dpp_sub<10>(my.Foi[0], R0);
-    f_oi = __builtin_fminf(f_oi, dpp_sub<11>(my.Foi[1], R0));
-    f_oi = __builtin_fminf(f_oi, dpp_sub<12>(my.Foi[2], R0));
-    f_oi = __builtin_fminf(f_oi, dpp_sub<13>(my.Foi[3], R0));
-    f_oi = __builtin_fminf(f_oi, dpp_sub<14>(my.Foi[4], R0));
-    f_oi = __builtin_fminf(f_oi, dpp_sub<15>(my.Foi[5], R0));
-    f_oi = __builtin_fminf(f_oi, dpp_sub<0>(my.Foi[6], R1));
-    f_oi = __builtin_fminf(f_oi, dpp_sub<1>(my.Foi[7], R1));
-    const float f_sky = dpp_sub<2>(my.Fsky, R1);
+    {
+        const float a1 = dpp_sub<11>(my.Foi[1], R0), a2 = dpp_sub<12>(my.Foi[2], R0);
+        f_oi = min3_raw(f_oi, a1, a2);
+        const float a3 = dpp_sub<13>(my.Foi[3], R0), a4 = dpp_sub<14>(my.Foi[4], R0);
+        f_oi = min3_raw(f_oi, a3, a4);
+        const float a5 = dpp_sub<15>(my.Foi[5], R0), a6 = dpp_sub<0>(my.Foi[6], R1);
+        f_oi = min3_raw(f_oi, a5, a6);
+        f_oi = min_raw(f_oi, dpp_sub<1>(my.Foi[7], R1));
+    }
+    float f_sky = 0.0f;
+    if (WANT & IS_WANT_SKY) f_sky = dpp_sub<2>(my.Fsky, R1);
     const float meanx = dpp_sub<8>(my.MX, R1);
     const float meany = dpp_sub<9>(my.MY, R1);
     const float d_x2h = dpp_sub<10>(my.MX2h, R1);
@@ -465,10 +500,12 @@ __device__ __forceinline__ SegTerms eval_segment_dpp(const RowRec& my, float R0,
     t.seg_g = f_g + nic;
     const float on = nic + f_on;
     const float oi = ic + f_oi;
-    t.seg_o = __builtin_fminf(oi, on);
+    t.seg_o = min_raw(oi, on); /* both finite in a FAST column */
     t.seg_s = f_sky + nic;
-    t.gd = dpp_sub<4>(my.G, R1);
-    t.sd = dpp_sub<5>(my.K, R1);
+    t.gd = 0.0f;
+    t.sd = 0.0f;
+    if (WANT & IS_WANT_GROUND) t.gd = dpp_sub<4>(my.G, R1);
+    if (WANT & IS_WANT_SKY) t.sd = dpp_sub<5>(my.K, R1);
     float mean;
     if (HAS_INVALID) {
         const float valid_dif = dpp_sub<7>(my.V, R1);

@@ -82,6 +82,37 @@ __global__ __launch_bounds__(512) void k_cvt_f32_f64(float* out, int n) {
     }
     out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3;
 }
+// EXEC-masked variants: does the SIMD skip a 32-lane half (or more) whose EXEC bits are all zero?
+#define MASK_KERNEL(NAME, MASK)                                                               \
+__global__ __launch_bounds__(512) void NAME(float* out, int n) {                              \
+    float a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, b = blockIdx.x;             \
+    asm volatile("s_mov_b64 exec, %0" : : "s"((unsigned long long)(MASK)));                    \
+    for (int i = 0; i < n; i++) {                                                              \
+        _Pragma("unroll") for (int u = 0; u < UNROLL; u++) {                                   \
+            asm volatile("v_add_f32 %0, %0, %4\n v_add_f32 %1, %1, %4\n v_add_f32 %2, %2, %4\n v_add_f32 %3, %3, %4" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b)); \
+        }                                                                                      \
+    }                                                                                          \
+    asm volatile("s_mov_b64 exec, -1");                                                        \
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3;                            \
+}
+MASK_KERNEL(k_add_lo32, 0x00000000FFFFFFFFull)
+MASK_KERNEL(k_add_hi32, 0xFFFFFFFF00000000ull)
+MASK_KERNEL(k_add_lo16, 0x000000000000FFFFull)
+MASK_KERNEL(k_add_one, 0x1ull)
+#define MASK_KERNEL4(NAME, MASK)                                                              \
+__global__ __launch_bounds__(512) void NAME(float* out, int n) {                              \
+    float a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, b = blockIdx.x;             \
+    asm volatile("s_mov_b64 exec, %0" : : "s"((unsigned long long)(MASK)));                    \
+    for (int i = 0; i < n; i++) {                                                              \
+        _Pragma("unroll") for (int u = 0; u < UNROLL; u++) {                                   \
+            asm volatile("v_min_f32 %0, %0, %4\n v_min_f32 %1, %1, %4\n v_min_f32 %2, %2, %4\n v_min_f32 %3, %3, %4" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b)); \
+        }                                                                                      \
+    }                                                                                          \
+    asm volatile("s_mov_b64 exec, -1");                                                        \
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3;                            \
+}
+MASK_KERNEL4(k_min_lo32, 0x00000000FFFFFFFFull)
+MASK_KERNEL4(k_min_hi32, 0xFFFFFFFF00000000ull)
 template <class K> void run(const char* name, K k, float* d, double ghz) {
     const int blocks = 256 * 4, threads = 512;  // 8 waves per SIMD
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -110,5 +141,8 @@ int main() {
     run("v_lshl_add_u32", k_lshl_add, d, ghz); run("v_max_f32", k_max_f32, d, ghz);
     run("v_subrev_f32 sgpr", k_sub_f32_sgpr, d, ghz); run("v_mov_b32", k_mov, d, ghz);
 
+    run("v_add_f32 exec lo32", k_add_lo32, d, ghz); run("v_add_f32 exec hi32", k_add_hi32, d, ghz);
+    run("v_add_f32 exec lo16", k_add_lo16, d, ghz); run("v_add_f32 exec 1 lane", k_add_one, d, ghz);
+    run("v_min_f32 exec lo32", k_min_lo32, d, ghz); run("v_min_f32 exec hi32", k_min_hi32, d, ghz);
     return 0;
 }
