@@ -372,7 +372,7 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
          * PruneRec: same monotonicity argument as in the unary kernel (is_k_unary.hip). */
         if (w <= vB_last) {
             cprune_t pq = (cprune_t)prec;
-            const float E1o = pq->E1o, E2 = pq->E2;
+            const float E1o = pq->E1o, E2 = 3.0f * pq->E2; /* see seg_o_lower_bound */
             const float E1gs = __builtin_fmaxf(pq->E1g, pq->E1s);
             const unsigned long long dead = ~__builtin_amdgcn_ballot_w64(live);
             const unsigned long long gdead = dead | __builtin_amdgcn_ballot_w64(my.G == IS_INF);
@@ -452,7 +452,7 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
                 od = my_tile[t.fni] - pick_lut<NR>(row, t.fni);                                    \
             }                                                                                      \
             pairwise_step<SKY, true, NOG, true>(P, st, vB, live, od, t, b);                        \
-            const float lb_o = (st.q_o - E1o) + P.sw * min_raw(t.f_on, t.f_oi - E2);              \
+            const float lb_o = (st.q_o - E1o) + P.sw * seg_o_lower_bound(t, E2);                   \
             const bool ok_o = (__builtin_amdgcn_ballot_w64(lb_o > b.o) | dead) == ~0ull
             /* ground / sky candidates of up to four vB (vB, vB - nw, ...) >= lo; closes `x_closed`
              * when the bound of the last one holds; leaves vB at the next unvisited value */
@@ -473,7 +473,8 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
                     c_f[j] = (SKY) ? (my.Fsky - rq->Fsky)                                          \
                                    : __builtin_fminf(my.Fg0 - rq->Fg0, my.Fg1 - rq->Fg1);         \
                     const float data = (SKY) ? (my.K - rq->K) : (my.G - rq->G);                    \
-                    c_cost[j] = P.dw * data + sq->pwmp + P.sw * (c_f[j] + nic);                    \
+                    c_f[j] += nic; /* f + nic: also monotone (lemma L2), and part of the cost */   \
+                    c_cost[j] = P.dw * data + sq->pwmp + P.sw * c_f[j];                            \
                     c_idx[j] = sq->idx_gs;                                                         \
                     c_q[j] = sq->q_gs;                                                             \
                 }                                                                                  \
@@ -493,7 +494,7 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
             const int sky_lo = max(vhor + 1, 1);
             for (; vB >= sky_lo; vB -= nw) { /* sky range: vB - 1 >= vhor */
                 IS_P1_STEP(true, false);
-                const float lb_s = (st.q_gs - E1gs) + P.sw * t.f_sky;
+                const float lb_s = (st.q_gs - E1gs) + P.sw * t.seg_s;
                 const bool ok_s = (__builtin_amdgcn_ballot_w64(lb_s > b.s) | dead) == ~0ull;
                 if (ok_o && ok_s) { done = true; break; }
                 if (ok_o) { o_closed = true; vB -= nw; break; }
@@ -513,7 +514,7 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
             } else if (!done) {
                 for (; vB >= 1; vB -= nw) { /* ground range: vB - 1 < vhor */
                     IS_P1_STEP(false, false);
-                    const float lb_g = (st.q_gs - E1gs) + P.sw * t.f_g;
+                    const float lb_g = (st.q_gs - E1gs) + P.sw * t.seg_g;
                     const bool ok_g = (__builtin_amdgcn_ballot_w64(lb_g > b.g) | gdead) == ~0ull;
                     if (ok_o && ok_g) { done = true; break; }
                     if (ok_o) { o_closed = true; vB -= nw; break; }

@@ -101,7 +101,7 @@ __device__ __forceinline__ SegTerms fast_step(const DevParams& P, const RowRec& 
 }
 
 struct PruneValsF {
-    float E1o, E1g, E1s, E2;
+    float E1o, E1g, E1s, E2; /* E2: three times PruneRec.E2, see seg_o_lower_bound */
     unsigned long long dead;  /* lanes with vT >= H: never stored                            */
     unsigned long long gdead; /* dead, or the ground data term of the lane is +inf for good   */
 };
@@ -111,14 +111,14 @@ struct PruneValsF {
 template <bool SKY, bool NOGROUND>
 __device__ __forceinline__ int fast_bounds(const DevParams& P, const PruneValsF& pv, const SegTerms& t,
                                            const UnaryBestF& b) {
-    const float lb_o = P.sw * min_raw(t.f_on, t.f_oi - pv.E2) - pv.E1o;
+    const float lb_o = P.sw * seg_o_lower_bound(t, pv.E2) - pv.E1o; /* (pv.E2 holds 3 * PruneRec.E2) */
     const bool ok_o = (__builtin_amdgcn_ballot_w64(lb_o > b.o) | pv.dead) == ~0ull;
     bool ok_x = true;
     if (SKY) {
-        const float lb_s = P.sw * t.f_sky - pv.E1s;
+        const float lb_s = P.sw * t.seg_s - pv.E1s;
         ok_x = (__builtin_amdgcn_ballot_w64(lb_s > b.s) | pv.dead) == ~0ull;
     } else if (!NOGROUND) {
-        const float lb_g = P.sw * t.f_g - pv.E1g;
+        const float lb_g = P.sw * t.seg_g - pv.E1g;
         ok_x = (__builtin_amdgcn_ballot_w64(lb_g > b.g) | pv.gdead) == ~0ull;
     }
     return (ok_o ? 1 : 0) | (ok_x ? 2 : 0);
@@ -141,16 +141,18 @@ __device__ __forceinline__ bool fast_step_gs(const DevParams& P, const PruneVals
     const float pwih = P.pw * r;
     if (SKY) {
         const float f = my.Fsky - q.z;
-        const float cost = P.dw * (my.K - gk.y) + pwih + P.sw * (f + nic);
+        const float seg = f + nic;
+        const float cost = P.dw * (my.K - gk.y) + pwih + P.sw * seg;
         take_if_le(b.s, b.vs, cost, vB);
-        const float lb = P.sw * f - pv.E1s;
+        const float lb = P.sw * seg - pv.E1s;
         return (__builtin_amdgcn_ballot_w64(lb > b.s) | pv.dead) == ~0ull;
     } else {
         const float2 g01 = *reinterpret_cast<const float2*>(rec);
         const float f = __builtin_fminf(my.Fg0 - g01.x, my.Fg1 - g01.y);
-        const float cost = P.dw * (my.G - gk.x) + pwih + P.sw * (f + nic);
+        const float seg = f + nic;
+        const float cost = P.dw * (my.G - gk.x) + pwih + P.sw * seg;
         take_if_le(b.g, b.vg, cost, vB);
-        const float lb = P.sw * f - pv.E1g;
+        const float lb = P.sw * seg - pv.E1g;
         return (__builtin_amdgcn_ballot_w64(lb > b.g) | pv.gdead) == ~0ull;
     }
 }
@@ -252,7 +254,7 @@ __global__ __launch_bounds__(ISF_THREADS, HAS_INVALID ? ISF_OCC_INV : ISF_OCC) v
     PruneValsF pv;
     {
         cprune_t pq = (cprune_t)(prune + colg);
-        pv.E1o = pq->E1o; pv.E1g = pq->E1g; pv.E1s = pq->E1s; pv.E2 = pq->E2;
+        pv.E1o = pq->E1o; pv.E1g = pq->E1g; pv.E1s = pq->E1s; pv.E2 = 3.0f * pq->E2;
         pv.dead = ~__builtin_amdgcn_ballot_w64(row_ok);
         pv.gdead = pv.dead | __builtin_amdgcn_ballot_w64(my.G == IS_INF);
     }

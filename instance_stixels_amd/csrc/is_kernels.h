@@ -63,6 +63,10 @@ struct SegTerms {
     /* float(min_c DownsampledSum_c) of the class groups: non-decreasing when the segment grows
      * in a FAST column (class values >= 0) -- the lower bounds of the branch-and-bound */
     float f_g, f_on, f_oi, f_sky;
+    /* also non-decreasing when the segment grows (lemmas L2 / L4): on = nic +
+     * f_on exactly (nic: iw * float(exact non-negative integer sum)), the instance term ic up to
+     * its rounding error (a sum of squared deviations only grows) */
+    float on, ic;
 };
 
 /* v_cvt_u32_f32: round toward zero, saturating (negative -> 0, NaN -> 0) */
@@ -153,6 +157,7 @@ __device__ __forceinline__ SegTerms eval_segment(const RowRec& my, const RowRec&
     t.seg_g = f_g + nic;
     const float on = nic + f_on;
     const float oi = ic + f_oi;
+    t.on = on; t.ic = ic;
     t.seg_o = FAST ? __builtin_fminf(oi, on) : ((oi < on) ? oi : on); /* both finite when FAST */
     t.seg_s = f_sky + nic;
 
@@ -441,6 +446,15 @@ __device__ __forceinline__ float min3_raw(float a, float b, float c) {
     return d;
 }
 
+/* Lower bound of the object semantic term seg_o(vB', vT) for every vB' <= vB from the terms of
+ * (vB, vT): min(on, fl(fl(ic - 3 E2) + f_oi)), E2 >= |computed ic - real ic| (PruneRec).  3 E2:
+ * 2 E2 for the two rounding errors, one more for the rounding of the subtraction itself (an ulp
+ * of ic is below E2 / 4). */
+__device__ __forceinline__ float seg_o_lower_bound(const SegTerms& t, float E2x3) {
+    return min_raw(t.on, (t.ic - E2x3) + t.f_oi);
+}
+
+
 /* what a step needs besides the object terms: the ground candidate's, the sky candidate's, both
  * (the first segment of the pairwise model, generic callers) or neither (tiles above the horizon) */
 #define IS_WANT_GROUND 1
@@ -500,6 +514,7 @@ __device__ __forceinline__ SegTerms eval_segment_dpp(const RowRec& my, float R0,
     t.seg_g = f_g + nic;
     const float on = nic + f_on;
     const float oi = ic + f_oi;
+    t.on = on; t.ic = ic;
     t.seg_o = min_raw(oi, on); /* both finite in a FAST column */
     t.seg_s = f_sky + nic;
     t.gd = 0.0f;
