@@ -17,9 +17,10 @@ struct __attribute__((aligned(64))) StepRec {
     float o_hi_thr, o_lo_thr;   /* pm + dif, pm - dif                                 :159, 163 */
     float p2_hi, p2_lo, p2_mid; /* cO + pw * GetPriorCostObjectFromObject, three cases :146-171 */
     float p3_yes, p3_no;        /* cS + pw * GetPriorCostObjectFromSky, fn > eps or not :173-183 */
-    /* branch-and-bound (DESIGN.md "Pruning"): running minima over vB' <= vB (and the first-segment
-     * priors of vB' = 0) of what a segment starting at vB' adds before its own data / semantic
-     * terms: q_o = pw * (smallest of the eight p fields), q_gs = pwmp */
+    /* branch-and-bound (DESIGN.md "Pruning"): running minima over the rows vB' <= vB of the SAME
+     * 64-row block (= the StepRecs one phase-2 launch builds) of what a segment starting at vB'
+     * adds before its own data / semantic terms: q_o = pw * (smallest of the eight p fields),
+     * q_gs = pwmp */
     float q_o, q_gs;
 };
 static_assert(sizeof(StepRec) == 64, "StepRec must be 64 bytes");
@@ -364,12 +365,73 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
     const int lane4 = lane * 4;
     const unsigned scr = lds_addr(s_scr + 8 * wl);
     if (FAST && IS_PRUNE) {
-        /* FAST columns: vB downwards with the exact branch-and-bound of DESIGN.md "Pruning".  A
-         * candidate vB' <= vB of lane vT costs at least
-         *     fl(fl(Q[vB] - E1) + fl(sw * m))      m = the class-group minimum of (vB, vT)
-         * where Q[vB] (StepRec.q_o / q_gs) is the smallest transition term pw * min_prev any
-         * vB' <= vB can contribute (running minimum kept by phase 2) and E1 / E2 are the slacks of
-         * PruneRec: same monotonicity argument as in the unary kernel (is_k_unary.hip). */
+        /* FAST columns: vB downwards with the exact branch-and-bound of DESIGN.md "Pruning".  The
+         * candidates of a tile fall into BLOCKS: block k >= 1 = the vB values 64 (k-1) + 1 .. 64 k
+         * whose StepRecs phase 2 of tile k - 1 built, block 0 = the first segment vB = 0.  A
+         * candidate vB' of block k with vB' <= vB costs lane vT at least
+         *     fl(fl(q[vB] - E1) + fl(sw * m(vB, vT)))      (same block as vB)
+         *     fl(fl(q[64 k] - E1) + fl(sw * m(64 k, vT)))  (lower block, from its TOP row)
+         * m = the monotone semantic term of the type (seg_g / seg_s / seg_o_lower_bound), q =
+         * StepRec.q_o / q_gs = the smallest transition term pw * min_prev of the block's rows up to
+         * vB (phase 2 restarts the running minimum with every tile, so q[64 k] is the minimum of
+         * the whole block), E1 / E2 the slacks of PruneRec: the monotonicity argument of the unary
+         * kernel, block by block.  The accumulated path cost inside q grows with vB, so a bound
+         * that may use the block's own q instead of the minimum over ALL lower rows closes a type a
+         * few rows below the region of the lane instead of vT / 16 rows further down.
+         *
+         * Pre-pass: the waves evaluate the semantic terms at the tops of all lower blocks (at most
+         * tile values of vB, no LUT access, no update) and leave, per type and block k, the
+         * smallest bound of the blocks BELOW k in LDS (s_lb); the walk closes a type for good when
+         * the bound of its own block and that entry both exceed the lane's best cost. */
+        float* s_lb = s_scr + 8 * nwl; /* [3 types][tile + 1][64 lanes] */
+        const int NLB = tile + 1;
+        {
+            cprune_t pq0 = (cprune_t)prec;
+            const float pE1o = pq0->E1o, pE2 = 3.0f * pq0->E2;
+            const float pE1gs = __builtin_fmaxf(pq0->E1g, pq0->E1s);
+            const bool pnog = IS_SKIP_GROUND_ABOVE_HORIZON && tile_lo >= vhor;
+            for (int k = wl; k < tile; k += nwl) { /* top of block k: vB = 64 k */
+                const int vBk = k * IS_TILE;
+                const RowRec rb = sload_rec(rcol + vBk);
+                const int h = vTc + 1 - vBk;
+                const SegTerms t = eval_segment<true, HAS_INVALID>(my, rb, (float)h, s_rcp[h], D, P.iw);
+                float q_o, q_gs;
+                if (k == 0) { /* the first segment's priors, :189-199 */
+                    q_o = P.pw * __builtin_fminf(P.first_o_below, P.first_o_above);
+                    q_gs = P.pw * P.first_g;
+                } else {
+                    cstep_t sq = (cstep_t)(scol + vBk);
+                    q_o = sq->q_o;
+                    q_gs = sq->q_gs;
+                }
+                /* ground candidates: rows with vB - 1 < vhor, sky candidates: vB - 1 >= vhor */
+                const bool has_g = !pnog && (k == 0 || vBk - IS_TILE < vhor);
+                const bool has_s = k >= 1 && vBk >= vhor + 1;
+                float lb_o = (q_o - pE1o) + P.sw * seg_o_lower_bound(t, pE2);
+                float lb_g = has_g ? (q_gs - pE1gs) + P.sw * t.seg_g : IS_INF;
+                float lb_s = has_s ? (q_gs - pE1gs) + P.sw * t.seg_s : IS_INF;
+                /* a NaN bound (inf - inf with the pruning switched off, NaN inputs) must never
+                 * close anything: -inf */
+                lb_o = (lb_o == lb_o) ? lb_o : -IS_INF;
+                lb_g = (lb_g == lb_g) ? lb_g : -IS_INF;
+                lb_s = (lb_s == lb_s) ? lb_s : -IS_INF;
+                s_lb[(0 * NLB + k) * 64 + lane] = lb_o;
+                s_lb[(1 * NLB + k) * 64 + lane] = lb_g;
+                s_lb[(2 * NLB + k) * 64 + lane] = lb_s;
+            }
+            __syncthreads();
+            if (tid < 3 * 64) { /* entry k <- smallest bound of the blocks below k */
+                float* q = s_lb + (size_t)(tid >> 6) * NLB * 64 + lane;
+                float run = IS_INF;
+                for (int k = 0; k < tile; k++) {
+                    const float v = q[k * 64];
+                    q[k * 64] = run;
+                    run = (v < run) ? v : run;
+                }
+                q[tile * 64] = run;
+            }
+            __syncthreads();
+        }
         if (w <= vB_last) {
             cprune_t pq = (cprune_t)prec;
             const float E1o = pq->E1o, E2 = 3.0f * pq->E2; /* see seg_o_lower_bound */
@@ -452,7 +514,8 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
                 od = my_tile[t.fni] - pick_lut<NR>(row, t.fni);                                    \
             }                                                                                      \
             pairwise_step<SKY, true, NOG, true>(P, st, vB, live, od, t, b);                        \
-            const float lb_o = (st.q_o - E1o) + P.sw * seg_o_lower_bound(t, E2);                   \
+            const float* lbp = s_lb + ((vB + 63) >> 6) * 64 + lane; /* (vB >= 1) */                \
+            const float lb_o = min_raw((st.q_o - E1o) + P.sw * seg_o_lower_bound(t, E2), lbp[0]);  \
             const bool ok_o = (__builtin_amdgcn_ballot_w64(lb_o > b.o) | dead) == ~0ull
             /* ground / sky candidates of up to four vB (vB, vB - nw, ...) >= lo; closes `x_closed`
              * when the bound of the last one holds; leaves vB at the next unvisited value */
@@ -486,7 +549,9 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
                         f_last = c_f[j]; q_last = c_q[j];                                          \
                     }                                                                              \
                 }                                                                                  \
-                const float lb_x = (q_last - E1gs) + P.sw * f_last;                                \
+                const int vb_l = vB - (n_here - 1) * nw; /* the lowest vB just evaluated */      \
+                const float lb_x = min_raw((q_last - E1gs) + P.sw * f_last,                        \
+                                           s_lb[(((SKY) ? 2 : 1) * NLB + ((vb_l + 63) >> 6)) * 64 + lane]); \
                 if ((__builtin_amdgcn_ballot_w64(lb_x > ((SKY) ? b.s : b.g)) | (x_dead)) == ~0ull) \
                     x_closed = true;                                                               \
                 vB -= n_here * nw;                                                                 \
@@ -494,7 +559,7 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
             const int sky_lo = max(vhor + 1, 1);
             for (; vB >= sky_lo; vB -= nw) { /* sky range: vB - 1 >= vhor */
                 IS_P1_STEP(true, false);
-                const float lb_s = (st.q_gs - E1gs) + P.sw * t.seg_s;
+                const float lb_s = min_raw((st.q_gs - E1gs) + P.sw * t.seg_s, lbp[2 * NLB * 64]);
                 const bool ok_s = (__builtin_amdgcn_ballot_w64(lb_s > b.s) | dead) == ~0ull;
                 if (ok_o && ok_s) { done = true; break; }
                 if (ok_o) { o_closed = true; vB -= nw; break; }
@@ -514,7 +579,7 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
             } else if (!done) {
                 for (; vB >= 1; vB -= nw) { /* ground range: vB - 1 < vhor */
                     IS_P1_STEP(false, false);
-                    const float lb_g = (st.q_gs - E1gs) + P.sw * t.seg_g;
+                    const float lb_g = min_raw((st.q_gs - E1gs) + P.sw * t.seg_g, lbp[NLB * 64]);
                     const bool ok_g = (__builtin_amdgcn_ballot_w64(lb_g > b.g) | gdead) == ~0ull;
                     if (ok_o && ok_g) { done = true; break; }
                     if (ok_o) { o_closed = true; vB -= nw; break; }
@@ -809,16 +874,9 @@ __device__ __forceinline__ void pw_phase2_body(const DevParams& P, char* smem, i
     st.pwmp = IS_INF; st.idx_gs = -1;
     st.g_hi_thr = st.g_lo_thr = st.p1_hi = st.p1_lo = st.p1_mid = st.o_hi_thr = st.o_lo_thr = 0.0f;
     st.p2_hi = st.p2_lo = st.p2_mid = st.p3_yes = st.p3_no = 0.0f;
-    /* running minima of the transition terms (StepRec.q_o / q_gs): continue the previous tile's */
-    float q_o, q_gs;
-    if (tile_lo == 0) {
-        q_o = P.pw * __builtin_fminf(P.first_o_below, P.first_o_above); /* vB' = 0, :189-194 */
-        q_gs = P.pw * P.first_g;                                         /* :196-199 */
-    } else {
-        cstep_t prev = (cstep_t)(scol + tile_lo);
-        q_o = prev->q_o;
-        q_gs = prev->q_gs;
-    }
+    /* running minima of the transition terms (StepRec.q_o / q_gs) over the rows of THIS tile:
+     * phase 1 bounds block by block (see pw_phase1_body) */
+    float q_o = IS_INF, q_gs = IS_INF;
     st.q_o = q_o; st.q_gs = q_gs;
     int ob_cached = -1;
     float S_obc = 0.0f, V_obc = 0.0f;
@@ -1093,15 +1151,7 @@ __device__ __forceinline__ void pw_phase2s_body(const DevParams& P, char* smem, 
         st.pwmp = IS_INF; st.idx_gs = -1;
         st.g_hi_thr = st.g_lo_thr = st.p1_hi = st.p1_lo = st.p1_mid = st.o_hi_thr = st.o_lo_thr = 0.0f;
         st.p2_hi = st.p2_lo = st.p2_mid = st.p3_yes = st.p3_no = 0.0f;
-        float q_o, q_gs;
-        if (tile_lo == 0) {
-            q_o = P.pw * __builtin_fminf(P.first_o_below, P.first_o_above);
-            q_gs = P.pw * P.first_g;
-        } else {
-            cstep_t prev = (cstep_t)(scol + tile_lo);
-            q_o = prev->q_o;
-            q_gs = prev->q_gs;
-        }
+        float q_o = IS_INF, q_gs = IS_INF; /* (per tile, see pw_phase2_body) */
         st.q_o = q_o; st.q_gs = q_gs;
         int ob_cached = -1;
         float S_obc = 0.0f, V_obc = 0.0f;
@@ -1230,7 +1280,9 @@ size_t isk_pairwise_lds_bytes(const DevParams* P, int nwaves) {
     const size_t rcp = sizeof(float) * (((size_t)P->H + 1 + 3) & ~(size_t)3);
     const size_t tile = sizeof(float) * (size_t)IS_TILE * (P->D + 1);
     const size_t merge = (size_t)nwaves * 3 * 64 * 8; /* aliases the tile after the loop */
-    return (tile > merge ? tile : merge) + rcp + sizeof(float) * 8 * (size_t)nwaves + 16;
+    /* + the block bounds of the pre-pass: [3][ntiles + 1][64] (a launch of tile t uses t + 1 entries) */
+    return (tile > merge ? tile : merge) + rcp + sizeof(float) * 8 * (size_t)nwaves +
+           sizeof(float) * 3 * 64 * ((size_t)P->ntiles + 1) + 16;
 }
 size_t isk_phase2_lds_bytes(const DevParams* P) {
     size_t need = sizeof(double) * 2 * IS_LOG_TABLE_SIZE +
@@ -1288,11 +1340,11 @@ hipError_t isk_launch_dp_pairwise(const DevParams* P, int ncols, int nwaves, con
     do {                                                                                           \
         if (IS_PW_PHASE1_ROW_REGS && P->D <= 128)                                                  \
             hipLaunchKernelGGL((k_pw_phase1<INV, 2>), dim3(((c1) - (c0)) * nsplit),                \
-                               dim3(nwaves * 64), lds1, st, *P, c0, c1, tile, nsplit, recs, lutT,  \
+                               dim3(nwaves * 64), lds1_t, st, *P, c0, c1, tile, nsplit, recs, lutT,  \
                                steps, rcp, vhor, col_flags, prune, part_cost, part_idx, counters); \
         else                                                                                       \
             hipLaunchKernelGGL((k_pw_phase1<INV, 0>), dim3(((c1) - (c0)) * nsplit),                \
-                               dim3(nwaves * 64), lds1, st, *P, c0, c1, tile, nsplit, recs, lutT,  \
+                               dim3(nwaves * 64), lds1_t, st, *P, c0, c1, tile, nsplit, recs, lutT,  \
                                steps, rcp, vhor, col_flags, prune, part_cost, part_idx, counters); \
     } while (0)
 #define IS_LAUNCH_P2(INV, c0, c1, st)                                                              \
@@ -1318,6 +1370,8 @@ hipError_t isk_launch_dp_pairwise(const DevParams* P, int ncols, int nwaves, con
             if ((e = hipStreamWaitEvent(aux[g - 1], ev_fork, 0)) != hipSuccess) return e;
     }
     for (int tile = 0; tile < P->ntiles; tile++) {
+        /* (the block bounds of tile t need t + 1 of the ntiles + 1 entries lds1 has room for) */
+        const size_t lds1_t = lds1 - sizeof(float) * 3 * 64 * (size_t)(P->ntiles - tile);
         for (int g = 0; g < groups; g++) {
             const int c0 = (int)((long long)ncols * g / groups);
             const int c1 = (int)((long long)ncols * (g + 1) / groups);
