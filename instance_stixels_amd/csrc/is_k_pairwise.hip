@@ -109,11 +109,13 @@ __device__ __forceinline__ PriorVals sload_prior(const PriorRec* p) {
     return v;
 }
 
+/* rcp_h: RN(1 / (r + 1 - obj_vB)) for the exact-division shortcut of FAST columns (fast_div,
+ * is_kernels.h: the prefix difference is 0 or within [2^-84, 2^75] there), 0 = IEEE division */
 template <bool HAS_INVALID>
 __device__ __forceinline__ StepVals make_step(const DevParams& P, float S_r1, float V_r1, float S_ob,
                                              float V_ob, const float* s_odr, const double* s_invc,
                                              const double* s_logc, const PriorVals* pr, int vhor, int r,
-                                             float cG, float cO, float cS, int obj_vB) {
+                                             float cG, float cO, float cS, int obj_vB, float rcp_h = 0.0f) {
     const int vB = r + 1;
     const float pw = P.pw;
     StepVals st;
@@ -123,6 +125,8 @@ __device__ __forceinline__ StepVals make_step(const DevParams& P, float S_r1, fl
     if (HAS_INVALID) {
         const float valid_dif = V_r1 - V_ob;
         pm = (valid_dif == 0) ? 0 : (S_r1 - S_ob) / valid_dif;
+    } else if (rcp_h != 0.0f) {
+        pm = fast_div(S_r1 - S_ob, (float)(r + 1 - obj_vB), rcp_h);
     } else {
         pm = (S_r1 - S_ob) / (float)(r + 1 - obj_vB);
     }
@@ -133,13 +137,13 @@ __device__ __forceinline__ StepVals make_step(const DevParams& P, float S_r1, fl
         const float prev_cost = pr->g_from;
         const float p1 = cG + pw * prev_cost;
         const float p2 = cO + pw * prev_cost;
-        st.pwmp = pw * __builtin_fminf(p1, p2);
+        st.pwmp = pw * min_raw(p1, p2); /* (computed values: quiet NaNs only, see min_raw) */
         st.idx_gs = vB * 3 + ((p1 < p2) ? IS_GROUND : IS_OBJECT);
     } else { /* sky, :729-775 */
         const float p1 = cG + pw * pr->s_from_g;
         const float so = (pm < P.epsilon) ? IS_INF : (P.log2c + pc); /* :88-96 */
         const float p2 = cO + pw * so;
-        st.pwmp = pw * __builtin_fminf(p1, p2);
+        st.pwmp = pw * min_raw(p1, p2);
         st.idx_gs = vB * 3 + ((p1 < p2) ? IS_GROUND : IS_OBJECT);
     }
     /* object from ground, :120-144 */
@@ -431,6 +435,7 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
                 q[tile * 64] = run;
             }
             __syncthreads();
+            ISP1_MARK(6); /* (debug build: the pre-pass) */
         }
         if (w <= vB_last) {
             cprune_t pq = (cprune_t)prec;
@@ -934,16 +939,20 @@ __device__ __forceinline__ void pw_phase2_body(const DevParams& P, char* smem, i
                 }
                 S_ob = S_obc; V_ob = V_obc;
             }
+            float rcp_h = 0.0f; /* RN(1 / h) of the chain's height for the exact-division shortcut */
+            if (FAST && !HAS_INVALID) {
+                typedef const __attribute__((address_space(4))) float* cflt_t;
+                rcp_h = *(cflt_t)(rcp + min(max(r + 1 - ob, 1), H));
+            }
             ISP2_MARK(5); /* broadcasts */
             st = make_step<HAS_INVALID>(P, S_r1, V_r1, S_ob, V_ob, s_odr, s_invc, s_logc, &pv, vhor, r,
-                                        cG, cO, cS, ob);
+                                        cG, cO, cS, ob, rcp_h);
             ISP2_MARK(6); /* make_step */
             /* fminf skips NaN fields: a candidate that selects one costs NaN and never wins */
-            const float m8 = __builtin_fminf(
-                __builtin_fminf(__builtin_fminf(st.p1_hi, st.p1_lo), __builtin_fminf(st.p1_mid, st.p2_hi)),
-                __builtin_fminf(__builtin_fminf(st.p2_lo, st.p2_mid), __builtin_fminf(st.p3_yes, st.p3_no)));
-            q_o = __builtin_fminf(q_o, P.pw * m8);
-            q_gs = __builtin_fminf(q_gs, st.pwmp);
+            const float m8 = min_raw(min3_raw(st.p1_hi, st.p1_lo, st.p1_mid),
+                                     min3_raw(min3_raw(st.p2_hi, st.p2_lo, st.p2_mid), st.p3_yes, st.p3_no));
+            q_o = min_raw(q_o, P.pw * m8);
+            q_gs = min_raw(q_gs, st.pwmp);
             st.q_o = q_o; st.q_gs = q_gs;
             if (lane == 0 && r + 1 < H) store_step(scol + r + 1, st);
             ISP2_MARK(7); /* running minima + store */
@@ -1198,11 +1207,10 @@ __device__ __forceinline__ void pw_phase2s_body(const DevParams& P, char* smem, 
                 }
                 st = make_step<HAS_INVALID>(P, S_r1, V_r1, S_ob, V_ob, s_odr, s_invc, s_logc, &pv, vhor, r,
                                             cG, cO, cS, ob);
-                const float m8 = __builtin_fminf(
-                    __builtin_fminf(__builtin_fminf(st.p1_hi, st.p1_lo), __builtin_fminf(st.p1_mid, st.p2_hi)),
-                    __builtin_fminf(__builtin_fminf(st.p2_lo, st.p2_mid), __builtin_fminf(st.p3_yes, st.p3_no)));
-                q_o = __builtin_fminf(q_o, P.pw * m8);
-                q_gs = __builtin_fminf(q_gs, st.pwmp);
+                const float m8 = min_raw(min3_raw(st.p1_hi, st.p1_lo, st.p1_mid),
+                                         min3_raw(min3_raw(st.p2_hi, st.p2_lo, st.p2_mid), st.p3_yes, st.p3_no));
+                q_o = min_raw(q_o, P.pw * m8);
+                q_gs = min_raw(q_gs, st.pwmp);
                 st.q_o = q_o; st.q_gs = q_gs;
                 if (lane == 0 && r + 1 < H) store_step(scol + r + 1, st);
             }

@@ -224,6 +224,14 @@ def test_tall_frame_2048_rows(preset):
     _assert_parity(case, got)
 
 
+def test_config5_all_512_columns_unary():
+    """BASELINE configs[4], every one of the 512 stixel columns of a 1024x4096x256 frame in the
+    unary mode against the oracle: Sections, instance candidates and the complete DP tables."""
+    case = helpers.build_case("drn_d_22_unary", 1024, 4096, 256, seed=18)
+    got = helpers.run_core(case, want_tables=True)
+    _assert_parity(case, got)
+
+
 def test_config5_ultrawide_1024x4096x256_column_subset():
     """BASELINE configs[4] (LDS-pressure shape): every 16th column against the oracle, structure
     checks on all 512 columns."""

@@ -13,8 +13,9 @@ try:
 finally:
     L.isk_debug_p1phases(out, 1)
     v = list(out)
-    tot = sum(v[:4]) or 1
-    for n, x in zip(["prologue", "walk", "wait for the other waves", "merge"], v[:4]):
+    tot = (sum(v[:4]) + v[6]) or 1
+    for n, x in zip(["prologue", "pre-pass (block bounds)", "walk", "wait for the other waves", "merge"],
+                    [v[0], v[6], v[1], v[2], v[3]]):
         print("  %-26s %14d  %5.1f%%" % (n, x, 100.0 * x / tot))
     print("  wave 0: %d full steps, %d ground/sky rounds; ticks per round trip of the walk: %.0f"
           % (v[4], v[5], v[1] / max(1, v[4] + v[5])))
