@@ -64,6 +64,8 @@ def parse():
     ap.add_argument("--no-verify", action="store_true",
                     help="skip the oracle check of the timed output (about one CPU-second per frame)")
     ap.add_argument("--verify", action="store_true", help="(default since round 3; kept for old command lines)")
+    ap.add_argument("--no-prune-stats", action="store_true",
+                    help="skip the untimed device-counter pass (profiling runs: its atomics distort per-kernel averages)")
     ap.add_argument("--no-variants", action="store_true",
                     help="skip the extra figures (see the module docstring)")
     ap.add_argument("--min-seconds", type=float, default=2.0,
@@ -573,7 +575,7 @@ def main():
                 raise SystemExit("bench.py verify: gathered copy of rank 0 differs from its output")
 
     # ---- what the branch-and-bound evaluated (device counters, separate untimed step)
-    prune = wl.prune_stats(core) if rank == 0 else None
+    prune = wl.prune_stats(core) if (rank == 0 and not args.no_prune_stats) else None
 
     # BASELINE.json configs[1] (ONE 1024x2048 frame per call) next to the batched headline value:
     # the same entry points with n_images = 1, i.e. the latency a per-frame caller sees
@@ -663,7 +665,7 @@ def main():
                                        "sections to rank 0, overlapped with the next step")
                                       if world > 1 else "single GPU"},
             "roofline": roof,
-            "valu": {"pair_evals_per_s": pairs_img * B * prune["evaluated_frac"] / dp_s,
+            "valu": {"pair_evals_per_s": (pairs_img * B * prune["evaluated_frac"] / dp_s) if prune else None,
                      "pair_evals_per_s_nominal": pairs_img * B / dp_s,
                      "pair_evals_per_image_nominal": pairs_img,
                      "lane_ops_peak_per_s": VALU_PEAK_LANEOPS,

@@ -3,7 +3,7 @@
 # usage: tools/profile.sh <tag> [bench args...]
 set -u
 TAG=${1:-r01}; shift || true
-ARGS=${@:---batch 8 --steps 2 --warmup 1 --no-cpu-baseline}
+ARGS=${@:---batch 64 --steps 3 --warmup 1 --no-cpu-baseline --no-variants --no-single --no-d2h --no-verify --no-prune-stats --min-seconds 0}
 OUT=gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
 echo "python3 bench.py $ARGS" > $OUT/command.txt
