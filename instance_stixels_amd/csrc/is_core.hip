@@ -29,11 +29,11 @@ struct StepRec;
 hipError_t isk_launch_priors(const DevParams*, const float*, PriorRec*, int, hipStream_t);
 hipError_t isk_launch_dp_unary(const DevParams*, int, int, const RowRec*, const float*, const float*,
                                const int*, const int*, const PruneRec*, float*, int32_t*, const int*,
-                               unsigned long long*, hipStream_t);
+                               unsigned long long*, const float*, const float*, hipStream_t);
 hipError_t isk_launch_dp_pairwise(const DevParams*, int, int, const RowRec*, const float*,
                                   const float*, const PriorRec*, const float*, const float*, const float*,
                                   const int*, const int*, const PruneRec*, StepRec*, float*, int*,
-                                  float*, int32_t*, unsigned long long*,
+                                  float*, int32_t*, unsigned long long*, const float*,
                                   hipStream_t, hipStream_t*, int, hipEvent_t, hipEvent_t*);
 hipError_t isk_launch_backtrace(const DevParams*, int, int, const RowRec*, const float*,
                                 const int32_t*, const int*, is_section*, int*, hipStream_t);
@@ -565,11 +565,12 @@ int is_compute(is_ctx* c, const float* d_joined, const int32_t* d_seg, const flo
                                        d_joined, c->d_priors, c->d_odr, c->d_rcp, c->d_sv, c->d_vhor,
                                        c->d_col_flags, c->d_prune, c->d_steps, c->d_part_cost,
                                        c->d_part_idx, ct, it, c->counting ? c->d_counters : nullptr,
-                                       stream, c->aux_streams, IS_AUX_STREAMS, c->ev_fork, c->ev_joins));
+                                       c->d_obj_cost_lut, stream, c->aux_streams, IS_AUX_STREAMS, c->ev_fork, c->ev_joins));
     else
         HIP_TRY(isk_launch_dp_unary(&P, ncols, c->nwaves_unary, c->d_recs, c->d_lutT, c->d_rcp,
                                     c->d_vhor, c->d_col_flags, c->d_prune, ct, it, c->d_n_generic,
-                                    c->counting ? c->d_counters : nullptr, stream));
+                                    c->counting ? c->d_counters : nullptr, d_joined, c->d_obj_cost_lut,
+                                    stream));
     if (c->timing) HIP_TRY(hipEventRecord(c->ev[2], stream));
     bool want_inst = false, want_labels = false;
     if (instances)

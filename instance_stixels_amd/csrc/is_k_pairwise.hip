@@ -295,6 +295,9 @@ __device__ __forceinline__ void touch_round(const RowRec* rcol, const StepRec* s
 #ifndef IS_P1_DPP
 #define IS_P1_DPP 1
 #endif
+#ifndef IS_P1_GEN_TILE
+#define IS_P1_GEN_TILE 0 /* see ISF_GEN_TILE (is_k_unary_fast.hip): -8.6 GB of reads, +4 % DP time */
+#endif
 #ifdef IS_ABL_P1PHASES
 /* debug build only: s_memtime cycles of wave 0 of every phase-1 workgroup in prologue / walk /
  * waiting for the other waves / merge, plus the number of full and ground-sky rounds of wave 0 */
@@ -328,7 +331,9 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
                                                const PruneRec* __restrict__ prec,
                                                float* __restrict__ part_cost,
                                                int* __restrict__ part_idx,
-                                               unsigned long long* __restrict__ counters) {
+                                               unsigned long long* __restrict__ counters,
+                                               const float* __restrict__ joined,
+                                               const float* __restrict__ cost_T) {
     const int H = P.H, D = P.D;
     const int DP = D + 1;
     float* s_tile = (float*)smem;             /* [64][D+1] */
@@ -351,10 +356,18 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
     unsigned long long t_p1 = __builtin_readcyclecounter();
 #endif
     const int vB_last = min(tile_lo, H - 1);
-    stage_tile_and_rcp(s_tile, s_rcp, lcol, rcp, tile_lo, H, D, tid, (int)blockDim.x);
     const int vT = tile_lo + lane;
     const int vTc = min(vT, H - 1);
+#if IS_P1_GEN_TILE
+    /* the vT-side lutT rows rebuilt in LDS (gen_lut_tile, is_kernels.h) */
+    gen_lut_tile(s_tile, lcol, joined + (size_t)colg * H, cost_T, tile_lo, H, D, wl, lane, nwl);
+    asm volatile("" ::: "memory");
     const RowRec my = load_rec(rcol + vTc + 1);
+    stage_rcp(s_rcp, rcp, H, tid, (int)blockDim.x);
+#else
+    stage_tile_and_rcp(s_tile, s_rcp, lcol, rcp, tile_lo, H, D, tid, (int)blockDim.x);
+    const RowRec my = load_rec(rcol + vTc + 1);
+#endif
     const float* my_tile = s_tile + lane * DP;
     const bool live = vT < H;
     __syncthreads();
@@ -718,7 +731,8 @@ __global__ __launch_bounds__(IS_UNARY_WAVES * 64, HAS_INVALID ? ISP1_OCC_INV : I
     const StepRec* __restrict__ steps, const float* __restrict__ rcp,
     const int* __restrict__ vhor_arr, const int* __restrict__ col_flags,
     const PruneRec* __restrict__ prune, float* __restrict__ part_cost, int* __restrict__ part_idx,
-    unsigned long long* __restrict__ counters) {
+    unsigned long long* __restrict__ counters, const float* __restrict__ joined,
+    const float* __restrict__ cost_T) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int colg = col_base + (int)(blockIdx.x / (unsigned)nsplit);
     const int split = __builtin_amdgcn_readfirstlane((int)(blockIdx.x % (unsigned)nsplit));
@@ -726,10 +740,10 @@ __global__ __launch_bounds__(IS_UNARY_WAVES * 64, HAS_INVALID ? ISP1_OCC_INV : I
     const int vhor = __builtin_amdgcn_readfirstlane(vhor_arr[colg / P.C]);
     if (__builtin_amdgcn_readfirstlane(col_flags[colg]) == 0)
         pw_phase1_body<true, HAS_INVALID, NR>(P, smem, colg, tile, recs, lutT, steps, rcp, vhor, split,
-                                              nsplit, prune + colg, part_cost, part_idx, counters);
+                                              nsplit, prune + colg, part_cost, part_idx, counters, joined, cost_T);
     else
         pw_phase1_body<false, HAS_INVALID, NR>(P, smem, colg, tile, recs, lutT, steps, rcp, vhor, split,
-                                               nsplit, prune + colg, part_cost, part_idx, counters);
+                                               nsplit, prune + colg, part_cost, part_idx, counters, joined, cost_T);
 }
 
 /* ---- phase 2: the fn window --------------------------------------------------------------
@@ -1314,6 +1328,7 @@ hipError_t isk_launch_dp_pairwise(const DevParams* P, int ncols, int nwaves, con
                                   const int* col_flags, const PruneRec* prune, StepRec* steps,
                                   float* part_cost, int* part_idx, float* cost_table,
                                   int32_t* index_table, unsigned long long* counters,
+                                  const float* cost_T,
                                   hipStream_t stream, hipStream_t* aux, int n_aux,
                                   hipEvent_t ev_fork, hipEvent_t* ev_join) {
     const size_t lds1 = isk_pairwise_lds_bytes(P, nwaves);
@@ -1349,11 +1364,13 @@ hipError_t isk_launch_dp_pairwise(const DevParams* P, int ncols, int nwaves, con
         if (IS_PW_PHASE1_ROW_REGS && P->D <= 128)                                                  \
             hipLaunchKernelGGL((k_pw_phase1<INV, 2>), dim3(((c1) - (c0)) * nsplit),                \
                                dim3(nwaves * 64), lds1_t, st, *P, c0, c1, tile, nsplit, recs, lutT,  \
-                               steps, rcp, vhor, col_flags, prune, part_cost, part_idx, counters); \
+                               steps, rcp, vhor, col_flags, prune, part_cost, part_idx, counters, \
+                               joined, cost_T);                                                    \
         else                                                                                       \
             hipLaunchKernelGGL((k_pw_phase1<INV, 0>), dim3(((c1) - (c0)) * nsplit),                \
                                dim3(nwaves * 64), lds1_t, st, *P, c0, c1, tile, nsplit, recs, lutT,  \
-                               steps, rcp, vhor, col_flags, prune, part_cost, part_idx, counters); \
+                               steps, rcp, vhor, col_flags, prune, part_cost, part_idx, counters,  \
+                               joined, cost_T);                                                    \
     } while (0)
 #define IS_LAUNCH_P2(INV, c0, c1, st)                                                              \
     hipLaunchKernelGGL(k_pw_phase2<INV>, dim3((c1) - (c0)), dim3(64), lds2, st, *P, c0, c1, tile,  \

@@ -444,7 +444,8 @@ __global__ __launch_bounds__(IS_UNARY_WAVES * 64, IS_UNARY_OCC) void k_dp_unary(
 
 extern "C" hipError_t isk_launch_dp_unary_fast(const DevParams*, int, const RowRec*, const float*,
                                                const float*, const int*, const int*, const PruneRec*,
-                                               float*, int32_t*, unsigned long long*, hipStream_t);
+                                               float*, int32_t*, unsigned long long*, const float*,
+                                               const float*, hipStream_t);
 
 extern "C" {
 
@@ -459,7 +460,8 @@ hipError_t isk_launch_dp_unary(const DevParams* P, int ncols, int nwaves, const 
                                const float* lutT, const float* rcp, const int* vhor,
                                const int* col_flags, const PruneRec* prune, float* cost_table,
                                int32_t* index_table, const int* n_generic,
-                               unsigned long long* counters, hipStream_t stream) {
+                               unsigned long long* counters, const float* joined, const float* cost_T,
+                               hipStream_t stream) {
     /* FAST columns: the chunk-staged kernel of is_k_unary_fast.hip whenever the shape allows it;
      * then only the generic columns are left for this file's kernel */
     /* (measured on MI355X, batch 64: 8.7 ms against 9.3 ms of the tile-pair kernel below, and no
@@ -467,7 +469,8 @@ hipError_t isk_launch_dp_unary(const DevParams* P, int ncols, int nwaves, const 
     const bool fast_kernel = isk_unary_fast_chunk_rows(P) > 0 && P->knob_ring_kernel != 0;
     if (fast_kernel) {
         const hipError_t e = isk_launch_dp_unary_fast(P, ncols, recs, lutT, rcp, vhor, col_flags, prune,
-                                                      cost_table, index_table, counters, stream);
+                                                      cost_table, index_table, counters, joined, cost_T,
+                                                      stream);
         if (e != hipSuccess) return e;
     }
     const int groups = (ncols + 7) / 8;

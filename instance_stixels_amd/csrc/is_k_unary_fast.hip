@@ -38,6 +38,9 @@
 #ifndef ISF_OCC
 #define ISF_OCC 6 /* waves per SIMD the kernel is compiled for */
 #endif
+#ifndef ISF_GEN_TILE
+#define ISF_GEN_TILE 0 /* 1: the vT-side lutT rows rebuilt in LDS (gen_lut_tile) instead of read back: -8.6 GB of HBM reads per 64 frames, but +9 % DP time (measured, round 3) */
+#endif
 #define ISF_THREADS (ISF_WAVES * 64)
 
 struct UnaryBestF {
@@ -201,7 +204,8 @@ __global__ __launch_bounds__(ISF_THREADS, HAS_INVALID ? ISF_OCC_INV : ISF_OCC) v
     const float* __restrict__ rcp, const int* __restrict__ vhor_arr,
     const int* __restrict__ col_flags, const PruneRec* __restrict__ prune,
     float* __restrict__ cost_table, int32_t* __restrict__ index_table,
-    unsigned long long* __restrict__ counters /* null, or the evaluation counters (is_device.h) */) {
+    unsigned long long* __restrict__ counters /* null, or the evaluation counters (is_device.h) */,
+    const float* __restrict__ joined, const float* __restrict__ cost_T) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int H = P.H, D = P.D;
     const int DP = D + 1;
@@ -246,9 +250,19 @@ __global__ __launch_bounds__(ISF_THREADS, HAS_INVALID ? ISF_OCC_INV : ISF_OCC) v
         ring_prefetch<NVR>(lcol, rcol, max(vB_top - ISF_WAVES * i, 0), D, my_ring + i * SLOT,
                            my_ring + i * SLOT + ROWF, lane);
     ISF_MARK(4); /* (debug build: ring requests issued) */
+#if ISF_GEN_TILE
+    /* (before this lane's record is requested: the 32 values of a block and the 32 dwords of the
+     * record together do not fit the register budget of 6 waves per SIMD) */
+    gen_lut_tile(s_tile, lcol, joined + (size_t)colg * H, cost_T, tile_lo, H, D, w, lane, ISF_WAVES);
+    asm volatile("" ::: "memory");
+    const RowRec my = load_rec(rcol + vTc + 1);
+    ISF_MARK(5); /* (debug build: record requested) */
+    stage_rcp(s_rcp, rcp, H, tid, ISF_THREADS);
+#else
     const RowRec my = load_rec(rcol + vTc + 1);
     ISF_MARK(5); /* (debug build: record requested) */
     stage_tile_and_rcp(s_tile, s_rcp, lcol, rcp, tile_lo, H, D, tid, ISF_THREADS);
+#endif
     ISF_MARK(6); /* (debug build: tile + 1/h table staged; mark 0 then = the barrier) */
 
     PruneValsF pv;
@@ -424,14 +438,15 @@ hipError_t isk_launch_dp_unary_fast(const DevParams* P, int ncols, const RowRec*
                                     const float* lutT, const float* rcp, const int* vhor,
                                     const int* col_flags, const PruneRec* prune, float* cost_table,
                                     int32_t* index_table, unsigned long long* counters,
-                                    hipStream_t stream) {
+                                    const float* joined, const float* cost_T, hipStream_t stream) {
     const int nvr = isk_unary_fast_chunk_rows(P);
     const int groups = (ncols + 7) / 8;
     const dim3 grid(groups * 8 * P->ntiles);
     const size_t lds = isk_unary_fast_lds_bytes(P, nvr);
 #define ISF_LAUNCH(INV, NVR)                                                                      \
     hipLaunchKernelGGL((k_dp_unary_fast<INV, NVR>), grid, dim3(ISF_THREADS), lds, stream, *P, ncols, \
-                       recs, lutT, rcp, vhor, col_flags, prune, cost_table, index_table, counters)
+                       recs, lutT, rcp, vhor, col_flags, prune, cost_table, index_table, counters, joined, \
+                       cost_T)
     if (P->invalid >= 0) {
         if (nvr == 2) ISF_LAUNCH(true, 2); else ISF_LAUNCH(true, 4);
     } else {

@@ -253,6 +253,58 @@ __device__ __forceinline__ void stage_lut_tile(float* s_tile, const float* __res
     }
 }
 
+/* The vT-side tile, lutT rows tile_lo + 1 .. tile_lo + 64, REBUILT in LDS instead of read back:
+ * k_object_lut chains 32-row blocks through their last row (StixelsKernels.cu:268-272), and those
+ * carry rows are part of lutT, so a block's rows follow from lutT[block start] (512 B), the 32
+ * disparities of the block and the L2-resident cost table -- the same Kogge-Stone network on the
+ * same values in the same order (k_object_lut, is_k_prepare.hip): bit-identical rows.  A wave
+ * takes one (block, 64 fn) task: 32 table loads + 129 additions + 32 LDS stores per lane against
+ * 33 KB of lutT per workgroup -- the one compulsory read of the table (8.6 GB per 64 frames)
+ * disappears from the DP's HBM traffic.  Rows beyond the image repeat lutT[H] like the staging
+ * functions do. */
+__device__ __forceinline__ void gen_lut_tile(float* s_tile, const float* __restrict__ lcol,
+                                             const float* __restrict__ dcol,
+                                             const float* __restrict__ cost_T, int tile_lo, int H, int D,
+                                             int wave, int lane, int nwaves) {
+    constexpr int LB = 32; /* LUT_BLOCK of k_object_lut */
+    const int DP = D + 1;
+    const int fn_groups = (D + 63) >> 6;
+    for (int task = wave; task < 2 * fn_groups; task += nwaves) {
+        const int blk = task / fn_groups, fg = task - blk * fn_groups;
+        const int fn = fg * 64 + lane;
+        const bool fn_ok = fn < D;
+        const int fnc = fn_ok ? fn : D - 1;
+        const int i = tile_lo + LB * blk; /* the block's first row */
+        float* dst = s_tile + (size_t)(LB * blk) * DP + fn;
+        const float vH = (i + LB > H) ? lcol[(size_t)H * D + fnc] : 0.0f; /* rows beyond the image */
+        if (i >= H) {
+            if (fn_ok)
+                for (int l = 0; l < LB; l++) dst[l * DP] = vH;
+            continue;
+        }
+        const int rl = i + (lane & (LB - 1));
+        int dis_l = 0;
+        if (rl < H) dis_l = (int)dcol[rl];
+        dis_l = min(max(dis_l, 0), D - 1);
+        float c[LB];
+#pragma unroll
+        for (int l = 0; l < LB; l++) {
+            const int dis = __builtin_amdgcn_readlane(dis_l, l);
+            c[l] = cost_T[(size_t)dis * D + fnc];
+        }
+        c[0] += lcol[(size_t)i * D + fnc]; /* the carry: lutT[i][fn] */
+#pragma unroll
+        for (int j = 1; j < LB; j <<= 1) {
+#pragma unroll
+            for (int l = LB - 1; l >= j; l--) c[l] += c[l - j];
+        }
+        if (fn_ok) {
+#pragma unroll
+            for (int l = 0; l < LB; l++) dst[l * DP] = (i + l < H) ? c[l] : vH;
+        }
+    }
+}
+
 /* s_rcp[0..H] <- rcp[0..H], four elements per thread and round trip (see stage_lut_tile) */
 __device__ __forceinline__ void stage_rcp(float* s_rcp, const float* __restrict__ rcp, int H, int tid,
                                           int nthreads) {
