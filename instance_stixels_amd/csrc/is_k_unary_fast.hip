@@ -1,8 +1,9 @@
 /* is_k_unary_fast.hip -- unary column DP of FAST columns, built for the pruned regime.
  *
  * With the exact branch-and-bound on vB (DESIGN.md "Pruning") a (column, 64-row tile) work item
- * shrinks to its 64 diagonal steps plus a few dozen steps below the tile, so the kernel is no
- * longer bound by VALU issue but by the latency of what every step fetches.  k_dp_unary (the
+ * shrinks to its 64 diagonal steps plus a few dozen steps below the tile, so what a step
+ * fetches must never stall it (with that achieved the kernel is bound by VALU issue again: 80-86 %
+ * of the issue slots, DESIGN.md sections 6-7).  k_dp_unary (the
  * kernel of the generic columns, is_k_unary.hip) takes the vB-side record through scalar loads
  * and the vB-side lutT row through a buffer load per wave and step: ~1 us of exposed latency
  * per step once the other waves no longer cover it.  Here NOTHING inside the step loop waits for
@@ -13,13 +14,16 @@
  *   - the slots are filled by `global_load_lds` (LDS-DMA: no VGPRs, no waiting), K steps ahead
  *     of their use; `s_waitcnt vmcnt(NV * (K - 1))` before a step guarantees that its own slot
  *     has landed while the K - 1 younger prefetches stay in flight (loads return in order);
- *   - the record comes out of LDS with eight broadcast ds_read_b128, the two LUT values with
+ *   - the 128-byte record of vB is never copied into 32 VGPRs: a lane reads two dwords of the slot
+ *     (R0 = rec[l & 15], R1 = rec[16 + (l & 15)]) and every subtraction takes its vB operand as a
+ *     DPP `row_newbcast:k` of R0 / R1 (eval_segment_dpp, is_kernels.h); the two LUT values are
  *     per-lane ds_read_b32; no barrier inside the loop: the waves of a workgroup only share the
  *     tile's lutT rows (vT side), the 1/h table and the final merge;
- *   - a wave whose bound says that nothing below can win leaves its loop.
+ *   - a wave whose bound says that nothing below can win leaves its loop; once the object bound
+ *     holds, its steps evaluate only the ground or the sky candidate (fast_step_gs).
  *
- * LDS per workgroup at 1024 x 128: 4 KB (1/h) + 33 KB (vT tile) + 8 x 8 x (512 + 128) B (rings)
- * = 77 KB, two workgroups per CU, <= 128 VGPRs, no scratch.
+ * LDS per workgroup at 1024 x 128: 4 KB (1/h) + 33 KB (vT tile, reused by the merge) + 8 waves x 3
+ * slots x (512 + 128) B (rings) = 52 KB: three workgroups = 24 waves per CU at 74 VGPRs, no scratch.
  */
 #include "is_kernels.h"
 
