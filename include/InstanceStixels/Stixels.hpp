@@ -138,6 +138,11 @@ private:
     Section* h_stixels = nullptr;
     int32_t* h_instance_head = nullptr;    /* [max_batch][8 per-class counts] */
     int32_t* h_instance_packed = nullptr;
+    /* every device operation of the object runs on this stream (an ordinary stream: it still
+     * synchronises with work the caller queued on the legacy NULL stream, like the reference's
+     * default-stream code; on the NULL stream itself the auxiliary streams of the core never
+     * overlap) */
+    void* m_stream = nullptr;
     int m_max_batch = 1;
     int m_device = -1;      /* requested (SetDevice) */
     int m_ctx_device = -1;  /* resolved at Initialize(): where the buffers live */

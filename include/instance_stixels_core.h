@@ -222,6 +222,11 @@ int is_memcpy_h2d(void* dst, const void* src, size_t bytes, void* stream);
 int is_memcpy_d2h(void* dst, const void* src, size_t bytes, void* stream);
 int is_memset(void* dst, int value, size_t bytes, void* stream);
 int is_stream_synchronize(void* stream);
+/* A stream of the current device.  blocking != 0: an ordinary stream that still synchronises
+ * implicitly with the legacy NULL stream, like every stream the reference's callers create
+ * (cudaStreamCreate); 0: hipStreamNonBlocking. */
+int is_stream_create(void** stream, int blocking);
+int is_stream_destroy(void* stream);
 int is_device_synchronize(void);
 
 /* Introspection used by bench.py / tests. */

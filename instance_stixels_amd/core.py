@@ -22,7 +22,7 @@ EXPORTS = [
     "is_get_kernel_times_ms", "is_scratch_bytes", "is_flip_and_pad", "is_road_vdisparity",
     "is_cluster_instances", "is_host_malloc", "is_host_free", "is_get_device", "is_set_device",
     "is_ctx_device", "is_set_eval_counters", "is_get_eval_counters",
-    "is_pack_sections", "is_unpack_sections",
+    "is_pack_sections", "is_unpack_sections", "is_stream_create", "is_stream_destroy",
 ]
 
 

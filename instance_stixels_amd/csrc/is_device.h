@@ -40,6 +40,7 @@
 #define IS_PAIRWISE_SPLIT_MIN_COLS 1024 /* columns per group before the pairwise DP uses one more stream */
 #define IS_PAIRWISE_MAX_GROUPS 1       /* column groups (streams) of the pairwise DP */
 #define IS_P2_SPLIT_MAX_COLS 2048     /* up to eight 2048-px frames: phase 2 of the pairwise DP as chain + evaluator wave per column */
+#define IS_BACKTRACE_STAGE_MAX_COLS 2048 /* up to eight 2048-px frames: the back-trace chases in LDS */
 #define IS_AUX_STREAMS 7               /* auxiliary streams a context owns */
 #define IS_N_ON 8           /* non-instance object classes 2..9   (Cityscapes.h:69) */
 #define IS_N_OI 8           /* instance object classes     11..18 (Cityscapes.h:75) */

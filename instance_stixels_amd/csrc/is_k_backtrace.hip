@@ -72,6 +72,10 @@ __device__ __forceinline__ is_section make_section(const DevParams& P, const Row
  * chain and records the cuts, then the lanes build the Sections in parallel (one per lane).  The
  * chase reads the tables where they lie (two dependent loads per section, a few dozen sections):
  * staging the column's 24 KB of tables in LDS first (round 1) limited a CU to five waves. */
+/* STAGE (few columns, i.e. latency matters more than waves per CU): the column's two tables are
+ * copied into LDS first (coalesced, one round trip) and the chase runs there (~0.1 us per section
+ * instead of a dependent global round trip): one frame 28 -> ~8 us. */
+template <bool STAGE>
 __global__ __launch_bounds__(64) void k_backtrace(const DevParams P, int ncols, int pairwise,
                                                   const RowRec* __restrict__ recs,
                                                   const float* __restrict__ cost_table,
@@ -91,8 +95,19 @@ __global__ __launch_bounds__(64) void k_backtrace(const DevParams P, int ncols, 
     const float* ct = cost_table + (size_t)colg * H * 3;
     const int32_t* it = index_table + (size_t)colg * H * 3;
     is_section* out = sections + (size_t)colg * S;
-    const float* s_cost = ct; /* (names kept: the walk below reads global memory) */
+    const float* s_cost = ct; /* (not STAGE: the walk below reads global memory) */
     const int32_t* s_idx = it;
+    if (STAGE) {
+        float* l_cost = (float*)(s_n + 4);
+        int32_t* l_idx = (int32_t*)(l_cost + 3 * H);
+        for (int i = lane; i < 3 * H; i += 64) {
+            l_cost[i] = ct[i];
+            l_idx[i] = it[i];
+        }
+        __syncthreads();
+        s_cost = l_cost;
+        s_idx = l_idx;
+    }
     if (lane == 0) {
         int vT = H - 1;
         const float last_ground = s_cost[vT * 3 + IS_GROUND];
@@ -253,9 +268,14 @@ hipError_t isk_launch_backtrace(const DevParams* P, int ncols, int pairwise, con
                                 const float* cost_table, const int32_t* index_table,
                                 const int* col_flags, is_section* sections, int* inst_cnt,
                                 hipStream_t stream) {
-    const size_t lds = sizeof(int) * (3 * (size_t)P->S + 4);
-    hipLaunchKernelGGL(k_backtrace, dim3(ncols), dim3(64), lds, stream, *P, ncols, pairwise, recs,
-                       cost_table, index_table, col_flags, sections, inst_cnt);
+    const size_t lds = sizeof(int) * (3 * (size_t)P->S + 8);
+    const size_t lds_staged = lds + sizeof(int) * 6 * (size_t)P->H;
+    if (ncols <= IS_BACKTRACE_STAGE_MAX_COLS && lds_staged <= 64 * 1024)
+        hipLaunchKernelGGL(k_backtrace<true>, dim3(ncols), dim3(64), lds_staged, stream, *P, ncols, pairwise,
+                           recs, cost_table, index_table, col_flags, sections, inst_cnt);
+    else
+        hipLaunchKernelGGL(k_backtrace<false>, dim3(ncols), dim3(64), lds, stream, *P, ncols, pairwise, recs,
+                           cost_table, index_table, col_flags, sections, inst_cnt);
     return hipGetLastError();
 }
 
@@ -273,9 +293,14 @@ hipError_t isk_launch_compact(const DevParams* P, int n_images, const is_section
 }
 
 hipError_t isk_set_lds_backtrace(const DevParams* P) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_backtrace, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)(sizeof(int) * (3 * (size_t)P->S + 4)));
+    hipError_t e = hipFuncSetAttribute((const void*)k_backtrace<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)(sizeof(int) * (3 * (size_t)P->S + 8)));
     if (e != hipSuccess) return e;
+    if (sizeof(int) * (3 * (size_t)P->S + 8 + 6 * (size_t)P->H) <= 64 * 1024) {
+        e = hipFuncSetAttribute((const void*)k_backtrace<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(sizeof(int) * (3 * (size_t)P->S + 8 + 6 * (size_t)P->H)));
+        if (e != hipSuccess) return e;
+    }
     /* more than ~2000 stixel columns: the per-column offsets exceed the 64 KiB default */
     return hipFuncSetAttribute((const void*)k_compact_instances, hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)compact_lds_bytes(P));

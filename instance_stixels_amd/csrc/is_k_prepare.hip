@@ -124,12 +124,11 @@ __device__ __forceinline__ void store_instance_prefix(RowRec* o, int slow, int64
     d[7] = b;
 }
 
-__global__ __launch_bounds__(PREP_THREADS) void k_prepare_columns(
-    const DevParams P, const float* __restrict__ joined, const int32_t* __restrict__ seg,
-    const float* __restrict__ ground /*[img][3][H]*/, const int* __restrict__ vhor_arr,
-    RowRec* __restrict__ recs, int* __restrict__ col_flags, float* __restrict__ sv_arr,
-    PruneRec* __restrict__ prune, int* __restrict__ n_generic) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void prepare_columns_body(
+    const DevParams& P, const int colg, char* smem, const float* __restrict__ joined,
+    const int32_t* __restrict__ seg, const float* __restrict__ ground /*[img][3][H]*/,
+    const int* __restrict__ vhor_arr, RowRec* __restrict__ recs, int* __restrict__ col_flags,
+    float* __restrict__ sv_arr, PruneRec* __restrict__ prune, int* __restrict__ n_generic) {
     const int H = P.H, P2 = P.P2, P2S = P.P2S, CH = P.CH, K = P.K;
     /* LDS stride of a segmentation channel: only its first H/8 + 1 entries matter (an exclusive
      * prefix at index <= H/8 never sees the zero padding up to P2S), and 21 channels of P2S = 256
@@ -152,7 +151,6 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_columns(
     float* s_red = (float*)(s_wave + 4);                /* [8] block reductions            */
     float* s_tot = s_red + 8;                           /* [2] sum mx^2 + my^2 of the column */
 
-    const int colg = blockIdx.x;
     const int img = colg / P.C, col = colg % P.C;
     const int vhor = vhor_arr[img];
     const float* gfun = ground + (size_t)img * 3 * H;
@@ -475,6 +473,16 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_columns(
     }
 }
 
+__global__ __launch_bounds__(PREP_THREADS) void k_prepare_columns(
+    const DevParams P, const float* __restrict__ joined, const int32_t* __restrict__ seg,
+    const float* __restrict__ ground, const int* __restrict__ vhor_arr, RowRec* __restrict__ recs,
+    int* __restrict__ col_flags, float* __restrict__ sv_arr, PruneRec* __restrict__ prune,
+    int* __restrict__ n_generic) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    prepare_columns_body(P, (int)blockIdx.x, smem, joined, seg, ground, vhor_arr, recs, col_flags, sv_arr,
+                         prune, n_generic);
+}
+
 /* ====================================================================================== */
 /* A4  object data-cost prefix table (ComputeObjectLUT, StixelsKernels.cu:236-296, 959-978) */
 /* ====================================================================================== */
@@ -487,14 +495,12 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_columns(
  * cross-lane traffic); the 64 lanes of a wave are 64 consecutive fn, so every load of the
  * transposed cost table and every store of a lutT row is one fully coalesced 256-byte access. */
 #define LUT_BLOCK 32
-__global__ __launch_bounds__(64) void k_object_lut(const DevParams P,
-                                                   const float* __restrict__ joined,
-                                                   const float* __restrict__ cost_T /*[dis][fn]*/,
-                                                   float* __restrict__ lutT) {
+__device__ __forceinline__ void object_lut_body(const DevParams& P, const int colg, const int fn_block,
+                                                const int lane, const float* __restrict__ joined,
+                                                const float* __restrict__ cost_T /*[dis][fn]*/,
+                                                float* __restrict__ lutT) {
     const int H = P.H, D = P.D;
-    const int colg = blockIdx.x;
-    const int lane = threadIdx.x;
-    const int fn = blockIdx.y * 64 + lane;
+    const int fn = fn_block * 64 + lane;
     const bool fn_ok = fn < D;
     const int fnc = fn_ok ? fn : D - 1;
     const float* dcol = joined + (size_t)colg * H;
@@ -535,6 +541,37 @@ __global__ __launch_bounds__(64) void k_object_lut(const DevParams P,
                 if (i + l < H) lcol[(size_t)(i + l + 1) * D + fn] = c[l]; /* :266 */
         }
         add = c[LUT_BLOCK - 1]; /* :268-272 */
+    }
+}
+
+__global__ __launch_bounds__(64) void k_object_lut(const DevParams P,
+                                                   const float* __restrict__ joined,
+                                                   const float* __restrict__ cost_T,
+                                                   float* __restrict__ lutT) {
+    object_lut_body(P, (int)blockIdx.x, (int)blockIdx.y, (int)threadIdx.x, joined, cost_T, lutT);
+}
+
+/* Both preparation kernels in ONE launch for SMALL calls (a frame or a few): neither kernel fills
+ * the chip then and both are latency chains (one frame: 59 + 58 us one after the other); on two
+ * streams they did not overlap in practice, as workgroups of one grid they run side by side.  A
+ * 256-thread workgroup is either one column of k_prepare_columns (blocks 0 .. ncols - 1) or four
+ * (column, 64 fn) units of k_object_lut.  Only for small calls: under 256-thread launch bounds the
+ * LUT body takes 166 VGPRs, which at batch 64 costs the occupancy both kernels live on (3.2 -> 8.2 ms
+ * per 64 frames, measured). */
+__global__ __launch_bounds__(PREP_THREADS) void k_prepare_fused(
+    const DevParams P, int ncols, const float* __restrict__ joined, const int32_t* __restrict__ seg,
+    const float* __restrict__ ground, const int* __restrict__ vhor_arr, const float* __restrict__ cost_T,
+    RowRec* __restrict__ recs, float* __restrict__ lutT, int* __restrict__ col_flags,
+    float* __restrict__ sv_arr, PruneRec* __restrict__ prune, int* __restrict__ n_generic) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int b = (int)blockIdx.x;
+    if (b >= ncols) {
+        const int fn_blocks = (P.D + 63) / 64;
+        const int unit = (b - ncols) * (PREP_THREADS / 64) + (int)(threadIdx.x >> 6);
+        if (unit < ncols * fn_blocks)
+            object_lut_body(P, unit / fn_blocks, unit % fn_blocks, (int)(threadIdx.x & 63), joined, cost_T, lutT);
+    } else {
+        prepare_columns_body(P, b, smem, joined, seg, ground, vhor_arr, recs, col_flags, sv_arr, prune, n_generic);
     }
 }
 
@@ -583,8 +620,20 @@ hipError_t isk_launch_prepare(const DevParams* P, int ncols, const float* joined
      * fills the chip and both are latency chains, so they run side by side on two streams; with
      * many columns they are throughput-bound (HBM writes) and stay in order on one stream. */
     bool side_by_side = aux != nullptr && ncols < IS_PREPARE_OVERLAP_MAX_COLS;
-    if (P->knob_prepare_overlap >= 0) side_by_side = aux != nullptr && P->knob_prepare_overlap != 0;
+    if (P->knob_prepare_overlap >= 0) side_by_side = aux != nullptr && P->knob_prepare_overlap == 1;
     hipError_t e;
+    /* small calls: one launch with workgroups of both kinds (k_prepare_fused); IS_PREPARE_OVERLAP=2
+     * forces it, 1 = two streams, 0 = in order on one stream */
+    const bool fused = P->knob_prepare_overlap == 2 ||
+                       (P->knob_prepare_overlap < 0 && ncols < IS_PREPARE_OVERLAP_MAX_COLS);
+    if (fused) {
+        const int units = ncols * ((P->D + 63) / 64);
+        const int n_lut = (units + PREP_THREADS / 64 - 1) / (PREP_THREADS / 64);
+        hipLaunchKernelGGL(k_prepare_fused, dim3(ncols + n_lut), dim3(PREP_THREADS),
+                           isk_prepare_lds_bytes(P), stream, *P, ncols, joined, seg, ground, vhor,
+                           cost_T, recs, lutT, col_flags, sv_arr, prune, n_generic);
+        return hipGetLastError();
+    }
     hipStream_t lut_stream = stream;
     if (side_by_side) {
         if ((e = hipEventRecord(ev_fork, stream)) != hipSuccess) return e;
@@ -612,7 +661,10 @@ hipError_t isk_launch_priors(const DevParams* P, const float* ground, PriorRec* 
 }
 
 hipError_t isk_set_lds_prepare(const DevParams* P) {
-    return hipFuncSetAttribute((const void*)k_prepare_columns, hipFuncAttributeMaxDynamicSharedMemorySize,
+    hipError_t e = hipFuncSetAttribute((const void*)k_prepare_columns, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)isk_prepare_lds_bytes(P));
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute((const void*)k_prepare_fused, hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)isk_prepare_lds_bytes(P));
 }
 

@@ -347,6 +347,7 @@ void Stixels::InitializeBatch(int max_batch) { /* Stixels.cu:43-248 */
     const DeviceGuard guard(device);
     IS_CHECK_RETURN(is_ctx_create(&m_params, m_obj_cost_lut.data(),
                                   m_object_disparity_range.data(), m_max_batch, device, &m_ctx));
+    IS_CHECK_RETURN(is_stream_create(&m_stream, 1));
     const size_t B = m_max_batch;
     IS_CHECK_RETURN(is_device_malloc((void**)&d_stixels,
                                      B * m_realcols * m_max_sections * sizeof(Section)));
@@ -393,6 +394,8 @@ void Stixels::Finish() { /* Stixels.cu:250-283 */
     h_stixels = nullptr; h_instance_head = nullptr; h_instance_packed = nullptr;
     IS_CHECK_RETURN(is_ctx_destroy(m_ctx));
     m_ctx = nullptr;
+    IS_CHECK_RETURN(is_stream_destroy(m_stream));
+    m_stream = nullptr;
     d_segmentation = nullptr; d_disparity_big = nullptr; d_disparity = nullptr;
     d_stixels = nullptr; d_instance_centerofmass = nullptr; d_instance_indices = nullptr;
     d_instance_core_candidates = nullptr; d_instances_per_class = nullptr;
@@ -407,8 +410,8 @@ void Stixels::Finish() { /* Stixels.cu:250-283 */
 void Stixels::SetSegmentation(const std::vector<int32_t>& segmentation) { /* :340-346 */
     const DeviceGuard guard(m_ctx_device);
     IS_CHECK_RETURN(is_memcpy_h2d(d_segmentation, segmentation.data(),
-                                  sizeof(int32_t) * segmentation.size(), nullptr));
-    IS_CHECK_RETURN(is_stream_synchronize(nullptr));
+                                  sizeof(int32_t) * segmentation.size(), m_stream));
+    IS_CHECK_RETURN(is_stream_synchronize(m_stream));
 }
 
 void Stixels::SetDisparityImage(const std::vector<pixel_t>& disp_im) { /* :348-355 */
@@ -416,8 +419,8 @@ void Stixels::SetDisparityImage(const std::vector<pixel_t>& disp_im) { /* :348-3
     /* the reference queues a cudaMemcpyAsync from the caller's pageable vector; the copy is
      * finished here before returning, so the vector may be a temporary */
     IS_CHECK_RETURN(is_memcpy_h2d(d_disparity_big, disp_im.data(),
-                                  sizeof(pixel_t) * disp_im.size(), nullptr));
-    IS_CHECK_RETURN(is_stream_synchronize(nullptr));
+                                  sizeof(pixel_t) * disp_im.size(), m_stream));
+    IS_CHECK_RETURN(is_stream_synchronize(m_stream));
 }
 
 pixel_t* Stixels::GetInputDisparityImageOnDevice() { return d_disparity_big; } /* :357-359 */
@@ -449,20 +452,20 @@ float Stixels::Compute(const bool pairwise, StixelsData& stixels_data,
     m_params.vhor = m_vhor;                                                       /* :532 */
 
     IS_CHECK_RETURN(is_join_columns(m_ctx, d_disparity_big, m_cols, m_median_join ? 1 : 0,
-                                    d_disparity, 1, nullptr)); /* :509-511 */
+                                    d_disparity, 1, m_stream)); /* :509-511 */
     /* the DP, the instance candidates and their clustering (ClusterInstances, :613) are queued
      * back to back on the device; nothing returns to the host in between */
     const is_instance_buffers ib = InstanceBuffers(0);
     IS_CHECK_RETURN(is_compute(m_ctx, d_disparity, d_segmentation_local, g.function.data(),
                                g.normalization.data(), g.inv_sigma2.data(), &m_vhor,
                                pairwise ? 1 : 0, 1, d_stixels, &ib, nullptr, nullptr,
-                               nullptr)); /* :535-590 */
+                               m_stream)); /* :535-590 */
     /* results into pinned memory, ONE synchronisation (:600, :629-633) */
     const size_t n_sec = (size_t)m_realcols * m_max_sections;
-    IS_CHECK_RETURN(is_memcpy_d2h(h_stixels, d_stixels, n_sec * sizeof(Section), nullptr));
+    IS_CHECK_RETURN(is_memcpy_d2h(h_stixels, d_stixels, n_sec * sizeof(Section), m_stream));
     IS_CHECK_RETURN(is_memcpy_d2h(h_instance_head, d_instances_per_class,
-                                  m_instance_classes * sizeof(int32_t), nullptr));
-    IS_CHECK_RETURN(is_stream_synchronize(nullptr));
+                                  m_instance_classes * sizeof(int32_t), m_stream));
+    IS_CHECK_RETURN(is_stream_synchronize(m_stream));
     for (int k = 0; k < m_instance_classes; k++) m_instances_per_class[k] = h_instance_head[k];
     m_labels_on_host = false;
 
@@ -499,6 +502,7 @@ void Stixels::ComputeBatch(bool pairwise, int n_images, const pixel_t* d_big,
     if (n_images < 1 || n_images > m_max_batch)
         throw std::invalid_argument("n_images outside [1, max_batch] of InitializeBatch().");
     const DeviceGuard guard(m_ctx_device);
+    if (stream == nullptr) stream = m_stream;
     std::vector<float> gf((size_t)n_images * m_rows), ng(gf.size()), ig(gf.size());
     std::vector<int> vh(n_images);
     for (int i = 0; i < n_images; i++) {
@@ -565,7 +569,7 @@ void Stixels::ComputeBatch(bool pairwise, int n_images, const pixel_t* d_big,
 float Stixels::ClusterInstances() {
     const DeviceGuard guard(m_ctx_device);
     const is_instance_buffers ib = InstanceBuffers();
-    IS_CHECK_RETURN(is_cluster_instances(m_ctx, &ib, nullptr));
+    IS_CHECK_RETURN(is_cluster_instances(m_ctx, &ib, m_stream));
     m_labels_on_host = false;
     return -1;
 }
@@ -579,8 +583,8 @@ std::map<std::pair<int, int>, int> Stixels::GetInstanceStixels() { /* Stixels.cu
         for (int k = 0; k < m_instance_classes; k++) total += m_instances_per_class[k];
         if (total > 0) {
             IS_CHECK_RETURN(is_memcpy_d2h(h_instance_packed, d_instance_packed,
-                                          (1 + 3 * (size_t)total) * sizeof(int32_t), nullptr));
-            IS_CHECK_RETURN(is_stream_synchronize(nullptr));
+                                          (1 + 3 * (size_t)total) * sizeof(int32_t), m_stream));
+            IS_CHECK_RETURN(is_stream_synchronize(m_stream));
         } else {
             h_instance_packed[0] = 0;
         }

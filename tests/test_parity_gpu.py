@@ -721,3 +721,46 @@ def test_branch_and_bound_is_exact_at_the_bounds(family, monkeypatch):
     assert pruned_steps < full_steps, (family, pruned_steps, full_steps)
     if family in ("confident_scene", "horizon_in_tile"):
         assert pruned_steps < 0.8 * full_steps, (family, pruned_steps, full_steps)
+
+
+@pytest.mark.parametrize("knob,value", [("IS_GRAPH", "1"), ("IS_PREPARE_OVERLAP", "0"),
+                                         ("IS_PREPARE_OVERLAP", "1")])
+@pytest.mark.parametrize("preset", ["drn_d_22_unary", "drn_d_38_pairwise"])
+def test_launch_path_knobs_change_nothing(preset, knob, value, monkeypatch):
+    """The launch-path alternatives a context can be created with -- hipGraph replay of small calls
+    (IS_GRAPH=1, opt-in), the two preparation kernels in order / on two streams instead of the
+    fused launch small calls use -- give the same bits; the graph is replayed: three calls on one
+    context with the same buffers, the ground model changing from call to call."""
+    import torch
+    from instance_stixels_amd.core import Core
+    from instance_stixels_amd.config import SECTION_DTYPE
+    monkeypatch.setenv(knob, value)
+    case = helpers.build_case(preset, 128, 256, 32, seed=71, n_images=2)
+    cfg, p = case["cfg"], case["params"]
+    dev = torch.device("cuda", 0)
+    core = Core(p, case["lut"], case["odr"], max_batch=2)
+    big = torch.from_numpy(case["disparity"]).to(dev)
+    seg = torch.from_numpy(case["segmentation"]).to(dev)
+    joined = torch.empty((2, p.cols, p.rows), dtype=torch.float32, device=dev)
+    sec = torch.empty((2, p.cols, p.max_sections, 8), dtype=torch.int32, device=dev)
+    stream = torch.cuda.Stream(dev)
+    refs = {}
+    for shift in (0, 5, 0):          # same buffers every call (one graph), another horizon in between
+        g = [oracle_mod().host_ground(cfg, f.vhor_image + shift, f.camera_tilt, f.camera_height,
+                                      f.alpha_ground) for f in case["frames"]]
+        with torch.cuda.stream(stream):
+            core.join_columns_ptr(big.data_ptr(), big.shape[2], False, joined.data_ptr(), 2, stream.cuda_stream)
+            core.compute_ptr(joined.data_ptr(), seg.data_ptr(), np.stack([x[0] for x in g]),
+                             np.stack([x[1] for x in g]), np.stack([x[2] for x in g]),
+                             np.array([x[3] for x in g], np.int32), bool(cfg.pairwise), 2, sec.data_ptr(),
+                             stream=stream.cuda_stream)
+        stream.synchronize()
+        got = sec.cpu().numpy().view(SECTION_DTYPE).reshape(2, p.cols, p.max_sections)
+        if shift not in refs:
+            c2 = dict(case)
+            c2["gf"], c2["ng"], c2["ig"] = (np.stack([x[k] for x in g]) for k in range(3))
+            c2["vhor"] = np.array([x[3] for x in g], np.int32)
+            refs[shift] = [helpers.run_oracle(c2, image=i)["sections"] for i in range(2)]
+        for i in range(2):
+            assert helpers.sections_equal(refs[shift][i], got[i]), (knob, shift, i)
+    core.close()
