@@ -64,6 +64,8 @@ def parse():
     ap.add_argument("--no-verify", action="store_true",
                     help="skip the oracle check of the timed output (about one CPU-second per frame)")
     ap.add_argument("--verify", action="store_true", help="(default since round 3; kept for old command lines)")
+    ap.add_argument("--side-stream", action="store_true",
+                    help="run the steps on a torch side stream instead of the (legacy NULL) default stream")
     ap.add_argument("--no-prune-stats", action="store_true",
                     help="skip the untimed device-counter pass (profiling runs: its atomics distort per-kernel averages)")
     ap.add_argument("--no-variants", action="store_true",
@@ -154,6 +156,8 @@ def committed_traffic(cfg, B, H, W, D):
 
 
 class Workload:
+    side_stream = False   # --side-stream
+
     """One configuration's batch, resident in HBM: host tables through the C++ Stixels class,
     `distinct` synthetic frames repeated to `batch`, device inputs and output buffers."""
 
@@ -187,7 +191,8 @@ class Workload:
         self.S = self.params.max_sections
         self.d_joined = torch.empty((batch, self.C, self.H), dtype=torch.float32, device=dev)
         self.d_sections = torch.empty((batch, self.C, self.S, 8), dtype=torch.int32, device=dev)
-        self.stream = torch.cuda.current_stream(dev).cuda_stream
+        self._side = torch.cuda.Stream(dev) if Workload.side_stream else None
+        self.stream = (self._side or torch.cuda.current_stream(dev)).cuda_stream
 
     def make_core(self, env=None, max_batch=None):
         """A context; `env`: IS_* knobs, which the library reads once, when a context is created."""
@@ -497,6 +502,7 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    Workload.side_stream = args.side_stream
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or args.force_dist  # --force-dist: RCCL plumbing with a single rank

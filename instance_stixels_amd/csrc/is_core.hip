@@ -33,7 +33,7 @@ hipError_t isk_launch_dp_unary(const DevParams*, int, int, const RowRec*, const 
 hipError_t isk_launch_dp_pairwise(const DevParams*, int, int, const RowRec*, const float*,
                                   const float*, const PriorRec*, const float*, const float*, const float*,
                                   const int*, const int*, const PruneRec*, StepRec*, float*, int*,
-                                  float*, int32_t*, unsigned long long*, const float*,
+                                  float*, int32_t*, unsigned long long*, const float*, const int*,
                                   hipStream_t, hipStream_t*, int, hipEvent_t, hipEvent_t*);
 hipError_t isk_launch_backtrace(const DevParams*, int, int, const RowRec*, const float*,
                                 const int32_t*, const int*, is_section*, int*, hipStream_t);
@@ -291,6 +291,7 @@ static int ctx_init(is_ctx* c, const is_stixel_params* p, const float* obj_cost_
         d.knob_p2_lds_floor = knob("IS_P2_LDS");
         d.knob_pw_groups = knob("IS_PW_GROUPS");
         d.knob_p2_split = knob("IS_P2_SPLIT");
+        d.knob_p2x = knob("IS_P2X");
     }
     {
         /* branch-and-bound constants (PruneRec, is_device.h).  gamma_d bounds the relative error of
@@ -588,7 +589,7 @@ static int compute_enqueue(is_ctx* c, const float* d_joined, const int32_t* d_se
                                        d_joined, c->d_priors, c->d_odr, c->d_rcp, c->d_sv, c->d_vhor,
                                        c->d_col_flags, c->d_prune, c->d_steps, c->d_part_cost,
                                        c->d_part_idx, ct, it, c->counting ? c->d_counters : nullptr,
-                                       c->d_obj_cost_lut, stream, c->aux_streams, IS_AUX_STREAMS, c->ev_fork, c->ev_joins));
+                                       c->d_obj_cost_lut, c->d_n_generic, stream, c->aux_streams, IS_AUX_STREAMS, c->ev_fork, c->ev_joins));
     else
         HIP_TRY(isk_launch_dp_unary(&P, ncols, c->nwaves_unary, c->d_recs, c->d_lutT, c->d_rcp,
                                     c->d_vhor, c->d_col_flags, c->d_prune, ct, it, c->d_n_generic,

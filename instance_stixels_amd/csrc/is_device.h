@@ -38,7 +38,7 @@
 #endif
 #define IS_PREPARE_OVERLAP_MAX_COLS 1024 /* below: the two prepare kernels run on two streams */
 #define IS_PAIRWISE_SPLIT_MIN_COLS 1024 /* columns per group before the pairwise DP uses one more stream */
-#define IS_PAIRWISE_MAX_GROUPS 1       /* column groups (streams) of the pairwise DP */
+#define IS_PAIRWISE_MAX_GROUPS 2       /* column groups (streams) of the pairwise DP: 2 = +2.4 % at batch 64 (round 3) */
 #define IS_P2_SPLIT_MAX_COLS 2048     /* up to eight 2048-px frames: phase 2 of the pairwise DP as chain + evaluator wave per column */
 #define IS_BACKTRACE_STAGE_MAX_COLS 2048 /* up to eight 2048-px frames: the back-trace chases in LDS */
 #define IS_AUX_STREAMS 7               /* auxiliary streams a context owns */
@@ -163,6 +163,7 @@ struct DevParams {
     int knob_p2_lds_floor;    /* IS_P2_LDS: floor on phase 2's LDS allocation (occupancy throttle) */
     int knob_pw_groups;       /* IS_PW_GROUPS: column groups (streams) of the pairwise DP */
     int knob_p2_split;        /* IS_P2_SPLIT: 1 = k_pw_phase2s, 0 = k_pw_phase2 */
+    int knob_p2x;             /* IS_P2X=0: large batches walk phase 2 with k_pw_phase2 (one column per wave) */
 };
 
 #endif /* IS_DEVICE_H_ */

@@ -94,8 +94,23 @@ __device__ __forceinline__ void neg_fastlog_div2(float neg_log_va, float v2a, fl
     *outb = neg_log_vb + lb;
 }
 
+/* the same for TWO columns in the two halves of the wave (k_pw_phase2x): the four logarithms run in
+ * the four 16-lane quarters, each half then reads its own two through ds_bpermute */
+__device__ __forceinline__ void neg_fastlog_div2x(float neg_log_va, float v2a, float neg_log_vb,
+                                                  float v2b, const double* s_invc,
+                                                  const double* s_logc, float* outa, float* outb) {
+    const int lane = threadIdx.x;
+    const float arg = (lane & 16) ? v2b : v2a;
+    const float l = is_logf_t(arg, s_invc, s_logc);
+    const int base = (lane & 32) << 2; /* byte address of lane 0 / 32 for ds_bpermute */
+    const float la = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(base, __builtin_bit_cast(int, l)));
+    const float lb = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(base + 64, __builtin_bit_cast(int, l)));
+    *outa = neg_log_va + la;
+    *outb = neg_log_vb + lb;
+}
+
 /* StepRec of vB = r + 1 from the final row r.  All inputs are wave-uniform; every lane computes
- * the same values. */
+ * the same values.  (TWOCOL: uniform per half of the wave, see k_pw_phase2x.) */
 /* register (SGPR) copy of a PriorRec: loaded at the top of a step together with the step's RowRec,
  * so that the serial chain waits for scalar memory once per step, not twice */
 struct PriorVals {
@@ -111,7 +126,7 @@ __device__ __forceinline__ PriorVals sload_prior(const PriorRec* p) {
 
 /* rcp_h: RN(1 / (r + 1 - obj_vB)) for the exact-division shortcut of FAST columns (fast_div,
  * is_kernels.h: the prefix difference is 0 or within [2^-84, 2^75] there), 0 = IEEE division */
-template <bool HAS_INVALID>
+template <bool HAS_INVALID, bool TWOCOL = false>
 __device__ __forceinline__ StepVals make_step(const DevParams& P, float S_r1, float V_r1, float S_ob,
                                              float V_ob, const float* s_odr, const double* s_invc,
                                              const double* s_logc, const PriorVals* pr, int vhor, int r,
@@ -162,8 +177,12 @@ __device__ __forceinline__ StepVals make_step(const DevParams& P, float S_r1, fl
     st.o_hi_thr = pm + dif;
     st.o_lo_thr = pm - dif;
     float nl_hi, nl_lo;
-    neg_fastlog_div2(P.nlog_pord, P.max_disf - pm - dif, P.nlog_1mpord, st.o_lo_thr, s_invc, s_logc,
-                     &nl_hi, &nl_lo);
+    if (TWOCOL)
+        neg_fastlog_div2x(P.nlog_pord, P.max_disf - pm - dif, P.nlog_1mpord, st.o_lo_thr, s_invc, s_logc,
+                          &nl_hi, &nl_lo);
+    else
+        neg_fastlog_div2(P.nlog_pord, P.max_disf - pm - dif, P.nlog_1mpord, st.o_lo_thr, s_invc, s_logc,
+                         &nl_hi, &nl_lo);
     st.p2_hi = cO + pw * (base + nl_hi);
     st.p2_lo = cO + pw * (base + nl_lo);
     st.p2_mid = cO + pw * IS_INF;
@@ -1009,6 +1028,347 @@ __global__ __launch_bounds__(64, ISP2_OCC) void k_pw_phase2(
 }
 
 /* ====================================================================================== */
+/* phase 2, TWO columns per wavefront (k_pw_phase2x, large batches)                         */
+/* ====================================================================================== */
+/* In k_pw_phase2 a step issues for 64 lanes although only 64 - s of them hold a live row, and
+ * ~45 % of its instructions (make_step, the broadcasts, the running minima) are wave-uniform work
+ * that every lane repeats.  Here a wave walks the diagonal blocks of two neighbouring columns X, Y
+ * of one image at once, X in lanes 0..31, Y in lanes 32..63, a lane owning vT = base + (lane & 31):
+ *
+ *   phase L  base = tile_lo:      steps s = 0..31, candidates vB = tile_lo + s for lanes >= s,
+ *                                 row tile_lo + s finalised (lower-left triangle)
+ *   phase S  base = tile_lo + 32: the 32 x 32 square: candidates vB = tile_lo + 1 .. + 31 (their
+ *                                 StepRecs are final: read back from memory) for all 32 rows
+ *   phase U  base = tile_lo + 32: steps s = 32..63 like phase L (upper-right triangle)
+ *
+ * 95 steps for two columns instead of 2 x 64, and every "uniform" value is uniform per half: the
+ * instructions that computed one column's StepRec 64 times now compute two columns' 32 times.  The
+ * record of vB comes as DPP operands (each 16-lane row reads its own column's record), the finished
+ * row is broadcast inside its half with ds_bpermute, the lutT windows, S / V prefixes of the tile
+ * rows and the StepRec handed from phase L to phase U live in LDS per column.  Arithmetic and
+ * operand order are those of pw_phase2_body: eval_segment_dpp == eval_segment<true> (phase 1 uses
+ * both), pairwise_step and make_step are the same functions.  Pairs with a generic column (or a
+ * last odd column) run pw_phase2_body column by column. */
+#ifndef ISP2X_OCC
+#define ISP2X_OCC 4 /* waves per SIMD k_pw_phase2x is compiled for (each wave: two columns) */
+#endif
+#define ISP2X_WF (ISP2_ROWS * ISP2_WS)         /* floats of one column's lutT window */
+
+__device__ __forceinline__ float half_bcast_f(float x, int src_lane) { /* src_lane: per lane */
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src_lane << 2, __builtin_bit_cast(int, x)));
+}
+__device__ __forceinline__ int half_bcast_i(int x, int src_lane) {
+    return __builtin_amdgcn_ds_bpermute(src_lane << 2, x);
+}
+__device__ __forceinline__ float half_min_f(float x) { /* minimum over the lane's 32-lane half */
+#pragma unroll
+    for (int m = 16; m >= 1; m >>= 1) x = __builtin_fminf(x, __shfl_xor(x, m, 64));
+    return x;
+}
+__device__ __forceinline__ float half_max_f(float x) {
+#pragma unroll
+    for (int m = 16; m >= 1; m >>= 1) x = __builtin_fmaxf(x, __shfl_xor(x, m, 64));
+    return x;
+}
+
+template <bool HAS_INVALID>
+__device__ __forceinline__ void pw_phase2x_body(const DevParams& P, char* smem, int col0, int tile,
+                                                const RowRec* __restrict__ recs,
+                                                const float* __restrict__ lutT,
+                                                const float* __restrict__ joined,
+                                                const PriorRec* __restrict__ priors,
+                                                const float* __restrict__ odr,
+                                                const float* __restrict__ rcp,
+                                                const float* __restrict__ sv_arr, int vhor, int nsplit,
+                                                const float* __restrict__ part_cost,
+                                                const int* __restrict__ part_idx,
+                                                StepRec* __restrict__ steps,
+                                                float* __restrict__ cost_table,
+                                                int32_t* __restrict__ index_table) {
+    const int H = P.H, D = P.D;
+    const int lane = threadIdx.x, li = lane & 31, l15 = lane & 15, hbase = lane & 32;
+    const int half = lane >> 5;
+    double* s_invc = (double*)smem;                      /* [32] */
+    double* s_logc = s_invc + IS_LOG_TABLE_SIZE;         /* [32] */
+    float* s_odr = (float*)(s_logc + IS_LOG_TABLE_SIZE); /* [D -> x4] */
+    float* s_rcp = s_odr + ((D + 3) & ~3);               /* [IS_TILE+1 -> x4] */
+    float* s_win = s_rcp + ((IS_TILE + 1 + 3) & ~3);     /* [2][65][ISP2_WS] lutT windows */
+    float* s_SV = s_win + 2 * ISP2X_WF;                  /* [2][2][66] S / V prefixes of the tile's rows */
+    float* s_st = s_SV + 2 * 2 * 66;                     /* [2][16] StepRec handed from phase L to phase U */
+    const int tile_lo = tile * IS_TILE;
+    const int colg = col0 + half;
+    const RowRec* rcol = recs + (size_t)colg * (H + 1);
+    const float* lcol = lutT + (size_t)colg * (H + 1) * D;
+    const PriorRec* pcol = priors + (size_t)(col0 / P.C) * H; /* (both columns: the same image) */
+    StepRec* scol = steps + (size_t)colg * H;
+    const float* sv = sv_arr + (size_t)colg * 2 * (H + 1);
+    const int n_rows = min(IS_TILE, H - tile_lo);
+    float* my_winbase = s_win + half * ISP2X_WF;
+    float* my_S = s_SV + half * 2 * 66;
+    float* my_V = my_S + 66;
+
+    /* ---- prologue: per column the fn window [lo, lo + W) of the tile's rows (pw_phase2_body) */
+    int lo, W;
+    {
+        float dmin = IS_INF, dmax = -IS_INF;
+        for (int k = 0; k < 2; k++) {
+            const int v = tile_lo + li + 32 * k;
+            const float d = joined[(size_t)colg * H + min(v, H - 1)];
+            const bool ok = (v < H) && !(HAS_INVALID && d == P.invalid);
+            dmin = __builtin_fminf(dmin, ok ? d : IS_INF);
+            dmax = __builtin_fmaxf(dmax, ok ? d : -IS_INF);
+        }
+        dmin = half_min_f(dmin);
+        dmax = half_max_f(dmax);
+        int l = (int)__builtin_fminf(__builtin_fmaxf(dmin, 1.0f), (float)D) - 1;
+        l = min(max(l, 0), D - 1);
+        int hh = (int)__builtin_fminf(__builtin_fmaxf(dmax, 0.0f), (float)(D - 1)) + 1;
+        hh = min(max(hh, l), min(D - 1, l + ISP2_WMAX - 1));
+        lo = l;
+        W = hh - l + 1;
+    }
+    { /* the window rows tile_lo .. tile_lo + 64 of this lane's column: 32 lanes, 16 columns at most */
+        constexpr int NL = (ISP2_ROWS * ISP2_WMAX + 31) / 32;
+        const int f = li & (ISP2_WMAX - 1), j0 = li >> 4; /* two rows per sweep of the half */
+        float tmp[NL];
+#pragma unroll
+        for (int k = 0; k < NL; k++) {
+            const int j = j0 + 2 * k;
+            tmp[k] = (j < ISP2_ROWS && f < W) ? lcol[(size_t)min(tile_lo + j, H) * D + lo + f] : 0.0f;
+        }
+#pragma unroll
+        for (int k = 0; k < NL; k++) {
+            const int j = j0 + 2 * k;
+            if (j < ISP2_ROWS && f < W) my_winbase[j * ISP2_WS + f] = tmp[k];
+        }
+    }
+    for (int j = li; j <= IS_TILE; j += 32) { /* S / V prefixes at tile_lo + j */
+        const RowRec* q = rcol + min(tile_lo + j, H);
+        my_S[j] = q->S;
+        my_V[j] = HAS_INVALID ? q->V : 0.0f;
+    }
+    if (lane == 0) is_log_tables(s_invc, s_logc);
+    for (int i = lane; i < D; i += 64) s_odr[i] = odr[i];
+    for (int i = lane; i <= IS_TILE; i += 64) s_rcp[i] = rcp[min(i, H)];
+    __syncthreads();
+
+    StepVals st;
+    st.pwmp = IS_INF; st.idx_gs = -1;
+    st.g_hi_thr = st.g_lo_thr = st.p1_hi = st.p1_lo = st.p1_mid = st.o_hi_thr = st.o_lo_thr = 0.0f;
+    st.p2_hi = st.p2_lo = st.p2_mid = st.p3_yes = st.p3_no = 0.0f;
+    float q_o = IS_INF, q_gs = IS_INF; /* (per tile, see pw_phase2_body) */
+    st.q_o = q_o; st.q_gs = q_gs;
+    int ob_cached = -1;
+    float S_obc = 0.0f, V_obc = 0.0f;
+
+    /* partial minima of phase 1 for the rows base + li (its nsplit workgroups merged) */
+    auto load_best = [&](int row_off, PairBest& b) {
+        const size_t o = (size_t)colg * nsplit * 3 * 64 + row_off + li;
+        b.g = part_cost[o]; b.ig = part_idx[o];
+        b.o = part_cost[o + 64]; b.io = part_idx[o + 64];
+        b.s = part_cost[o + 128]; b.is = part_idx[o + 128];
+        for (int sp = 1; sp < nsplit; sp++) {
+            const size_t q = o + (size_t)sp * 3 * 64;
+            float c2 = part_cost[q]; int i2 = part_idx[q];
+            if ((c2 < b.g) || (c2 == b.g && c2 < IS_INF && (i2 / 3) < (b.ig / 3))) { b.g = c2; b.ig = i2; }
+            c2 = part_cost[q + 64]; i2 = part_idx[q + 64];
+            if ((c2 < b.o) || (c2 == b.o && c2 < IS_INF && (i2 / 3) < (b.io / 3))) { b.o = c2; b.io = i2; }
+            c2 = part_cost[q + 128]; i2 = part_idx[q + 128];
+            if ((c2 < b.s) || (c2 == b.s && c2 < IS_INF && (i2 / 3) < (b.is / 3))) { b.s = c2; b.is = i2; }
+        }
+    };
+    auto store_rows = [&](int vT, const PairBest& b) {
+        if (vT < H) {
+            const size_t o = ((size_t)colg * H + vT) * 3;
+            cost_table[o + 0] = b.g; cost_table[o + 1] = b.o; cost_table[o + 2] = b.s;
+            index_table[o + 0] = b.ig; index_table[o + 1] = b.io; index_table[o + 2] = b.is;
+        }
+    };
+    /* the candidates that start at vB = r for the lanes `live`: eval + lutT values + update */
+    auto candidates = [&](const RowRec& my, int vTc, const float* my_win, int r, bool live, float R0, float R1,
+                          const StepVals& stv, PairBest& b) {
+        const int hc = max(vTc + 1 - r, 1);
+        const float rh = s_rcp[min(hc, IS_TILE)];
+        const bool sky = !(r - 1 < vhor);
+        SegTerms t;
+        if (sky) t = eval_segment_dpp<HAS_INVALID, IS_WANT_SKY>(my, R0, R1, (float)hc, rh, D, P.iw);
+        else t = eval_segment_dpp<HAS_INVALID, IS_WANT_GROUND>(my, R0, R1, (float)hc, rh, D, P.iw);
+        const int fo = t.fni - lo;
+        const bool inwin = (unsigned)fo < (unsigned)W;
+        const int foc = inwin ? fo : 0;
+        float od = my_win[foc] - my_winbase[(r - tile_lo) * ISP2_WS + foc];
+        if (__builtin_amdgcn_ballot_w64(live && !inwin) != 0ull) { /* outside the window: rare */
+            const float og = (lcol + (size_t)(vTc + 1) * D)[(unsigned)t.fni] - (lcol + (size_t)r * D)[(unsigned)t.fni];
+            od = inwin ? od : og;
+        }
+        if (sky) pairwise_step<true>(P, stv, r, live, od, t, b);
+        else pairwise_step<false>(P, stv, r, live, od, t, b);
+    };
+    /* row r is final in lane `src` of each half: broadcast it, build and publish StepRec(r + 1) */
+    auto finalize = [&](int r, int src, const PairBest& b, float myS_r1, float myV_r1) {
+        const PriorVals pv = sload_prior(pcol + min(r + 1, H - 1));
+        const int sl = hbase + src;
+        const float cG = half_bcast_f(b.g, sl), cO = half_bcast_f(b.o, sl), cS = half_bcast_f(b.s, sl);
+        const int ob = half_bcast_i(b.io, sl) / 3; /* start of the best object chain */
+        const float S_r1 = half_bcast_f(myS_r1, sl);
+        const float V_r1 = HAS_INVALID ? half_bcast_f(myV_r1, sl) : 0.0f;
+        float S_ob, V_ob = 0.0f;
+        const bool below = ob <= tile_lo;
+        if (__builtin_amdgcn_ballot_w64(below && ob != ob_cached) != 0ull) {
+            if (below && ob != ob_cached) { /* repeated only when the chain's start changes */
+                S_obc = sv[ob];
+                if (HAS_INVALID) V_obc = sv[(H + 1) + ob];
+                ob_cached = ob;
+            }
+        }
+        const int oi = min(max(ob - tile_lo, 0), IS_TILE);
+        S_ob = below ? S_obc : my_S[oi];
+        if (HAS_INVALID) V_ob = below ? V_obc : my_V[oi];
+        st = make_step<HAS_INVALID, true>(P, S_r1, V_r1, S_ob, V_ob, s_odr, s_invc, s_logc, &pv, vhor, r, cG,
+                                          cO, cS, ob);
+        const float m8 = min_raw(min3_raw(st.p1_hi, st.p1_lo, st.p1_mid),
+                                 min3_raw(min3_raw(st.p2_hi, st.p2_lo, st.p2_mid), st.p3_yes, st.p3_no));
+        q_o = min_raw(q_o, P.pw * m8);
+        q_gs = min_raw(q_gs, st.pwmp);
+        st.q_o = q_o; st.q_gs = q_gs;
+        if (li == 0 && r + 1 < H) store_step(scol + r + 1, st);
+    };
+    auto rec_dpp = [&](int v, float& R0, float& R1) { /* the record of v of this lane's column, DPP layout */
+        const float* q = (const float*)(rcol + min(v, H));
+        R0 = q[l15];
+        R1 = q[16 + l15];
+    };
+
+    /* ================= phase L: rows tile_lo .. tile_lo + 31 ================= */
+    {
+        const int vT = tile_lo + li, vTc = min(vT, H - 1);
+        const RowRec my = load_rec(rcol + vTc + 1);
+        const float* my_win = my_winbase + (vTc + 1 - tile_lo) * ISP2_WS;
+        PairBest b;
+        load_best(0, b);
+        float n0, n1;
+        rec_dpp(tile_lo + 1, n0, n1);
+        const int nL = min(32, n_rows);
+        for (int s = 0; s < nL; s++) {
+            const int r = tile_lo + s;
+            if (s > 0) {
+                const float R0 = n0, R1 = n1;
+                rec_dpp(r + 1, n0, n1);
+                candidates(my, vTc, my_win, r, (vT < H) && (vT >= r), R0, R1, st, b);
+            }
+            finalize(r, s, b, my.S, my.V);
+        }
+        store_rows(vT, b);
+        if (li == 0) { /* StepRec(tile_lo + 32) for phase U */
+            float* d = s_st + half * 16;
+            d[0] = st.pwmp; d[1] = __builtin_bit_cast(float, st.idx_gs); d[2] = st.g_hi_thr; d[3] = st.g_lo_thr;
+            d[4] = st.p1_hi; d[5] = st.p1_lo; d[6] = st.p1_mid; d[7] = st.o_hi_thr; d[8] = st.o_lo_thr;
+            d[9] = st.p2_hi; d[10] = st.p2_lo; d[11] = st.p2_mid; d[12] = st.p3_yes; d[13] = st.p3_no;
+            d[14] = st.q_o; d[15] = st.q_gs;
+        }
+    }
+    if (n_rows <= 32) return;
+    /* this wave's StepRec stores of phase L must have reached the L2 before phase S reads them */
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+
+    /* ================= phases S and U: rows tile_lo + 32 .. tile_lo + 63 ================= */
+    {
+        const int vT = tile_lo + 32 + li, vTc = min(vT, H - 1);
+        const RowRec my = load_rec(rcol + vTc + 1);
+        const float* my_win = my_winbase + (vTc + 1 - tile_lo) * ISP2_WS;
+        PairBest b;
+        load_best(32, b);
+        const bool live_all = vT < H;
+        float n0, n1;
+        rec_dpp(tile_lo + 1, n0, n1);
+        for (int sp = 1; sp < 32; sp++) { /* the square: vB = tile_lo + sp, every row of the half */
+            const int r = tile_lo + sp;
+            const float R0 = n0, R1 = n1;
+            rec_dpp(r + 1, n0, n1);
+            /* the StepRec of r (built in phase L by this wave): requested now, needed after the eval */
+            const float4* sq = reinterpret_cast<const float4*>(scol + r);
+            const float4 a0 = sq[0], a1 = sq[1], a2 = sq[2], a3 = sq[3];
+            StepVals sv_;
+            sv_.pwmp = a0.x; sv_.idx_gs = __builtin_bit_cast(int, a0.y); sv_.g_hi_thr = a0.z; sv_.g_lo_thr = a0.w;
+            sv_.p1_hi = a1.x; sv_.p1_lo = a1.y; sv_.p1_mid = a1.z; sv_.o_hi_thr = a1.w;
+            sv_.o_lo_thr = a2.x; sv_.p2_hi = a2.y; sv_.p2_lo = a2.z; sv_.p2_mid = a2.w;
+            sv_.p3_yes = a3.x; sv_.p3_no = a3.y; sv_.q_o = a3.z; sv_.q_gs = a3.w;
+            candidates(my, vTc, my_win, r, live_all, R0, R1, sv_, b);
+        }
+        { /* StepRec(tile_lo + 32), the running minima with it */
+            const float* d = s_st + half * 16;
+            st.pwmp = d[0]; st.idx_gs = __builtin_bit_cast(int, d[1]); st.g_hi_thr = d[2]; st.g_lo_thr = d[3];
+            st.p1_hi = d[4]; st.p1_lo = d[5]; st.p1_mid = d[6]; st.o_hi_thr = d[7]; st.o_lo_thr = d[8];
+            st.p2_hi = d[9]; st.p2_lo = d[10]; st.p2_mid = d[11]; st.p3_yes = d[12]; st.p3_no = d[13];
+            st.q_o = d[14]; st.q_gs = d[15];
+            q_o = st.q_o; q_gs = st.q_gs;
+        }
+        rec_dpp(tile_lo + 32, n0, n1);
+        for (int s = 32; s < n_rows; s++) {
+            const int r = tile_lo + s;
+            const float R0 = n0, R1 = n1;
+            rec_dpp(r + 1, n0, n1);
+            candidates(my, vTc, my_win, r, (vT < H) && (vT >= r), R0, R1, st, b);
+            finalize(r, s - 32, b, my.S, my.V);
+        }
+        store_rows(vT, b);
+    }
+}
+
+template <bool HAS_INVALID>
+__global__ __launch_bounds__(64, ISP2X_OCC) void k_pw_phase2x(
+    const DevParams P, int col_base, int ncols, int tile, int nsplit,
+    const RowRec* __restrict__ recs, const float* __restrict__ lutT,
+    const float* __restrict__ joined, const PriorRec* __restrict__ priors,
+    const float* __restrict__ odr, const float* __restrict__ rcp,
+    const float* __restrict__ sv_arr, const int* __restrict__ vhor_arr,
+    const int* __restrict__ col_flags, const float* __restrict__ part_cost,
+    const int* __restrict__ part_idx, StepRec* __restrict__ steps, float* __restrict__ cost_table,
+    int32_t* __restrict__ index_table) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int col0 = col_base + 2 * (int)blockIdx.x; /* col_base even, P.C even: one image per pair */
+    if (col0 >= ncols) return;
+    const int vhor = __builtin_amdgcn_readfirstlane(vhor_arr[col0 / P.C]);
+    const int f0 = __builtin_amdgcn_readfirstlane(col_flags[col0]);
+    const int f1 = col0 + 1 < ncols ? __builtin_amdgcn_readfirstlane(col_flags[col0 + 1]) : 1;
+    if (f0 == 0 && f1 == 0)
+        pw_phase2x_body<HAS_INVALID>(P, smem, col0, tile, recs, lutT, joined, priors, odr, rcp, sv_arr, vhor, nsplit,
+                                     part_cost, part_idx, steps, cost_table, index_table);
+    /* (a pair with a generic column: k_pw_phase2_generic walks it, column by column) */
+}
+
+/* The columns k_pw_phase2x leaves out: both columns of every pair that contains a generic-encoding
+ * column.  A small grid that leaves at once when k_prepare_columns counted no generic column. */
+template <bool HAS_INVALID>
+__global__ __launch_bounds__(64, 2) void k_pw_phase2_generic(
+    const DevParams P, int col_base, int ncols, int tile, int nsplit,
+    const RowRec* __restrict__ recs, const float* __restrict__ lutT,
+    const float* __restrict__ joined, const PriorRec* __restrict__ priors,
+    const float* __restrict__ odr, const float* __restrict__ rcp,
+    const float* __restrict__ sv_arr, const int* __restrict__ vhor_arr,
+    const int* __restrict__ col_flags, const float* __restrict__ part_cost,
+    const int* __restrict__ part_idx, StepRec* __restrict__ steps, float* __restrict__ cost_table,
+    int32_t* __restrict__ index_table, const int* __restrict__ n_generic) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (__builtin_amdgcn_readfirstlane(*n_generic) == 0) return;
+    for (int colg = col_base + (int)blockIdx.x; colg < ncols; colg += (int)gridDim.x) {
+        const int f0 = __builtin_amdgcn_readfirstlane(col_flags[colg & ~1]);
+        const int f1 = (colg | 1) < ncols ? __builtin_amdgcn_readfirstlane(col_flags[colg | 1]) : 1;
+        if (f0 == 0 && f1 == 0) continue; /* k_pw_phase2x has the pair */
+        const int vhor = __builtin_amdgcn_readfirstlane(vhor_arr[colg / P.C]);
+        if (__builtin_amdgcn_readfirstlane(col_flags[colg]) == 0)
+            pw_phase2_body<true, HAS_INVALID>(P, smem, colg, tile, recs, lutT, joined, priors, odr, rcp, sv_arr, vhor,
+                                              nsplit, part_cost, part_idx, steps, cost_table, index_table);
+        else
+            pw_phase2_body<false, HAS_INVALID>(P, smem, colg, tile, recs, lutT, joined, priors, odr, rcp, sv_arr, vhor,
+                                               nsplit, part_cost, part_idx, steps, cost_table, index_table);
+        __syncthreads();
+    }
+}
+
+
+/* ====================================================================================== */
 /* phase 2, split over the waves of a workgroup (k_pw_phase2s)                              */
 /* ====================================================================================== */
 /* A lone wavefront retires a dependent instruction every ~8 cycles, and a step of k_pw_phase2 is
@@ -1314,6 +1674,14 @@ size_t isk_phase2_lds_bytes(const DevParams* P) {
     return need > floor_bytes ? need : floor_bytes;
 }
 
+size_t isk_phase2x_lds_bytes(const DevParams* P) {
+    const size_t x = sizeof(double) * 2 * IS_LOG_TABLE_SIZE +
+                     sizeof(float) * (((P->D + 3) & ~3) + ((IS_TILE + 1 + 3) & ~3) + 2 * (size_t)ISP2X_WF +
+                                      2 * 2 * 66 + 2 * 16) + 32;
+    const size_t one = isk_phase2_lds_bytes(P); /* the one-column fallback inside the kernel */
+    return x > one ? x : one;
+}
+
 size_t isk_phase2s_lds_bytes(const DevParams* P) {
     return sizeof(double) * 2 * IS_LOG_TABLE_SIZE +
            sizeof(float) * (((P->D + 3) & ~3) + ((IS_TILE + 1 + 3) & ~3) +
@@ -1328,7 +1696,7 @@ hipError_t isk_launch_dp_pairwise(const DevParams* P, int ncols, int nwaves, con
                                   const int* col_flags, const PruneRec* prune, StepRec* steps,
                                   float* part_cost, int* part_idx, float* cost_table,
                                   int32_t* index_table, unsigned long long* counters,
-                                  const float* cost_T,
+                                  const float* cost_T, const int* n_generic,
                                   hipStream_t stream, hipStream_t* aux, int n_aux,
                                   hipEvent_t ev_fork, hipEvent_t* ev_join) {
     const size_t lds1 = isk_pairwise_lds_bytes(P, nwaves);
@@ -1377,6 +1745,16 @@ hipError_t isk_launch_dp_pairwise(const DevParams* P, int ncols, int nwaves, con
                        nsplit, recs, lutT, joined, priors, odr, rcp, sv_arr, vhor, col_flags,      \
                        part_cost,                                                                  \
                        part_idx, steps, cost_table, index_table)
+#define IS_LAUNCH_P2X(INV, c0, c1, st)                                                             \
+    do {                                                                                           \
+        hipLaunchKernelGGL(k_pw_phase2x<INV>, dim3(((c1) - (c0) + 1) / 2), dim3(64), lds2x, st, *P, c0, \
+                           c1, tile, nsplit, recs, lutT, joined, priors, odr, rcp, sv_arr, vhor,   \
+                           col_flags, part_cost, part_idx, steps, cost_table, index_table);        \
+        hipLaunchKernelGGL(k_pw_phase2_generic<INV>, dim3(min((c1) - (c0), 512)), dim3(64), lds2, st, \
+                           *P, c0, c1, tile, nsplit, recs, lutT, joined, priors, odr, rcp, sv_arr, \
+                           vhor, col_flags, part_cost, part_idx, steps, cost_table, index_table,   \
+                           n_generic);                                                             \
+    } while (0)
 #define IS_LAUNCH_P2S(INV, c0, c1, st)                                                             \
     hipLaunchKernelGGL(k_pw_phase2s<INV>, dim3((c1) - (c0)), dim3(ISP2S_WAVES * 64), lds2s, st, *P, \
                        c0, c1, tile, nsplit, recs, lutT, joined, priors, odr, rcp, sv_arr, vhor,   \
@@ -1389,6 +1767,10 @@ hipError_t isk_launch_dp_pairwise(const DevParams* P, int ncols, int nwaves, con
     bool split2 = ncols <= IS_P2_SPLIT_MAX_COLS;
     if (P->knob_p2_split >= 0) split2 = P->knob_p2_split != 0;
     const size_t lds2s = isk_phase2s_lds_bytes(P);
+    /* large batches: two columns per wave in phase 2 (k_pw_phase2x); needs an even number of
+     * columns per image (a pair never straddles two images); IS_P2X=0 selects k_pw_phase2 */
+    const size_t lds2x = isk_phase2x_lds_bytes(P);
+    const bool two_col = !split2 && (P->C % 2) == 0 && P->knob_p2x != 0 && lds2x <= 64 * 1024;
     if (groups > 1) {
         if ((e = hipEventRecord(ev_fork, stream)) != hipSuccess) return e;
         for (int g = 1; g < groups; g++)
@@ -1398,12 +1780,14 @@ hipError_t isk_launch_dp_pairwise(const DevParams* P, int ncols, int nwaves, con
         /* (the block bounds of tile t need t + 1 of the ntiles + 1 entries lds1 has room for) */
         const size_t lds1_t = lds1 - sizeof(float) * 3 * 64 * (size_t)(P->ntiles - tile);
         for (int g = 0; g < groups; g++) {
-            const int c0 = (int)((long long)ncols * g / groups);
-            const int c1 = (int)((long long)ncols * (g + 1) / groups);
+            const int c0 = (int)((long long)ncols * g / groups) & ~1; /* (even: column pairs) */
+            const int c1 = g + 1 == groups ? ncols : ((int)((long long)ncols * (g + 1) / groups) & ~1);
             hipStream_t st = g == 0 ? stream : aux[g - 1];
             if (inv) IS_LAUNCH_P1(true, c0, c1, st); else IS_LAUNCH_P1(false, c0, c1, st);
             if (split2) {
                 if (inv) IS_LAUNCH_P2S(true, c0, c1, st); else IS_LAUNCH_P2S(false, c0, c1, st);
+            } else if (two_col) {
+                if (inv) IS_LAUNCH_P2X(true, c0, c1, st); else IS_LAUNCH_P2X(false, c0, c1, st);
             } else {
                 if (inv) IS_LAUNCH_P2(true, c0, c1, st); else IS_LAUNCH_P2(false, c0, c1, st);
             }
@@ -1412,6 +1796,7 @@ hipError_t isk_launch_dp_pairwise(const DevParams* P, int ncols, int nwaves, con
 #undef IS_LAUNCH_P1
 #undef IS_LAUNCH_P2
 #undef IS_LAUNCH_P2S
+#undef IS_LAUNCH_P2X
     for (int g = 1; g < groups; g++) {
         if ((e = hipEventRecord(ev_join[g - 1], aux[g - 1])) != hipSuccess) return e;
         if ((e = hipStreamWaitEvent(stream, ev_join[g - 1], 0)) != hipSuccess) return e;

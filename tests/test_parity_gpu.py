@@ -94,6 +94,34 @@ def test_random_configs_bit_exact(k):
     _assert_parity(case, got)
 
 
+@pytest.mark.parametrize("k", range(1, 24, 2))
+def test_random_pairwise_configs_two_column_phase2(k, monkeypatch):
+    """The random pairwise configurations through the kernels of LARGE batches: IS_P2_SPLIT=0 makes
+    a small call walk phase 2 with k_pw_phase2x (two columns per wave; odd k = the pairwise
+    presets of _random_case), incl. partial last tiles, invalid disparities and median joins."""
+    monkeypatch.setenv("IS_P2_SPLIT", "0")
+    preset, rows, cols, D, ov = _random_case(k)
+    assert "pairwise" in preset
+    case = helpers.build_case(preset, rows, cols, D, seed=300 + k, n_images=2, **ov)
+    got = helpers.run_core(case)
+    _assert_parity(case, got)
+    monkeypatch.setenv("IS_P2X", "0")           # and the one-column kernel of large batches
+    got = helpers.run_core(case)
+    _assert_parity(case, got)
+
+
+@pytest.mark.parametrize("k", range(1, 8, 2))
+def test_hostile_pairwise_inputs_two_column_phase2(k, monkeypatch):
+    """Generic-encoding columns next to FAST ones under the large-batch kernels: pairs with a
+    generic column are left to k_pw_phase2_generic, the others to k_pw_phase2x."""
+    monkeypatch.setenv("IS_P2_SPLIT", "0")
+    preset, rows, cols, D, ov = _random_case(k)
+    case = helpers.make_hostile(helpers.build_case(preset, rows, cols, D, seed=6000 + k, n_images=2, **ov),
+                                seed=7000 + k)
+    got = helpers.run_core(case)
+    _assert_parity(case, got)
+
+
 @pytest.mark.parametrize("k", range(8))
 def test_hostile_inputs_bit_exact(k):
     """Random configurations whose columns are overwritten with out-of-encoding inputs (generic
