@@ -2,7 +2,7 @@
 # GPU box: kernel trace of one pairwise bench run; per-tile durations of k_pw_phase1 / k_pw_phase2 (last step).
 # usage: bash tools/trace_tiles.sh [bench args]
 set -u
-ARGS=${@:---preset drn_d_38_pairwise --steps 2 --warmup 1 --no-cpu-baseline --no-single --no-d2h --no-variants --no-verify --min-seconds 0}
+ARGS=${@:---preset drn_d_38_pairwise --steps 2 --warmup 1 --no-cpu-baseline --no-single --no-d2h --no-variants --no-verify --no-prune-stats --min-seconds 0}
 OUT=gpurun_out/trace_tiles
 rm -rf $OUT; mkdir -p $OUT
 export TMPDIR=/tmp
@@ -14,11 +14,11 @@ for f in glob.glob("$OUT/**/*kernel_trace.csv", recursive=True):
     rows += list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 p1 = [r for r in rows if "k_pw_phase1" in r["Kernel_Name"]]
-p2 = [r for r in rows if "k_pw_phase2" in r["Kernel_Name"]]
+p2 = [r for r in rows if "k_pw_phase2" in r["Kernel_Name"] and "generic" not in r["Kernel_Name"]]
 d = lambda r: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
 n = 16
 if p1:
-    a, b = p1[-2*n:-n], p2[-2*n:-n]   # (the very last step is the untimed counter pass)
+    a, b = p1[-n:], p2[-n:]
     print("tile  phase1_us  phase2_us  gap_before_p1_us")
     for i in range(n):
         gap = (int(a[i]["Start_Timestamp"]) - int((b[i-1] if i else a[i])["End_Timestamp"])) / 1e3 if i else 0
