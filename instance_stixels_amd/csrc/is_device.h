@@ -38,7 +38,7 @@
 #endif
 #define IS_PREPARE_OVERLAP_MAX_COLS 1024 /* below: the two prepare kernels run on two streams */
 #define IS_PAIRWISE_SPLIT_MIN_COLS 1024 /* columns per group before the pairwise DP uses one more stream */
-#define IS_PAIRWISE_MAX_GROUPS 2       /* column groups (streams) of the pairwise DP: 2 = +2.4 % at batch 64 (round 3) */
+#define IS_PAIRWISE_MAX_GROUPS 1       /* column groups (streams) of the pairwise DP: 2 groups measured +0.4 % alone but -9 % beside the RCCL gather pipeline (round 3); IS_PW_GROUPS overrides */
 #define IS_P2_SPLIT_MAX_COLS 2048     /* up to eight 2048-px frames: phase 2 of the pairwise DP as chain + evaluator wave per column */
 #define IS_BACKTRACE_STAGE_MAX_COLS 2048 /* up to eight 2048-px frames: the back-trace chases in LDS */
 #define IS_AUX_STREAMS 7               /* auxiliary streams a context owns */
