@@ -16,7 +16,7 @@ import os
 import re
 import sys
 
-DP_KERNELS = {"unary": ("k_dp_unary",), "pairwise": ("k_pw_phase1", "k_pw_phase2")}
+DP_KERNELS = {"unary": ("k_dp_unary",), "pairwise": ("k_pw_phase1", "k_pw_phase2")}  # (k_pw_phase2 matches k_pw_phase2x and k_pw_phase2_generic too)
 
 
 def counters(d, which):
