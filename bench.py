@@ -156,10 +156,10 @@ def committed_traffic(cfg, B, H, W, D):
 
 
 class Workload:
-    side_stream = False   # --side-stream
-
     """One configuration's batch, resident in HBM: host tables through the C++ Stixels class,
     `distinct` synthetic frames repeated to `batch`, device inputs and output buffers."""
+
+    side_stream = False   # --side-stream: steps on a torch side stream instead of the default stream
 
     def __init__(self, preset, H, W, D, batch, distinct, dev, local_rank, seed0=17, family="scene",
                  **overrides):
