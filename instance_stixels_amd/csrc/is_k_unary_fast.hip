@@ -40,7 +40,7 @@
 #define ISF_OCC_INV 5 /* with an invalid-disparity value: 9 spilled VGPRs at 6 */
 #endif
 #ifndef ISF_OCC
-#define ISF_OCC 6 /* waves per SIMD the kernel is compiled for */
+#define ISF_OCC 7 /* waves per SIMD the kernel is compiled for: 68 VGPRs without spills; LDS keeps three workgroups = 6 per SIMD resident (7 measured 0.5-1 % faster than 6) */
 #endif
 #ifndef ISF_GEN_TILE
 #define ISF_GEN_TILE 0 /* 1: the vT-side lutT rows rebuilt in LDS (gen_lut_tile) instead of read back: -8.6 GB of HBM reads per 64 frames, but +9 % DP time (measured, round 3) */
