@@ -42,6 +42,9 @@
 #ifndef ISF_OCC
 #define ISF_OCC 7 /* waves per SIMD the kernel is compiled for: 68 VGPRs without spills; LDS keeps three workgroups = 6 per SIMD resident (7 measured 0.5-1 % faster than 6) */
 #endif
+#ifndef ISF_SREC
+#define ISF_SREC 1 /* the class-prefix half of the vB record as scalar operands (eval_segment_mix) */
+#endif
 #ifndef ISF_GEN_TILE
 #define ISF_GEN_TILE 0 /* 1: the vT-side lutT rows rebuilt in LDS (gen_lut_tile) instead of read back: -8.6 GB of HBM reads per 64 frames, but +9 % DP time (measured, round 3) */
 #endif
@@ -58,7 +61,7 @@ template <bool HAS_INVALID, bool SKY, bool DIAG, bool FIRST, bool NOGROUND>
 __device__ __forceinline__ SegTerms fast_step(const DevParams& P, const RowRec& my, const float* srec,
                                               const float* lrow, const float* my_tile,
                                               const float* s_rcp, int vT, int vTc, int vhor, int vB,
-                                              bool row_ok, UnaryBestF& b) {
+                                              bool row_ok, UnaryBestF& b, const isk_f16v& S) {
     const int h = vTc + 1 - vB;
     const bool live = DIAG ? ((h > 0) && row_ok) : row_ok;
     const int hc = DIAG ? max(h, 1) : h;
@@ -67,8 +70,12 @@ __device__ __forceinline__ SegTerms fast_step(const DevParams& P, const RowRec& 
     const int l15 = threadIdx.x & 15;
     /* FIRST (vB = 0): ground + object; otherwise the sky OR the ground candidate, or neither */
     constexpr int WANT = SKY ? IS_WANT_SKY : (NOGROUND ? 0 : IS_WANT_GROUND);
+#if ISF_SREC
+    const SegTerms t = eval_segment_mix<HAS_INVALID, WANT>(my, S, srec[16 + l15], (float)hc, r, P.D, P.iw);
+#else
     const SegTerms t = eval_segment_dpp<HAS_INVALID, WANT>(my, srec[l15], srec[16 + l15], (float)hc, r, P.D,
                                                            P.iw);
+#endif
 #else
     const RowRec rb = lds_rec(srec);
     const SegTerms t = eval_segment<true, HAS_INVALID>(my, rb, (float)hc, r, P.D, P.iw);
@@ -289,8 +296,15 @@ __global__ __launch_bounds__(ISF_THREADS, HAS_INVALID ? ISF_OCC_INV : ISF_OCC) v
     int slot = 0;
     bool o_closed = false;
     int n_full = 0, n_gs = 0; /* steps below the diagonal block (wave-uniform: SALU only) */
+    isk_f16v S; /* the class prefixes of the record of vB as scalars, requested one step ahead */
+#if ISF_SREC
+    srec_request(S, rcol + vB_top);
+#endif
     for (int vB = vB_top; vB >= 0; vB -= ISF_WAVES) {
         wait_vmcnt<(NVR + 1) * (K - 1)>(); /* this step's slot has landed; K - 1 prefetches in flight */
+#if ISF_SREC
+        srec_arrived(S);
+#endif
         float* s_row = my_ring + slot * SLOT;
         const float* rb = s_row + ROWF; /* the record of vB in the ring slot */
         const float* lrow = s_row;
@@ -310,30 +324,30 @@ __global__ __launch_bounds__(ISF_THREADS, HAS_INVALID ? ISF_OCC_INV : ISF_OCC) v
         if (vB == 0) { /* first segment (:481-594): ground + object */
             if (diag)
                 fast_step<HAS_INVALID, false, true, true, false>(P, my, rb, lrow, my_tile, s_rcp, vT, vTc, vhor,
-                                                                 0, row_ok, b);
+                                                                 0, row_ok, b, S);
             else
                 fast_step<HAS_INVALID, false, false, true, false>(P, my, rb, lrow, my_tile, s_rcp, vT, vTc,
-                                                                  vhor, 0, row_ok, b);
+                                                                  vhor, 0, row_ok, b, S);
         } else if (vB > vhor) { /* vB - 1 >= vhor: sky + object (:729) */
             if (diag) {
                 fast_step<HAS_INVALID, true, true, false, false>(P, my, rb, lrow, my_tile, s_rcp, vT, vTc, vhor,
-                                                                 vB, row_ok, b);
+                                                                 vB, row_ok, b, S);
             } else {
                 const SegTerms t = fast_step<HAS_INVALID, true, false, false, false>(
-                    P, my, rb, lrow, my_tile, s_rcp, vT, vTc, vhor, vB, row_ok, b);
+                    P, my, rb, lrow, my_tile, s_rcp, vT, vTc, vhor, vB, row_ok, b, S);
                 if (IS_PRUNE) ok = fast_bounds<true, false>(P, pv, t, b);
             }
         } else { /* ground + object (:687) */
             if (diag) {
                 fast_step<HAS_INVALID, false, true, false, false>(P, my, rb, lrow, my_tile, s_rcp, vT, vTc, vhor,
-                                                                  vB, row_ok, b);
+                                                                  vB, row_ok, b, S);
             } else if (nog) {
                 const SegTerms t = fast_step<HAS_INVALID, false, false, false, true>(
-                    P, my, rb, lrow, my_tile, s_rcp, vT, vTc, vhor, vB, row_ok, b);
+                    P, my, rb, lrow, my_tile, s_rcp, vT, vTc, vhor, vB, row_ok, b, S);
                 if (IS_PRUNE) ok = fast_bounds<false, true>(P, pv, t, b);
             } else {
                 const SegTerms t = fast_step<HAS_INVALID, false, false, false, false>(
-                    P, my, rb, lrow, my_tile, s_rcp, vT, vTc, vhor, vB, row_ok, b);
+                    P, my, rb, lrow, my_tile, s_rcp, vT, vTc, vhor, vB, row_ok, b, S);
                 if (IS_PRUNE) ok = fast_bounds<false, false>(P, pv, t, b);
             }
         }
@@ -345,8 +359,15 @@ __global__ __launch_bounds__(ISF_THREADS, HAS_INVALID ? ISF_OCC_INV : ISF_OCC) v
         /* refill the slot just consumed (its reads have returned: their values were used) */
         asm volatile("" ::: "memory");
         ring_prefetch<NVR>(lcol, rcol, max(vB - ISF_WAVES * K, 0), D, s_row, s_row + ROWF, lane);
+#if ISF_SREC
+        srec_request(S, rcol + max(vB - ISF_WAVES, 0));
+#endif
         slot = (slot + 1 == K) ? 0 : slot + 1;
     }
+#if ISF_SREC
+    srec_arrived(S); /* a walk that ran to vB = 0 leaves a request in flight: it must not land in
+                      * registers that hold something else by then */
+#endif
     ISF_MARK(1);
     if (counters != nullptr && lane == 0) {
         atomicAdd(counters + IS_CNT_UNARY_FULL, (unsigned long long)n_full);

@@ -586,6 +586,71 @@ __device__ __forceinline__ SegTerms eval_segment_dpp(const RowRec& my, float R0,
     return t;
 }
 
+/* eval_segment_dpp with the FIRST half of the vB record (the 16 class prefixes Fg0, Fg1, Fon[8],
+ * Foi[0..5]) as SCALAR operands S: a subtraction with an SGPR operand issues in 2 cycles, with a
+ * DPP operand in 4, and a step of the unary ring kernel is bound by exactly that.  Identical
+ * operations in identical order per value.  The caller brings S in with srec_request() one step
+ * ahead and srec_arrived() before the step (one s_load_dwordx16 from the record's line in global
+ * memory -- the ring's LDS-DMA has brought that line into the L2 steps before). */
+typedef float isk_f16v __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ void srec_request(isk_f16v& S, const RowRec* grec) {
+    asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(S) : "s"(grec));
+}
+__device__ __forceinline__ void srec_arrived(isk_f16v& S) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(S)); }
+
+template <bool HAS_INVALID, int WANT = IS_WANT_GROUND | IS_WANT_SKY>
+__device__ __forceinline__ SegTerms eval_segment_mix(const RowRec& my, const isk_f16v& S, float R1,
+                                                     float height, float r, int D, float iw) {
+    SegTerms t;
+    const float nic = iw * (float)dpp_sub_i_first<3>(my.Fnic, R1);
+    float f_g = 0.0f;
+    if (WANT & IS_WANT_GROUND) f_g = __builtin_fminf(my.Fg0 - S[0], my.Fg1 - S[1]);
+    float f_on = my.Fon[0] - S[2];
+#pragma unroll
+    for (int c = 1; c < IS_N_ON; c++) f_on = __builtin_fminf(f_on, my.Fon[c] - S[2 + c]);
+    float f_oi = my.Foi[0] - S[10];
+#pragma unroll
+    for (int c = 1; c < 6; c++) f_oi = __builtin_fminf(f_oi, my.Foi[c] - S[10 + c]);
+    {
+        const float a6 = dpp_sub<0>(my.Foi[6], R1), a7 = dpp_sub<1>(my.Foi[7], R1);
+        f_oi = min3_raw(f_oi, a6, a7);
+    }
+    float f_sky = 0.0f;
+    if (WANT & IS_WANT_SKY) f_sky = dpp_sub<2>(my.Fsky, R1);
+    const float meanx = dpp_sub<8>(my.MX, R1);
+    const float meany = dpp_sub<9>(my.MY, R1);
+    const float d_x2h = dpp_sub<10>(my.MX2h, R1);
+    const float d_x2l = dpp_sub<11>(my.MX2l, R1);
+    const float d_y2h = dpp_sub<12>(my.MY2h, R1);
+    const float d_y2l = dpp_sub<13>(my.MY2l, R1);
+    const float meanx2 = d_x2h + d_x2l;
+    const float meany2 = d_y2h + d_y2l;
+    const float ic = iw * (meanx2 - fast_div(meanx * meanx, height, r) + meany2 -
+                           fast_div(meany * meany, height, r));
+    t.f_g = f_g; t.f_on = f_on; t.f_oi = f_oi; t.f_sky = f_sky;
+    t.seg_g = f_g + nic;
+    const float on = nic + f_on;
+    const float oi = ic + f_oi;
+    t.on = on; t.ic = ic;
+    t.seg_o = min_raw(oi, on); /* both finite in a FAST column */
+    t.seg_s = f_sky + nic;
+    t.gd = 0.0f;
+    t.sd = 0.0f;
+    if (WANT & IS_WANT_GROUND) t.gd = dpp_sub<4>(my.G, R1);
+    if (WANT & IS_WANT_SKY) t.sd = dpp_sub<5>(my.K, R1);
+    float mean;
+    if (HAS_INVALID) {
+        const float valid_dif = dpp_sub<7>(my.V, R1);
+        const float sdif = dpp_sub<6>(my.S, R1);
+        mean = (valid_dif == 0) ? 0 : sdif / valid_dif;
+    } else {
+        mean = fast_div(dpp_sub<6>(my.S, R1), height, r);
+    }
+    t.fni = (int)min(cvt_u32_sat(mean), (unsigned)(D - 1));
+    t.mean = __builtin_fmaxf(mean, 0.0f);
+    return t;
+}
+
 /* ====================================================================================== */
 /* Wave-private LDS rings filled by LDS-DMA (is_k_unary_fast.hip, k_pw_phase1_ring)         */
 /* ====================================================================================== */
