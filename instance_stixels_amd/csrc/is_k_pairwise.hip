@@ -62,6 +62,26 @@ __device__ __forceinline__ StepVals sload_step(const StepRec* p) {
     return r;
 }
 
+/* the two halves of sload_step apart: the loads where they are requested, the pinning where the
+ * values are first needed (pinning makes the compiler wait for the loads) */
+__device__ __forceinline__ StepVals sload_step_raw(const StepRec* p) {
+    cstep_t q = (cstep_t)p;
+    StepVals r;
+    r.pwmp = q->pwmp; r.idx_gs = q->idx_gs;
+    r.g_hi_thr = q->g_hi_thr; r.g_lo_thr = q->g_lo_thr;
+    r.p1_hi = q->p1_hi; r.p1_lo = q->p1_lo; r.p1_mid = q->p1_mid;
+    r.o_hi_thr = q->o_hi_thr; r.o_lo_thr = q->o_lo_thr;
+    r.p2_hi = q->p2_hi; r.p2_lo = q->p2_lo; r.p2_mid = q->p2_mid;
+    r.p3_yes = q->p3_yes; r.p3_no = q->p3_no;
+    r.q_o = q->q_o; r.q_gs = q->q_gs;
+    return r;
+}
+__device__ __forceinline__ void pin_step(StepVals& r) {
+    r.p1_hi = opaque_s(r.p1_hi); r.p1_lo = opaque_s(r.p1_lo); r.p1_mid = opaque_s(r.p1_mid);
+    r.p2_hi = opaque_s(r.p2_hi); r.p2_lo = opaque_s(r.p2_lo); r.p2_mid = opaque_s(r.p2_mid);
+    r.p3_yes = opaque_s(r.p3_yes); r.p3_no = opaque_s(r.p3_no);
+}
+
 /* sload_rec with every field pinned into its SGPR right here: the compiler otherwise sinks the
  * loads of the fields towards their first uses and the serial chain of phase 2 waits for scalar
  * memory twice per step (mean first, the class prefixes later) instead of once */
@@ -317,6 +337,15 @@ __device__ __forceinline__ void touch_round(const RowRec* rcol, const StepRec* s
 #ifndef IS_P1_MY_FIRST
 #define IS_P1_MY_FIRST 0 /* 1: the lane record requested before the tile staging: measured 2 % slower (more loads in flight at once) */
 #endif
+#ifndef IS_P1_SREC_LATE
+#define IS_P1_SREC_LATE 1 /* StepRec of the next step: loaded at the end of the step, pinned (= waited for) at its use */
+#endif
+#ifndef IS_P1_SREC_FIRST
+#define IS_P1_SREC_FIRST 0
+#endif
+#ifndef IS_P1_SREC
+#define IS_P1_SREC 1 /* class-prefix half of the vB record as scalar operands (see eval_segment_mix) */
+#endif
 #ifndef IS_P1_GEN_TILE
 #define IS_P1_GEN_TILE 0 /* see ISF_GEN_TILE (is_k_unary_fast.hip): -8.6 GB of reads, +4 % DP time */
 #endif
@@ -518,12 +547,28 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
             const int l15 = lane & 15;
             float c_r0 = 0.0f, c_r1 = 0.0f, n_r0 = 0.0f, n_r1 = 0.0f;
             StepVals st_next;
+            isk_f16v S; /* IS_P1_SREC: the class-prefix half of the record of vB as scalars (eval_segment_mix) */
             if (USE_DPP) { /* (requesting these before the tile staging of the prologue measured 2.5 % slower) */
                 const float* q0 = (const float*)(rcol + vB);
                 const float* q1 = (const float*)(rcol + max(vB - nw, 0));
-                c_r0 = q0[l15]; c_r1 = q0[16 + l15];
-                n_r0 = q1[l15]; n_r1 = q1[16 + l15];
+                if (!IS_P1_SREC) { c_r0 = q0[l15]; n_r0 = q1[l15]; }
+                c_r1 = q0[16 + l15];
+                n_r1 = q1[16 + l15];
                 st_next = sload_step(scol + vB);
+                if (IS_P1_SREC) srec_request(S, rcol + vB);
+            }
+#define IS_P1_DRAIN() if (USE_DPP && IS_P1_SREC) srec_arrived(S) /* a request is in flight after every step */
+            /* IS_P1_SREC: the StepRec and the scalar half of the record of the next step are requested
+             * when the step has read its own for the last time (the bounds): one set of registers
+             * each instead of two, and the loads have the first half of the next step to arrive */
+#define IS_P1_REQUEST_NEXT(last_use)                                                               \
+            if (USE_DPP && IS_P1_SREC) {                                                           \
+                const int vn = max(vB - nw, 0);                                                    \
+                const StepRec* sn = scol + vn;                                                     \
+                asm volatile("" : "+s"(sn) : "s"((int)(last_use)));                                     \
+                if (IS_P1_SREC_FIRST) srec_request_next(S, rcol + vn);                             \
+                st_next = IS_P1_SREC_LATE ? sload_step_raw(sn) : sload_step(sn);                   \
+                if (!IS_P1_SREC_FIRST) srec_request_next(S, rcol + vn);                            \
             }
 #define IS_P1_STEP(SKY, NOG)                                                                       \
             ISP1_COUNT(4);                                                                         \
@@ -542,16 +587,25 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
                 c_r0 = n_r0; c_r1 = n_r1;                                                          \
                 {                                                                                  \
                     const float* q2 = (const float*)(rcol + max(vB - 2 * nw, 0));                  \
-                    n_r0 = q2[l15]; n_r1 = q2[16 + l15];                                           \
+                    if (!IS_P1_SREC) n_r0 = q2[l15];                                               \
+                    n_r1 = q2[16 + l15];                                                           \
                 }                                                                                  \
-                t = eval_segment_dpp<HAS_INVALID, (SKY) ? IS_WANT_SKY : ((NOG) ? 0 : IS_WANT_GROUND)>(  \
-                    my, r0, r1, (float)h, s_rcp[h], D, P.iw);                                      \
+                constexpr int WANT = (SKY) ? IS_WANT_SKY : ((NOG) ? 0 : IS_WANT_GROUND);           \
+                if (IS_P1_SREC) {                                                                  \
+                    if (IS_P1_SREC_LATE) pin_step(st);                                             \
+                    srec_arrived(S);                                                               \
+                    t = eval_segment_mix<HAS_INVALID, WANT>(my, S, r1, (float)h, s_rcp[h], D, P.iw); \
+                } else {                                                                           \
+                    t = eval_segment_dpp<HAS_INVALID, WANT>(my, r0, r1, (float)h, s_rcp[h], D, P.iw); \
+                }                                                                                  \
                 od = my_tile[t.fni] - pick_lut<NR>(row, t.fni);                                    \
-                /* the next StepRec: requested only now -- every LDS wait is an lgkmcnt(0) wait    \
-                 * and would wait for this scalar load too (SMEM returns out of order) */          \
-                const StepRec* sn = scol + max(vB - nw, 0);                                        \
-                asm volatile("" : "+s"(sn) : "v"(od));                                             \
-                st_next = sload_step(sn);                                                          \
+                if (!IS_P1_SREC) {                                                                 \
+                    /* the next StepRec: requested only now -- every LDS wait is an lgkmcnt(0)     \
+                     * wait and would wait for this scalar load too (SMEM returns out of order) */ \
+                    const StepRec* sn = scol + max(vB - nw, 0);                                    \
+                    asm volatile("" : "+s"(sn) : "v"(od));                                         \
+                    st_next = sload_step(sn);                                                      \
+                }                                                                                  \
             } else {                                                                               \
                 const RowRec rb = sload_rec(rcol + vB);                                            \
                 st = sload_step(scol + vB);                                                        \
@@ -606,9 +660,11 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
                 IS_P1_STEP(true, false);
                 const float lb_s = min_raw((st.q_gs - E1gs) + P.sw * t.seg_s, lbp[2 * NLB * 64]);
                 const bool ok_s = (__builtin_amdgcn_ballot_w64(lb_s > b.s) | dead) == ~0ull;
+                IS_P1_REQUEST_NEXT(ok_s);
                 if (ok_o && ok_s) { done = true; break; }
                 if (ok_o) { o_closed = true; vB -= nw; break; }
             }
+            IS_P1_DRAIN();
             if (!done && o_closed) {
                 /* a tile with a sky range lies above the horizon: no ground candidates, and the
                  * first segment's object candidate is closed too -- only sky candidates are left */
@@ -619,16 +675,20 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
             if (!done && nog) {
                 for (; vB >= 1; vB -= nw) { /* ground range, ground candidates are +inf */
                     IS_P1_STEP(false, true);
+                    IS_P1_REQUEST_NEXT(ok_o);
                     if (ok_o) { done = true; break; }
                 }
+                IS_P1_DRAIN();
             } else if (!done) {
                 for (; vB >= 1; vB -= nw) { /* ground range: vB - 1 < vhor */
                     IS_P1_STEP(false, false);
                     const float lb_g = min_raw((st.q_gs - E1gs) + P.sw * t.seg_g, lbp[NLB * 64]);
                     const bool ok_g = (__builtin_amdgcn_ballot_w64(lb_g > b.g) | gdead) == ~0ull;
+                    IS_P1_REQUEST_NEXT(ok_g);
                     if (ok_o && ok_g) { done = true; break; }
                     if (ok_o) { o_closed = true; vB -= nw; break; }
                 }
+                IS_P1_DRAIN();
                 if (!done && o_closed) {
                     bool g_closed = false;
                     while (vB >= 1 && !g_closed) IS_P1_GS4(false, 1, gdead, g_closed)
@@ -638,6 +698,8 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
 #undef IS_P1_STEP
 #undef IS_P1_NEXT_ROW
 #undef IS_P1_GS4
+#undef IS_P1_DRAIN
+#undef IS_P1_REQUEST_NEXT
             if (!done && vB == 0) { /* first segment, :481-594 */
                 n_full++;
                 const RowRec rb = sload_rec(rcol);

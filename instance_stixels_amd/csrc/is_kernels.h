@@ -593,8 +593,16 @@ __device__ __forceinline__ SegTerms eval_segment_dpp(const RowRec& my, float R0,
  * ahead and srec_arrived() before the step (one s_load_dwordx16 from the record's line in global
  * memory -- the ring's LDS-DMA has brought that line into the L2 steps before). */
 typedef float isk_f16v __attribute__((ext_vector_type(16)));
+#ifndef IS_MIX_PK
+#define IS_MIX_PK 1 /* the sixteen scalar-operand subtractions as eight v_pk_add_f32 (neg modifiers): -1.5 % */
+#endif
 __device__ __forceinline__ void srec_request(isk_f16v& S, const RowRec* grec) {
     asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(S) : "s"(grec));
+}
+/* the same for a value that is live: the old contents are consumed here, so the compiler keeps
+ * every use of them in front of the request */
+__device__ __forceinline__ void srec_request_next(isk_f16v& S, const RowRec* grec) {
+    asm volatile("s_load_dwordx16 %0, %1, 0x0" : "+s"(S) : "s"(grec));
 }
 __device__ __forceinline__ void srec_arrived(isk_f16v& S) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(S)); }
 
@@ -604,6 +612,29 @@ __device__ __forceinline__ SegTerms eval_segment_mix(const RowRec& my, const isk
     SegTerms t;
     const float nic = iw * (float)dpp_sub_i_first<3>(my.Fnic, R1);
     float f_g = 0.0f;
+#if IS_MIX_PK
+    typedef float f2 __attribute__((ext_vector_type(2)));
+#define IS_PK_SUB(a0, a1, k) (f2{a0, a1} - f2{S[k], S[(k) + 1]})
+    if (WANT & IS_WANT_GROUND) {
+        const f2 d = IS_PK_SUB(my.Fg0, my.Fg1, 0);
+        f_g = __builtin_fminf(d.x, d.y);
+    }
+    float f_on, f_oi;
+    {
+        const f2 d0 = IS_PK_SUB(my.Fon[0], my.Fon[1], 2), d1 = IS_PK_SUB(my.Fon[2], my.Fon[3], 4),
+                 d2 = IS_PK_SUB(my.Fon[4], my.Fon[5], 6), d3 = IS_PK_SUB(my.Fon[6], my.Fon[7], 8);
+        f_on = __builtin_fminf(d0.x, d0.y);
+        f_on = __builtin_fminf(__builtin_fminf(f_on, d1.x), d1.y);
+        f_on = __builtin_fminf(__builtin_fminf(f_on, d2.x), d2.y);
+        f_on = __builtin_fminf(__builtin_fminf(f_on, d3.x), d3.y);
+        const f2 e0 = IS_PK_SUB(my.Foi[0], my.Foi[1], 10), e1 = IS_PK_SUB(my.Foi[2], my.Foi[3], 12),
+                 e2 = IS_PK_SUB(my.Foi[4], my.Foi[5], 14);
+        f_oi = __builtin_fminf(e0.x, e0.y);
+        f_oi = __builtin_fminf(__builtin_fminf(f_oi, e1.x), e1.y);
+        f_oi = __builtin_fminf(__builtin_fminf(f_oi, e2.x), e2.y);
+    }
+#undef IS_PK_SUB
+#else
     if (WANT & IS_WANT_GROUND) f_g = __builtin_fminf(my.Fg0 - S[0], my.Fg1 - S[1]);
     float f_on = my.Fon[0] - S[2];
 #pragma unroll
@@ -611,6 +642,7 @@ __device__ __forceinline__ SegTerms eval_segment_mix(const RowRec& my, const isk
     float f_oi = my.Foi[0] - S[10];
 #pragma unroll
     for (int c = 1; c < 6; c++) f_oi = __builtin_fminf(f_oi, my.Foi[c] - S[10 + c]);
+#endif
     {
         const float a6 = dpp_sub<0>(my.Foi[6], R1), a7 = dpp_sub<1>(my.Foi[7], R1);
         f_oi = min3_raw(f_oi, a6, a7);
