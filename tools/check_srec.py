@@ -22,9 +22,14 @@ for i, l in enumerate(body):
     if "s_load_dwordx16" in l and i > 0 and "ASMSTART" in body[i - 1]:
         m = re.search(r"s_load_dwordx16 s\[(\d+):(\d+)\]", l)
         dst = set(range(int(m.group(1)), int(m.group(2)) + 1))
+        k = i + 1 # further loads of the same asm statement (srec_request_tail)
+        while "ASMEND" not in body[k]:
+            m2 = re.search(r"s_load_dwordx\d+ s\[(\d+):(\d+)\]", body[k])
+            if m2: dst |= set(range(int(m2.group(1)), int(m2.group(2)) + 1))
+            k += 1
         n += 1
         # walk every path from i+1 until an asm wait
-        seen, work = set(), [i + 1]
+        seen, work = set(), [k]
         while work:
             j = work.pop()
             while j < len(body):
@@ -34,8 +39,8 @@ for i, l in enumerate(body):
                 if "ASMSTART" in x and j + 1 < len(body) and "s_waitcnt lgkmcnt(0)" in body[j + 1]: break
                 if is_inst(x):
                     if "s_endpgm" in x: break
-                    if sregs(x) & dst and not ("s_load_dwordx16" in x and j == i):
-                        print(f"line {j}: {x.strip()}   touches s[{min(dst)}:{max(dst)}] requested at line {i}")
+                    if sregs(x) & dst:
+                        print(f"line {j}: {x.strip()}   touches {sorted(dst)} requested at line {i}")
                         bad += 1
                     mb = re.match(r"\s+(s_cbranch_\w+|s_branch)\s+(\.LBB\d+_\d+)", x)
                     if mb:
