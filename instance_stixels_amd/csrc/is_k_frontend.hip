@@ -26,8 +26,17 @@ __device__ __forceinline__ float join_median(float* tmp_row, int n) {
 __device__ __forceinline__ float join_one(const float* __restrict__ src, int step, bool median,
                                           float invalid) {
     float v[16];
+    if (step == 8 && (((uintptr_t)src) & 15) == 0) {
+        /* the usual stixel width: the eight values as two 16-byte loads instead of eight dword loads */
+        const float4 a = reinterpret_cast<const float4*>(src)[0], b = reinterpret_cast<const float4*>(src)[1];
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+        v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
 #pragma unroll
-    for (int i = 0; i < 16; i++) v[i] = (i < step) ? src[i] : 0.0f;
+        for (int i = 8; i < 16; i++) v[i] = 0.0f;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 16; i++) v[i] = (i < step) ? src[i] : 0.0f;
+    }
     if (median) {
         if (invalid >= 0) {
             float t[16];

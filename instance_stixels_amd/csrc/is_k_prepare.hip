@@ -607,7 +607,11 @@ extern "C" {
 
 size_t isk_prepare_lds_bytes(const DevParams* P) {
     return sizeof(float) * (size_t)prep_scan_leaves(P->H, P->P2) * 3 +
-           sizeof(int32_t) * (size_t)P->CH * prep_seg_stride(P->H) + 192;
+           sizeof(int32_t) * (size_t)P->CH * prep_seg_stride(P->H) + 192
+#ifdef PREP_LDS_PAD /* occupancy experiments */
+           + PREP_LDS_PAD
+#endif
+        ;
 }
 
 hipError_t isk_launch_prepare(const DevParams* P, int ncols, const float* joined,
