@@ -222,18 +222,27 @@ __device__ __forceinline__ void prepare_columns_body(
                 (s_abs[1] >= (unsigned long long)IS_FAST_INSTANCE_LIMIT);
         __syncthreads(); /* s_wave is reused by the scans below */
     }
-    if (tid < K) { /* class channels of a FAST column: values >= 0, full-resolution total < 2^24 */
-        const int32_t* ch = s_seg + tid * SS;
-        uint64_t total = 0;
-        int negative = 0;
-        for (int k = 0; k < SS; k++) {
-            /* (rotated start: spreads the 19 threads over the LDS banks) */
-            const int kk = (k + tid < SS) ? k + tid : k + tid - SS;
-            const int32_t x = ch[kk % SS];
-            negative |= (x < 0);
-            total += (uint64_t)(uint32_t)x;
+    { /* class channels of a FAST column: values >= 0, full-resolution total < 2^24.  One wave per
+       * channel (round robin), a lane sums every 64th entry, the wave adds the lane sums (the
+       * nineteen channels used to be walked by nineteen lanes of wave 0: 132 serial iterations
+       * with an integer modulo each, a tenth of the workgroup's life) */
+        const int lane = tid & 63, wv = tid >> 6;
+        for (int c = wv; c < K; c += PREP_THREADS / 64) {
+            const int32_t* ch = s_seg + c * SS;
+            uint64_t total = 0;
+            int negative = 0;
+            for (int k = lane; k < SS; k += 64) {
+                const int32_t x = ch[k];
+                negative |= (x < 0);
+                total += (uint64_t)(uint32_t)x;
+            }
+#pragma unroll
+            for (int j = 32; j >= 1; j >>= 1) {
+                total += (uint64_t)__shfl_xor((unsigned long long)total, j, 64);
+                negative |= __shfl_xor(negative, j, 64);
+            }
+            slow |= negative | (total * IS_DOWNSAMPLE_FACTOR >= (uint64_t)IS_FAST_CLASS_LIMIT);
         }
-        slow |= negative | (total * IS_DOWNSAMPLE_FACTOR >= (uint64_t)IS_FAST_CLASS_LIMIT);
     }
     slow = __syncthreads_or(slow);
     if (tid == 0) {
@@ -320,23 +329,50 @@ __device__ __forceinline__ void prepare_columns_body(
     }
     __syncthreads();
     /* dwords 0..19 of every record (class prefixes + squared-offset prefix) as five 16-byte
-     * chunks: consecutive threads write consecutive chunks */
-    for (int i = tid; i < (H + 1) * 5; i += PREP_THREADS) {
-        const int v = i / 5, q = i - v * 5;
-        int32_t x[4];
+     * chunks.  A thread owns one chunk of the EIGHT rows of a 1/8-resolution block: the full-resolution
+     * prefix at row 8 kb + m is ps[kb] * 8 + (ps[kb + 1] - ps[kb]) * m (full_prefix, wrapping
+     * uint32 arithmetic), so the two table entries are read once per block and the rows follow by
+     * repeated addition -- an eighth of the LDS reads and a fifth of the instructions of one
+     * (row, chunk) item per thread. */
+    {
+        const int NB = (H >> 3) + 1; /* blocks; the last one holds row H only */
+        for (int it = tid; it < NB * 5; it += PREP_THREADS) {
+            const int kb = it / 5, q = it - kb * 5;
+            const int kn = min(kb + 1, SS - 1); /* (the last block has one row: its increment is never used) */
+            uint32_t cur[4], dif[4];
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int dw = q * 4 + j; /* dword of RowRec: Fg0 Fg1 Fon[8] Foi[8] Fsky Fnic */
-            if (dw == 19) {
-                x[j] = (int32_t)((uint32_t)full_prefix(s_seg + (K + 1) * SS, v) +
-                                 (uint32_t)full_prefix(s_seg + K * SS, v));
-            } else {
-                const int chn = dw < 10 ? dw : (dw < 18 ? dw + 1 : 10);
-                const int32_t f = full_prefix(s_seg + chn * SS, v);
-                x[j] = slow ? f : __float_as_int((float)f);
+            for (int j = 0; j < 4; j++) {
+                const int dw = q * 4 + j; /* dword of RowRec: Fg0 Fg1 Fon[8] Foi[8] Fsky Fnic */
+                if (dw == 19) {
+                    const int32_t* px = s_seg + (K + 1) * SS;
+                    const int32_t* py = s_seg + K * SS;
+                    const uint32_t ax = (uint32_t)px[kb], ay = (uint32_t)py[kb];
+                    cur[j] = ax * 8u + ay * 8u;
+                    dif[j] = ((uint32_t)px[kn] - ax) + ((uint32_t)py[kn] - ay);
+                } else {
+                    const int chn = dw < 10 ? dw : (dw < 18 ? dw + 1 : 10);
+                    const int32_t* ps = s_seg + chn * SS;
+                    const uint32_t a = (uint32_t)ps[kb];
+                    cur[j] = a * 8u;
+                    dif[j] = (uint32_t)ps[kn] - a;
+                }
+            }
+            const bool is_count = (q == 4); /* dword 19 (Fnic) stays an integer in both encodings */
+#pragma unroll
+            for (int m = 0; m < 8; m++) {
+                const int v = kb * 8 + m;
+                if (v <= H) {
+                    int32_t x[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const int32_t f = (int32_t)cur[j];
+                        x[j] = (slow || (is_count && j == 3)) ? f : __float_as_int((float)f);
+                        cur[j] += dif[j];
+                    }
+                    reinterpret_cast<int4*>(rcol + v)[q] = make_int4(x[0], x[1], x[2], x[3]);
+                }
             }
         }
-        reinterpret_cast<int4*>(rcol + v)[q] = make_int4(x[0], x[1], x[2], x[3]);
     }
 
     /* ---- fp32 prefixes with the reference's block-scan association (:452-461).  A thread keeps
