@@ -36,7 +36,7 @@ hipError_t isk_launch_dp_pairwise(const DevParams*, int, int, const RowRec*, con
                                   float*, int32_t*, unsigned long long*, const float*, const int*,
                                   hipStream_t, hipStream_t*, int, hipEvent_t, hipEvent_t*);
 hipError_t isk_launch_backtrace(const DevParams*, int, int, const RowRec*, const float*,
-                                const int32_t*, const int*, is_section*, int*, hipStream_t);
+                                const int32_t*, const int*, is_section*, int*, int*, hipStream_t);
 hipError_t isk_launch_compact(const DevParams*, int, const is_section*, const int*,
                               const is_instance_buffers*, hipStream_t);
 hipError_t isk_set_lds_prepare(const DevParams*);
@@ -100,8 +100,14 @@ struct is_ctx {
     PruneRec* d_prune;       /* [max_batch*C] branch-and-bound slacks of the column */
     int* d_n_generic;        /* [1] generic-encoding columns of the current call */
     /* per-call device inputs */
-    float* d_ground;         /* [max_batch][3][H] */
-    int* d_vhor;             /* [max_batch] */
+    /* one block [ground: max_batch x 3 x H floats][instance table: max_batch][vhor: max_batch ints], on
+     * the device and in every pinned staging slot: a full batch (the host class's single frame
+     * included) travels in ONE copy */
+    char* d_stage;
+    size_t stage_bytes, stage_off_inst, stage_off_vhor;
+    char* h_stage[IS_STAGE_SLOTS];
+    float* d_ground;         /* [max_batch][3][H]            (in d_stage) */
+    int* d_vhor;             /* [max_batch]                  (in d_stage) */
     /* ring of pinned staging slots: a call blocks the host only when the slot it wants is still
      * being read by the H2D copy of the call IS_STAGE_SLOTS calls ago */
     float* h_ground_pinned[IS_STAGE_SLOTS];
@@ -339,8 +345,14 @@ static int ctx_init(is_ctx* c, const is_stixel_params* p, const float* obj_cost_
     ALLOC(c->d_col_flags, sizeof(int) * B * C);
     ALLOC(c->d_prune, sizeof(PruneRec) * B * C);
     ALLOC(c->d_n_generic, sizeof(int));
-    ALLOC(c->d_ground, sizeof(float) * B * 3 * H);
-    ALLOC(c->d_vhor, sizeof(int) * B);
+    HIP_TRY(hipMemset(c->d_n_generic, 0, sizeof(int))); /* later calls: k_backtrace clears it */
+    c->stage_off_inst = sizeof(float) * B * 3 * H; /* (H is a multiple of 8: 8-byte aligned) */
+    c->stage_off_vhor = c->stage_off_inst + sizeof(is_instance_buffers) * B;
+    c->stage_bytes = c->stage_off_vhor + sizeof(int) * B;
+    ALLOC(c->d_stage, c->stage_bytes);
+    c->d_ground = (float*)c->d_stage;
+    c->d_inst_tbl = (is_instance_buffers*)(c->d_stage + c->stage_off_inst);
+    c->d_vhor = (int*)(c->d_stage + c->stage_off_vhor);
     ALLOC(c->d_recs, sizeof(RowRec) * B * C * (H + 1));
     ALLOC(c->d_lutT, sizeof(float) * B * C * (H + 1) * D);
     ALLOC(c->d_priors, sizeof(PriorRec) * B * H);
@@ -354,15 +366,16 @@ static int ctx_init(is_ctx* c, const is_stixel_params* p, const float* obj_cost_
     ALLOC(c->d_cost_table, sizeof(float) * B * C * H * 3);
     ALLOC(c->d_index_table, sizeof(int32_t) * B * C * H * 3);
     ALLOC(c->d_cluster_scratch, sizeof(int32_t) * B * IS_INSTANCE_CLASSES * 2 * C * (size_t)d.S);
-    ALLOC(c->d_inst_tbl, sizeof(is_instance_buffers) * B);
     ALLOC(c->d_inst_cnt, sizeof(int) * B * C * IS_INSTANCE_CLASSES);
     ALLOC(c->d_counters, sizeof(unsigned long long) * IS_CNT_N);
 #undef ALLOC
     c->scratch_bytes = total;
     for (int i = 0; i < IS_STAGE_SLOTS; i++) {
-        HIP_TRY(hipHostMalloc((void**)&c->h_ground_pinned[i], sizeof(float) * B * 3 * H));
-        HIP_TRY(hipHostMalloc((void**)&c->h_vhor_pinned[i], sizeof(int) * B));
-        HIP_TRY(hipHostMalloc((void**)&c->h_inst_pinned[i], sizeof(is_instance_buffers) * B));
+        HIP_TRY(hipHostMalloc((void**)&c->h_stage[i], c->stage_bytes));
+        memset(c->h_stage[i], 0, c->stage_bytes);
+        c->h_ground_pinned[i] = (float*)c->h_stage[i];
+        c->h_inst_pinned[i] = (is_instance_buffers*)(c->h_stage[i] + c->stage_off_inst);
+        c->h_vhor_pinned[i] = (int*)(c->h_stage[i] + c->stage_off_vhor);
         HIP_TRY(hipEventCreateWithFlags(&c->staging_free[i], hipEventDisableTiming));
     }
     for (int i = 0; i < IS_AUX_STREAMS; i++) {
@@ -419,14 +432,12 @@ int is_ctx_destroy(is_ctx* c) {
             if (c->graph_cache[i].valid) (void)hipGraphExecDestroy(c->graph_cache[i].exec);
         free(c->graph_cache);
     }
-    (void)hipFree(c->d_obj_cost_lut); (void)hipFree(c->d_odr); (void)hipFree(c->d_rcp); (void)hipFree(c->d_col_flags); (void)hipFree(c->d_prune); (void)hipFree(c->d_n_generic); (void)hipFree(c->d_ground);
-    (void)hipFree(c->d_vhor); (void)hipFree(c->d_recs); (void)hipFree(c->d_lutT); (void)hipFree(c->d_priors); (void)hipFree(c->d_steps); (void)hipFree(c->d_part_cost); (void)hipFree(c->d_part_idx); (void)hipFree(c->d_sv);
+    (void)hipFree(c->d_obj_cost_lut); (void)hipFree(c->d_odr); (void)hipFree(c->d_rcp); (void)hipFree(c->d_col_flags); (void)hipFree(c->d_prune); (void)hipFree(c->d_n_generic); (void)hipFree(c->d_stage);
+    (void)hipFree(c->d_recs); (void)hipFree(c->d_lutT); (void)hipFree(c->d_priors); (void)hipFree(c->d_steps); (void)hipFree(c->d_part_cost); (void)hipFree(c->d_part_idx); (void)hipFree(c->d_sv);
     (void)hipFree(c->d_cost_table); (void)hipFree(c->d_index_table); (void)hipFree(c->d_cluster_scratch);
-    (void)hipFree(c->d_inst_tbl); (void)hipFree(c->d_inst_cnt); (void)hipFree(c->d_counters);
+    (void)hipFree(c->d_inst_cnt); (void)hipFree(c->d_counters);
     for (int i = 0; i < IS_STAGE_SLOTS; i++) {
-        if (c->h_ground_pinned[i]) (void)hipHostFree(c->h_ground_pinned[i]);
-        if (c->h_vhor_pinned[i]) (void)hipHostFree(c->h_vhor_pinned[i]);
-        if (c->h_inst_pinned[i]) (void)hipHostFree(c->h_inst_pinned[i]);
+        if (c->h_stage[i]) (void)hipHostFree(c->h_stage[i]);
         if (c->staging_free[i]) (void)hipEventDestroy(c->staging_free[i]);
     }
     for (int i = 0; i < IS_AUX_STREAMS; i++) {
@@ -557,10 +568,15 @@ static int compute_enqueue(is_ctx* c, const float* d_joined, const int32_t* d_se
     const size_t H = P.H;
     const int ncols = n_images * P.C;
     const bool timing = c->timing && !capturing;
-    HIP_TRY(hipMemcpyAsync(c->d_ground, c->h_ground_pinned[slot], sizeof(float) * n_images * 3 * H,
-                           hipMemcpyHostToDevice, stream));
-    HIP_TRY(hipMemcpyAsync(c->d_vhor, c->h_vhor_pinned[slot], sizeof(int) * n_images,
-                           hipMemcpyHostToDevice, stream));
+    const bool one_copy = n_images == c->max_batch;
+    if (one_copy) {
+        HIP_TRY(hipMemcpyAsync(c->d_stage, c->h_stage[slot], c->stage_bytes, hipMemcpyHostToDevice, stream));
+    } else {
+        HIP_TRY(hipMemcpyAsync(c->d_ground, c->h_ground_pinned[slot], sizeof(float) * n_images * 3 * H,
+                               hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipMemcpyAsync(c->d_vhor, c->h_vhor_pinned[slot], sizeof(int) * n_images,
+                               hipMemcpyHostToDevice, stream));
+    }
     bool want_inst = false, want_labels = false;
     if (instances)
         for (int i = 0; i < n_images; i++) {
@@ -569,7 +585,7 @@ static int compute_enqueue(is_ctx* c, const float* d_joined, const int32_t* d_se
                         ib.d_instances_per_class;
             want_labels = want_labels || ib.d_labels;
         }
-    if (want_inst) /* the per-image output pointers travel through the pinned staging slot of this call */
+    if (want_inst && !one_copy) /* the per-image output pointers travel through the pinned staging slot of this call */
         HIP_TRY(hipMemcpyAsync(c->d_inst_tbl, c->h_inst_pinned[slot], sizeof(is_instance_buffers) * n_images,
                                hipMemcpyHostToDevice, stream));
     if (!capturing) HIP_TRY(hipEventRecord(c->staging_free[slot], stream));
@@ -578,7 +594,7 @@ static int compute_enqueue(is_ctx* c, const float* d_joined, const int32_t* d_se
     int32_t* it = d_index_table ? d_index_table : c->d_index_table;
 
     if (timing) HIP_TRY(hipEventRecord(c->ev[0], stream));
-    HIP_TRY(hipMemsetAsync(c->d_n_generic, 0, sizeof(int), stream));
+    /* (d_n_generic is zero here: cleared at creation and by k_backtrace at the end of every call) */
     HIP_TRY(isk_launch_prepare(&P, ncols, d_joined, d_seg, c->d_ground, c->d_vhor,
                                c->d_obj_cost_lut, c->d_recs, c->d_lutT, c->d_col_flags, c->d_sv,
                                c->d_prune, c->d_n_generic, stream, c->aux_stream, c->ev_fork, c->ev_join));
@@ -597,7 +613,7 @@ static int compute_enqueue(is_ctx* c, const float* d_joined, const int32_t* d_se
                                     stream));
     if (timing) HIP_TRY(hipEventRecord(c->ev[2], stream));
     HIP_TRY(isk_launch_backtrace(&P, ncols, pairwise ? 1 : 0, c->d_recs, ct, it, c->d_col_flags,
-                                 d_sections, want_inst ? c->d_inst_cnt : nullptr, stream));
+                                 d_sections, want_inst ? c->d_inst_cnt : nullptr, c->d_n_generic, stream));
     if (want_inst) {
         /* the instance candidates (StixelsKernels.cu:926-942) and their clustering
          * (Stixels::ClusterInstances, Stixels.cu:613) of the WHOLE batch: two launches */

@@ -82,11 +82,16 @@ __global__ __launch_bounds__(64) void k_backtrace(const DevParams P, int ncols, 
                                                   const int32_t* __restrict__ index_table,
                                                   const int* __restrict__ col_flags,
                                                   is_section* __restrict__ sections,
-                                                  int* __restrict__ inst_cnt /* [ncols][8] or null */) {
+                                                  int* __restrict__ inst_cnt /* [ncols][8] or null */,
+                                                  int* __restrict__ n_generic /* reset for the next call */) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int colg = blockIdx.x;
     if (colg >= ncols) return;
     const int lane = threadIdx.x;
+    /* the count of generic-encoding columns (k_prepare_columns adds to it, the generic DP kernels of
+     * this call have read it: they precede this launch in stream order) goes back to zero here --
+     * a memset node per call costs a single frame ten microseconds of queue time */
+    if (colg == 0 && lane == 0) *n_generic = 0;
     const int H = P.H, S = P.S;
     int* s_cut = (int*)smem;                /* [S][3]: vT, vB, type */
     int* s_n = s_cut + 3 * S;               /* [1] */
@@ -267,15 +272,15 @@ extern "C" {
 hipError_t isk_launch_backtrace(const DevParams* P, int ncols, int pairwise, const RowRec* recs,
                                 const float* cost_table, const int32_t* index_table,
                                 const int* col_flags, is_section* sections, int* inst_cnt,
-                                hipStream_t stream) {
+                                int* n_generic, hipStream_t stream) {
     const size_t lds = sizeof(int) * (3 * (size_t)P->S + 8);
     const size_t lds_staged = lds + sizeof(int) * 6 * (size_t)P->H;
     if (ncols <= IS_BACKTRACE_STAGE_MAX_COLS && lds_staged <= 64 * 1024)
         hipLaunchKernelGGL(k_backtrace<true>, dim3(ncols), dim3(64), lds_staged, stream, *P, ncols, pairwise,
-                           recs, cost_table, index_table, col_flags, sections, inst_cnt);
+                           recs, cost_table, index_table, col_flags, sections, inst_cnt, n_generic);
     else
         hipLaunchKernelGGL(k_backtrace<false>, dim3(ncols), dim3(64), lds, stream, *P, ncols, pairwise, recs,
-                           cost_table, index_table, col_flags, sections, inst_cnt);
+                           cost_table, index_table, col_flags, sections, inst_cnt, n_generic);
     return hipGetLastError();
 }
 
