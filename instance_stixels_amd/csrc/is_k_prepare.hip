@@ -547,37 +547,63 @@ __device__ __forceinline__ void object_lut_body(const DevParams& P, const int co
      * a wave's memory operations retire in order, so loads queued behind the stores would wait
      * for the whole store latency */
     float cn[LUT_BLOCK];
-    auto fetch = [&](int i, float (&c)[LUT_BLOCK]) {
-        /* (int)d of the block's 32 rows: one coalesced load, then wave-uniform broadcasts */
+    /* (int)d of a block's 32 rows: one coalesced load, requested a block before its costs are (a
+     * wave that is alone on its SIMD -- a single frame -- otherwise waits for two dependent memory
+     * round trips per block: the disparities, then the table entries they select) */
+    auto fetch_d = [&](int i) -> float {
         const int rl = i + (lane & (LUT_BLOCK - 1));
-        int dis_l = 0; /* rows beyond the image use dis = 0, :244-247 */
-        if (rl < H) dis_l = (int)dcol[rl];
+        return (rl < H) ? dcol[rl] : 0.0f; /* rows beyond the image use dis = 0, :244-247 */
+    };
+    auto fetch = [&](float d_l, float (&c)[LUT_BLOCK]) {
+        int dis_l = (int)d_l;
         dis_l = min(max(dis_l, 0), D - 1); /* memory safety outside the input domain (Q8) */
 #pragma unroll
-        for (int l = 0; l < LUT_BLOCK; l++) {
+        for (int l = 0; l < LUT_BLOCK; l++) { /* wave-uniform broadcasts */
             const int dis = __builtin_amdgcn_readlane(dis_l, l);
             c[l] = cost_T[(size_t)dis * D + fnc];
         }
     };
-    fetch(0, cn);
-    for (int i = 0; i < H; i += LUT_BLOCK) {
+    fetch(fetch_d(0), cn);
+    float d_next = fetch_d(LUT_BLOCK);
+    /* One block: the next block's disparities and costs are requested, then this block's network runs
+     * and its 32 rows are stored.  FULL blocks store unconditionally (lanes beyond D hold lane D - 1's
+     * values and write them to its address again), so that the number of memory operations between
+     * a request and its use is the same on every path and the compiler waits with a counted
+     * s_waitcnt vmcnt(32) for the costs instead of vmcnt(0) for the previous block's stores as
+     * well -- half of a block's time when the wave is alone on its SIMD (a single frame).  For the
+     * same reason the first block is peeled: the loop is entered in its steady state. */
+    auto block = [&](int i, bool full) {
         float c[LUT_BLOCK];
 #pragma unroll
         for (int l = 0; l < LUT_BLOCK; l++) c[l] = cn[l];
-        if (i + LUT_BLOCK < H) fetch(i + LUT_BLOCK, cn);
+        if (i + LUT_BLOCK < H) {
+            const float d_here = d_next;
+            d_next = fetch_d(i + 2 * LUT_BLOCK);
+            fetch(d_here, cn);
+        }
         c[0] += add; /* :249-251 */
 #pragma unroll
         for (int j = 1; j < LUT_BLOCK; j <<= 1) { /* :255-263; descending l reads pre-step values */
 #pragma unroll
             for (int l = LUT_BLOCK - 1; l >= j; l--) c[l] += c[l - j];
         }
-        if (fn_ok) {
+        if (full) {
+#pragma unroll
+            for (int l = 0; l < LUT_BLOCK; l++) lcol[(size_t)(i + l + 1) * D + fnc] = c[l]; /* :266 */
+        } else if (fn_ok) {
 #pragma unroll
             for (int l = 0; l < LUT_BLOCK; l++)
-                if (i + l < H) lcol[(size_t)(i + l + 1) * D + fn] = c[l]; /* :266 */
+                if (i + l < H) lcol[(size_t)(i + l + 1) * D + fn] = c[l];
         }
         add = c[LUT_BLOCK - 1]; /* :268-272 */
+    };
+    int i = 0;
+    if (LUT_BLOCK <= H) { /* peeled */
+        block(0, true);
+        i = LUT_BLOCK;
     }
+    for (; i + LUT_BLOCK <= H; i += LUT_BLOCK) block(i, true);
+    if (i < H) block(i, false);
 }
 
 __global__ __launch_bounds__(64) void k_object_lut(const DevParams P,
