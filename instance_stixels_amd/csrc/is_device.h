@@ -36,7 +36,6 @@
 #ifndef IS_PW_SPLIT_MAX_COLS
 #define IS_PW_SPLIT_MAX_COLS 512     /* up to that many columns: two phase-1 workgroups per (column, tile) */
 #endif
-#define IS_PREPARE_OVERLAP_MAX_COLS 1024 /* below: the two prepare kernels run on two streams */
 #define IS_PAIRWISE_SPLIT_MIN_COLS 1024 /* columns per group before the pairwise DP uses one more stream */
 #define IS_PAIRWISE_MAX_GROUPS 1       /* column groups (streams) of the pairwise DP: 2 groups measured +0.4 % alone but -9 % beside the RCCL gather pipeline (round 3); IS_PW_GROUPS overrides */
 #define IS_P2_SPLIT_MAX_COLS 2048     /* up to eight 2048-px frames: phase 2 of the pairwise DP as chain + evaluator wave per column */
@@ -159,7 +158,7 @@ struct DevParams {
     /* host-side launch knobs: the IS_* environment variables, read ONCE in is_ctx_create (never
      * per call); -1 = automatic.  The kernels ignore them. */
     int knob_ring_kernel;     /* IS_NO_RING_KERNEL=1 -> 0: unary FAST columns through k_dp_unary */
-    int knob_prepare_overlap; /* IS_PREPARE_OVERLAP: the two prepare kernels on two streams */
+    int knob_prepare_overlap; /* IS_PREPARE_OVERLAP: 0 = two prepare launches in order, 1 = on two streams, 2 / unset = one fused launch */
     int knob_p2_lds_floor;    /* IS_P2_LDS: floor on phase 2's LDS allocation (occupancy throttle) */
     int knob_pw_groups;       /* IS_PW_GROUPS: column groups (streams) of the pairwise DP */
     int knob_p2_split;        /* IS_P2_SPLIT: 1 = k_pw_phase2s, 0 = k_pw_phase2 */

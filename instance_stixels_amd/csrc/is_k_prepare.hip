@@ -613,27 +613,35 @@ __global__ __launch_bounds__(64) void k_object_lut(const DevParams P,
     object_lut_body(P, (int)blockIdx.x, (int)blockIdx.y, (int)threadIdx.x, joined, cost_T, lutT);
 }
 
-/* Both preparation kernels in ONE launch for SMALL calls (a frame or a few): neither kernel fills
- * the chip then and both are latency chains (one frame: 59 + 58 us one after the other); on two
- * streams they did not overlap in practice, as workgroups of one grid they run side by side.  A
- * 256-thread workgroup is either one column of k_prepare_columns (blocks 0 .. ncols - 1) or four
- * (column, 64 fn) units of k_object_lut.  Only for small calls: under 256-thread launch bounds the
- * LUT body takes 166 VGPRs, which at batch 64 costs the occupancy both kernels live on (3.2 -> 8.2 ms
- * per 64 frames, measured). */
+/* Both preparation kernels in ONE launch: a 256-thread workgroup is either one column of
+ * k_prepare_columns (blocks 0 .. ncols - 1) or four (column, 64 fn) units of k_object_lut (the
+ * blocks after them).  A frame or a few: neither kernel fills the chip and both are latency chains
+ * (59 + 45 us one after the other, 51 us together; on two streams they did not overlap in
+ * practice).  A batch of 64: the LUT blocks start while the last column blocks drain, 2.85 instead
+ * of 3.1 ms for two launches.  MEASURED alternatives: the two kinds interleaved in block order, so
+ * that they share the CUs for the whole launch: 3.7 ms (and a single frame 0.349 instead of
+ * 0.325 ms) -- side by side they take the memory system from each other.  (Until the LUT loop
+ * stored unconditionally its body took 166 VGPRs under this kernel's launch bounds and the fused
+ * launch cost a large batch the occupancy both bodies live on: 8.2 ms.) */
+#ifndef IS_FUSED_LUT_FIRST
+#define IS_FUSED_LUT_FIRST 0
+#endif
 __global__ __launch_bounds__(PREP_THREADS) void k_prepare_fused(
-    const DevParams P, int ncols, const float* __restrict__ joined, const int32_t* __restrict__ seg,
+    const DevParams P, int ncols, int n_lut, const float* __restrict__ joined, const int32_t* __restrict__ seg,
     const float* __restrict__ ground, const int* __restrict__ vhor_arr, const float* __restrict__ cost_T,
     RowRec* __restrict__ recs, float* __restrict__ lutT, int* __restrict__ col_flags,
     float* __restrict__ sv_arr, PruneRec* __restrict__ prune, int* __restrict__ n_generic) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int b = (int)blockIdx.x;
-    if (b >= ncols) {
+    const bool is_lut = IS_FUSED_LUT_FIRST ? b < n_lut : b >= ncols;
+    if (is_lut) {
         const int fn_blocks = (P.D + 63) / 64;
-        const int unit = (b - ncols) * (PREP_THREADS / 64) + (int)(threadIdx.x >> 6);
+        const int unit = (IS_FUSED_LUT_FIRST ? b : b - ncols) * (PREP_THREADS / 64) + (int)(threadIdx.x >> 6);
         if (unit < ncols * fn_blocks)
             object_lut_body(P, unit / fn_blocks, unit % fn_blocks, (int)(threadIdx.x & 63), joined, cost_T, lutT);
     } else {
-        prepare_columns_body(P, b, smem, joined, seg, ground, vhor_arr, recs, col_flags, sv_arr, prune, n_generic);
+        prepare_columns_body(P, IS_FUSED_LUT_FIRST ? b - n_lut : b, smem, joined, seg, ground, vhor_arr, recs,
+                             col_flags, sv_arr, prune, n_generic);
     }
 }
 
@@ -682,21 +690,17 @@ hipError_t isk_launch_prepare(const DevParams* P, int ncols, const float* joined
                               int* col_flags, float* sv_arr, PruneRec* prune, int* n_generic,
                               hipStream_t stream,
                               hipStream_t aux, hipEvent_t ev_fork, hipEvent_t ev_join) {
-    /* The two prepare kernels are independent.  With few columns (a single frame = 256) neither
-     * fills the chip and both are latency chains, so they run side by side on two streams; with
-     * many columns they are throughput-bound (HBM writes) and stay in order on one stream. */
-    bool side_by_side = aux != nullptr && ncols < IS_PREPARE_OVERLAP_MAX_COLS;
-    if (P->knob_prepare_overlap >= 0) side_by_side = aux != nullptr && P->knob_prepare_overlap == 1;
+    /* The two prepare kernels are independent: one launch with workgroups of both kinds
+     * (k_prepare_fused) by default.  IS_PREPARE_OVERLAP = 0: two launches in order on one stream,
+     * 1: two launches on two streams (did not overlap in practice), 2: the default. */
+    const bool side_by_side = aux != nullptr && P->knob_prepare_overlap == 1;
     hipError_t e;
-    /* small calls: one launch with workgroups of both kinds (k_prepare_fused); IS_PREPARE_OVERLAP=2
-     * forces it, 1 = two streams, 0 = in order on one stream */
-    const bool fused = P->knob_prepare_overlap == 2 ||
-                       (P->knob_prepare_overlap < 0 && ncols < IS_PREPARE_OVERLAP_MAX_COLS);
+    const bool fused = P->knob_prepare_overlap == 2 || P->knob_prepare_overlap < 0;
     if (fused) {
         const int units = ncols * ((P->D + 63) / 64);
         const int n_lut = (units + PREP_THREADS / 64 - 1) / (PREP_THREADS / 64);
         hipLaunchKernelGGL(k_prepare_fused, dim3(ncols + n_lut), dim3(PREP_THREADS),
-                           isk_prepare_lds_bytes(P), stream, *P, ncols, joined, seg, ground, vhor,
+                           isk_prepare_lds_bytes(P), stream, *P, ncols, n_lut, joined, seg, ground, vhor,
                            cost_T, recs, lutT, col_flags, sv_arr, prune, n_generic);
         return hipGetLastError();
     }
