@@ -136,6 +136,14 @@ private:
     int32_t* d_instance_packed = nullptr;  /* [1 + 3*classes*realcols*max_sections], see is_instance_buffers */
     /* pinned host mirrors: Compute() ends with ONE stream synchronisation */
     Section* h_stixels = nullptr;
+    /* One device block: header rows (the per-class candidate counts, d_instances_per_class) in
+     * front of the sections (d_stixels).  Compute() fetches the header and the first
+     * m_head_sections sections of every column with ONE pitched copy into h_stixels_head; a column
+     * without a terminator among them (rare) makes it fetch the complete array. */
+    Section* d_stixels_block = nullptr;
+    Section* h_stixels_head = nullptr;
+    int m_header_rows = 0;
+    int m_head_sections = 0;
     int32_t* h_instance_head = nullptr;    /* [max_batch][8 per-class counts] */
     int32_t* h_instance_packed = nullptr;
     /* every device operation of the object runs on this stream (an ordinary stream: it still

@@ -220,6 +220,10 @@ int is_set_device(int device);
 int is_ctx_device(const is_ctx* ctx);         /* the device a context lives on */
 int is_memcpy_h2d(void* dst, const void* src, size_t bytes, void* stream);
 int is_memcpy_d2h(void* dst, const void* src, size_t bytes, void* stream);
+/* `height` rows of `width` bytes from a pitched device array into a pitched (pinned) host array:
+ * the host class fetches the first sections of every column this way instead of all max_sections */
+int is_memcpy2d_d2h(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height,
+                    void* stream);
 int is_memset(void* dst, int value, size_t bytes, void* stream);
 int is_stream_synchronize(void* stream);
 /* A stream of the current device.  blocking != 0: an ordinary stream that still synchronises

@@ -17,7 +17,7 @@ _LIB = None
 
 EXPORTS = [
     "is_ctx_create", "is_ctx_destroy", "is_join_columns", "is_compute", "is_device_malloc",
-    "is_device_free", "is_memcpy_h2d", "is_memcpy_d2h", "is_memset", "is_stream_synchronize",
+    "is_device_free", "is_memcpy_h2d", "is_memcpy_d2h", "is_memcpy2d_d2h", "is_memset", "is_stream_synchronize",
     "is_device_synchronize", "is_last_error", "is_version", "is_set_kernel_timing",
     "is_get_kernel_times_ms", "is_scratch_bytes", "is_flip_and_pad", "is_road_vdisparity",
     "is_cluster_instances", "is_host_malloc", "is_host_free", "is_get_device", "is_set_device",
@@ -62,6 +62,7 @@ def lib():
         L.is_device_free.argtypes = [vp]
         L.is_memcpy_h2d.argtypes = [vp, vp, ctypes.c_size_t, vp]
         L.is_memcpy_d2h.argtypes = [vp, vp, ctypes.c_size_t, vp]
+        L.is_memcpy2d_d2h.argtypes = [vp, ctypes.c_size_t, vp, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t, vp]
         L.is_memset.argtypes = [vp, ci, ctypes.c_size_t, vp]
         L.is_stream_synchronize.argtypes = [vp]
         L.is_last_error.restype = ctypes.c_char_p

@@ -195,6 +195,11 @@ int is_memcpy_d2h(void* dst, const void* src, size_t bytes, void* stream) {
     HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
     return IS_OK;
 }
+int is_memcpy2d_d2h(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height,
+                    void* stream) {
+    HIP_TRY(hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    return IS_OK;
+}
 int is_memset(void* dst, int value, size_t bytes, void* stream) {
     HIP_TRY(hipMemsetAsync(dst, value, bytes, (hipStream_t)stream));
     return IS_OK;

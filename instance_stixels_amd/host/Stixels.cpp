@@ -349,15 +349,19 @@ void Stixels::InitializeBatch(int max_batch) { /* Stixels.cu:43-248 */
                                   m_object_disparity_range.data(), m_max_batch, device, &m_ctx));
     IS_CHECK_RETURN(is_stream_create(&m_stream, 1));
     const size_t B = m_max_batch;
-    IS_CHECK_RETURN(is_device_malloc((void**)&d_stixels,
-                                     B * m_realcols * m_max_sections * sizeof(Section)));
+    /* [header rows: per-class counts][B x C x S sections]: one pitched copy fetches both */
+    const size_t row_bytes = (size_t)m_max_sections * sizeof(Section);
+    m_header_rows = (int)((B * m_instance_classes * sizeof(int32_t) + row_bytes - 1) / row_bytes);
+    m_head_sections = m_max_sections < 64 ? m_max_sections : 64;
+    IS_CHECK_RETURN(is_device_malloc((void**)&d_stixels_block,
+                                     ((size_t)m_header_rows + B * m_realcols) * row_bytes));
+    d_stixels = d_stixels_block + (size_t)m_header_rows * m_max_sections;
+    d_instances_per_class = reinterpret_cast<int32_t*>(d_stixels_block);
     IS_CHECK_RETURN(is_device_malloc((void**)&d_instance_centerofmass,
                                      B * inst_n * 2 * sizeof(float)));
     IS_CHECK_RETURN(is_device_malloc((void**)&d_instance_indices,
                                      B * inst_n * 2 * sizeof(int32_t)));
     IS_CHECK_RETURN(is_device_malloc((void**)&d_instance_core_candidates, B * inst_n));
-    IS_CHECK_RETURN(is_device_malloc((void**)&d_instances_per_class,
-                                     B * m_instance_classes * sizeof(int32_t)));
     IS_CHECK_RETURN(is_device_malloc(
         (void**)&d_segmentation,
         (size_t)rows_power2_segmentation * m_realcols * m_segmentation_channels * sizeof(int32_t)));
@@ -369,6 +373,8 @@ void Stixels::InitializeBatch(int max_batch) { /* Stixels.cu:43-248 */
     IS_CHECK_RETURN(is_device_malloc((void**)&d_instance_packed, B * (1 + 3 * inst_n) * sizeof(int32_t)));
     IS_CHECK_RETURN(is_host_malloc((void**)&h_stixels,
                                    (size_t)m_realcols * m_max_sections * sizeof(Section)));
+    IS_CHECK_RETURN(is_host_malloc((void**)&h_stixels_head,
+                                   ((size_t)m_header_rows + m_realcols) * m_head_sections * sizeof(Section)));
     IS_CHECK_RETURN(is_host_malloc((void**)&h_instance_head, B * 16 * sizeof(int32_t)));
     IS_CHECK_RETURN(is_host_malloc((void**)&h_instance_packed, (1 + 3 * inst_n) * sizeof(int32_t)));
     h_instance_packed[0] = 0;
@@ -380,14 +386,15 @@ void Stixels::Finish() { /* Stixels.cu:250-283 */
     IS_CHECK_RETURN(is_device_free(d_segmentation));
     IS_CHECK_RETURN(is_device_free(d_disparity_big));
     IS_CHECK_RETURN(is_device_free(d_disparity));
-    IS_CHECK_RETURN(is_device_free(d_stixels));
+    IS_CHECK_RETURN(is_device_free(d_stixels_block));
     IS_CHECK_RETURN(is_device_free(d_instance_centerofmass));
     IS_CHECK_RETURN(is_device_free(d_instance_indices));
     IS_CHECK_RETURN(is_device_free(d_instance_core_candidates));
-    IS_CHECK_RETURN(is_device_free(d_instances_per_class));
     IS_CHECK_RETURN(is_device_free(d_instance_labels));
     IS_CHECK_RETURN(is_device_free(d_instance_packed));
     IS_CHECK_RETURN(is_host_free(h_stixels));
+    IS_CHECK_RETURN(is_host_free(h_stixels_head));
+    h_stixels_head = nullptr; d_stixels_block = nullptr;
     IS_CHECK_RETURN(is_host_free(h_instance_head));
     IS_CHECK_RETURN(is_host_free(h_instance_packed));
     d_instance_labels = nullptr; d_instance_packed = nullptr;
@@ -460,24 +467,43 @@ float Stixels::Compute(const bool pairwise, StixelsData& stixels_data,
                                g.normalization.data(), g.inv_sigma2.data(), &m_vhor,
                                pairwise ? 1 : 0, 1, d_stixels, &ib, nullptr, nullptr,
                                m_stream)); /* :535-590 */
-    /* results into pinned memory, ONE synchronisation (:600, :629-633) */
-    const size_t n_sec = (size_t)m_realcols * m_max_sections;
-    IS_CHECK_RETURN(is_memcpy_d2h(h_stixels, d_stixels, n_sec * sizeof(Section), m_stream));
-    IS_CHECK_RETURN(is_memcpy_d2h(h_instance_head, d_instances_per_class,
-                                  m_instance_classes * sizeof(int32_t), m_stream));
+    /* results into pinned memory, ONE copy and ONE synchronisation (:600, :629-633): the header
+     * row(s) with the per-class counts and the first m_head_sections sections of every column (a
+     * column rarely has more: 10-40 on road scenes) */
+    const int K = m_head_sections;
+    const size_t row_bytes = (size_t)m_max_sections * sizeof(Section);
+    IS_CHECK_RETURN(is_memcpy2d_d2h(h_stixels_head, (size_t)K * sizeof(Section), d_stixels_block, row_bytes,
+                                    (size_t)K * sizeof(Section), (size_t)m_header_rows + m_realcols,
+                                    m_stream));
     IS_CHECK_RETURN(is_stream_synchronize(m_stream));
-    for (int k = 0; k < m_instance_classes; k++) m_instances_per_class[k] = h_instance_head[k];
+    const int32_t* head = reinterpret_cast<const int32_t*>(h_stixels_head);
+    for (int k = 0; k < m_instance_classes; k++) m_instances_per_class[k] = head[k];
     m_labels_on_host = false;
 
     FillHeader(stixels_data, m_alpha_ground, m_vhor);
     /* sections of every column up to and including its terminator; what lies behind a
      * terminator is unspecified (in the reference: whatever the device buffer held) */
     Section* out = stixels_data.sections.data();
-    for (int c = 0; c < m_realcols; c++) {
-        const Section* src = h_stixels + (size_t)c * m_max_sections;
+    const Section* cols = h_stixels_head + (size_t)m_header_rows * K;
+    bool complete = true;
+    for (int c = 0; c < m_realcols && complete; c++) {
+        const Section* src = cols + (size_t)c * K;
         int n = 0;
-        while (n < m_max_sections - 1 && src[n].type != -1) n++;
+        while (n < K && src[n].type != -1) n++;
+        if (n == K && K < m_max_sections) { complete = false; break; } /* no terminator among the first K */
+        if (n == K) n = K - 1; /* (K == max_sections: the last slot ends the column, as below) */
         std::memcpy(out + (size_t)c * m_max_sections, src, (size_t)(n + 1) * sizeof(Section));
+    }
+    if (!complete) { /* a column with more than K sections: fetch everything */
+        const size_t n_sec = (size_t)m_realcols * m_max_sections;
+        IS_CHECK_RETURN(is_memcpy_d2h(h_stixels, d_stixels, n_sec * sizeof(Section), m_stream));
+        IS_CHECK_RETURN(is_stream_synchronize(m_stream));
+        for (int c = 0; c < m_realcols; c++) {
+            const Section* src = h_stixels + (size_t)c * m_max_sections;
+            int n = 0;
+            while (n < m_max_sections - 1 && src[n].type != -1) n++;
+            std::memcpy(out + (size_t)c * m_max_sections, src, (size_t)(n + 1) * sizeof(Section));
+        }
     }
     return -1; /* the reference's timers are commented out, Stixels.cu:636 */
 }

@@ -483,6 +483,48 @@ def test_host_class_call_sequence(preset, tmp_path):
     st.close()
 
 
+@pytest.mark.parametrize("preset", ["drn_d_22_unary", "drn_d_38_pairwise"])
+def test_host_class_columns_with_many_sections(preset):
+    """Stixels::Compute fetches the first 64 sections of every column with one pitched copy and the
+    complete array only when a column has no terminator among them: four columns of this frame
+    alternate between two object classes and two disparities every 8 rows (96 sections each)."""
+    from instance_stixels_amd import host
+    case = helpers.build_case(preset, 768, 64, 32, seed=5)
+    cfg, f = case["cfg"], case["frames"][0]
+    seg, d = case["segmentation"], case["disparity"]
+    for c in range(4):
+        for k in range(768 // 8):
+            seg[0, c, :19, k] = 400 * 8
+            seg[0, c, 11 if k % 2 == 0 else 13, k] = 0
+            seg[0, c, 19:, k] = 0
+            r0 = 768 - 8 * (k + 1)
+            d[0, r0:r0 + 8, c * 8:(c + 1) * 8] = 20.0 if k % 2 == 0 else 10.0
+    ref = helpers.run_oracle(case)
+    counts = [helpers.n_sections(ref["sections"][c]) for c in range(8)]
+    assert max(counts) > 64 and min(counts) < 64, counts
+    st = host.Stixels()
+    st.SetConfig(cfg)
+    st.Initialize()
+    for frame_has_many in (True, False, True):   # both copy paths, alternating on one object
+        if frame_has_many:
+            dd, ss, want = d[0], seg[0], ref
+        else:
+            plain = helpers.build_case(preset, 768, 64, 32, seed=5)
+            dd, ss, want = plain["disparity"][0], plain["segmentation"][0], helpers.run_oracle(plain)
+        st.SetDisparityImage(dd)
+        st.SetSegmentation(ss)
+        st.SetRoadParameters(f.vhor_image, f.camera_tilt, f.camera_height, f.alpha_ground)
+        data = st.Compute(cfg.pairwise)
+        mapping = st.GetInstanceStixels()
+        got = dict(joined=want["joined"][None], sections=data.sections[None])
+        assert not helpers.compare(want, got, 0, cfg, check_tables=False)
+        want_keys = {(int(c), int(i)) for cls in range(8)
+                     for c, i in want["inst_indices"][cls][:want["inst_per_class"][cls]]}
+        assert set(mapping) == want_keys
+    st.Finish()
+    st.close()
+
+
 def test_core_rejects_bad_shapes():
     from instance_stixels_amd.core import Core, CoreError
     case = helpers.build_case("drn_d_22_unary", 64, 64, 32, seed=1)
