@@ -454,12 +454,12 @@ float Stixels::Compute(const bool pairwise, StixelsData& stixels_data,
     if (d_segmentation_local == nullptr) d_segmentation_local = d_segmentation;
     const DeviceGuard guard(m_ctx_device);
 
+    /* JoinColumns does not need the ground model: it runs while the host computes it */
+    IS_CHECK_RETURN(is_join_columns(m_ctx, d_disparity_big, m_cols, m_median_join ? 1 : 0,
+                                    d_disparity, 1, m_stream)); /* :509-511 */
     GroundModel& g = m_ground;
     PrecomputeGround(m_vhor, m_camera_tilt, m_camera_height, m_alpha_ground, g); /* :463 */
     m_params.vhor = m_vhor;                                                       /* :532 */
-
-    IS_CHECK_RETURN(is_join_columns(m_ctx, d_disparity_big, m_cols, m_median_join ? 1 : 0,
-                                    d_disparity, 1, m_stream)); /* :509-511 */
     /* the DP, the instance candidates and their clustering (ClusterInstances, :613) are queued
      * back to back on the device; nothing returns to the host in between */
     const is_instance_buffers ib = InstanceBuffers(0);
