@@ -120,6 +120,11 @@ private:
     void FillHeader(StixelsData& d, float alpha_ground, int vhor_lib) const;
     is_instance_buffers InstanceBuffers(int image = 0) const;
     GroundModel m_ground; /* per-frame ground model, storage reused between frames */
+    /* the road parameters m_ground was computed for: a frame with the same parameters (a fixed
+     * camera model, a replayed sequence) reuses it -- 1024 rows of erf / sqrt / log on the host
+     * are 12 us of a 0.26 ms frame.  Invalidated by Initialize(). */
+    float m_ground_key[12] = {0};  /* every input of PrecomputeGround */
+    bool m_ground_valid = false;
 
     /* device (owned between Initialize and Finish, Stixels.cu:53-74, 136-163) */
     is_ctx* m_ctx = nullptr;

@@ -194,7 +194,7 @@ __global__ __launch_bounds__(64) void k_backtrace(const DevParams P, int ncols, 
  * reads Section i, its slot is offset[column][class] + the number of same-class candidates in
  * the lanes below it (ballot + mbcnt).  `tbl[image]`: the caller's per-image output arrays. */
 #define ISC_THREADS 256
-#define ISC_CHUNKS 4
+#define ISC_CHUNKS 16
 __global__ __launch_bounds__(ISC_THREADS) void k_compact_instances(
     const DevParams P, const is_section* __restrict__ sections, const int* __restrict__ inst_cnt,
     const is_instance_buffers* __restrict__ tbl) {

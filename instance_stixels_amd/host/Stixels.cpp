@@ -378,6 +378,7 @@ void Stixels::InitializeBatch(int max_batch) { /* Stixels.cu:43-248 */
     IS_CHECK_RETURN(is_host_malloc((void**)&h_instance_head, B * 16 * sizeof(int32_t)));
     IS_CHECK_RETURN(is_host_malloc((void**)&h_instance_packed, (1 + 3 * inst_n) * sizeof(int32_t)));
     h_instance_packed[0] = 0;
+    m_ground_valid = false; /* (the ground model depends on the configuration just applied) */
     m_is_initialized = true;
 }
 
@@ -458,7 +459,15 @@ float Stixels::Compute(const bool pairwise, StixelsData& stixels_data,
     IS_CHECK_RETURN(is_join_columns(m_ctx, d_disparity_big, m_cols, m_median_join ? 1 : 0,
                                     d_disparity, 1, m_stream)); /* :509-511 */
     GroundModel& g = m_ground;
-    PrecomputeGround(m_vhor, m_camera_tilt, m_camera_height, m_alpha_ground, g); /* :463 */
+    const float key[12] = {(float)m_vhor, m_camera_tilt, m_camera_height, m_alpha_ground, m_focal, m_baseline,
+                           m_pout, m_sigma_camera_height, m_sigma_camera_tilt, m_sigma_disparity_ground,
+                           m_max_disf, (float)m_rows};
+    /* (memcmp: a NaN parameter compares equal to itself here, the model it gives is the same) */
+    if (!m_ground_valid || std::memcmp(key, m_ground_key, sizeof(key)) != 0) {
+        PrecomputeGround(m_vhor, m_camera_tilt, m_camera_height, m_alpha_ground, g); /* :463 */
+        std::memcpy(m_ground_key, key, sizeof(key));
+        m_ground_valid = true;
+    }
     m_params.vhor = m_vhor;                                                       /* :532 */
     /* the DP, the instance candidates and their clustering (ClusterInstances, :613) are queued
      * back to back on the device; nothing returns to the host in between */

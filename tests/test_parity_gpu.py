@@ -525,6 +525,37 @@ def test_host_class_columns_with_many_sections(preset):
     st.close()
 
 
+def test_host_class_road_parameters_change_between_frames():
+    """Stixels::Compute keeps the host ground model of the last frame while the road parameters stay
+    the same: frames with parameters A, B, A, A on one object must each match the oracle."""
+    from instance_stixels_amd import host
+    import dataclasses
+    case_a = helpers.build_case("drn_d_22_unary", 128, 256, 32, seed=77)
+    cfg, fa = case_a["cfg"], case_a["frames"][0]
+    fb = dataclasses.replace(fa, vhor_image=fa.vhor_image + 7, camera_tilt=fa.camera_tilt * 1.5,
+                             camera_height=fa.camera_height * 0.9, alpha_ground=fa.alpha_ground * 1.1)
+    case_b = dict(case_a)
+    case_b["frames"] = [fb]
+    g = helpers.oracle.host_ground(cfg, fb.vhor_image, fb.camera_tilt, fb.camera_height, fb.alpha_ground)
+    case_b["gf"], case_b["ng"], case_b["ig"] = g[0][None], g[1][None], g[2][None]
+    case_b["vhor"] = np.array([g[3]], np.int32)
+    refs = {"a": helpers.run_oracle(case_a), "b": helpers.run_oracle(case_b)}
+    assert not helpers.sections_equal(refs["a"]["sections"], refs["b"]["sections"])  # the change matters
+    st = host.Stixels()
+    st.SetConfig(cfg)
+    st.Initialize()
+    st.SetDisparityImage(fa.disparity)
+    st.SetSegmentation(fa.segmentation)
+    for which in "abaa":
+        f = fa if which == "a" else fb
+        st.SetRoadParameters(f.vhor_image, f.camera_tilt, f.camera_height, f.alpha_ground)
+        data = st.Compute(cfg.pairwise)
+        got = dict(joined=refs[which]["joined"][None], sections=data.sections[None])
+        assert not helpers.compare(refs[which], got, 0, cfg, check_tables=False), which
+    st.Finish()
+    st.close()
+
+
 def test_core_rejects_bad_shapes():
     from instance_stixels_amd.core import Core, CoreError
     case = helpers.build_case("drn_d_22_unary", 64, 64, 32, seed=1)
