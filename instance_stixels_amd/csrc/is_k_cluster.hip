@@ -35,11 +35,25 @@ __device__ __forceinline__ float clu_d2(const float2 a, const float2 b) {
  *   >= 0  core point, value = smallest core index known to be in the same cluster
  *   -2    large, not core        -3   small
  * rank / out are scratch of n ints each. */
+#define CLU_LDS_N 2048 /* classes with up to this many candidates are clustered out of LDS copies */
 __device__ __forceinline__ void cluster_class(int n, float eps2, int min_pts, const float2* com,
-                                              const uint8_t* cand, int32_t* labels, int32_t* rank,
-                                              int32_t* out, int* s_red) {
+                                              const uint8_t* cand, int32_t* const labels_out, int32_t* rank,
+                                              int32_t* out, int* s_red, float2* s_com, uint8_t* s_cand,
+                                              int32_t* s_lab) {
     const int tid = threadIdx.x;
     if (n == 0) return;
+    /* The sweeps below read centre, flag and component of EVERY candidate j for every candidate i:
+     * the same address in all lanes, one dependent L2 round trip per j when the arrays lie in
+     * global memory (a class of 300 candidates: 85 us).  Up to CLU_LDS_N candidates the three
+     * arrays are copied into LDS first and the same code runs on the copies (generic pointers). */
+    int32_t* labels = labels_out;
+    if (n <= CLU_LDS_N) {
+        for (int i = tid; i < n; i += CLU_THREADS) { s_com[i] = com[i]; s_cand[i] = cand[i]; }
+        __syncthreads();
+        com = s_com;
+        cand = s_cand;
+        labels = s_lab;
+    }
 
     /* number of large points: the twin clusters only if it exceeds min_pts (:926) */
     int cnt = 0;
@@ -53,7 +67,7 @@ __device__ __forceinline__ void cluster_class(int n, float eps2, int min_pts, co
     const int n_large = s_red[0];
     __syncthreads();
     if (n_large <= min_pts) {
-        for (int i = tid; i < n; i += CLU_THREADS) labels[i] = -1;
+        for (int i = tid; i < n; i += CLU_THREADS) labels_out[i] = -1;
         return;
     }
 
@@ -135,7 +149,7 @@ __device__ __forceinline__ void cluster_class(int n, float eps2, int min_pts, co
         out[i] = res;
     }
     __syncthreads();
-    for (int i = tid; i < n; i += CLU_THREADS) labels[i] = out[i];
+    for (int i = tid; i < n; i += CLU_THREADS) labels_out[i] = out[i];
 }
 
 /* One workgroup per (instance class, image): grid = (8, n_images).  `tbl[image]` holds the
@@ -147,6 +161,9 @@ __global__ __launch_bounds__(CLU_THREADS) void k_cluster_instances(
     int n_slots, float eps2, int min_pts, const is_instance_buffers* __restrict__ tbl,
     const is_instance_buffers one, int32_t* __restrict__ scratch) {
     __shared__ int s_red[CLU_THREADS];
+    __shared__ float2 s_com[CLU_LDS_N];
+    __shared__ int32_t s_lab[CLU_LDS_N];
+    __shared__ uint8_t s_cand[CLU_LDS_N];
     const int cls = blockIdx.x, img = blockIdx.y, tid = threadIdx.x;
     const is_instance_buffers ib = tbl ? tbl[img] : one;
     if (!ib.d_labels) return;
@@ -156,7 +173,7 @@ __global__ __launch_bounds__(CLU_THREADS) void k_cluster_instances(
     const uint8_t* cand = ib.d_core_candidates + (size_t)cls * n_slots;
     int32_t* labels = ib.d_labels + (size_t)cls * n_slots;
     int32_t* rank = scratch + ((size_t)img * IS_INSTANCE_CLASSES + cls) * 2 * n_slots;
-    cluster_class(n, eps2, min_pts, com, cand, labels, rank, rank + n_slots, s_red);
+    cluster_class(n, eps2, min_pts, com, cand, labels, rank, rank + n_slots, s_red, s_com, s_cand, s_lab);
     int32_t* packed = ib.d_packed;
     if (packed && ib.d_indices) {
         __syncthreads();
