@@ -26,7 +26,13 @@
 
 #define CLU_THREADS 256
 
-__device__ __forceinline__ float clu_d2(const float2 a, const float2 b) {
+/* LDS pointer types: with them the sweeps compile to ds_read (pipelined, unrolled) instead of flat loads */
+typedef float clu_f2 __attribute__((ext_vector_type(2))); /* (a builtin vector: loadable from any address space) */
+typedef __attribute__((address_space(3))) clu_f2 lds_float2;
+typedef __attribute__((address_space(3))) uint8_t lds_u8;
+typedef __attribute__((address_space(3))) int32_t lds_i32;
+
+__device__ __forceinline__ float clu_d2(const clu_f2 a, const clu_f2 b) {
     const float dx = a.x - b.x, dy = a.y - b.y;
     return dx * dx + dy * dy;
 }
@@ -36,25 +42,14 @@ __device__ __forceinline__ float clu_d2(const float2 a, const float2 b) {
  *   -2    large, not core        -3   small
  * rank / out are scratch of n ints each. */
 #define CLU_LDS_N 2048 /* classes with up to this many candidates are clustered out of LDS copies */
-__device__ __forceinline__ void cluster_class(int n, float eps2, int min_pts, const float2* com,
-                                              const uint8_t* cand, int32_t* const labels_out, int32_t* rank,
-                                              int32_t* out, int* s_red, float2* s_com, uint8_t* s_cand,
-                                              int32_t* s_lab) {
+/* COM / CAND / LAB: pointers to the centre, large-flag and component arrays -- global memory, or the
+ * LDS copies (address_space(3) types, so that the sweeps are ds_read code the compiler can unroll and
+ * pipeline).  labels_out: the caller's array in global memory. */
+template <class COM, class CAND, class LAB>
+__device__ __forceinline__ void cluster_body(int n, float eps2, int min_pts, COM com, CAND cand, LAB labels,
+                                             int32_t* const labels_out, int32_t* rank, int32_t* out,
+                                             int* s_red) {
     const int tid = threadIdx.x;
-    if (n == 0) return;
-    /* The sweeps below read centre, flag and component of EVERY candidate j for every candidate i:
-     * the same address in all lanes, one dependent L2 round trip per j when the arrays lie in
-     * global memory (a class of 300 candidates: 85 us).  Up to CLU_LDS_N candidates the three
-     * arrays are copied into LDS first and the same code runs on the copies (generic pointers). */
-    int32_t* labels = labels_out;
-    if (n <= CLU_LDS_N) {
-        for (int i = tid; i < n; i += CLU_THREADS) { s_com[i] = com[i]; s_cand[i] = cand[i]; }
-        __syncthreads();
-        com = s_com;
-        cand = s_cand;
-        labels = s_lab;
-    }
-
     /* number of large points: the twin clusters only if it exceeds min_pts (:926) */
     int cnt = 0;
     for (int i = tid; i < n; i += CLU_THREADS) cnt += cand[i] != 0;
@@ -75,7 +70,7 @@ __device__ __forceinline__ void cluster_class(int n, float eps2, int min_pts, co
     for (int i = tid; i < n; i += CLU_THREADS) {
         int l = -3;
         if (cand[i]) {
-            const float2 p = com[i];
+            const clu_f2 p = com[i];
             int c = 0;
             for (int j = 0; j < n; j++) c += (cand[j] != 0) && (clu_d2(p, com[j]) <= eps2);
             l = (c >= min_pts) ? i : -2;
@@ -91,7 +86,7 @@ __device__ __forceinline__ void cluster_class(int n, float eps2, int min_pts, co
         for (int i = tid; i < n; i += CLU_THREADS) {
             const int li = labels[i];
             if (li < 0) continue;
-            const float2 p = com[i];
+            const clu_f2 p = com[i];
             int m = li;
             for (int j = 0; j < n; j++) {
                 const int lj = labels[j];
@@ -127,7 +122,7 @@ __device__ __forceinline__ void cluster_class(int n, float eps2, int min_pts, co
         if (li >= 0) {
             res = rank[li];
         } else {
-            const float2 p = com[i];
+            const clu_f2 p = com[i];
             if (li == -2) { /* border point: lowest-numbered cluster among the core neighbours */
                 int best = n;
                 for (int j = 0; j < n; j++) {
@@ -152,6 +147,27 @@ __device__ __forceinline__ void cluster_class(int n, float eps2, int min_pts, co
     for (int i = tid; i < n; i += CLU_THREADS) labels_out[i] = out[i];
 }
 
+
+__device__ __forceinline__ void cluster_class(int n, float eps2, int min_pts, const clu_f2* com,
+                                              const uint8_t* cand, int32_t* const labels_out, int32_t* rank,
+                                              int32_t* out, int* s_red, clu_f2* s_com, uint8_t* s_cand,
+                                              int32_t* s_lab) {
+    const int tid = threadIdx.x;
+    if (n == 0) return;
+    /* The sweeps read centre, flag and component of EVERY candidate j for every candidate i: the
+     * same address in all lanes, one dependent L2 round trip per j when the arrays lie in global
+     * memory (a class of 300 candidates: 85 us).  Up to CLU_LDS_N candidates the three arrays are
+     * copied into LDS first. */
+    if (n <= CLU_LDS_N) {
+        for (int i = tid; i < n; i += CLU_THREADS) { s_com[i] = com[i]; s_cand[i] = cand[i]; }
+        __syncthreads();
+        cluster_body(n, eps2, min_pts, (const lds_float2*)s_com, (const lds_u8*)s_cand, (lds_i32*)s_lab,
+                     labels_out, rank, out, s_red);
+    } else {
+        cluster_body(n, eps2, min_pts, com, cand, labels_out, labels_out, rank, out, s_red);
+    }
+}
+
 /* One workgroup per (instance class, image): grid = (8, n_images).  `tbl[image]` holds the
  * image's candidate arrays (NULL: the single image `one`); images without d_labels are skipped.
  * `packed` (optional, per image): packed[0] = number of candidates of all classes, then one
@@ -161,7 +177,7 @@ __global__ __launch_bounds__(CLU_THREADS) void k_cluster_instances(
     int n_slots, float eps2, int min_pts, const is_instance_buffers* __restrict__ tbl,
     const is_instance_buffers one, int32_t* __restrict__ scratch) {
     __shared__ int s_red[CLU_THREADS];
-    __shared__ float2 s_com[CLU_LDS_N];
+    __shared__ clu_f2 s_com[CLU_LDS_N];
     __shared__ int32_t s_lab[CLU_LDS_N];
     __shared__ uint8_t s_cand[CLU_LDS_N];
     const int cls = blockIdx.x, img = blockIdx.y, tid = threadIdx.x;
@@ -169,7 +185,7 @@ __global__ __launch_bounds__(CLU_THREADS) void k_cluster_instances(
     if (!ib.d_labels) return;
     const int32_t* per_class = ib.d_instances_per_class;
     const int n = min(max(per_class[cls], 0), n_slots);
-    const float2* com = reinterpret_cast<const float2*>(ib.d_centerofmass) + (size_t)cls * n_slots;
+    const clu_f2* com = reinterpret_cast<const clu_f2*>(ib.d_centerofmass) + (size_t)cls * n_slots;
     const uint8_t* cand = ib.d_core_candidates + (size_t)cls * n_slots;
     int32_t* labels = ib.d_labels + (size_t)cls * n_slots;
     int32_t* rank = scratch + ((size_t)img * IS_INSTANCE_CLASSES + cls) * 2 * n_slots;
