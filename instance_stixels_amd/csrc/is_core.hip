@@ -303,6 +303,7 @@ static int ctx_init(is_ctx* c, const is_stixel_params* p, const float* obj_cost_
         d.knob_pw_groups = knob("IS_PW_GROUPS");
         d.knob_p2_split = knob("IS_P2_SPLIT");
         d.knob_p2x = knob("IS_P2X");
+        d.knob_unary_diag = knob("IS_UNARY_DIAG") == 1; /* (experiment: off unless asked for) */
     }
     {
         /* branch-and-bound constants (PruneRec, is_device.h).  gamma_d bounds the relative error of

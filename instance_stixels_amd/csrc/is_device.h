@@ -163,6 +163,7 @@ struct DevParams {
     int knob_pw_groups;       /* IS_PW_GROUPS: column groups (streams) of the pairwise DP */
     int knob_p2_split;        /* IS_P2_SPLIT: 1 = k_pw_phase2s, 0 = k_pw_phase2 */
     int knob_p2x;             /* IS_P2X=0: large batches walk phase 2 with k_pw_phase2 (one column per wave) */
+    int knob_unary_diag;      /* IS_UNARY_DIAG=1: the diagonal blocks of the unary DP in k_dp_unary_diag (two columns per wave) */
 };
 
 #endif /* IS_DEVICE_H_ */

@@ -216,7 +216,8 @@ __global__ __launch_bounds__(ISF_THREADS, HAS_INVALID ? ISF_OCC_INV : ISF_OCC) v
     const int* __restrict__ col_flags, const PruneRec* __restrict__ prune,
     float* __restrict__ cost_table, int32_t* __restrict__ index_table,
     unsigned long long* __restrict__ counters /* null, or the evaluation counters (is_device.h) */,
-    const float* __restrict__ joined, const float* __restrict__ cost_T) {
+    const float* __restrict__ joined, const float* __restrict__ cost_T,
+    int pre_diag /* k_dp_unary_diag has run: the tables hold the minima over the vB inside the tiles */) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int H = P.H, D = P.D;
     const int DP = D + 1;
@@ -239,6 +240,9 @@ __global__ __launch_bounds__(ISF_THREADS, HAS_INVALID ? ISF_OCC_INV : ISF_OCC) v
     if (colg >= ncols) return;
     if (__builtin_amdgcn_readfirstlane(col_flags[colg]) != 0) return; /* generic column: k_dp_unary */
     const int vhor = __builtin_amdgcn_readfirstlane(vhor_arr[colg / P.C]);
+    /* (pairs with a generic-encoding column are skipped by the diagonal kernel) */
+    const bool pre = pre_diag != 0 && (colg | 1) < ncols &&
+                     (__builtin_amdgcn_readfirstlane(col_flags[colg ^ 1]) == 0);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -255,7 +259,7 @@ __global__ __launch_bounds__(ISF_THREADS, HAS_INVALID ? ISF_OCC_INV : ISF_OCC) v
     /* ---- prologue: the wave's first K slots are requested first, then the tile's lutT rows,
      * the 1/h table and this lane's record.  The wave's steps: vB_top, vB_top - 8, ... >= 0
      * (H >= 8 = the number of waves, so vB_top >= 0). */
-    const int vB_top = vB_end - w;
+    const int vB_top = (pre ? tile_lo : vB_end) - w; /* (pre: may be negative = no step for this wave) */
 #pragma unroll
     for (int i = 0; i < K; i++)
         ring_prefetch<NVR>(lcol, rcol, max(vB_top - ISF_WAVES * i, 0), D, my_ring + i * SLOT,
@@ -287,6 +291,11 @@ __global__ __launch_bounds__(ISF_THREADS, HAS_INVALID ? ISF_OCC_INV : ISF_OCC) v
     b.g = b.o = b.s = IS_INF;
     b.vg = b.vs = -1;
     b.vo = 0; /* index_table[vT*3+OBJECT] = OBJECT at vB = 0, :592 */
+    if (pre && row_ok) { /* every wave starts from the diagonal block's minima: the bounds bite at once */
+        const size_t o = ((size_t)colg * H + vT) * 3;
+        b.g = cost_table[o + 0]; b.o = cost_table[o + 1]; b.s = cost_table[o + 2];
+        b.vg = index_table[o + 0]; b.vo = index_table[o + 1]; b.vs = index_table[o + 2];
+    }
     const float* my_tile = s_tile + lane * DP;
     const bool nog = IS_SKIP_GROUND_ABOVE_HORIZON && tile_lo >= vhor;
     __syncthreads(); /* the tile and the 1/h table: the only data the waves share */
@@ -298,7 +307,7 @@ __global__ __launch_bounds__(ISF_THREADS, HAS_INVALID ? ISF_OCC_INV : ISF_OCC) v
     int n_full = 0, n_gs = 0; /* steps below the diagonal block (wave-uniform: SALU only) */
     isk_f16v S; /* the class prefixes of the record of vB as scalars, requested one step ahead */
 #if ISF_SREC
-    srec_request(S, rcol + vB_top);
+    srec_request(S, rcol + max(vB_top, 0));
 #endif
     for (int vB = vB_top; vB >= 0; vB -= ISF_WAVES) {
         wait_vmcnt<(NVR + 1) * (K - 1)>(); /* this step's slot has landed; K - 1 prefetches in flight */
@@ -417,6 +426,174 @@ __global__ __launch_bounds__(ISF_THREADS, HAS_INVALID ? ISF_OCC_INV : ISF_OCC) v
     ISF_MARK(3);
 }
 
+/* ====================================================================================== */
+/* The diagonal blocks as a kernel of their own (IS_UNARY_DIAG)                              */
+/* ====================================================================================== */
+/* In k_dp_unary_fast a lane owns one row vT of a 64-row tile, so the 63 steps whose vB lies INSIDE
+ * the tile run with the lanes vT < vB dead: 32.5 of 64 live on average, and on pruned walks these
+ * steps are more than half of the kernel's work.  Here ONE wave takes the
+ * diagonal blocks of a column PAIR (the decomposition of k_pw_phase2x, without its serial chain):
+ * column X in lanes 0-31, column Y in lanes 32-63, and per column
+ *     rows 32-63 against vB = tile_lo + 63 ... tile_lo + 1   (upper triangle, then the square),
+ *     rows  0-31 against vB = tile_lo + 31 ... tile_lo + 1   (lower triangle):
+ * 94 wave-steps for two columns instead of 2 x 63.  The vB record is a DPP operand (two dwords per
+ * lane, fetched two steps ahead from the column's own record: a 16-lane row only ever reads its own
+ * column), the lutT values of both ends come from the fn window of the tile (pw_phase2_body: a
+ * segment inside the tile has its mean between the tile's smallest and largest disparity; a lane
+ * outside the window reads global memory).  Candidates, operand order and the `<=` update of a
+ * descending walk are those of fast_step.  The result -- the minima over the vB of the tile -- goes
+ * into the rows of cost_table / index_table as PRELIMINARY values: k_dp_unary_fast (pre_diag) starts
+ * every wave of the tile from them and walks vB <= tile_lo only.  Pairs with a generic-encoding
+ * column are left alone (their FAST column walks its diagonal itself). */
+#define ISD_WMAX 16
+#define ISD_WS (ISD_WMAX + 1) /* odd row stride: lanes reading one window column of 32 rows hit 32 banks */
+#define ISD_ROWS (IS_TILE + 1)
+#define ISD_WF (ISD_ROWS * ISD_WS)
+#ifndef ISD_OCC
+#define ISD_OCC 5
+#endif
+__device__ __forceinline__ float isd_half_min(float x) {
+#pragma unroll
+    for (int m = 16; m >= 1; m >>= 1) x = __builtin_fminf(x, __shfl_xor(x, m, 64));
+    return x;
+}
+__device__ __forceinline__ float isd_half_max(float x) {
+#pragma unroll
+    for (int m = 16; m >= 1; m >>= 1) x = __builtin_fmaxf(x, __shfl_xor(x, m, 64));
+    return x;
+}
+
+template <bool HAS_INVALID>
+__global__ __launch_bounds__(64, ISD_OCC) void k_dp_unary_diag(
+    const DevParams P, int ncols, const RowRec* __restrict__ recs, const float* __restrict__ lutT,
+    const float* __restrict__ joined, const float* __restrict__ rcp, const int* __restrict__ vhor_arr,
+    const int* __restrict__ col_flags, float* __restrict__ cost_table, int32_t* __restrict__ index_table) {
+    __shared__ float s_rcp[(IS_TILE + 1 + 3) & ~3];
+    __shared__ float s_win[2 * ISD_WF];
+    const int H = P.H, D = P.D;
+    const int lane = threadIdx.x, li = lane & 31, l15 = lane & 15, half = lane >> 5;
+    /* consecutive workgroups: the tiles of one column pair (neighbouring lutT rows, one XCD's L2 by
+     * and large), tallest first is irrelevant here -- every workgroup does the same work */
+    const int pair = (int)(blockIdx.x / (unsigned)P.ntiles), tile = (int)(blockIdx.x % (unsigned)P.ntiles);
+    const int col0 = pair * 2;
+    if (col0 + 1 >= ncols) return;
+    if ((__builtin_amdgcn_readfirstlane(col_flags[col0]) | __builtin_amdgcn_readfirstlane(col_flags[col0 + 1])) != 0)
+        return;
+    const int vhor = __builtin_amdgcn_readfirstlane(vhor_arr[col0 / P.C]);
+    const int tile_lo = tile * IS_TILE;
+    const int colg = col0 + half;
+    const RowRec* rcol = recs + (size_t)colg * (H + 1);
+    const float* lcol = lutT + (size_t)colg * (H + 1) * D;
+    float* my_winbase = s_win + half * ISD_WF;
+
+    /* ---- the fn window [lo, lo + W) of this column's tile rows */
+    int lo, W;
+    {
+        float dmin = IS_INF, dmax = -IS_INF;
+        for (int k = 0; k < 2; k++) {
+            const int v = tile_lo + li + 32 * k;
+            const float d = joined[(size_t)colg * H + min(v, H - 1)];
+            const bool ok = (v < H) && !(HAS_INVALID && d == P.invalid);
+            dmin = __builtin_fminf(dmin, ok ? d : IS_INF);
+            dmax = __builtin_fmaxf(dmax, ok ? d : -IS_INF);
+        }
+        dmin = isd_half_min(dmin);
+        dmax = isd_half_max(dmax);
+        int l = (int)__builtin_fminf(__builtin_fmaxf(dmin, 1.0f), (float)D) - 1;
+        l = min(max(l, 0), D - 1);
+        int hh = (int)__builtin_fminf(__builtin_fmaxf(dmax, 0.0f), (float)(D - 1)) + 1;
+        hh = min(max(hh, l), min(D - 1, l + ISD_WMAX - 1));
+        lo = l;
+        W = hh - l + 1;
+    }
+    { /* window rows tile_lo .. tile_lo + 64: 32 lanes, 16 columns at most, two rows per sweep */
+        constexpr int NL = (ISD_ROWS * ISD_WMAX + 31) / 32;
+        const int f = li & (ISD_WMAX - 1), j0 = li >> 4;
+        float tmp[NL];
+#pragma unroll
+        for (int k = 0; k < NL; k++) {
+            const int j = j0 + 2 * k;
+            tmp[k] = (j < ISD_ROWS && f < W) ? lcol[(size_t)min(tile_lo + j, H) * D + lo + f] : 0.0f;
+        }
+#pragma unroll
+        for (int k = 0; k < NL; k++) {
+            const int j = j0 + 2 * k;
+            if (j < ISD_ROWS && f < W) my_winbase[j * ISD_WS + f] = tmp[k];
+        }
+    }
+    for (int i = lane; i <= IS_TILE; i += 64) s_rcp[i] = rcp[min(i, H)];
+    __syncthreads();
+
+    /* one phase: the rows base + li of the column against vB = tile_lo + a_hi ... tile_lo + 1 */
+    auto phase = [&](const int base, const int a_hi) {
+        const int r = base + li;            /* row of the tile */
+        const int vT = tile_lo + r, vTc = min(vT, H - 1);
+        const bool row_ok = vT < H;
+        const RowRec my = load_rec(rcol + vTc + 1);
+        const float* my_win = my_winbase + (r + 1) * ISD_WS; /* lutT row vT + 1 */
+        UnaryBestF b;
+        b.g = b.o = b.s = IS_INF;
+        b.vg = b.vs = -1;
+        b.vo = 0;
+        /* records of vB two steps ahead (rows beyond H are never live: clamped for the address only) */
+        auto rec_dw = [&](int a, float& r0, float& r1) {
+            const float* q = (const float*)(rcol + min(max(tile_lo + a, 0), H));
+            r0 = q[l15];
+            r1 = q[16 + l15];
+        };
+        float c0, c1, n0, n1;
+        rec_dw(a_hi, c0, c1);
+        rec_dw(a_hi - 1, n0, n1);
+        for (int a = a_hi; a >= 1; a--) {
+            const int vB = tile_lo + a;
+            const float R0 = c0, R1 = c1;
+            c0 = n0; c1 = n1;
+            rec_dw(a - 2, n0, n1);
+            const int h = vTc + 1 - vB;
+            const bool live = (h > 0) && row_ok;
+            const int hc = max(h, 1);
+            const float rh = s_rcp[min(hc, IS_TILE)];
+            const bool sky = vB > vhor; /* vB - 1 >= vhor: sky + object (:729), else ground + object (:687) */
+            SegTerms t;
+            if (sky) t = eval_segment_dpp<HAS_INVALID, IS_WANT_SKY>(my, R0, R1, (float)hc, rh, D, P.iw);
+            else t = eval_segment_dpp<HAS_INVALID, IS_WANT_GROUND>(my, R0, R1, (float)hc, rh, D, P.iw);
+            const int fo = t.fni - lo;
+            const bool inwin = (unsigned)fo < (unsigned)W;
+            const int foc = inwin ? fo : 0;
+            float od = my_win[foc] - my_winbase[a * ISD_WS + foc];
+            if (__builtin_amdgcn_ballot_w64(live && !inwin) != 0ull) { /* outside the window: rare */
+                const float og = (lcol + (size_t)(vTc + 1) * D)[(unsigned)t.fni] -
+                                 (lcol + (size_t)min(vB, H) * D)[(unsigned)t.fni];
+                od = inwin ? od : og;
+            }
+            const float pwih = P.pw * rh;
+            /* cost = dw*data + pw*(1/h) + sw*seg, left to right (fast_step) */
+            const float cost_o = P.dw * od + pwih + P.sw * t.seg_o;
+            const bool uo = live && (cost_o <= b.o);
+            b.o = uo ? cost_o : b.o;
+            b.vo = uo ? vB : b.vo;
+            if (sky) {
+                const float cost_s = P.dw * t.sd + pwih + P.sw * t.seg_s;
+                const bool us = live && (cost_s <= b.s);
+                b.s = us ? cost_s : b.s;
+                b.vs = us ? vB : b.vs;
+            } else {
+                const float cost_g = P.dw * t.gd + pwih + P.sw * t.seg_g;
+                const bool ug = live && (cost_g <= b.g);
+                b.g = ug ? cost_g : b.g;
+                b.vg = ug ? vB : b.vg;
+            }
+        }
+        if (row_ok) {
+            const size_t o = ((size_t)colg * H + vT) * 3;
+            cost_table[o + 0] = b.g; cost_table[o + 1] = b.o; cost_table[o + 2] = b.s;
+            index_table[o + 0] = b.vg; index_table[o + 1] = b.vo; index_table[o + 2] = b.vs;
+        }
+    };
+    phase(32, 63);
+    phase(0, 31);
+}
+
 extern "C" {
 
 /* NVR = 64-lane loads per lutT row; 0 = the shape cannot use this kernel */
@@ -465,13 +642,26 @@ hipError_t isk_launch_dp_unary_fast(const DevParams* P, int ncols, const RowRec*
                                     int32_t* index_table, unsigned long long* counters,
                                     const float* joined, const float* cost_T, hipStream_t stream) {
     const int nvr = isk_unary_fast_chunk_rows(P);
+    /* the diagonal blocks first, two columns per wave (k_dp_unary_diag); needs an even number of
+     * columns per image (a pair never straddles two images); IS_UNARY_DIAG=0: the ring kernel walks
+     * them itself */
+    const int pre_diag = (P->knob_unary_diag != 0 && (P->C % 2) == 0 && (ncols % 2) == 0) ? 1 : 0;
+    if (pre_diag) {
+        const dim3 dgrid((unsigned)(ncols / 2) * (unsigned)P->ntiles);
+        if (P->invalid >= 0)
+            hipLaunchKernelGGL(k_dp_unary_diag<true>, dgrid, dim3(64), 0, stream, *P, ncols, recs, lutT, joined,
+                               rcp, vhor, col_flags, cost_table, index_table);
+        else
+            hipLaunchKernelGGL(k_dp_unary_diag<false>, dgrid, dim3(64), 0, stream, *P, ncols, recs, lutT, joined,
+                               rcp, vhor, col_flags, cost_table, index_table);
+    }
     const int groups = (ncols + 7) / 8;
     const dim3 grid(groups * 8 * P->ntiles);
     const size_t lds = isk_unary_fast_lds_bytes(P, nvr);
 #define ISF_LAUNCH(INV, NVR)                                                                      \
     hipLaunchKernelGGL((k_dp_unary_fast<INV, NVR>), grid, dim3(ISF_THREADS), lds, stream, *P, ncols, \
                        recs, lutT, rcp, vhor, col_flags, prune, cost_table, index_table, counters, joined, \
-                       cost_T)
+                       cost_T, pre_diag)
     if (P->invalid >= 0) {
         if (nvr == 2) ISF_LAUNCH(true, 2); else ISF_LAUNCH(true, 4);
     } else {

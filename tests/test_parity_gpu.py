@@ -827,7 +827,7 @@ def test_branch_and_bound_is_exact_at_the_bounds(family, monkeypatch):
 
 
 @pytest.mark.parametrize("knob,value", [("IS_GRAPH", "1"), ("IS_PREPARE_OVERLAP", "0"),
-                                         ("IS_PREPARE_OVERLAP", "1")])
+                                         ("IS_PREPARE_OVERLAP", "1"), ("IS_UNARY_DIAG", "1")])
 @pytest.mark.parametrize("preset", ["drn_d_22_unary", "drn_d_38_pairwise"])
 def test_launch_path_knobs_change_nothing(preset, knob, value, monkeypatch):
     """The launch-path alternatives a context can be created with -- hipGraph replay of small calls
