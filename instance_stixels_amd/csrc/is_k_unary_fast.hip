@@ -209,7 +209,9 @@ __device__ __forceinline__ void ring_prefetch(const float* __restrict__ lcol,
         dma_dword((const float*)(rcol + vB) + lane, lds_addr(slot_rec));
 }
 
-template <bool HAS_INVALID, int NVR>
+/* PRE_DIAG: the instantiation that starts from the minima k_dp_unary_diag left in the tables (an
+ * instantiation of its own: as a run-time flag the path cost the unpruned walk 1.8 %) */
+template <bool HAS_INVALID, int NVR, bool PRE_DIAG = false>
 __global__ __launch_bounds__(ISF_THREADS, HAS_INVALID ? ISF_OCC_INV : ISF_OCC) void k_dp_unary_fast(
     const DevParams P, int ncols, const RowRec* __restrict__ recs, const float* __restrict__ lutT,
     const float* __restrict__ rcp, const int* __restrict__ vhor_arr,
@@ -241,7 +243,7 @@ __global__ __launch_bounds__(ISF_THREADS, HAS_INVALID ? ISF_OCC_INV : ISF_OCC) v
     if (__builtin_amdgcn_readfirstlane(col_flags[colg]) != 0) return; /* generic column: k_dp_unary */
     const int vhor = __builtin_amdgcn_readfirstlane(vhor_arr[colg / P.C]);
     /* (pairs with a generic-encoding column are skipped by the diagonal kernel) */
-    const bool pre = pre_diag != 0 && (colg | 1) < ncols &&
+    const bool pre = PRE_DIAG && pre_diag != 0 && (colg | 1) < ncols &&
                      (__builtin_amdgcn_readfirstlane(col_flags[colg ^ 1]) == 0);
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -628,7 +630,10 @@ hipError_t isk_set_lds_unary_fast(const DevParams* P) {
     hipError_t e = hipSuccess;
 #define ISF_SET(INV, NVR)                                                                         \
     if (e == hipSuccess)                                                                          \
-    e = hipFuncSetAttribute((const void*)k_dp_unary_fast<INV, NVR>,                               \
+    e = hipFuncSetAttribute((const void*)k_dp_unary_fast<INV, NVR, false>,                        \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, b);                       \
+    if (e == hipSuccess)                                                                          \
+    e = hipFuncSetAttribute((const void*)k_dp_unary_fast<INV, NVR, true>,                         \
                             hipFuncAttributeMaxDynamicSharedMemorySize, b)
     if (nvr == 2) { ISF_SET(true, 2); ISF_SET(false, 2); } else { ISF_SET(true, 4); ISF_SET(false, 4); }
 #undef ISF_SET
@@ -659,9 +664,16 @@ hipError_t isk_launch_dp_unary_fast(const DevParams* P, int ncols, const RowRec*
     const dim3 grid(groups * 8 * P->ntiles);
     const size_t lds = isk_unary_fast_lds_bytes(P, nvr);
 #define ISF_LAUNCH(INV, NVR)                                                                      \
-    hipLaunchKernelGGL((k_dp_unary_fast<INV, NVR>), grid, dim3(ISF_THREADS), lds, stream, *P, ncols, \
-                       recs, lutT, rcp, vhor, col_flags, prune, cost_table, index_table, counters, joined, \
-                       cost_T, pre_diag)
+    do {                                                                                          \
+        if (pre_diag)                                                                             \
+            hipLaunchKernelGGL((k_dp_unary_fast<INV, NVR, true>), grid, dim3(ISF_THREADS), lds, stream, *P, \
+                               ncols, recs, lutT, rcp, vhor, col_flags, prune, cost_table, index_table, \
+                               counters, joined, cost_T, pre_diag);                                \
+        else                                                                                      \
+            hipLaunchKernelGGL((k_dp_unary_fast<INV, NVR, false>), grid, dim3(ISF_THREADS), lds, stream, *P, \
+                               ncols, recs, lutT, rcp, vhor, col_flags, prune, cost_table, index_table, \
+                               counters, joined, cost_T, pre_diag);                                \
+    } while (0)
     if (P->invalid >= 0) {
         if (nvr == 2) ISF_LAUNCH(true, 2); else ISF_LAUNCH(true, 4);
     } else {

@@ -13,9 +13,9 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-CASES = [("is_k_unary_fast", "k_dp_unary_fastILb0ELi2", 2), ("is_k_unary_fast", "k_dp_unary_fastILb1ELi2", 2),
-         ("is_k_unary_fast", "k_dp_unary_fastILb0ELi4", 2), ("is_k_unary_fast", "k_dp_unary_fastILb1ELi4", 2),
-         ("is_k_pairwise", "k_pw_phase1ILb0ELi2", 4), ("is_k_pairwise", "k_pw_phase1ILb0ELi0", 4),
+CASES = [("is_k_unary_fast", "k_dp_unary_fastILb%dELi%dELb%dE" % (inv, nvr, pre), 2)
+         for inv in (0, 1) for nvr in (2, 4) for pre in (0, 1)] + \
+        [("is_k_pairwise", "k_pw_phase1ILb0ELi2", 4), ("is_k_pairwise", "k_pw_phase1ILb0ELi0", 4),
          ("is_k_pairwise", "k_pw_phase1ILb1ELi2", 0), ("is_k_pairwise", "k_pw_phase1ILb1ELi0", 0)]
 
 
