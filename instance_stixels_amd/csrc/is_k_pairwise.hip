@@ -337,6 +337,9 @@ __device__ __forceinline__ void touch_round(const RowRec* rcol, const StepRec* s
 #ifndef IS_P1_MY_FIRST
 #define IS_P1_MY_FIRST 0 /* 1: the lane record requested before the tile staging: measured 2 % slower (more loads in flight at once) */
 #endif
+#ifndef IS_P1_TILE0_DIRECT
+#define IS_P1_TILE0_DIRECT 1
+#endif
 #ifndef IS_P1_SREC_LATE
 #define IS_P1_SREC_LATE 1 /* StepRec of the next step: loaded at the end of the step, pinned (= waited for) at its use */
 #endif
@@ -402,6 +405,43 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
     const RowRec* rcol = recs + (size_t)colg * (H + 1);
     const float* lcol = lutT + (size_t)colg * (H + 1) * D;
     const StepRec* scol = steps + (size_t)colg * H;
+
+#if IS_P1_TILE0_DIRECT
+    /* Tile 0 has ONE candidate per row, the first segment (vB = 0, :481-594), and it belongs to wave 0
+     * of split 0: that wave computes it with its operands straight from global memory (1/h, the two
+     * lutT values of the lane) and writes the partial minima in the form the merge below would; no
+     * tile staging, no barrier, the other waves leave at once.  (The full prologue + merge made the
+     * tile-0 launch as long as a launch with work: 0.24 ms per 64 frames.) */
+    if (tile == 0) {
+        if (wl != 0) return;
+        const int vT = lane;
+        const int vTc = min(vT, H - 1);
+        const bool live = vT < H;
+        float cg = IS_INF, co = IS_INF;
+        int ig = -1, io = IS_OBJECT;
+        if (split == 0) {
+            const RowRec my = load_rec(rcol + vTc + 1);
+            const RowRec rb = sload_rec(rcol);
+            const int h = vTc + 1;
+            const SegTerms t = eval_segment<FAST, HAS_INVALID>(my, rb, (float)h, rcp[min(h, H)], D, P.iw);
+            const float od = lcol[(size_t)min(vT + 1, H) * D + (unsigned)t.fni] - lcol[(unsigned)t.fni];
+            const bool below = vT <= vhor;
+            const float cost_g = P.dw * t.gd + P.pw * P.first_g + P.sw * t.seg_g;
+            const bool ug = live && below && (cost_g < IS_INF); /* (a +inf candidate keeps the initial index) */
+            cg = ug ? cost_g : cg;
+            ig = ug ? IS_GROUND : ig;
+            const float prior = below ? P.first_o_below : P.first_o_above;
+            const float cost = P.dw * od + P.pw * prior + P.sw * t.seg_o;
+            co = (live && cost < IS_INF) ? cost : co;
+        }
+        const size_t o = (((size_t)colg * nsplit + split) * 3) * 64 + lane;
+        part_cost[o] = cg;            part_idx[o] = ig;
+        part_cost[o + 64] = co;       part_idx[o + 64] = io;
+        part_cost[o + 128] = IS_INF;  part_idx[o + 128] = -1;
+        if (counters != nullptr && lane == 0 && split == 0) atomicAdd(counters + IS_CNT_P1_FULL, 1ull);
+        return;
+    }
+#endif
 
 #ifdef IS_ABL_P1PHASES
     unsigned long long t_p1 = __builtin_readcyclecounter();
