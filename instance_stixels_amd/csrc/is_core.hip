@@ -33,7 +33,7 @@ hipError_t isk_launch_dp_unary(const DevParams*, int, int, const RowRec*, const 
 hipError_t isk_launch_dp_pairwise(const DevParams*, int, int, const RowRec*, const float*,
                                   const float*, const PriorRec*, const float*, const float*, const float*,
                                   const int*, const int*, const PruneRec*, StepRec*, float*, int*,
-                                  float*, int32_t*, unsigned long long*, const float*, const int*,
+                                  float*, int32_t*, unsigned long long*, const float*, const int*, float*,
                                   hipStream_t, hipStream_t*, int, hipEvent_t, hipEvent_t*);
 hipError_t isk_launch_backtrace(const DevParams*, int, int, const RowRec*, const float*,
                                 const int32_t*, const int*, is_section*, int*, int*, hipStream_t);
@@ -137,6 +137,7 @@ struct is_ctx {
     float* d_part_cost;      /* [max_batch*C][3][64] merged partial minima of the current tile */
     int* d_part_idx;         /* [max_batch*C][3][64] */
     float* d_sv;             /* [max_batch*C][2][H+1] compact S / V prefixes */
+    float* d_blksum;         /* [max_batch*C][ntiles+1][8] block summaries of the pairwise DP (lemma L7) */
     float* d_cost_table;     /* [max_batch*C][H][3] */
     int32_t* d_index_table;  /* [max_batch*C][H][3] */
     size_t scratch_bytes;
@@ -369,6 +370,7 @@ static int ctx_init(is_ctx* c, const is_stixel_params* p, const float* obj_cost_
     ALLOC(c->d_part_cost, sizeof(float) * part_slots * 3 * 64);
     ALLOC(c->d_part_idx, sizeof(int) * part_slots * 3 * 64);
     ALLOC(c->d_sv, sizeof(float) * B * C * 2 * (H + 1));
+    ALLOC(c->d_blksum, sizeof(float) * B * C * ((size_t)d.ntiles + 1) * 8);
     ALLOC(c->d_cost_table, sizeof(float) * B * C * H * 3);
     ALLOC(c->d_index_table, sizeof(int32_t) * B * C * H * 3);
     ALLOC(c->d_cluster_scratch, sizeof(int32_t) * B * IS_INSTANCE_CLASSES * 2 * C * (size_t)d.S);
@@ -439,7 +441,7 @@ int is_ctx_destroy(is_ctx* c) {
         free(c->graph_cache);
     }
     (void)hipFree(c->d_obj_cost_lut); (void)hipFree(c->d_odr); (void)hipFree(c->d_rcp); (void)hipFree(c->d_col_flags); (void)hipFree(c->d_prune); (void)hipFree(c->d_n_generic); (void)hipFree(c->d_stage);
-    (void)hipFree(c->d_recs); (void)hipFree(c->d_lutT); (void)hipFree(c->d_priors); (void)hipFree(c->d_steps); (void)hipFree(c->d_part_cost); (void)hipFree(c->d_part_idx); (void)hipFree(c->d_sv);
+    (void)hipFree(c->d_recs); (void)hipFree(c->d_lutT); (void)hipFree(c->d_priors); (void)hipFree(c->d_steps); (void)hipFree(c->d_part_cost); (void)hipFree(c->d_part_idx); (void)hipFree(c->d_sv); (void)hipFree(c->d_blksum);
     (void)hipFree(c->d_cost_table); (void)hipFree(c->d_index_table); (void)hipFree(c->d_cluster_scratch);
     (void)hipFree(c->d_inst_cnt); (void)hipFree(c->d_counters);
     for (int i = 0; i < IS_STAGE_SLOTS; i++) {
@@ -611,7 +613,8 @@ static int compute_enqueue(is_ctx* c, const float* d_joined, const int32_t* d_se
                                        d_joined, c->d_priors, c->d_odr, c->d_rcp, c->d_sv, c->d_vhor,
                                        c->d_col_flags, c->d_prune, c->d_steps, c->d_part_cost,
                                        c->d_part_idx, ct, it, c->counting ? c->d_counters : nullptr,
-                                       c->d_obj_cost_lut, c->d_n_generic, stream, c->aux_streams, IS_AUX_STREAMS, c->ev_fork, c->ev_joins));
+                                       c->d_obj_cost_lut, c->d_n_generic, c->d_blksum, stream, c->aux_streams,
+                                       IS_AUX_STREAMS, c->ev_fork, c->ev_joins));
     else
         HIP_TRY(isk_launch_dp_unary(&P, ncols, c->nwaves_unary, c->d_recs, c->d_lutT, c->d_rcp,
                                     c->d_vhor, c->d_col_flags, c->d_prune, ct, it, c->d_n_generic,

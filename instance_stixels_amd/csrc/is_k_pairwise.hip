@@ -217,6 +217,147 @@ struct PairBest {
     int ig, io, is; /* vB*3 + prev type */
 };
 
+/* ---- separable block bounds of the ground / sky candidates (lemma L7) --------
+ * A ground candidate costs  C(vB, vT) = fl(fl(dw fl(G[vT+1] - G[vB])) + T[vB]) + fl(sw fl(f + n)),
+ * f = min_c (F_c[vT+1] - F_c[vB]) over the classes c of the type, n = fl(iw float(N[vT+1] - N[vB])),
+ * T = StepRec.pwmp (sky: K instead of G, one class).  As real numbers
+ *     dw (G1 - G0) + T + sw (f + iw dN) = min_c [ a_c(vB) + b_c(vT) ],
+ *     a_c(vB) = T - dw G[vB] - sw (F_c[vB] + iw N[vB]),   b_c(vT) = dw G[vT+1] + sw (F_c[vT+1] + iw N[vT+1]),
+ * and every term of C passes through at most five roundings, so with u = 2^-24
+ *     | C - min_c (a_c + b_c) | <= 5.01 u (mu_c(vB) + nu_c(vT)),  mu_c = |T| + dw |G0| + sw (F_c0 + iw N0),
+ *                                                                nu_c = dw |G1| + sw (F_c1 + iw N1)
+ * for every class c (f <= F_c[vT+1], dN <= N[vT+1]: class values and squared offsets are >= 0 in a
+ * column whose pruning is on).  The computed fp32 values a^_c, b^_c lie within 5.01 u mu_c / nu_c of
+ * a_c, b_c.  Hence, with slack(x) = 2^-20 x + 2^-90 (16 u: 10.02 u for the two errors, 1 u for the
+ * rounding of the subtraction below, the rest covers mu^ >= (1 - u)^4 mu),
+ *     alo_c = fl(a^_c - slack(mu^_c)) <= a_c - 10.02 u mu_c,   ahi_c = fl(a^_c + slack(mu^_c)) >= a_c + 10.02 u mu_c
+ * and likewise blo_c / bhi_c:   min_c (alo_c(vB) + blo_c(vT)) <= C(vB, vT) <= ahi_c(vB) + bhi_c(vT) for EVERY c.
+ * Phase 2 leaves, per 64-row block of candidates (= the rows whose StepRecs one launch builds) and
+ * class, the minima of alo_c and ahi_c over the block's rows of the type (l7_row_bounds + a wave
+ * minimum; rows of the other type, rows beyond the image and NaN / +inf rows -- whose candidates
+ * cost NaN / +inf and never win -- count as +inf).  Phase 1 turns them into a lower bound of every
+ * candidate of the block and an upper bound of the block's best one per lane (pw_phase1_body). */
+#define IS_L7_REL 0x1p-20f
+#define IS_L7_ABS 0x1p-90f
+struct L7Row { float lo_g0, lo_g1, lo_s, hi_g0, hi_g1, hi_s; };
+__device__ __forceinline__ void l7_ab(float t, float dterm, float fterm, float* lo, float* hi) {
+    const float a = (t - dterm) - fterm;
+    const float mu = (__builtin_fabsf(t) + __builtin_fabsf(dterm)) + fterm; /* fterm >= 0 */
+    const float sl = mu * IS_L7_REL + IS_L7_ABS;
+    *lo = a - sl;
+    *hi = a + sl;
+}
+/* bounds of the candidate row vB whose record fields are given (FAST encoding), T = its pwmp;
+ * ground_row: vB - 1 < vhor.  `ok`: vB is a candidate row at all (1 <= vB <= H - 1). */
+__device__ __forceinline__ L7Row l7_row_bounds(const DevParams& P, float T, float G, float K, float Fg0,
+                                               float Fg1, float Fsky, int Fnic, bool ground_row, bool ok) {
+    L7Row r;
+    const float n = P.iw * (float)Fnic;
+    const float dg = P.dw * G, dk = P.dw * K;
+    l7_ab(T, dg, P.sw * (Fg0 + n), &r.lo_g0, &r.hi_g0);
+    l7_ab(T, dg, P.sw * (Fg1 + n), &r.lo_g1, &r.hi_g1);
+    l7_ab(T, dk, P.sw * (Fsky + n), &r.lo_s, &r.hi_s);
+    const bool g = ok && ground_row, s = ok && !ground_row;
+    /* (NaN bounds -- a NaN or infinite T -- are skipped by the minima: fminf ignores a quiet NaN) */
+    r.lo_g0 = g ? r.lo_g0 : IS_INF; r.hi_g0 = g ? r.hi_g0 : IS_INF;
+    r.lo_g1 = g ? r.lo_g1 : IS_INF; r.hi_g1 = g ? r.hi_g1 : IS_INF;
+    r.lo_s = s ? r.lo_s : IS_INF;   r.hi_s = s ? r.hi_s : IS_INF;
+    return r;
+}
+/* minimum over a group of 2^LOG lanes (NaN-skipping), every lane gets it */
+template <int LOG>
+__device__ __forceinline__ float l7_group_min(float x) {
+    x = __builtin_fminf(x, IS_INF); /* a NaN becomes +inf */
+#pragma unroll
+    for (int m = (1 << LOG) >> 1; m >= 1; m >>= 1) x = __builtin_fminf(x, __shfl_xor(x, m, 64));
+    return x;
+}
+template <int LOG>
+__device__ __forceinline__ L7Row l7_group_min_row(L7Row r) {
+    r.lo_g0 = l7_group_min<LOG>(r.lo_g0); r.lo_g1 = l7_group_min<LOG>(r.lo_g1); r.lo_s = l7_group_min<LOG>(r.lo_s);
+    r.hi_g0 = l7_group_min<LOG>(r.hi_g0); r.hi_g1 = l7_group_min<LOG>(r.hi_g1); r.hi_s = l7_group_min<LOG>(r.hi_s);
+    return r;
+}
+__device__ __forceinline__ void l7_store(float* dst /* 8 floats, 32-byte aligned */, const L7Row& r) {
+    float4* d = reinterpret_cast<float4*>(dst);
+    d[0] = make_float4(r.lo_g0, r.lo_g1, r.lo_s, 0.0f);
+    d[1] = make_float4(r.hi_g0, r.hi_g1, r.hi_s, 0.0f);
+}
+/* summary of a block that must never be skipped (generic columns; phase 1 ignores the summaries of
+ * a column whose pruning is off anyway) */
+__device__ __forceinline__ L7Row l7_never() {
+    L7Row r;
+    r.lo_g0 = r.lo_g1 = r.lo_s = -IS_INF;
+    r.hi_g0 = r.hi_g1 = r.hi_s = IS_INF;
+    return r;
+}
+#define IS_L7_F 8 /* floats per block summary */
+
+/* ---- phase-1 side of lemma L7 ----------------------------------------------------------------
+ * Per lane (vT) and class: blo_c / bhi_c from the lane's own record; per block k and type: a lower
+ * bound LB_k of every candidate of the block and an upper bound UB_k of its best one,
+ *     LB_k = min_c dn(Mlo_c[k] + blo_c),   UB_k = min_c up(Mhi_c[k] + bhi_c),   dn / up(s) = s -+ 2^-22 |s|
+ * (4 u |s|: covers the rounding of the sum and of the correction itself).  thr = min_k UB_k is an
+ * upper bound of the lane's FINAL cost of the type (some candidate of some block costs no more), so
+ * a block with LB_k > thr in every lane holds no candidate that wins or ties anywhere in the tile:
+ * its 64 rows are never visited.  In a homogeneous road or sky stretch -- where the sticky bounds
+ * never close, every split being a near-optimal candidate -- exactly the block with the stretch's
+ * first row survives (tools/l7_study.py). */
+#ifndef IS_P1_L7
+#define IS_P1_L7 1
+#endif
+#define IS_P1_L7_WORDS 136 /* LDS words of the exchange: [2][64] threshold keys + 2 masks, padded */
+struct L7B { float lo_g0, lo_g1, lo_s, hi_g0, hi_g1, hi_s; };
+__device__ __forceinline__ void l7_b(float dterm, float fterm, float* lo, float* hi) {
+    const float b = dterm + fterm;
+    const float nu = __builtin_fabsf(dterm) + fterm;
+    const float sl = nu * IS_L7_REL + IS_L7_ABS;
+    *lo = b - sl;
+    *hi = b + sl;
+}
+__device__ __forceinline__ L7B l7_lane_bounds(const DevParams& P, const RowRec& my) {
+    L7B b;
+    const float n = P.iw * (float)my.Fnic;
+    const float dg = P.dw * my.G, dk = P.dw * my.K;
+    l7_b(dg, P.sw * (my.Fg0 + n), &b.lo_g0, &b.hi_g0);
+    l7_b(dg, P.sw * (my.Fg1 + n), &b.lo_g1, &b.hi_g1);
+    l7_b(dk, P.sw * (my.Fsky + n), &b.lo_s, &b.hi_s);
+    return b;
+}
+/* summary of block k (wave-uniform, scalar loads); block 0 = the first segment: a ground candidate
+ * with T = pw * first_g and every prefix 0 (:196-199, :481-594) */
+__device__ __forceinline__ L7Row l7_block_summary(const DevParams& P, const float* bcol, int k) {
+    L7Row m;
+    if (k == 0) {
+        l7_ab(P.pw * P.first_g, 0.0f, 0.0f, &m.lo_g0, &m.hi_g0);
+        m.lo_g1 = m.lo_g0; m.hi_g1 = m.hi_g0;
+        m.lo_s = m.hi_s = IS_INF;
+    } else {
+        typedef const __attribute__((address_space(4))) float* cflt_t;
+        cflt_t q = (cflt_t)(bcol + (size_t)k * IS_L7_F);
+        m.lo_g0 = q[0]; m.lo_g1 = q[1]; m.lo_s = q[2];
+        m.hi_g0 = q[4]; m.hi_g1 = q[5]; m.hi_s = q[6];
+    }
+    return m;
+}
+__device__ __forceinline__ float l7_dn(float s) { return s - __builtin_fabsf(s) * 0x1p-22f; }
+__device__ __forceinline__ float l7_up(float s) { return s + __builtin_fabsf(s) * 0x1p-22f; }
+__device__ __forceinline__ void l7_combine(const L7Row& m, const L7B& b, float* lbg, float* ubg, float* lbs,
+                                           float* ubs) {
+    *lbg = __builtin_fminf(l7_dn(m.lo_g0 + b.lo_g0), l7_dn(m.lo_g1 + b.lo_g1));
+    *ubg = __builtin_fminf(l7_up(m.hi_g0 + b.hi_g0), l7_up(m.hi_g1 + b.hi_g1));
+    *lbs = l7_dn(m.lo_s + b.lo_s);
+    *ubs = l7_up(m.hi_s + b.hi_s);
+}
+/* order-preserving map float -> unsigned (for ds_min_u32); NaNs are never mapped */
+__device__ __forceinline__ unsigned l7_key(float x) {
+    const unsigned u = __float_as_uint(x);
+    return u ^ ((unsigned)((int)u >> 31) | 0x80000000u);
+}
+__device__ __forceinline__ float l7_unkey(unsigned k) {
+    return __uint_as_float((k & 0x80000000u) ? (k ^ 0x80000000u) : ~k);
+}
+
 /* One (vB >= 1, vT) evaluation of the pairwise model for the lane owning vT; `st` is the
  * wave-uniform StepRec of vB.  SKY: vB-1 >= vhor (:729), else ground (:687). */
 /* DESC: the caller walks vB downwards, so a candidate of EQUAL cost replaces the best one (the
@@ -387,7 +528,8 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
                                                int* __restrict__ part_idx,
                                                unsigned long long* __restrict__ counters,
                                                const float* __restrict__ joined,
-                                               const float* __restrict__ cost_T) {
+                                               const float* __restrict__ cost_T,
+                                               const float* __restrict__ blksum) {
     const int H = P.H, D = P.D;
     const int DP = D + 1;
     float* s_tile = (float*)smem;             /* [64][D+1] */
@@ -466,6 +608,10 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
 #endif
     const float* my_tile = s_tile + lane * DP;
     const bool live = vT < H;
+    /* lemma L7: per-lane thresholds (order-preserving keys, +inf) and the two survive masks */
+    unsigned* s_thr = (unsigned*)(s_scr + 8 * nwl); /* [2][64] + [4] */
+    if (tid < 2 * 64) s_thr[tid] = 0xFF800000u;
+    if (tid < 4) s_thr[2 * 64 + tid] = 0u;
     __syncthreads();
     ISP1_MARK(0);
 
@@ -496,13 +642,37 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
          * tile values of vB, no LUT access, no update) and leave, per type and block k, the
          * smallest bound of the blocks BELOW k in LDS (s_lb); the walk closes a type for good when
          * the bound of its own block and that entry both exceed the lane's best cost. */
-        float* s_lb = s_scr + 8 * nwl; /* [3 types][tile + 1][64 lanes] */
+        float* s_lb = s_scr + 8 * nwl + IS_P1_L7_WORDS; /* [3 types][tile + 1][64 lanes] */
         const int NLB = tile + 1;
+        const unsigned long long dead = ~__builtin_amdgcn_ballot_w64(live);
+        const unsigned long long gdead = dead | __builtin_amdgcn_ballot_w64(my.G == IS_INF);
+        /* Separable block bounds of the ground / sky candidates (lemma L7, see l7_row_bounds): bit k
+         * of mask_g / mask_s = block k may hold the winning ground / sky candidate of some lane of
+         * this tile; the walk below never enters the other blocks.  Off (all ones) when the column's
+         * pruning is off or the column has more blocks than the masks have bits. */
+        unsigned mask_g = ~0u, mask_s = ~0u;
+        L7B bl7;
+        bool l7 = false;
         {
             cprune_t pq0 = (cprune_t)prec;
             const float pE1o = pq0->E1o, pE2 = 3.0f * pq0->E2;
             const float pE1gs = __builtin_fmaxf(pq0->E1g, pq0->E1s);
             const bool pnog = IS_SKIP_GROUND_ABOVE_HORIZON && tile_lo >= vhor;
+            l7 = IS_P1_L7 && (pE1gs < IS_INF) && tile < 31;
+            const float* bcol = blksum + (size_t)colg * (P.ntiles + 1) * IS_L7_F;
+            if (l7) {
+                bl7 = l7_lane_bounds(P, my);
+                float thr_g = IS_INF, thr_s = IS_INF;
+                for (int k = wl; k <= tile; k += nwl) {
+                    const L7Row m = l7_block_summary(P, bcol, k);
+                    float lbg, ubg, lbs, ubs;
+                    l7_combine(m, bl7, &lbg, &ubg, &lbs, &ubs);
+                    thr_g = __builtin_fminf(thr_g, ubg);
+                    thr_s = __builtin_fminf(thr_s, ubs);
+                }
+                if (!pnog && thr_g == thr_g) atomicMin(&s_thr[lane], l7_key(thr_g));
+                if (thr_s == thr_s) atomicMin(&s_thr[64 + lane], l7_key(thr_s));
+            }
             for (int k = wl; k < tile; k += nwl) { /* top of block k: vB = 64 k */
                 const int vBk = k * IS_TILE;
                 const RowRec rb = sload_rec(rcol + vBk);
@@ -543,15 +713,34 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
                 }
                 q[tile * 64] = run;
             }
+            if (l7) { /* a block survives when its lower bound reaches the threshold in some lane */
+                const float thr_g = l7_unkey(s_thr[lane]), thr_s = l7_unkey(s_thr[64 + lane]);
+                unsigned mg = 0u, ms = 0u;
+                for (int k = wl; k <= tile; k += nwl) {
+                    const L7Row m = l7_block_summary(P, bcol, k);
+                    float lbg, ubg, lbs, ubs;
+                    l7_combine(m, bl7, &lbg, &ubg, &lbs, &ubs);
+                    const bool has_g = !pnog && (m.lo_g0 < IS_INF || m.lo_g1 < IS_INF);
+                    const bool has_s = m.lo_s < IS_INF;
+                    if (has_g && (__builtin_amdgcn_ballot_w64(lbg > thr_g) | gdead) != ~0ull) mg |= 1u << k;
+                    if (has_s && (__builtin_amdgcn_ballot_w64(lbs > thr_s) | dead) != ~0ull) ms |= 1u << k;
+                }
+                if (lane == 0) {
+                    atomicOr(&s_thr[2 * 64 + 0], mg);
+                    atomicOr(&s_thr[2 * 64 + 1], ms);
+                }
+            }
             __syncthreads();
+            if (l7) {
+                mask_g = __builtin_amdgcn_readfirstlane(s_thr[2 * 64 + 0]);
+                mask_s = __builtin_amdgcn_readfirstlane(s_thr[2 * 64 + 1]);
+            }
             ISP1_MARK(6); /* (debug build: the pre-pass) */
         }
         if (w <= vB_last) {
             cprune_t pq = (cprune_t)prec;
             const float E1o = pq->E1o, E2 = 3.0f * pq->E2; /* see seg_o_lower_bound */
             const float E1gs = __builtin_fmaxf(pq->E1g, pq->E1s);
-            const unsigned long long dead = ~__builtin_amdgcn_ballot_w64(live);
-            const unsigned long long gdead = dead | __builtin_amdgcn_ballot_w64(my.G == IS_INF);
             const bool nog = IS_SKIP_GROUND_ABOVE_HORIZON && tile_lo >= vhor;
             int vB = vB_last - (vB_last - w) % nw; /* the wave's largest vB */
             LutRow<NR> next_row;
@@ -695,11 +884,30 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
                     x_closed = true;                                                               \
                 vB -= n_here * nw;                                                                 \
             }
+            /* lemma L7: no block at or below block k holds a possible winner */
+#define IS_L7_NONE_LE(mask, k) (((mask) & ((2u << min((k), 30)) - 1u)) == 0u)
+            /* in front of a ground / sky round: close the type when no surviving block is left at or
+             * below the block of vB; jump over the blocks that cannot hold the winner to this wave's
+             * largest vB in the next surviving block (block 0 = the first segment, vB = 0) */
+#define IS_P1_L7_SKIP(mask, x_closed)                                                              \
+            {                                                                                      \
+                const int kb = min((vB + 63) >> 6, 30);                                            \
+                const unsigned at_or_below = (mask) & ((2u << kb) - 1u);                           \
+                if (at_or_below == 0u) { x_closed = true; break; }                                 \
+                if (!(((mask) >> kb) & 1u)) {                                                      \
+                    const int top = (31 - __builtin_clz(at_or_below)) << 6;                        \
+                    int dd = (top - w) % nw;                                                       \
+                    dd = dd < 0 ? dd + nw : dd;                                                    \
+                    vB = top - dd;                                                                 \
+                    continue;                                                                      \
+                }                                                                                  \
+            }
             const int sky_lo = max(vhor + 1, 1);
             for (; vB >= sky_lo; vB -= nw) { /* sky range: vB - 1 >= vhor */
                 IS_P1_STEP(true, false);
                 const float lb_s = min_raw((st.q_gs - E1gs) + P.sw * t.seg_s, lbp[2 * NLB * 64]);
-                const bool ok_s = (__builtin_amdgcn_ballot_w64(lb_s > b.s) | dead) == ~0ull;
+                const bool ok_s = (__builtin_amdgcn_ballot_w64(lb_s > b.s) | dead) == ~0ull ||
+                                  IS_L7_NONE_LE(mask_s, (vB + 63) >> 6);
                 IS_P1_REQUEST_NEXT(ok_s);
                 if (ok_o && ok_s) { done = true; break; }
                 if (ok_o) { o_closed = true; vB -= nw; break; }
@@ -709,7 +917,10 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
                 /* a tile with a sky range lies above the horizon: no ground candidates, and the
                  * first segment's object candidate is closed too -- only sky candidates are left */
                 bool s_closed = false;
-                while (vB >= sky_lo && !s_closed) IS_P1_GS4(true, sky_lo, dead, s_closed)
+                while (vB >= sky_lo && !s_closed) {
+                    IS_P1_L7_SKIP(mask_s, s_closed)
+                    IS_P1_GS4(true, sky_lo, dead, s_closed)
+                }
                 done = true;
             }
             if (!done && nog) {
@@ -723,7 +934,8 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
                 for (; vB >= 1; vB -= nw) { /* ground range: vB - 1 < vhor */
                     IS_P1_STEP(false, false);
                     const float lb_g = min_raw((st.q_gs - E1gs) + P.sw * t.seg_g, lbp[NLB * 64]);
-                    const bool ok_g = (__builtin_amdgcn_ballot_w64(lb_g > b.g) | gdead) == ~0ull;
+                    const bool ok_g = (__builtin_amdgcn_ballot_w64(lb_g > b.g) | gdead) == ~0ull ||
+                                      IS_L7_NONE_LE(mask_g, (vB + 63) >> 6);
                     IS_P1_REQUEST_NEXT(ok_g);
                     if (ok_o && ok_g) { done = true; break; }
                     if (ok_o) { o_closed = true; vB -= nw; break; }
@@ -731,13 +943,18 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
                 IS_P1_DRAIN();
                 if (!done && o_closed) {
                     bool g_closed = false;
-                    while (vB >= 1 && !g_closed) IS_P1_GS4(false, 1, gdead, g_closed)
+                    while (vB >= 1 && !g_closed) {
+                        IS_P1_L7_SKIP(mask_g, g_closed)
+                        IS_P1_GS4(false, 1, gdead, g_closed)
+                    }
                     if (g_closed) done = true; /* else vB <= 0: the first segment is still to come */
                 }
             }
 #undef IS_P1_STEP
 #undef IS_P1_NEXT_ROW
 #undef IS_P1_GS4
+#undef IS_P1_L7_SKIP
+#undef IS_L7_NONE_LE
 #undef IS_P1_DRAIN
 #undef IS_P1_REQUEST_NEXT
             if (!done && vB == 0) { /* first segment, :481-594 */
@@ -861,7 +1078,7 @@ __global__ __launch_bounds__(IS_UNARY_WAVES * 64, HAS_INVALID ? ISP1_OCC_INV : I
     const int* __restrict__ vhor_arr, const int* __restrict__ col_flags,
     const PruneRec* __restrict__ prune, float* __restrict__ part_cost, int* __restrict__ part_idx,
     unsigned long long* __restrict__ counters, const float* __restrict__ joined,
-    const float* __restrict__ cost_T) {
+    const float* __restrict__ cost_T, const float* __restrict__ blksum) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int colg = col_base + (int)(blockIdx.x / (unsigned)nsplit);
     const int split = __builtin_amdgcn_readfirstlane((int)(blockIdx.x % (unsigned)nsplit));
@@ -869,10 +1086,12 @@ __global__ __launch_bounds__(IS_UNARY_WAVES * 64, HAS_INVALID ? ISP1_OCC_INV : I
     const int vhor = __builtin_amdgcn_readfirstlane(vhor_arr[colg / P.C]);
     if (__builtin_amdgcn_readfirstlane(col_flags[colg]) == 0)
         pw_phase1_body<true, HAS_INVALID, NR>(P, smem, colg, tile, recs, lutT, steps, rcp, vhor, split,
-                                              nsplit, prune + colg, part_cost, part_idx, counters, joined, cost_T);
+                                              nsplit, prune + colg, part_cost, part_idx, counters, joined, cost_T,
+                                              blksum);
     else
         pw_phase1_body<false, HAS_INVALID, NR>(P, smem, colg, tile, recs, lutT, steps, rcp, vhor, split,
-                                               nsplit, prune + colg, part_cost, part_idx, counters, joined, cost_T);
+                                               nsplit, prune + colg, part_cost, part_idx, counters, joined, cost_T,
+                                               blksum);
 }
 
 /* ---- phase 2: the fn window --------------------------------------------------------------
@@ -938,7 +1157,8 @@ __device__ __forceinline__ void pw_phase2_body(const DevParams& P, char* smem, i
                                                const int* __restrict__ part_idx,
                                                StepRec* __restrict__ steps,
                                                float* __restrict__ cost_table,
-                                               int32_t* __restrict__ index_table) {
+                                               int32_t* __restrict__ index_table,
+                                               float* __restrict__ blksum) {
     const int H = P.H, D = P.D;
     const int lane = threadIdx.x;
     double* s_invc = (double*)smem;                    /* [32] */
@@ -1028,6 +1248,7 @@ __device__ __forceinline__ void pw_phase2_body(const DevParams& P, char* smem, i
     st.q_o = q_o; st.q_gs = q_gs;
     int ob_cached = -1;
     float S_obc = 0.0f, V_obc = 0.0f;
+    float pw_keep = IS_INF; /* lane s: pwmp of the StepRec of vB = tile_lo + s + 1 (block summary, lemma L7) */
 #ifdef IS_ABL_P2PHASES
     unsigned long long acc_p2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
@@ -1097,6 +1318,7 @@ __device__ __forceinline__ void pw_phase2_body(const DevParams& P, char* smem, i
             q_o = min_raw(q_o, P.pw * m8);
             q_gs = min_raw(q_gs, st.pwmp);
             st.q_o = q_o; st.q_gs = q_gs;
+            pw_keep = (lane == s) ? st.pwmp : pw_keep;
             if (lane == 0 && r + 1 < H) store_step(scol + r + 1, st);
             ISP2_MARK(7); /* running minima + store */
         }
@@ -1109,6 +1331,17 @@ __device__ __forceinline__ void pw_phase2_body(const DevParams& P, char* smem, i
         const size_t o = ((size_t)colg * H + vT) * 3;
         cost_table[o + 0] = b.g; cost_table[o + 1] = b.o; cost_table[o + 2] = b.s;
         index_table[o + 0] = b.ig; index_table[o + 1] = b.io; index_table[o + 2] = b.is;
+    }
+    { /* block summary of the candidate rows vB = tile_lo + 1 .. tile_lo + 64 (block tile + 1, lemma L7):
+       * lane s holds the record of vB = vT + 1 (`my`) and its pwmp */
+        L7Row sum;
+        if (FAST) {
+            sum = l7_row_bounds(P, pw_keep, my.G, my.K, my.Fg0, my.Fg1, my.Fsky, my.Fnic, vT < vhor, vT + 1 < H);
+            sum = l7_group_min_row<6>(sum);
+        } else {
+            sum = l7_never();
+        }
+        if (lane == 0) l7_store(blksum + ((size_t)colg * (P.ntiles + 1) + tile + 1) * IS_L7_F, sum);
     }
 }
 
@@ -1124,17 +1357,17 @@ __global__ __launch_bounds__(64, ISP2_OCC) void k_pw_phase2(
     const float* __restrict__ sv_arr, const int* __restrict__ vhor_arr,
     const int* __restrict__ col_flags, const float* __restrict__ part_cost,
     const int* __restrict__ part_idx, StepRec* __restrict__ steps, float* __restrict__ cost_table,
-    int32_t* __restrict__ index_table) {
+    int32_t* __restrict__ index_table, float* __restrict__ blksum) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int colg = col_base + blockIdx.x;
     if (colg >= ncols) return;
     const int vhor = __builtin_amdgcn_readfirstlane(vhor_arr[colg / P.C]);
     if (__builtin_amdgcn_readfirstlane(col_flags[colg]) == 0)
         pw_phase2_body<true, HAS_INVALID>(P, smem, colg, tile, recs, lutT, joined, priors, odr, rcp, sv_arr, vhor,
-                                          nsplit, part_cost, part_idx, steps, cost_table, index_table);
+                                          nsplit, part_cost, part_idx, steps, cost_table, index_table, blksum);
     else
         pw_phase2_body<false, HAS_INVALID>(P, smem, colg, tile, recs, lutT, joined, priors, odr, rcp, sv_arr, vhor,
-                                           nsplit, part_cost, part_idx, steps, cost_table, index_table);
+                                           nsplit, part_cost, part_idx, steps, cost_table, index_table, blksum);
 }
 
 /* ====================================================================================== */
@@ -1194,7 +1427,8 @@ __device__ __forceinline__ void pw_phase2x_body(const DevParams& P, char* smem, 
                                                 const int* __restrict__ part_idx,
                                                 StepRec* __restrict__ steps,
                                                 float* __restrict__ cost_table,
-                                                int32_t* __restrict__ index_table) {
+                                                int32_t* __restrict__ index_table,
+                                                float* __restrict__ blksum) {
     const int H = P.H, D = P.D;
     const int lane = threadIdx.x, li = lane & 31, l15 = lane & 15, hbase = lane & 32;
     const int half = lane >> 5;
@@ -1270,6 +1504,8 @@ __device__ __forceinline__ void pw_phase2x_body(const DevParams& P, char* smem, 
     st.q_o = q_o; st.q_gs = q_gs;
     int ob_cached = -1;
     float S_obc = 0.0f, V_obc = 0.0f;
+    float pw_keep = IS_INF; /* pwmp of the StepRec of vB = (this lane's vT) + 1: block summary, lemma L7 */
+    float* const my_blk = blksum + ((size_t)colg * (P.ntiles + 1) + tile + 1) * IS_L7_F;
 
     /* partial minima of phase 1 for the rows base + li (its nsplit workgroups merged) */
     auto load_best = [&](int row_off, PairBest& b) {
@@ -1341,6 +1577,7 @@ __device__ __forceinline__ void pw_phase2x_body(const DevParams& P, char* smem, 
         q_o = min_raw(q_o, P.pw * m8);
         q_gs = min_raw(q_gs, st.pwmp);
         st.q_o = q_o; st.q_gs = q_gs;
+        pw_keep = (li == src) ? st.pwmp : pw_keep;
         if (li == 0 && r + 1 < H) store_step(scol + r + 1, st);
     };
     auto rec_dpp = [&](int v, float& R0, float& R1) { /* the record of v of this lane's column, DPP layout */
@@ -1349,6 +1586,7 @@ __device__ __forceinline__ void pw_phase2x_body(const DevParams& P, char* smem, 
         R1 = q[16 + l15];
     };
 
+    L7Row sumL; /* block summary of the rows of phase L (uniform per half) */
     /* ================= phase L: rows tile_lo .. tile_lo + 31 ================= */
     {
         const int vT = tile_lo + li, vTc = min(vT, H - 1);
@@ -1369,6 +1607,9 @@ __device__ __forceinline__ void pw_phase2x_body(const DevParams& P, char* smem, 
             finalize(r, s, b, my.S, my.V);
         }
         store_rows(vT, b);
+        sumL = l7_group_min_row<5>(l7_row_bounds(P, pw_keep, my.G, my.K, my.Fg0, my.Fg1, my.Fsky, my.Fnic,
+                                                 vT < vhor, vT + 1 < H));
+        pw_keep = IS_INF;
         if (li == 0) { /* StepRec(tile_lo + 32) for phase U */
             float* d = s_st + half * 16;
             d[0] = st.pwmp; d[1] = __builtin_bit_cast(float, st.idx_gs); d[2] = st.g_hi_thr; d[3] = st.g_lo_thr;
@@ -1377,7 +1618,10 @@ __device__ __forceinline__ void pw_phase2x_body(const DevParams& P, char* smem, 
             d[14] = st.q_o; d[15] = st.q_gs;
         }
     }
-    if (n_rows <= 32) return;
+    if (n_rows <= 32) {
+        if (li == 0) l7_store(my_blk, sumL);
+        return;
+    }
     /* this wave's StepRec stores of phase L must have reached the L2 before phase S reads them */
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
@@ -1423,6 +1667,16 @@ __device__ __forceinline__ void pw_phase2x_body(const DevParams& P, char* smem, 
             finalize(r, s - 32, b, my.S, my.V);
         }
         store_rows(vT, b);
+        const L7Row sumU = l7_group_min_row<5>(l7_row_bounds(P, pw_keep, my.G, my.K, my.Fg0, my.Fg1, my.Fsky,
+                                                             my.Fnic, vT < vhor, vT + 1 < H));
+        if (li == 0) {
+            L7Row sum;
+            sum.lo_g0 = __builtin_fminf(sumL.lo_g0, sumU.lo_g0); sum.lo_g1 = __builtin_fminf(sumL.lo_g1, sumU.lo_g1);
+            sum.lo_s = __builtin_fminf(sumL.lo_s, sumU.lo_s);
+            sum.hi_g0 = __builtin_fminf(sumL.hi_g0, sumU.hi_g0); sum.hi_g1 = __builtin_fminf(sumL.hi_g1, sumU.hi_g1);
+            sum.hi_s = __builtin_fminf(sumL.hi_s, sumU.hi_s);
+            l7_store(my_blk, sum);
+        }
     }
 }
 
@@ -1435,7 +1689,7 @@ __global__ __launch_bounds__(64, ISP2X_OCC) void k_pw_phase2x(
     const float* __restrict__ sv_arr, const int* __restrict__ vhor_arr,
     const int* __restrict__ col_flags, const float* __restrict__ part_cost,
     const int* __restrict__ part_idx, StepRec* __restrict__ steps, float* __restrict__ cost_table,
-    int32_t* __restrict__ index_table) {
+    int32_t* __restrict__ index_table, float* __restrict__ blksum) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int col0 = col_base + 2 * (int)blockIdx.x; /* col_base even, P.C even: one image per pair */
     if (col0 >= ncols) return;
@@ -1444,7 +1698,7 @@ __global__ __launch_bounds__(64, ISP2X_OCC) void k_pw_phase2x(
     const int f1 = col0 + 1 < ncols ? __builtin_amdgcn_readfirstlane(col_flags[col0 + 1]) : 1;
     if (f0 == 0 && f1 == 0)
         pw_phase2x_body<HAS_INVALID>(P, smem, col0, tile, recs, lutT, joined, priors, odr, rcp, sv_arr, vhor, nsplit,
-                                     part_cost, part_idx, steps, cost_table, index_table);
+                                     part_cost, part_idx, steps, cost_table, index_table, blksum);
     /* (a pair with a generic column: k_pw_phase2_generic walks it, column by column) */
 }
 
@@ -1459,7 +1713,7 @@ __global__ __launch_bounds__(64, 2) void k_pw_phase2_generic(
     const float* __restrict__ sv_arr, const int* __restrict__ vhor_arr,
     const int* __restrict__ col_flags, const float* __restrict__ part_cost,
     const int* __restrict__ part_idx, StepRec* __restrict__ steps, float* __restrict__ cost_table,
-    int32_t* __restrict__ index_table, const int* __restrict__ n_generic) {
+    int32_t* __restrict__ index_table, const int* __restrict__ n_generic, float* __restrict__ blksum) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (__builtin_amdgcn_readfirstlane(*n_generic) == 0) return;
     for (int colg = col_base + (int)blockIdx.x; colg < ncols; colg += (int)gridDim.x) {
@@ -1469,10 +1723,10 @@ __global__ __launch_bounds__(64, 2) void k_pw_phase2_generic(
         const int vhor = __builtin_amdgcn_readfirstlane(vhor_arr[colg / P.C]);
         if (__builtin_amdgcn_readfirstlane(col_flags[colg]) == 0)
             pw_phase2_body<true, HAS_INVALID>(P, smem, colg, tile, recs, lutT, joined, priors, odr, rcp, sv_arr, vhor,
-                                              nsplit, part_cost, part_idx, steps, cost_table, index_table);
+                                              nsplit, part_cost, part_idx, steps, cost_table, index_table, blksum);
         else
             pw_phase2_body<false, HAS_INVALID>(P, smem, colg, tile, recs, lutT, joined, priors, odr, rcp, sv_arr, vhor,
-                                               nsplit, part_cost, part_idx, steps, cost_table, index_table);
+                                               nsplit, part_cost, part_idx, steps, cost_table, index_table, blksum);
         __syncthreads();
     }
 }
@@ -1554,7 +1808,8 @@ __device__ __forceinline__ void pw_phase2s_body(const DevParams& P, char* smem, 
                                                 const int* __restrict__ part_idx,
                                                 StepRec* __restrict__ steps,
                                                 float* __restrict__ cost_table,
-                                                int32_t* __restrict__ index_table) {
+                                                int32_t* __restrict__ index_table,
+                                                float* __restrict__ blksum) {
     const int H = P.H, D = P.D;
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1648,6 +1903,7 @@ __device__ __forceinline__ void pw_phase2s_body(const DevParams& P, char* smem, 
         st.q_o = q_o; st.q_gs = q_gs;
         int ob_cached = -1;
         float S_obc = 0.0f, V_obc = 0.0f;
+        float pw_keep = IS_INF; /* (block summary, see pw_phase2_body) */
         for (int s = 0; s < n_rows; s++) {
             const int r = tile_lo + s;
             PriorVals pv;
@@ -1696,6 +1952,7 @@ __device__ __forceinline__ void pw_phase2s_body(const DevParams& P, char* smem, 
                 q_o = min_raw(q_o, P.pw * m8);
                 q_gs = min_raw(q_gs, st.pwmp);
                 st.q_o = q_o; st.q_gs = q_gs;
+                pw_keep = (lane == s) ? st.pwmp : pw_keep;
                 if (lane == 0 && r + 1 < H) store_step(scol + r + 1, st);
             }
         }
@@ -1703,6 +1960,18 @@ __device__ __forceinline__ void pw_phase2s_body(const DevParams& P, char* smem, 
             const size_t o = ((size_t)colg * H + vT) * 3;
             cost_table[o + 0] = b.g; cost_table[o + 1] = b.o; cost_table[o + 2] = b.s;
             index_table[o + 0] = b.ig; index_table[o + 1] = b.io; index_table[o + 2] = b.is;
+        }
+        { /* block summary (lemma L7, see pw_phase2_body); the chain wave fetches the record fields here */
+            L7Row sum;
+            if (FAST) {
+                const RowRec* mr = rcol + vTc + 1;
+                sum = l7_row_bounds(P, pw_keep, mr->G, mr->K, mr->Fg0, mr->Fg1, mr->Fsky, mr->Fnic, vT < vhor,
+                                    vT + 1 < H);
+                sum = l7_group_min_row<6>(sum);
+            } else {
+                sum = l7_never();
+            }
+            if (lane == 0) l7_store(blksum + ((size_t)colg * (P.ntiles + 1) + tile + 1) * IS_L7_F, sum);
         }
     } else {
         /* ================================ evaluator waves ================================ */
@@ -1753,17 +2022,17 @@ __global__ __launch_bounds__(ISP2S_WAVES * 64, 5) void k_pw_phase2s(
     const float* __restrict__ sv_arr, const int* __restrict__ vhor_arr,
     const int* __restrict__ col_flags, const float* __restrict__ part_cost,
     const int* __restrict__ part_idx, StepRec* __restrict__ steps, float* __restrict__ cost_table,
-    int32_t* __restrict__ index_table) {
+    int32_t* __restrict__ index_table, float* __restrict__ blksum) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int colg = col_base + blockIdx.x;
     if (colg >= ncols) return;
     const int vhor = __builtin_amdgcn_readfirstlane(vhor_arr[colg / P.C]);
     if (__builtin_amdgcn_readfirstlane(col_flags[colg]) == 0)
         pw_phase2s_body<true, HAS_INVALID>(P, smem, colg, tile, recs, lutT, joined, priors, odr, rcp, sv_arr,
-                                           vhor, nsplit, part_cost, part_idx, steps, cost_table, index_table);
+                                           vhor, nsplit, part_cost, part_idx, steps, cost_table, index_table, blksum);
     else
         pw_phase2s_body<false, HAS_INVALID>(P, smem, colg, tile, recs, lutT, joined, priors, odr, rcp, sv_arr,
-                                            vhor, nsplit, part_cost, part_idx, steps, cost_table, index_table);
+                                            vhor, nsplit, part_cost, part_idx, steps, cost_table, index_table, blksum);
 }
 
 extern "C" {
@@ -1774,7 +2043,7 @@ size_t isk_pairwise_lds_bytes(const DevParams* P, int nwaves) {
     const size_t merge = (size_t)nwaves * 3 * 64 * 8; /* aliases the tile after the loop */
     /* + the block bounds of the pre-pass: [3][ntiles + 1][64] (a launch of tile t uses t + 1 entries) */
     return (tile > merge ? tile : merge) + rcp + sizeof(float) * 8 * (size_t)nwaves +
-           sizeof(float) * 3 * 64 * ((size_t)P->ntiles + 1) + 16;
+           sizeof(float) * IS_P1_L7_WORDS + sizeof(float) * 3 * 64 * ((size_t)P->ntiles + 1) + 16;
 }
 size_t isk_phase2_lds_bytes(const DevParams* P) {
     size_t need = sizeof(double) * 2 * IS_LOG_TABLE_SIZE +
@@ -1806,7 +2075,7 @@ hipError_t isk_launch_dp_pairwise(const DevParams* P, int ncols, int nwaves, con
                                   const int* col_flags, const PruneRec* prune, StepRec* steps,
                                   float* part_cost, int* part_idx, float* cost_table,
                                   int32_t* index_table, unsigned long long* counters,
-                                  const float* cost_T, const int* n_generic,
+                                  const float* cost_T, const int* n_generic, float* blksum,
                                   hipStream_t stream, hipStream_t* aux, int n_aux,
                                   hipEvent_t ev_fork, hipEvent_t* ev_join) {
     const size_t lds1 = isk_pairwise_lds_bytes(P, nwaves);
@@ -1843,32 +2112,32 @@ hipError_t isk_launch_dp_pairwise(const DevParams* P, int ncols, int nwaves, con
             hipLaunchKernelGGL((k_pw_phase1<INV, 2>), dim3(((c1) - (c0)) * nsplit),                \
                                dim3(nwaves * 64), lds1_t, st, *P, c0, c1, tile, nsplit, recs, lutT,  \
                                steps, rcp, vhor, col_flags, prune, part_cost, part_idx, counters, \
-                               joined, cost_T);                                                    \
+                               joined, cost_T, blksum);                                            \
         else                                                                                       \
             hipLaunchKernelGGL((k_pw_phase1<INV, 0>), dim3(((c1) - (c0)) * nsplit),                \
                                dim3(nwaves * 64), lds1_t, st, *P, c0, c1, tile, nsplit, recs, lutT,  \
                                steps, rcp, vhor, col_flags, prune, part_cost, part_idx, counters,  \
-                               joined, cost_T);                                                    \
+                               joined, cost_T, blksum);                                            \
     } while (0)
 #define IS_LAUNCH_P2(INV, c0, c1, st)                                                              \
     hipLaunchKernelGGL(k_pw_phase2<INV>, dim3((c1) - (c0)), dim3(64), lds2, st, *P, c0, c1, tile,  \
                        nsplit, recs, lutT, joined, priors, odr, rcp, sv_arr, vhor, col_flags,      \
                        part_cost,                                                                  \
-                       part_idx, steps, cost_table, index_table)
+                       part_idx, steps, cost_table, index_table, blksum)
 #define IS_LAUNCH_P2X(INV, c0, c1, st)                                                             \
     do {                                                                                           \
         hipLaunchKernelGGL(k_pw_phase2x<INV>, dim3(((c1) - (c0) + 1) / 2), dim3(64), lds2x, st, *P, c0, \
                            c1, tile, nsplit, recs, lutT, joined, priors, odr, rcp, sv_arr, vhor,   \
-                           col_flags, part_cost, part_idx, steps, cost_table, index_table);        \
+                           col_flags, part_cost, part_idx, steps, cost_table, index_table, blksum); \
         hipLaunchKernelGGL(k_pw_phase2_generic<INV>, dim3(min((c1) - (c0), 512)), dim3(64), lds2, st, \
                            *P, c0, c1, tile, nsplit, recs, lutT, joined, priors, odr, rcp, sv_arr, \
                            vhor, col_flags, part_cost, part_idx, steps, cost_table, index_table,   \
-                           n_generic);                                                             \
+                           n_generic, blksum);                                                     \
     } while (0)
 #define IS_LAUNCH_P2S(INV, c0, c1, st)                                                             \
     hipLaunchKernelGGL(k_pw_phase2s<INV>, dim3((c1) - (c0)), dim3(ISP2S_WAVES * 64), lds2s, st, *P, \
                        c0, c1, tile, nsplit, recs, lutT, joined, priors, odr, rcp, sv_arr, vhor,   \
-                       col_flags, part_cost, part_idx, steps, cost_table, index_table)
+                       col_flags, part_cost, part_idx, steps, cost_table, index_table, blksum)
     const bool inv = P->invalid >= 0;
     /* phase 2 split over four waves per column (k_pw_phase2s) while the columns are too few to fill
      * the chip with one wave each: it shortens the serial chain of a column (one frame: 82 -> 74 us
