@@ -525,7 +525,7 @@ def main():
     pipe = None
     if use_dist and not args.no_gather:
         if args.gather == "compact":
-            pipe = PipelinedCompactGather(wl.d_sections, core, depth=2, dst=0)
+            pipe = PipelinedCompactGather(wl.d_sections, core, depth=4, dst=0)
         else:
             pipe = PipelinedGather(wl.d_sections, depth=2, dst=0)
 
@@ -547,13 +547,17 @@ def main():
         step()
     barrier()
 
-    def timed_block():
+    local_blocks = []   # this rank's own clock of every block (before the max over ranks)
+
+    def timed_block(fn=None):
         """EXACTLY args.steps steps between barrier + synchronize on both sides; max over ranks."""
+        fn = fn or step
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            step()
+            fn()
         barrier()
         d = time.perf_counter() - t0
+        local_blocks.append(d)
         if use_dist:
             t = torch.tensor([d], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -570,6 +574,25 @@ def main():
     # per-kernel durations of the LAST timed step, measured with HIP events on the launch stream
     kt = core.kernel_times_ms()
     timed_out = wl.d_sections if pipe is None else pipe.last_local()
+    gather_stats = pipe.stats() if pipe is not None else None
+
+    # N > 1 (or --force-dist): what every rank measured by itself, and the same K steps WITHOUT the
+    # gather (outputs stay on the rank) -- the difference is what the gather costs the step
+    # ("exposed": not hidden behind the compute); both outside `value`
+    per_rank = None
+    if use_dist:
+        mine = {"rank": rank, "ms_per_step_own_clock": float(np.median(local_blocks)) / args.steps * 1e3,
+                "dp_ms": kt["dp_ms"], "prepare_ms": kt["prepare_ms"]}
+        if pipe is not None:
+            n_before = len(local_blocks)
+            d_plain = timed_block(lambda: wl.step(core))
+            mine["ms_per_step_without_gather_own_clock"] = local_blocks[n_before] / args.steps * 1e3
+            gather_stats["ms_per_step_without_gather"] = d_plain / args.steps * 1e3
+            gather_stats["exposed_ms_per_step"] = (dt - d_plain) / args.steps * 1e3
+            local_blocks.pop()
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        per_rank = gathered
 
     # ---- verify (default): frames of the TIMED output (the batch geometry the value is measured on)
     verify = None
@@ -691,7 +714,9 @@ def main():
         out["timed_blocks"] = {"count": len(blocks), "steps_per_block": args.steps,
                                "seconds": [round(x, 5) for x in blocks], "reported": "median"}
         if pipe is not None:
-            out["gather"] = pipe.stats()
+            out["gather"] = gather_stats
+        if per_rank is not None:
+            out["per_rank"] = per_rank
         if verify is not None:
             out["verify"] = verify
         if variants is not None:

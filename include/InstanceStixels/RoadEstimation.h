@@ -35,6 +35,17 @@ public:
     int GetHorizonPoint() { return m_horizonPoint; }
     bool IsInitialized() { return m_is_initialized; }
 
+    /* ---- additions (not in the reference) ----
+     * Device the next Initialize() allocates on; default (-1): the calling thread's current HIP
+     * device at Initialize() time.  Every later call (Compute, Finish) runs on that device
+     * whatever the caller's current device is, on a stream of the object's own (an ordinary stream
+     * that synchronises with the legacy NULL stream, like Stixels): together with
+     * Stixels::SetDevice(d) the wrapper sequence GetInputDisparityImageOnDevice() ->
+     * RoadEstimation::Compute(ptr) (apps/stixels_wrapper.cu:187) stays on device d. */
+    void SetDevice(int device) { m_device = device; }
+    int GetDevice() const { return m_device; }
+    int GetActiveDevice() const { return m_ctx_device; }
+
     /* additions for tests */
     const std::vector<uint8_t>& GetBinaryVDisparity() const { return m_vDisp; }
     /* Standard Hough transform of a rows x cols 8-bit image; returns (rho, theta) pairs sorted
@@ -50,6 +61,9 @@ private:
                       float& cameraHeight, float& slope);
 
     bool m_is_initialized = false;
+    int m_device = -1;      /* requested (SetDevice) */
+    int m_ctx_device = -1;  /* where the buffers of the last Initialize() live */
+    void* m_stream = nullptr;
     pixel_t* d_disparity = nullptr;
     int* d_vDisp = nullptr;
     int* d_maximum = nullptr;

@@ -162,7 +162,10 @@ int is_join_columns(is_ctx* ctx, const float* d_disparity_big, int full_cols, in
  * Device: the call runs on the context's device whatever the caller's current device is (the
  * current device is restored on return); `stream` must belong to that device.
  * Asynchronous with respect to the host: work is queued on `stream`; the host arrays are copied
- * into a ring of pinned staging slots before the call returns. */
+ * into a ring of pinned staging slots before the call returns.
+ * Internal invariant: the context's generic-column counter is zero between calls (counted by the
+ * prepare kernel, cleared by the back-trace at the end of the call); a call that returns an error
+ * clears it itself. */
 int is_compute(is_ctx* ctx, const float* d_joined, const int32_t* d_segmentation,
                const float* h_ground_function, const float* h_normalization_ground,
                const float* h_inv_sigma2_ground, const int* h_vhor, int pairwise,
@@ -233,6 +236,12 @@ int is_stream_create(void** stream, int blocking);
 int is_stream_destroy(void* stream);
 int is_device_synchronize(void);
 
+/* Test hook (A4, ComputeObjectLUT): copies the object data-cost prefix table of ONE stixel column
+ * (0 <= column < n_images * realcols) as the last is_compute call on this context left it into
+ * host memory, h_out[(rows + 1) * max_dis] = lutT[v][fn] -- the transpose of the reference's
+ * d_object_lut[fn][v] (Stixels.cu:159-160, StixelsKernels.cu:959-978).  Synchronises the device. */
+int is_debug_read_object_lut(is_ctx* ctx, int column, float* h_out);
+
 /* Introspection used by bench.py / tests. */
 const char* is_last_error(void);
 const char* is_version(void);
@@ -245,8 +254,11 @@ size_t is_scratch_bytes(const is_ctx* ctx);
  * OUTSIDE a timed region: while enabled, the DP kernels of FAST columns add the number of 64-pair
  * wave-steps they evaluated below the diagonal blocks to a device array (enabling resets it).
  *   out[0] unary full steps, out[1] unary ground/sky-only steps,
- *   out[2] pairwise phase-1 full steps, out[3] pairwise phase-1 ground/sky-only candidates.
- * Both calls synchronise the device. */
+ *   out[2] pairwise phase-1 full steps, out[3] pairwise phase-1 ground/sky-only candidates,
+ *   out[4] pairwise phase-1 steps that stopped after the transition term (lazy steps);
+ *   out[8 + 3 t + j], t < 64: the phase-1 launch of 64-row tile t alone, j = 0 full, 1 lazy, 2
+ *   ground/sky-only.  n <= IS_EVAL_COUNTERS.  Both calls synchronise the device. */
+#define IS_EVAL_COUNTERS 200
 int is_set_eval_counters(is_ctx* ctx, int enabled);
 int is_get_eval_counters(is_ctx* ctx, unsigned long long* out, int n);
 

@@ -23,6 +23,7 @@ EXPORTS = [
     "is_cluster_instances", "is_host_malloc", "is_host_free", "is_get_device", "is_set_device",
     "is_ctx_device", "is_set_eval_counters", "is_get_eval_counters",
     "is_pack_sections", "is_unpack_sections", "is_stream_create", "is_stream_destroy",
+    "is_debug_read_object_lut",
 ]
 
 
@@ -84,6 +85,7 @@ def lib():
         L.is_unpack_sections.argtypes = [vp, vp, vp, ci, ci, vp, vp]
         L.is_scratch_bytes.argtypes = [vp]
         L.is_scratch_bytes.restype = ctypes.c_size_t
+        L.is_debug_read_object_lut.argtypes = [vp, ci, vp]
         _LIB = L
     return _LIB
 
@@ -136,9 +138,17 @@ class Core:
         _check(lib().is_set_eval_counters(self._ctx, int(enabled)), "is_set_eval_counters")
 
     def eval_counters(self):
-        out = np.zeros(8, np.uint64)
-        _check(lib().is_get_eval_counters(self._ctx, _hp(out), 8), "is_get_eval_counters")
-        return dict(unary_full=int(out[0]), unary_gs=int(out[1]), p1_full=int(out[2]), p1_gs=int(out[3]))
+        out = np.zeros(200, np.uint64)   # IS_EVAL_COUNTERS
+        _check(lib().is_get_eval_counters(self._ctx, _hp(out), 200), "is_get_eval_counters")
+        return dict(unary_full=int(out[0]), unary_gs=int(out[1]), p1_full=int(out[2]), p1_gs=int(out[3]),
+                    p1_lazy=int(out[4]),
+                    p1_per_tile=[[int(out[8 + 3 * t + j]) for j in range(3)] for t in range(64)])
+
+    def read_object_lut(self, column):
+        """lutT[v][fn] of one stixel column as the last compute call left it (test hook, A4)."""
+        out = np.zeros((self.params.rows + 1, self.params.max_dis), np.float32)
+        _check(lib().is_debug_read_object_lut(self._ctx, int(column), _hp(out)), "is_debug_read_object_lut")
+        return out
 
     def kernel_times_ms(self):
         a, b, c = ctypes.c_float(), ctypes.c_float(), ctypes.c_float()

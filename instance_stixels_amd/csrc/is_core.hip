@@ -538,10 +538,20 @@ int is_set_eval_counters(is_ctx* c, int enabled) {
 
 int is_get_eval_counters(is_ctx* c, unsigned long long* out, int n) {
     if (!c || !out) return fail_arg("null pointer");
-    if (n < 1 || n > IS_CNT_N) return fail_arg("n outside [1, 8]");
+    if (n < 1 || n > IS_CNT_N) return fail_arg("n outside [1, IS_EVAL_COUNTERS]");
     ON_CTX_DEVICE(c);
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(out, c->d_counters, sizeof(unsigned long long) * n, hipMemcpyDeviceToHost));
+    return IS_OK;
+}
+
+int is_debug_read_object_lut(is_ctx* c, int column, float* h_out) {
+    if (!c || !h_out) return fail_arg("null pointer");
+    if (column < 0 || column >= c->max_batch * c->dp.C) return fail_arg("column outside the context's scratch");
+    ON_CTX_DEVICE(c);
+    HIP_TRY(hipDeviceSynchronize());
+    const size_t n = ((size_t)c->dp.H + 1) * c->dp.D;
+    HIP_TRY(hipMemcpy(h_out, c->d_lutT + (size_t)column * n, sizeof(float) * n, hipMemcpyDeviceToHost));
     return IS_OK;
 }
 
@@ -647,7 +657,10 @@ static int compute_enqueue(is_ctx* c, const float* d_joined, const int32_t* d_se
  * 1024x2048 frame through Stixels::Compute): 0.455 ms replayed against 0.400 ms launched eagerly
  * (pairwise 1.92 vs 1.91 ms) -- the gaps between dependent dispatches are the GPU's, not the
  * host's, and a replay adds its own launch cost; so the path is off unless IS_GRAPH is set
- * (bit-exact on the whole GPU suite).  Needs a real stream: the legacy NULL stream cannot be captured. */
+ * (bit-exact on the whole GPU suite).  Needs a real stream: the legacy NULL stream cannot be captured.
+ * A cached graph owns ONE pinned staging slot (its copy nodes read it): every replay waits on the host
+ * for the previous replay's staging event before it refills the slot, i.e. replays of one graph
+ * serialise on that copy. */
 static bool graph_matches(const is_graph_entry& e, const float* d_joined, const int32_t* d_seg, int pairwise,
                           int n_images, const is_section* d_sections, const is_instance_buffers* instances,
                           const float* ct, const int32_t* it) {
@@ -702,7 +715,10 @@ int is_compute(is_ctx* c, const float* d_joined, const int32_t* d_seg, const flo
         memcpy(dst + 2 * H, h_is2 + (size_t)i * H, sizeof(float) * H);
         c->h_vhor_pinned[slot][i] = h_vhor[i];
     }
+    /* (no instances: zeros, so that the one-copy path of a full batch never leaves pointers of an
+     * older call -- possibly freed since -- in d_inst_tbl) */
     if (instances) memcpy(c->h_inst_pinned[slot], instances, sizeof(is_instance_buffers) * n_images);
+    else memset(c->h_inst_pinned[slot], 0, sizeof(is_instance_buffers) * n_images);
 
     if (graph_ok && !ge) { /* first call with these arguments: record it */
         is_graph_entry* victim = &c->graph_cache[0];
@@ -749,6 +765,11 @@ int is_compute(is_ctx* c, const float* d_joined, const int32_t* d_seg, const flo
         return IS_OK;
     }
     c->staging_pending[slot] = true;
-    return compute_enqueue(c, d_joined, d_seg, pairwise, n_images, d_sections, instances, d_cost_table,
-                           d_index_table, stream, slot, false);
+    const int rc = compute_enqueue(c, d_joined, d_seg, pairwise, n_images, d_sections, instances, d_cost_table,
+                                   d_index_table, stream, slot, false);
+    /* Invariant the early-outs of k_dp_unary / k_pw_phase2_generic rely on: d_n_generic is zero
+     * between calls (k_prepare counts the generic columns of a call, block 0 of k_backtrace clears
+     * the counter at its end).  A call that failed half way may have counted without clearing. */
+    if (rc != IS_OK) (void)hipMemsetAsync(c->d_n_generic, 0, sizeof(int), stream);
+    return rc;
 }

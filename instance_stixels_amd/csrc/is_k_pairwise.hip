@@ -76,10 +76,16 @@ __device__ __forceinline__ StepVals sload_step_raw(const StepRec* p) {
     r.q_o = q->q_o; r.q_gs = q->q_gs;
     return r;
 }
+/* (opaque_u: readfirstlane in front of the pin -- a no-op for a value that lives in an SGPR; when the
+ * register allocator has carried a field around the loop in a VGPR (it feeds v_cndmask, which takes
+ * one scalar operand only) the plain "+s" pin asks for a VGPR -> SGPR copy, which does not exist) */
+__device__ __forceinline__ float opaque_u(float x) {
+    return opaque_s(__builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x))));
+}
 __device__ __forceinline__ void pin_step(StepVals& r) {
-    r.p1_hi = opaque_s(r.p1_hi); r.p1_lo = opaque_s(r.p1_lo); r.p1_mid = opaque_s(r.p1_mid);
-    r.p2_hi = opaque_s(r.p2_hi); r.p2_lo = opaque_s(r.p2_lo); r.p2_mid = opaque_s(r.p2_mid);
-    r.p3_yes = opaque_s(r.p3_yes); r.p3_no = opaque_s(r.p3_no);
+    r.p1_hi = opaque_u(r.p1_hi); r.p1_lo = opaque_u(r.p1_lo); r.p1_mid = opaque_u(r.p1_mid);
+    r.p2_hi = opaque_u(r.p2_hi); r.p2_lo = opaque_u(r.p2_lo); r.p2_mid = opaque_u(r.p2_mid);
+    r.p3_yes = opaque_u(r.p3_yes); r.p3_no = opaque_u(r.p3_no);
 }
 
 /* sload_rec with every field pinned into its SGPR right here: the compiler otherwise sinks the
@@ -490,6 +496,12 @@ __device__ __forceinline__ void touch_round(const RowRec* rcol, const StepRec* s
 #ifndef IS_P1_SREC
 #define IS_P1_SREC 1 /* class-prefix half of the vB record as scalar operands (see eval_segment_mix) */
 #endif
+#ifndef IS_P1_LAZY
+#define IS_P1_LAZY 0 /* 1: transition term first, the rest of a step only when its object candidate can still win
+                       * (see IS_P1_STEP).  MEASURED (round 4, batch 64, bit-exact): 35 % of the steps stop after the
+                       * transition term, but the DP takes 16.5-16.7 instead of 15.6 ms -- a step is bound by the
+                       * latency of what it prefetches, not by its instructions, and a shorter step hides less */
+#endif
 #ifndef IS_P1_GEN_TILE
 #define IS_P1_GEN_TILE 0 /* see ISF_GEN_TILE (is_k_unary_fast.hip): -8.6 GB of reads, +4 % DP time */
 #endif
@@ -759,7 +771,11 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
              * no LUT access -- a fifth of the instructions of a full step; they are evaluated FOUR
              * vB at a time so that one scalar-load latency covers four steps. */
             bool done = false, o_closed = false;
-            int n_full = 0, n_gs = 0; /* evaluation counters (wave-uniform) */
+            int n_full = 0, n_gs = 0, n_lazy = 0; /* evaluation counters (wave-uniform) */
+            /* lower bound of seg_o(vB', vT) for every vB' below the last fully evaluated step; before
+             * the first one: on >= 0, and X = fl(fl(ic - 3 E2) + f_oi) >= -4 E2 (1 + u) since the computed
+             * ic >= -E2 and f_oi >= 0 (`E2` here is 3 E2 of PruneRec: -2 * that = -6 E2) */
+            float lbseg = -2.0f * E2;
 #if IS_P1_ROW_AHEAD == 2
 #define IS_P1_NEXT_ROW()                                                                           \
             next_row = next2_row;                                                                  \
@@ -794,57 +810,155 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
             if (USE_DPP && IS_P1_SREC) {                                                           \
                 const int vn = max(vB - nw, 0);                                                    \
                 const StepRec* sn = scol + vn;                                                     \
-                asm volatile("" : "+s"(sn) : "s"((int)(last_use)));                                     \
+                asm volatile("" : "+s"(sn) : "s"(__builtin_amdgcn_readfirstlane((int)(last_use))));    \
                 if (IS_P1_SREC_FIRST) srec_request_next(S, rcol + vn);                             \
                 st_next = IS_P1_SREC_LATE ? sload_step_raw(sn) : sload_step(sn);                   \
                 if (!IS_P1_SREC_FIRST) srec_request_next(S, rcol + vn);                            \
             }
+            /* ---- one step = the three candidates that start at vB, TRANSITION FIRST (IS_P1_LAZY).
+             * The object bound of the walk takes the smallest transition term of a block (q_o); the
+             * candidate's own term pw * min(p1, p2, p3) needs only the segment's mean disparity (one
+             * DPP subtraction + the exact division) and the step's StepRec, and it is often far larger:
+             * inside a homogeneous object the object -> object transition is forbidden (the means
+             * agree: p2 = +inf, :159-171) and the ground / sky paths into the object are expensive.
+             * So a step computes mean and transition term first and tests
+             *     fl(fl(pw mp - E1o) + fl(sw lbseg)) > best_o          in every live lane,
+             * lbseg = seg_o_lower_bound of the last fully evaluated step of this wave, a lower bound
+             * of seg_o(vB', vT) for every vB' below it (lemmas L2, L4; the data term >= -E1o, L3; L1
+             * carries the roundings: the cost is fl(fl(fl(dw od) + fl(pw mp)) + fl(sw seg_o))).  When
+             * the test holds the object candidate of vB cannot win or tie in any lane: the sixteen
+             * class differences, the instance term and the two LUT values are not computed; the
+             * ground / sky candidate of vB is evaluated only when its block can hold a winner of its
+             * type (lemma L7).  The type-closing bounds are evaluated on full steps only. */
 #define IS_P1_STEP(SKY, NOG)                                                                       \
             ISP1_COUNT(4);                                                                         \
-            n_full++;                                                                              \
             const LutRow<NR> row = next_row;                                                       \
             if (IS_P1_TOUCH_AHEAD > 0)                                                             \
                 touch_step(rcol, scol, max(vB - IS_P1_TOUCH_AHEAD * nw, 0), lane, scr);            \
             IS_P1_NEXT_ROW();                                                                      \
             const int h = vTc + 1 - vB;                                                            \
-            SegTerms t;                                                                            \
-            StepVals st;                                                                           \
-            float od;                                                                              \
-            if (USE_DPP) {                                                                         \
-                const float r0 = c_r0, r1 = c_r1;                                                  \
-                st = st_next;                                                                      \
-                c_r0 = n_r0; c_r1 = n_r1;                                                          \
-                {                                                                                  \
-                    const float* q2 = (const float*)(rcol + max(vB - 2 * nw, 0));                  \
-                    if (!IS_P1_SREC) n_r0 = q2[l15];                                               \
-                    n_r1 = q2[16 + l15];                                                           \
-                }                                                                                  \
+            const int kb = min((vB + 63) >> 6, 30); /* the block of vB (lemma L7 masks) */         \
+            const float* lbp = s_lb + ((vB + 63) >> 6) * 64 + lane; /* (vB >= 1) */                \
+            bool ok_o = false, ok_x = (NOG);                                                       \
+            if (USE_DPP && IS_P1_SREC && IS_P1_LAZY) {                                             \
+                const float r1 = c_r1;                                                             \
+                StepVals st = st_next;                                                             \
+                c_r1 = n_r1;                                                                       \
+                n_r1 = ((const float*)(rcol + max(vB - 2 * nw, 0)))[16 + l15];                     \
                 constexpr int WANT = (SKY) ? IS_WANT_SKY : ((NOG) ? 0 : IS_WANT_GROUND);           \
-                if (IS_P1_SREC) {                                                                  \
-                    if (IS_P1_SREC_LATE) pin_step(st);                                             \
-                    srec_arrived(S);                                                               \
-                    t = eval_segment_mix<HAS_INVALID, WANT>(my, S, r1, (float)h, s_rcp[h], D, P.iw); \
+                if (IS_P1_SREC_LATE) pin_step(st);                                                 \
+                srec_arrived(S);                                                                   \
+                const float mean_raw = fast_div(dpp_sub_first<6>(my.S, r1), (float)h, s_rcp[h]);   \
+                const float fn = __builtin_fmaxf(mean_raw, 0.0f);                                  \
+                const float p1 = (fn > st.g_hi_thr) ? st.p1_hi : ((fn < st.g_lo_thr) ? st.p1_lo : st.p1_mid); \
+                const float p2 = (fn > st.o_hi_thr) ? st.p2_hi : ((fn < st.o_lo_thr) ? st.p2_lo : st.p2_mid); \
+                const float p3 = (fn > P.epsilon) ? st.p3_yes : st.p3_no;                          \
+                const float m12 = min_raw(p1, p2);                                                 \
+                const float pwmp_o = P.pw * min_raw(m12, p3);                                      \
+                int base3 = vB * 3;                                                                \
+                asm volatile("" : "+s"(base3));                                                    \
+                int sel = (p1 < p2) ? IS_GROUND : IS_OBJECT;                                       \
+                sel = (p3 < m12) ? IS_SKY : sel;                                                   \
+                const float lbc = (pwmp_o - E1o) + P.sw * lbseg;                                   \
+                const bool x_open = !(NOG) && ((((SKY) ? mask_s : mask_g) >> kb) & 1u);            \
+                /* (a candidate whose bound is +inf costs +inf: it never wins either -- rows whose     \
+                 * final cost is +inf keep the initial index, see the merge -- and above the horizon   \
+                 * that is every object candidate of a sky lane until the walk reaches the ground)    \
+                 */                                                                                \
+                if ((__builtin_amdgcn_ballot_w64(lbc > b.o || lbc == IS_INF) | dead) != ~0ull) {   \
+                    n_full++;                                                                      \
+                    const SegTerms t = eval_segment_mix<HAS_INVALID, WANT, true>(                  \
+                        my, S, r1, (float)h, s_rcp[h], D, P.iw, mean_raw);                         \
+                    const float od = my_tile[t.fni] - pick_lut<NR>(row, t.fni);                    \
+                    if (SKY) {                                                                     \
+                        take_if_le(b.s, b.is, P.dw * t.sd + st.pwmp + P.sw * t.seg_s, st.idx_gs);  \
+                    } else if (!(NOG)) {                                                           \
+                        take_if_le(b.g, b.ig, P.dw * t.gd + st.pwmp + P.sw * t.seg_g, st.idx_gs);  \
+                    }                                                                              \
+                    take_if_le_v(b.o, b.io, P.dw * od + pwmp_o + P.sw * t.seg_o, base3 + sel);     \
+                    lbseg = seg_o_lower_bound(t, E2);                                              \
+                    const float lb_o = min_raw((st.q_o - E1o) + P.sw * lbseg, lbp[0]);             \
+                    ok_o = (__builtin_amdgcn_ballot_w64(lb_o > b.o) | dead) == ~0ull;              \
+                    if (SKY) {                                                                     \
+                        const float lb_s = min_raw((st.q_gs - E1gs) + P.sw * t.seg_s, lbp[2 * NLB * 64]); \
+                        ok_x = (__builtin_amdgcn_ballot_w64(lb_s > b.s) | dead) == ~0ull;          \
+                    } else if (!(NOG)) {                                                           \
+                        const float lb_g = min_raw((st.q_gs - E1gs) + P.sw * t.seg_g, lbp[NLB * 64]); \
+                        ok_x = (__builtin_amdgcn_ballot_w64(lb_g > b.g) | gdead) == ~0ull;         \
+                    }                                                                              \
                 } else {                                                                           \
-                    t = eval_segment_dpp<HAS_INVALID, WANT>(my, r0, r1, (float)h, s_rcp[h], D, P.iw); \
-                }                                                                                  \
-                od = my_tile[t.fni] - pick_lut<NR>(row, t.fni);                                    \
-                if (!IS_P1_SREC) {                                                                 \
-                    /* the next StepRec: requested only now -- every LDS wait is an lgkmcnt(0)     \
-                     * wait and would wait for this scalar load too (SMEM returns out of order) */ \
-                    const StepRec* sn = scol + max(vB - nw, 0);                                    \
-                    asm volatile("" : "+s"(sn) : "v"(od));                                         \
-                    st_next = sload_step(sn);                                                      \
+                    n_lazy++;                                                                      \
+                    if (x_open) { /* the ground / sky candidate alone (the terms of IS_P1_GS4) */  \
+                        const float nic = P.iw * (float)dpp_sub_i_first<3>(my.Fnic, r1);           \
+                        float f_x, data;                                                           \
+                        if (SKY) {                                                                 \
+                            f_x = dpp_sub<2>(my.Fsky, r1);                                         \
+                            data = dpp_sub<5>(my.K, r1);                                           \
+                        } else {                                                                   \
+                            f_x = __builtin_fminf(my.Fg0 - S[0], my.Fg1 - S[1]);                   \
+                            data = dpp_sub<4>(my.G, r1);                                           \
+                        }                                                                          \
+                        f_x += nic;                                                                \
+                        const float cost_x = P.dw * data + st.pwmp + P.sw * f_x;                   \
+                        const float lb_x = min_raw((st.q_gs - E1gs) + P.sw * f_x,                  \
+                                                   lbp[((SKY) ? 2 : 1) * NLB * 64]);               \
+                        if (SKY) {                                                                 \
+                            take_if_le(b.s, b.is, cost_x, st.idx_gs);                              \
+                            ok_x = (__builtin_amdgcn_ballot_w64(lb_x > b.s) | dead) == ~0ull;      \
+                        } else {                                                                   \
+                            take_if_le(b.g, b.ig, cost_x, st.idx_gs);                              \
+                            ok_x = (__builtin_amdgcn_ballot_w64(lb_x > b.g) | gdead) == ~0ull;     \
+                        }                                                                          \
+                    }                                                                              \
                 }                                                                                  \
             } else {                                                                               \
-                const RowRec rb = sload_rec(rcol + vB);                                            \
-                st = sload_step(scol + vB);                                                        \
-                t = eval_segment<true, HAS_INVALID>(my, rb, (float)h, s_rcp[h], D, P.iw);          \
-                od = my_tile[t.fni] - pick_lut<NR>(row, t.fni);                                    \
+                n_full++;                                                                          \
+                SegTerms t;                                                                        \
+                StepVals st;                                                                       \
+                float od;                                                                          \
+                if (USE_DPP) {                                                                     \
+                    const float r0 = c_r0, r1 = c_r1;                                              \
+                    st = st_next;                                                                  \
+                    c_r0 = n_r0; c_r1 = n_r1;                                                      \
+                    {                                                                              \
+                        const float* q2 = (const float*)(rcol + max(vB - 2 * nw, 0));              \
+                        if (!IS_P1_SREC) n_r0 = q2[l15];                                           \
+                        n_r1 = q2[16 + l15];                                                       \
+                    }                                                                              \
+                    constexpr int WANT = (SKY) ? IS_WANT_SKY : ((NOG) ? 0 : IS_WANT_GROUND);       \
+                    if (IS_P1_SREC) {                                                              \
+                        if (IS_P1_SREC_LATE) pin_step(st);                                         \
+                        srec_arrived(S);                                                           \
+                        t = eval_segment_mix<HAS_INVALID, WANT>(my, S, r1, (float)h, s_rcp[h], D, P.iw); \
+                    } else {                                                                       \
+                        t = eval_segment_dpp<HAS_INVALID, WANT>(my, r0, r1, (float)h, s_rcp[h], D, P.iw); \
+                    }                                                                              \
+                    od = my_tile[t.fni] - pick_lut<NR>(row, t.fni);                                \
+                    if (!IS_P1_SREC) {                                                             \
+                        /* the next StepRec: requested only now -- every LDS wait is an lgkmcnt(0) \
+                         * wait and would wait for this scalar load too (SMEM returns out of order) */ \
+                        const StepRec* sn = scol + max(vB - nw, 0);                                \
+                        asm volatile("" : "+s"(sn) : "v"(od));                                     \
+                        st_next = sload_step(sn);                                                  \
+                    }                                                                              \
+                } else {                                                                           \
+                    const RowRec rb = sload_rec(rcol + vB);                                        \
+                    st = sload_step(scol + vB);                                                    \
+                    t = eval_segment<true, HAS_INVALID>(my, rb, (float)h, s_rcp[h], D, P.iw);      \
+                    od = my_tile[t.fni] - pick_lut<NR>(row, t.fni);                                \
+                }                                                                                  \
+                pairwise_step<SKY, true, NOG, true>(P, st, vB, live, od, t, b);                    \
+                const float lb_o = min_raw((st.q_o - E1o) + P.sw * seg_o_lower_bound(t, E2), lbp[0]); \
+                ok_o = (__builtin_amdgcn_ballot_w64(lb_o > b.o) | dead) == ~0ull;                  \
+                if (SKY) {                                                                         \
+                    const float lb_s = min_raw((st.q_gs - E1gs) + P.sw * t.seg_s, lbp[2 * NLB * 64]); \
+                    ok_x = (__builtin_amdgcn_ballot_w64(lb_s > b.s) | dead) == ~0ull;              \
+                } else if (!(NOG)) {                                                               \
+                    const float lb_g = min_raw((st.q_gs - E1gs) + P.sw * t.seg_g, lbp[NLB * 64]);  \
+                    ok_x = (__builtin_amdgcn_ballot_w64(lb_g > b.g) | gdead) == ~0ull;             \
+                }                                                                                  \
             }                                                                                      \
-            pairwise_step<SKY, true, NOG, true>(P, st, vB, live, od, t, b);                        \
-            const float* lbp = s_lb + ((vB + 63) >> 6) * 64 + lane; /* (vB >= 1) */                \
-            const float lb_o = min_raw((st.q_o - E1o) + P.sw * seg_o_lower_bound(t, E2), lbp[0]);  \
-            const bool ok_o = (__builtin_amdgcn_ballot_w64(lb_o > b.o) | dead) == ~0ull
+            if (!(NOG)) ok_x = ok_x || IS_L7_NONE_LE((SKY) ? mask_s : mask_g, kb)
             /* ground / sky candidates of up to four vB (vB, vB - nw, ...) >= lo; closes `x_closed`
              * when the bound of the last one holds; leaves vB at the next unvisited value */
 #define IS_P1_GS4(SKY, lo, x_dead, x_closed)                                                       \
@@ -905,11 +1019,8 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
             const int sky_lo = max(vhor + 1, 1);
             for (; vB >= sky_lo; vB -= nw) { /* sky range: vB - 1 >= vhor */
                 IS_P1_STEP(true, false);
-                const float lb_s = min_raw((st.q_gs - E1gs) + P.sw * t.seg_s, lbp[2 * NLB * 64]);
-                const bool ok_s = (__builtin_amdgcn_ballot_w64(lb_s > b.s) | dead) == ~0ull ||
-                                  IS_L7_NONE_LE(mask_s, (vB + 63) >> 6);
-                IS_P1_REQUEST_NEXT(ok_s);
-                if (ok_o && ok_s) { done = true; break; }
+                IS_P1_REQUEST_NEXT(ok_x);
+                if (ok_o && ok_x) { done = true; break; }
                 if (ok_o) { o_closed = true; vB -= nw; break; }
             }
             IS_P1_DRAIN();
@@ -933,11 +1044,8 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
             } else if (!done) {
                 for (; vB >= 1; vB -= nw) { /* ground range: vB - 1 < vhor */
                     IS_P1_STEP(false, false);
-                    const float lb_g = min_raw((st.q_gs - E1gs) + P.sw * t.seg_g, lbp[NLB * 64]);
-                    const bool ok_g = (__builtin_amdgcn_ballot_w64(lb_g > b.g) | gdead) == ~0ull ||
-                                      IS_L7_NONE_LE(mask_g, (vB + 63) >> 6);
-                    IS_P1_REQUEST_NEXT(ok_g);
-                    if (ok_o && ok_g) { done = true; break; }
+                    IS_P1_REQUEST_NEXT(ok_x);
+                    if (ok_o && ok_x) { done = true; break; }
                     if (ok_o) { o_closed = true; vB -= nw; break; }
                 }
                 IS_P1_DRAIN();
@@ -977,6 +1085,11 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
             if (counters != nullptr && lane == 0) {
                 atomicAdd(counters + IS_CNT_P1_FULL, (unsigned long long)n_full);
                 atomicAdd(counters + IS_CNT_P1_GS, (unsigned long long)n_gs);
+                atomicAdd(counters + IS_CNT_P1_LAZY, (unsigned long long)n_lazy);
+                unsigned long long* ct = counters + IS_CNT_TILE0 + 3 * min(tile, 63);
+                atomicAdd(ct + 0, (unsigned long long)n_full);
+                atomicAdd(ct + 1, (unsigned long long)n_lazy);
+                atomicAdd(ct + 2, (unsigned long long)n_gs);
             }
         }
     } else {

@@ -606,9 +606,13 @@ __device__ __forceinline__ void srec_request_next(isk_f16v& S, const RowRec* gre
 }
 __device__ __forceinline__ void srec_arrived(isk_f16v& S) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(S)); }
 
-template <bool HAS_INVALID, int WANT = IS_WANT_GROUND | IS_WANT_SKY>
+/* MEAN_GIVEN: the caller has computed the raw mean (fast_div(my.S - S[vB], h, r), the first DPP read
+ * of R1 in the step) already -- pairwise phase 1 evaluates the transition term before the rest */
+template <bool HAS_INVALID, int WANT = IS_WANT_GROUND | IS_WANT_SKY, bool MEAN_GIVEN = false>
 __device__ __forceinline__ SegTerms eval_segment_mix(const RowRec& my, const isk_f16v& S, float R1,
-                                                     float height, float r, int D, float iw) {
+                                                     float height, float r, int D, float iw,
+                                                     float mean_in = 0.0f) {
+    /* (MEAN_GIVEN with HAS_INVALID is instantiated but never executed: the lazy step is the DPP path) */
     SegTerms t;
     const float nic = iw * (float)dpp_sub_i_first<3>(my.Fnic, R1);
     float f_g = 0.0f;
@@ -671,7 +675,9 @@ __device__ __forceinline__ SegTerms eval_segment_mix(const RowRec& my, const isk
     if (WANT & IS_WANT_GROUND) t.gd = dpp_sub<4>(my.G, R1);
     if (WANT & IS_WANT_SKY) t.sd = dpp_sub<5>(my.K, R1);
     float mean;
-    if (HAS_INVALID) {
+    if (MEAN_GIVEN) {
+        mean = mean_in;
+    } else if (HAS_INVALID) {
         const float valid_dif = dpp_sub<7>(my.V, R1);
         const float sdif = dpp_sub<6>(my.S, R1);
         mean = (valid_dif == 0) ? 0 : sdif / valid_dif;

@@ -27,7 +27,8 @@ EXPORTS = [
     "ish_get_instance_stixels", "ish_get_3d_vertices", "ish_save_stixels", "ish_time_compute",
     "ish_set_device", "ish_compute_batch", "ish_time_compute_batch",
     "ire_create", "ire_destroy", "ire_initialize", "ire_finish", "ire_compute", "ire_get_binary",
-    "ire_hough_lines",
+    "ire_hough_lines", "ire_set_device", "ire_active_device", "ire_compute_device",
+    "ish_get_input_disparity_on_device",
 ]
 
 
@@ -90,6 +91,11 @@ def lib():
         L.ire_compute.argtypes = [vp, vp, ctypes.c_size_t, vp]
         L.ire_get_binary.argtypes = [vp, vp, ctypes.c_size_t]
         L.ire_hough_lines.argtypes = [vp, ci, ci, cf, cf, ci, vp, ci]
+        L.ire_set_device.argtypes = [vp, ci]
+        L.ire_active_device.argtypes = [vp]
+        L.ire_compute_device.argtypes = [vp, vp, vp]
+        L.ish_get_input_disparity_on_device.argtypes = [vp]
+        L.ish_get_input_disparity_on_device.restype = vp
         _LIB = L
     return _LIB
 
@@ -147,6 +153,10 @@ class Stixels:
     def SetDevice(self, device):
         """GPU of the next Initialize() (default: the caller's current HIP device)."""
         self._check(lib().ish_set_device(self._h, int(device)), "SetDevice")
+
+    def GetInputDisparityImageOnDevice(self):
+        """Device address of the internal full-resolution disparity buffer (Stixels.cu:357-359)."""
+        return int(lib().ish_get_input_disparity_on_device(self._h) or 0)
 
     def time_compute(self, pairwise, n_iter=100, with_instances=False):
         """Seconds per frame of n_iter Stixels::Compute() calls timed inside the C++ library."""
@@ -308,6 +318,23 @@ class RoadEstimation:
         a = np.ascontiguousarray(disparity, np.float32)
         out = np.zeros(4, np.float32)
         rc = lib().ire_compute(self._h, a.ctypes.data, a.size, out.ctypes.data)
+        if rc < 0:
+            raise RuntimeError(lib().ish_last_error().decode())
+        self.pitch, self.camera_height, self.slope = float(out[0]), float(out[1]), float(out[2])
+        self.horizon_point = int(out[3])
+        return bool(rc)
+
+    def SetDevice(self, device):
+        """Device of the next Initialize() (RoadEstimation::SetDevice, an addition like Stixels::SetDevice)."""
+        lib().ire_set_device(self._h, int(device))
+
+    def GetActiveDevice(self):
+        return int(lib().ire_active_device(self._h))
+
+    def ComputeOnDevice(self, d_ptr):
+        """RoadEstimation::Compute(pixel_t* d_im): the image is on the object's device already."""
+        out = np.zeros(4, np.float32)
+        rc = lib().ire_compute_device(self._h, ctypes.c_void_p(int(d_ptr)), out.ctypes.data)
         if rc < 0:
             raise RuntimeError(lib().ish_last_error().decode())
         self.pitch, self.camera_height, self.slope = float(out[0]), float(out[1]), float(out[2])

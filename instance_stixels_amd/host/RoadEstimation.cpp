@@ -6,6 +6,7 @@
  * the reference's cv::HoughLines call, with an own implementation of the standard transform.
  */
 #include "InstanceStixels/RoadEstimation.h"
+#include "DeviceGuard.h"
 
 #include <algorithm>
 #include <cmath>
@@ -35,6 +36,12 @@ void RoadEstimation::Initialize(const float camera_center_y, const float baselin
     m_horizonPoint = 0;
     m_pitch = m_cameraHeight = 0;
     m_vDisp.assign((size_t)m_max_dis * m_rows, 0);
+    /* the device of the buffers: SetDevice(), else the caller's current one (like Stixels::Initialize) */
+    int device = m_device;
+    if (device < 0) IS_CHECK_RETURN(is_get_device(&device));
+    m_ctx_device = device;
+    const DeviceGuard guard(device);
+    IS_CHECK_RETURN(is_stream_create(&m_stream, 1));
     IS_CHECK_RETURN(is_device_malloc((void**)&d_disparity, (size_t)m_cols * m_rows * sizeof(float)));
     IS_CHECK_RETURN(is_device_malloc((void**)&d_vDisp, (size_t)m_max_dis * m_rows * sizeof(int)));
     IS_CHECK_RETURN(is_device_malloc((void**)&d_maximum, sizeof(int)));
@@ -43,6 +50,12 @@ void RoadEstimation::Initialize(const float camera_center_y, const float baselin
 }
 
 void RoadEstimation::Finish() { /* RE.cu:84-92 */
+    const DeviceGuard guard(m_ctx_device);
+    if (m_stream) {
+        IS_CHECK_RETURN(is_stream_synchronize(m_stream));
+        IS_CHECK_RETURN(is_stream_destroy(m_stream));
+        m_stream = nullptr;
+    }
     IS_CHECK_RETURN(is_device_free(d_vDisp));
     IS_CHECK_RETURN(is_device_free(d_disparity));
     IS_CHECK_RETURN(is_device_free(d_maximum));
@@ -52,14 +65,18 @@ void RoadEstimation::Finish() { /* RE.cu:84-92 */
 }
 
 bool RoadEstimation::Compute(const std::vector<pixel_t>& im) { /* RE.cu:94-102 */
-    IS_CHECK_RETURN(is_memcpy_h2d(d_disparity, im.data(), im.size() * sizeof(pixel_t), nullptr));
-    IS_CHECK_RETURN(is_stream_synchronize(nullptr)); /* the caller's vector may be a temporary */
+    {
+        const DeviceGuard guard(m_ctx_device);
+        IS_CHECK_RETURN(is_memcpy_h2d(d_disparity, im.data(), im.size() * sizeof(pixel_t), m_stream));
+        IS_CHECK_RETURN(is_stream_synchronize(m_stream)); /* the caller's vector may be a temporary */
+    }
     return Compute(d_disparity);
 }
 
 bool RoadEstimation::Compute(pixel_t* d_im) { /* RE.cu:104-138 */
+    const DeviceGuard guard(m_ctx_device); /* (d_im lives on the object's device: Stixels::SetDevice(d) + SetDevice(d)) */
     IS_CHECK_RETURN(is_road_vdisparity(d_im, m_rows, m_cols, m_max_dis, m_binThr, d_vDisp, d_maximum,
-                                       d_vDispBinary, nullptr));
+                                       d_vDispBinary, m_stream));
     float rho, theta, horizonPoint, pitch, cameraHeight, slope;
     bool ok = false;
     if (ComputeHough(rho, theta, horizonPoint, pitch, cameraHeight, slope)) {
@@ -124,8 +141,9 @@ std::vector<std::pair<float, float>> RoadEstimation::HoughLines(const uint8_t* i
 
 bool RoadEstimation::ComputeHough(float& rho, float& theta, float& horizonPoint, float& pitch,
                                   float& cameraHeight, float& slope) { /* RE.cu:140-176 */
-    IS_CHECK_RETURN(is_memcpy_d2h(m_vDisp.data(), d_vDispBinary, (size_t)m_max_dis * m_rows, nullptr));
-    IS_CHECK_RETURN(is_stream_synchronize(nullptr));
+    /* (called from Compute, under its device guard) */
+    IS_CHECK_RETURN(is_memcpy_d2h(m_vDisp.data(), d_vDispBinary, (size_t)m_max_dis * m_rows, m_stream));
+    IS_CHECK_RETURN(is_stream_synchronize(m_stream));
     const auto lines = HoughLines(m_vDisp.data(), m_rows, m_max_dis, 1.0f, kPi / 180, m_HoughAccumThr);
     for (const auto& l : lines) {
         rho = std::abs(l.first);

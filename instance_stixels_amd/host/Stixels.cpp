@@ -16,31 +16,7 @@
 #include <iostream>
 #include <stdexcept>
 
-namespace {
-/* Runs a public method on the device of the object's buffers and puts the caller's current
- * device back on every exit path (SetDevice() contract in Stixels.hpp): the copies and
- * synchronisations below use the NULL stream, which belongs to the CURRENT device. */
-class DeviceGuard {
-public:
-    explicit DeviceGuard(int device) {
-        if (device < 0) return;
-        IS_CHECK_RETURN(is_get_device(&m_prev));
-        if (m_prev != device) {
-            IS_CHECK_RETURN(is_set_device(device));
-            m_switched = true;
-        }
-    }
-    ~DeviceGuard() {
-        if (m_switched) (void)is_set_device(m_prev);
-    }
-    DeviceGuard(const DeviceGuard&) = delete;
-    DeviceGuard& operator=(const DeviceGuard&) = delete;
-
-private:
-    int m_prev = -1;
-    bool m_switched = false;
-};
-}  // namespace
+#include "DeviceGuard.h"
 
 Stixels::Stixels() {}
 Stixels::~Stixels() {} /* like the reference, buffers are released by Finish(), Stixels.cu:36-37 */

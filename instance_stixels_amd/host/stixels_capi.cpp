@@ -294,6 +294,25 @@ int ire_compute(void* h, const float* image, size_t n, float* out4) {
     });
     return rc ? rc : ok;
 }
+int ire_set_device(void* h, int device) {
+    return guard([&] { ((RoadEstimation*)h)->SetDevice(device); });
+}
+int ire_active_device(void* h) { return ((RoadEstimation*)h)->GetActiveDevice(); }
+/* Compute(pixel_t* d_im): the disparity image is on the device already -- what the wrapper passes
+ * after Stixels::GetInputDisparityImageOnDevice() (apps/stixels_wrapper.cu:187) */
+int ire_compute_device(void* h, float* d_image, float* out4) {
+    int ok = 0;
+    const int rc = guard([&] {
+        RoadEstimation* r = (RoadEstimation*)h;
+        ok = r->Compute(d_image) ? 1 : 0;
+        out4[0] = r->GetPitch(); out4[1] = r->GetCameraHeight(); out4[2] = r->GetSlope();
+        out4[3] = (float)r->GetHorizonPoint();
+    });
+    return rc ? rc : ok;
+}
+void* ish_get_input_disparity_on_device(void* h) {
+    return (void*)((Stixels*)h)->GetInputDisparityImageOnDevice();
+}
 int ire_get_binary(void* h, uint8_t* out, size_t n) {
     const auto& v = ((RoadEstimation*)h)->GetBinaryVDisparity();
     std::memcpy(out, v.data(), std::min(n, v.size()));

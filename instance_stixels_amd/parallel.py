@@ -15,11 +15,12 @@ def shard_range(n_items: int, rank: int, world: int):
 
 
 def gather_sections(local: torch.Tensor, gathered, dst: int = 0, group=None):
-    """Gathers every rank's fixed-stride Section tensor ([B][C][S][8] int32) on `dst`.
+    """Gathers every rank's fixed-stride Section tensor ([B][C][S][8] int32) on `dst` (a rank of
+    `group`, like everywhere in this module).
 
     `gathered` is a list of world_size tensors on `dst` and None elsewhere."""
     rank = dist.get_rank(group)
-    dist.gather(local, gather_list=gathered if rank == dst else None, dst=dst, group=group)
+    dist.gather(local, gather_list=gathered if rank == dst else None, group=group, group_dst=dst)
     return gathered
 
 
@@ -31,7 +32,7 @@ def gather_variable(local: torch.Tensor, dst: int = 0, group=None):
     n = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
     sizes = [torch.zeros_like(n) for _ in range(world)]
     dist.all_gather(sizes, n, group=group)
-    sizes = [int(s.item()) for s in sizes]
+    sizes = [int(v) for v in torch.cat(sizes).cpu().tolist()]
     m = max(sizes)
     padded = local
     if local.shape[0] < m:
@@ -39,7 +40,7 @@ def gather_variable(local: torch.Tensor, dst: int = 0, group=None):
                           device=local.device)
         padded = torch.cat([local, pad], dim=0)
     out = [torch.empty_like(padded) for _ in range(world)] if rank == dst else None
-    dist.gather(padded.contiguous(), gather_list=out, dst=dst, group=group)
+    dist.gather(padded.contiguous(), gather_list=out, group=group, group_dst=dst)
     if rank != dst:
         return None
     return torch.cat([o[:s] for o, s in zip(out, sizes)], dim=0)
@@ -78,7 +79,7 @@ class PipelinedGather:
         slot = self.step % self.depth
         self.inflight[slot] = dist.gather(
             self.buffers[slot], gather_list=self.gathered[slot] if self.rank == self.dst else None,
-            dst=self.dst, group=self.group, async_op=True)
+            group=self.group, group_dst=self.dst, async_op=True)
         self.step += 1
         return slot
 
@@ -156,17 +157,14 @@ def unpack_sections(counts: torch.Tensor, packed: torch.Tensor, max_sections: in
     return out
 
 
-def _exchange_compact(counts, packed, dst, group, recv=None):
-    """The collective part: sizes by all_gather, then counts + packed sections of every rank to
-    `dst` with point-to-point transfers sized by what each rank really has.  Returns on `dst` a
-    list of (counts_r, packed_r) per rank (its own: the inputs), None elsewhere; `works`: the
-    asynchronous handles still in flight."""
-    world, rank = dist.get_world_size(group), dist.get_rank(group)
+def _post_compact(counts, packed, sizes, dst, group, recv=None):
+    """The point-to-point part of the compacted gather: counts + packed sections of every rank to
+    the GROUP rank `dst`, sized by `sizes` = [(n_columns_r, n_sections_r)] of all group ranks (known
+    on every rank).  `recv(r, n_columns, n_sections)` (optional) returns the landing tensors of
+    rank r.  Returns (out, works): on `dst` the list of (counts_r, packed_r) per group rank (its
+    own: the inputs), None elsewhere; `works`: the asynchronous handles in flight."""
+    rank = dist.get_rank(group)
     dev = counts.device
-    mine = torch.tensor([counts.numel(), packed.shape[0]], dtype=torch.int64, device=dev)
-    sizes = [torch.zeros_like(mine) for _ in range(world)]
-    dist.all_gather(sizes, mine, group=group)
-    sizes = [(int(s[0].item()), int(s[1].item())) for s in sizes]
     ops, out = [], None
     if rank == dst:
         out = []
@@ -175,25 +173,38 @@ def _exchange_compact(counts, packed, dst, group, recv=None):
                 out.append((counts, packed))
                 continue
             if recv is not None:
-                c_r, p_r = recv[r][0][:nc], recv[r][1][:n]
+                c_r, p_r = recv(r, nc, n)
             else:
                 c_r = torch.empty(nc, dtype=torch.int32, device=dev)
                 p_r = torch.empty((n, 8), dtype=torch.int32, device=dev)
-            ops.append(dist.P2POp(dist.irecv, c_r, r, group))
+            # group_peer: ranks of `group` (with a sub-group they differ from the global ranks)
+            ops.append(dist.P2POp(dist.irecv, c_r, group=group, group_peer=r))
             if n > 0:
-                ops.append(dist.P2POp(dist.irecv, p_r, r, group))
+                ops.append(dist.P2POp(dist.irecv, p_r, group=group, group_peer=r))
             out.append((c_r, p_r))
     else:
-        ops.append(dist.P2POp(dist.isend, counts, dst, group))
+        ops.append(dist.P2POp(dist.isend, counts, group=group, group_peer=dst))
         if packed.shape[0] > 0:
-            ops.append(dist.P2POp(dist.isend, packed, dst, group))
+            ops.append(dist.P2POp(dist.isend, packed, group=group, group_peer=dst))
     works = dist.batch_isend_irecv(ops) if ops else []
+    return out, works
+
+
+def _exchange_compact(counts, packed, dst, group, recv=None):
+    """Sizes by all_gather (ONE device-to-host copy of all of them), then _post_compact.  `dst` is
+    a rank of `group`.  Returns (out, works, sizes)."""
+    world = dist.get_world_size(group)
+    mine = torch.tensor([counts.numel(), packed.shape[0]], dtype=torch.int64, device=counts.device)
+    sizes = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(sizes, mine, group=group)
+    sizes = [tuple(int(v) for v in row) for row in torch.stack(sizes).cpu().tolist()]
+    out, works = _post_compact(counts, packed, sizes, dst, group, recv)
     return out, works, sizes
 
 
 def gather_compact(sections: torch.Tensor, dst: int = 0, group=None):
     """Compacted gather of every rank's Section tensor ([n_r][C][S][8] int32, n_r may differ per
-    rank) on `dst`: returns there the list of per-rank (counts, packed) pairs (see
+    rank) on the GROUP rank `dst`: returns there the list of per-rank (counts, packed) pairs (see
     pack_sections), None on the other ranks.  About 10 x fewer bytes than the fixed-stride gather:
     10-40 of the 200 slots of a column are used."""
     counts, packed = pack_sections(sections)
@@ -204,38 +215,59 @@ def gather_compact(sections: torch.Tensor, dst: int = 0, group=None):
 
 
 class PipelinedCompactGather:
-    """PipelinedGather with the compacted payload.  Step k computes into buffer k % depth and its
-    pack kernels are queued behind it; the exchange of step k-1 (whose size the host must read:
-    one 4-byte copy) is started right after step k has been queued, on a side stream that waits
-    only for step k-1's pack -- so the transfer overlaps step k's compute and the host never
-    leaves the GPU without queued work.  `flush()` finishes what is still pending."""
+    """PipelinedGather with the compacted payload, without a host wait on recent GPU work.
 
-    def __init__(self, like: torch.Tensor, core=None, depth: int = 2, dst: int = 0, group=None):
-        self.dst, self.group, self.depth = dst, group, depth
+    Step k computes into buffer k % depth; its pack kernels are queued behind it and the two
+    sizes of the payload (columns, sections) are all-gathered ASYNCHRONOUSLY, on the device, on a
+    side stream that waits only for the pack.  The point-to-point transfers of step k are posted
+    `lag` (= 2) steps later, with the exact sizes of every rank: the host reads the gathered sizes
+    of a step whose kernels ran two steps ago (one small copy on the side stream, nothing of the
+    compute stream in front of it), so it never waits for work the GPU has not finished long ago,
+    never leaves the GPU without queued work, and no size is ever guessed (no truncation, no
+    worst-case transfer).  The transfer of step k overlaps the compute of steps k+2, k+3; its
+    buffers are reused at step k + depth (depth >= lag + 2).  `dst` is a rank of `group`.  The
+    landing buffers on `dst` grow on demand from what really arrives (not depth x ranks x the
+    worst case).  `flush()` finishes what is still pending."""
+
+    def __init__(self, like: torch.Tensor, core=None, depth: int = 4, dst: int = 0, group=None, lag: int = 2):
+        if depth < lag + 1:
+            raise ValueError("PipelinedCompactGather: depth must be at least lag + 1")
+        self.dst, self.group, self.depth, self.lag = dst, group, depth, lag
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
         self.S = like.shape[-2]
         self.n_columns = like.numel() // (self.S * 8)
         dev = like.device
         self.dev = dev
+        self.cuda = dev.type == "cuda"
         cap = self.n_columns * (self.S - 1)
         self.buffers = [torch.empty_like(like) for _ in range(depth)]
         self.counts = [torch.empty(self.n_columns, dtype=torch.int32, device=dev) for _ in range(depth)]
         self.offsets = [torch.empty(self.n_columns + 1, dtype=torch.int32, device=dev) for _ in range(depth)]
         self.packed = [torch.empty((cap, 8), dtype=torch.int32, device=dev) for _ in range(depth)]
-        self.total = [torch.zeros(1, dtype=torch.int32).pin_memory() if dev.type == "cuda"
-                      else torch.zeros(1, dtype=torch.int32) for _ in range(depth)]
-        self.events = [torch.cuda.Event() if dev.type == "cuda" else None for _ in range(depth)]
-        self.comm = torch.cuda.Stream(dev) if dev.type == "cuda" else None
-        self.recv = None
-        if self.rank == dst:   # worst-case landing buffers per slot and rank
-            self.recv = [[(torch.empty(self.n_columns, dtype=torch.int32, device=dev),
-                           torch.empty((cap, 8), dtype=torch.int32, device=dev)) if r != dst else None
-                          for r in range(self.world)] for _ in range(depth)]
+        self.size_mine = [torch.tensor([self.n_columns, 0], dtype=torch.int64, device=dev) for _ in range(depth)]
+        self.size_all = [[torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(self.world)]
+                         for _ in range(depth)]
+        self.size_work = [None] * depth
+        self.events = [torch.cuda.Event() if self.cuda else None for _ in range(depth)]
+        self.comm = torch.cuda.Stream(dev) if self.cuda else None
+        self.landing = [dict() for _ in range(depth)]   # slot -> {rank: (counts, packed)} grown on demand
         self.works = [[] for _ in range(depth)]
         self.result = [None] * depth
         self.sizes = [None] * depth
-        self.pending = []
+        self.pending = []          # slots whose transfers are not posted yet, oldest first
         self.step = 0
+        self.host_seconds = {"post": 0.0, "wait": 0.0}   # host time inside the size read / the waits
+
+    # ---- landing buffers of rank r in a slot: reused, grown by half when a payload outgrows them
+    def _landing(self, slot, r, nc, n):
+        c_r, p_r = self.landing[slot].get(r, (None, None))
+        if c_r is None or c_r.numel() < nc:
+            c_r = torch.empty(nc, dtype=torch.int32, device=self.dev)
+        if p_r is None or p_r.shape[0] < n:
+            p_r = torch.empty((max(n, int(1.5 * (0 if p_r is None else p_r.shape[0]))), 8),
+                              dtype=torch.int32, device=self.dev)
+        self.landing[slot][r] = (c_r, p_r)
+        return c_r[:nc], p_r[:n]
 
     def next_buffer(self) -> torch.Tensor:
         slot = self.step % self.depth
@@ -243,52 +275,65 @@ class PipelinedCompactGather:
         return self.buffers[slot]
 
     def _finish(self, slot):
-        if slot in self.pending:
-            self._exchange(slot)
+        import time
+        while slot in self.pending:          # (only when fewer than `lag` steps follow: flush, tiny runs)
+            self._post(self.pending[0])
+        t0 = time.perf_counter()
         for w in self.works[slot]:
             w.wait()
         self.works[slot] = []
+        self.host_seconds["wait"] += time.perf_counter() - t0
 
     def submit(self):
         slot = self.step % self.depth
-        if self.dev.type == "cuda":
+        if self.cuda:
             from . import core
             stream = torch.cuda.current_stream(self.dev)
             core.pack_sections_ptr(self.buffers[slot].data_ptr(), self.n_columns, self.S,
                                    self.counts[slot].data_ptr(), self.offsets[slot].data_ptr(),
                                    self.packed[slot].data_ptr(), stream.cuda_stream)
-            self.total[slot].copy_(self.offsets[slot][-1:], non_blocking=True)
+            self.size_mine[slot][1:2].copy_(self.offsets[slot][-1:])       # (device to device)
             self.events[slot].record(stream)
+            self.comm.wait_event(self.events[slot])
+            with torch.cuda.stream(self.comm):
+                self.size_work[slot] = dist.all_gather(self.size_all[slot], self.size_mine[slot],
+                                                       group=self.group, async_op=True)
         else:
             c, p = pack_sections(self.buffers[slot])
             self.counts[slot].copy_(c)
             self.packed[slot][: p.shape[0]].copy_(p)
-            self.total[slot][0] = p.shape[0]
-        older = list(self.pending)
+            self.size_mine[slot][1] = p.shape[0]
+            self.size_work[slot] = dist.all_gather(self.size_all[slot], self.size_mine[slot],
+                                                   group=self.group, async_op=True)
         self.pending.append(slot)
         self.step += 1
-        for s in older:      # the exchange of the step before, overlapped with the one just queued
-            self._exchange(s)
+        while len(self.pending) > self.lag:   # the transfers of the step `lag` steps back
+            self._post(self.pending[0])
         return slot
 
-    def _exchange(self, slot):
+    def _post(self, slot):
+        import time
+        t0 = time.perf_counter()
         self.pending.remove(slot)
-        if self.dev.type == "cuda":
-            self.events[slot].synchronize()
-            n = int(self.total[slot][0])
-            self.comm.wait_event(self.events[slot])
-            with torch.cuda.stream(self.comm):
-                out, works, sizes = _exchange_compact(self.counts[slot], self.packed[slot][:n], self.dst,
-                                                      self.group, None if self.recv is None else self.recv[slot])
+
+        def go():
+            self.size_work[slot].wait()
+            sizes = [tuple(int(v) for v in row) for row in torch.stack(self.size_all[slot]).cpu().tolist()]
+            n = sizes[self.rank][1]
+            out, works = _post_compact(self.counts[slot], self.packed[slot][:n], sizes, self.dst, self.group,
+                                       lambda r, nc, m: self._landing(slot, r, nc, m))
+            return out, works, sizes
+        if self.cuda:
+            with torch.cuda.stream(self.comm):   # nothing of the compute stream in front of the size copy
+                out, works, sizes = go()
         else:
-            n = int(self.total[slot][0])
-            out, works, sizes = _exchange_compact(self.counts[slot], self.packed[slot][:n], self.dst,
-                                                  self.group, None if self.recv is None else self.recv[slot])
+            out, works, sizes = go()
         self.works[slot], self.result[slot], self.sizes[slot] = works, out, sizes
+        self.host_seconds["post"] += time.perf_counter() - t0
 
     def flush(self):
-        for slot in list(self.pending):
-            self._exchange(slot)
+        while self.pending:
+            self._post(self.pending[0])
         for slot in range(self.depth):
             for w in self.works[slot]:
                 w.wait()
@@ -324,6 +369,10 @@ class PipelinedCompactGather:
         sizes = self.sizes[slot] or []
         fixed = self.buffers[0].numel() * 4
         per_rank = [4 * nc + 32 * n for nc, n in sizes]
+        landing = sum(c.numel() * 4 + p.numel() * 4 for d in self.landing for c, p in d.values())
         return {"kind": "compact", "bytes_per_rank_per_step": per_rank,
                 "fixed_stride_bytes_per_rank_per_step": fixed,
-                "ratio_vs_fixed": (sum(per_rank) / len(per_rank) / fixed) if per_rank else None}
+                "ratio_vs_fixed": (sum(per_rank) / len(per_rank) / fixed) if per_rank else None,
+                "lag_steps": self.lag, "depth": self.depth, "landing_buffer_bytes_on_dst": landing,
+                "host_seconds_in_size_read_and_posting": self.host_seconds["post"],
+                "host_seconds_in_waits": self.host_seconds["wait"]}

@@ -292,6 +292,27 @@ def test_device_clustering_equals_twin_random(seed):
 
 
 @pytest.mark.gpu
+def test_device_clustering_large_classes_global_memory_path():
+    """Classes with more candidates than the LDS copies hold (CLU_LDS_N = 2048, is_k_cluster.hip)
+    are clustered out of global memory: exactly 2048 (last LDS size), 2049 (first global size), a
+    few thousand, next to small classes in the same launch."""
+    cfg = make_config("drn_d_22_unary", 256, 1024, 64)
+    sizes = [2048, 2049, 3000, 300, 2047, 4100, 0, 2500]
+    sets = [random_candidates(7000 + c, n, 3 + c) if n else (np.zeros((0, 2), np.float32), np.zeros(0, bool))
+            for c, n in enumerate(sizes)]
+    # a long chain in the largest class: roots propagate over thousands of indices
+    chain = np.stack([np.arange(4100) * 10.0, np.zeros(4100)], axis=1).astype(np.float32)[::-1].copy()
+    sets[5] = (chain, np.arange(4100) % 5 > 0)
+    got = device_cluster(cfg, sets)
+    n_lab = 0
+    for c, (X, large) in enumerate(sets):
+        want = oracle.cluster_instances(X, large, cfg.eps, cfg.min_pts)
+        assert np.array_equal(got[c], want), f"class {c} ({sizes[c]} candidates): label ids differ"
+        n_lab += int((want >= 0).sum())
+    assert n_lab > 5000
+
+
+@pytest.mark.gpu
 def test_device_clustering_edge_cases():
     cfg = make_config("drn_d_22_unary", 256, 1024, 64, eps=25.0, min_pts=4)
     X, large = random_candidates(7, 60, 2)

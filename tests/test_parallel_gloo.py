@@ -117,27 +117,97 @@ def _worker_compact(rank, world, port, n_images, out_path):
         assert got is None
     # pipelined: three steps, step k sends the first image of the shard with vB fields + k
     like = full[lo:lo + 1].contiguous()
-    pipe = PipelinedCompactGather(like, depth=2, dst=0)
-    for k in range(3):
-        buf = pipe.next_buffer()
-        buf.copy_(like)
-        buf[..., 1] += k
-        pipe.submit()
-    pipe.flush()
-    if rank == 0:
-        res = pipe.last_gathered()
-        firsts = [shard_range(n_images, r, world)[0] for r in range(world)]
-        for r, f in enumerate(firsts):
-            want = full[f:f + 1].clone()
-            want[..., 1] += 2
-            wc, wp = pack_sections(want)
-            assert torch.equal(res[r][0], wc) and torch.equal(res[r][1], wp), r
-        chk = pipe.check_last()
-        assert chk["payload_consistent"] and chk["rank0_copy_equals_local"]
-        st = pipe.stats()
-        assert st["ratio_vs_fixed"] < 0.5
+    firsts = [shard_range(n_images, r, world)[0] for r in range(world)]
+    for depth, lag, n_steps in ((4, 2, 7), (3, 2, 5), (2, 1, 3), (4, 2, 1)):
+        # the transfers of step k are posted `lag` steps later with the exact sizes of every rank;
+        # payload sizes change from step to step (columns are emptied): the landing buffers grow
+        pipe = PipelinedCompactGather(like, depth=depth, dst=0, lag=lag)
+        seen = {}
+        for k in range(n_steps):
+            buf = pipe.next_buffer()
+            buf.copy_(like)
+            buf[..., 1] += k
+            if k % 2 == 1:
+                buf[0, :: (k + 1), 0, 0] = -1          # fewer sections in the odd steps
+            pipe.submit()
+            if rank == 0:
+                for slot in range(depth):              # whatever has been posted so far is consistent
+                    if pipe.result[slot] is not None and not pipe.works[slot]:
+                        seen[slot] = True
+        pipe.flush()
+        if rank == 0:
+            res = pipe.last_gathered()
+            k = n_steps - 1
+            for r, f in enumerate(firsts):
+                want = full[f:f + 1].clone()
+                want[..., 1] += k
+                if k % 2 == 1:
+                    want[0, :: (k + 1), 0, 0] = -1
+                wc, wp = pack_sections(want)
+                assert torch.equal(res[r][0], wc) and torch.equal(res[r][1], wp), (depth, lag, r)
+            chk = pipe.check_last()
+            assert chk["payload_consistent"] and chk["rank0_copy_equals_local"]
+            st = pipe.stats()
+            assert st["ratio_vs_fixed"] < 0.5 and st["lag_steps"] == lag
+            assert st["landing_buffer_bytes_on_dst"] < 0.8 * (world - 1) * depth * like.numel() * 4
     dist.barrier()
     dist.destroy_process_group()
+
+
+def _worker_subgroup(rank, world, port, out_path):
+    """Three processes, the gather inside the sub-group of global ranks [1, 2] (group ranks 0, 1):
+    group ranks differ from global ranks, `dst` is a GROUP rank everywhere in parallel.py."""
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from instance_stixels_amd.parallel import (gather_compact, gather_sections, gather_variable, unpack_sections,
+                                               PipelinedCompactGather, PipelinedGather, pack_sections)
+    group = dist.new_group([1, 2])
+    full = _sections_with_empty_columns(2)
+    S = full.shape[2]
+    if rank in (1, 2):
+        grank = dist.get_rank(group)                   # global 1 -> 0, global 2 -> 1
+        assert grank == rank - 1
+        mine = full[grank:grank + 1].contiguous()
+        dst = 1                                        # group rank 1 = global rank 2
+        got = gather_compact(mine, dst=dst, group=group)
+        lst = [torch.empty_like(mine) for _ in range(2)] if grank == dst else None
+        gather_sections(mine, lst, dst=dst, group=group)
+        var = gather_variable(mine, dst=dst, group=group)
+        pipe = PipelinedCompactGather(mine, dst=dst, group=group)
+        fpipe = PipelinedGather(mine, depth=2, dst=dst, group=group)
+        for k in range(5):
+            for pp in (pipe, fpipe):
+                b = pp.next_buffer()
+                b.copy_(mine)
+                b[..., 2] += k
+                pp.submit()
+        pipe.flush(); fpipe.flush()
+        if grank == dst:
+            back = torch.cat([unpack_sections(c, p, S) for c, p in got], dim=0)
+            wc, wp = pack_sections(full)
+            assert torch.equal(back, unpack_sections(wc, wp, S))
+            assert torch.equal(torch.cat(lst), full) and torch.equal(var, full)
+            res = pipe.last_gathered()
+            for r in range(2):
+                want = full[r:r + 1].clone()
+                want[..., 2] += 4
+                c_, p_ = pack_sections(want)
+                assert torch.equal(res[r][0], c_) and torch.equal(res[r][1], p_)
+                assert torch.equal(fpipe.last_gathered()[r], want)
+            np.save(out_path, back.numpy())
+        else:
+            assert got is None and var is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_inside_a_subgroup_uses_group_ranks(tmp_path):
+    out = str(tmp_path / "sub.npy")
+    mp.spawn(_worker_subgroup, args=(3, _free_port(), out), nprocs=3, join=True)
+    assert os.path.exists(out)
 
 
 def test_pack_unpack_sections_round_trip():

@@ -556,6 +556,34 @@ def test_host_class_road_parameters_change_between_frames():
     st.close()
 
 
+@pytest.mark.parametrize("preset,rows,cols,D,ov", [
+    ("drn_d_22_unary", 128, 64, 32, {}), ("drn_d_38_pairwise", 136, 64, 16, dict(invalid_disparity=0.0)),
+    ("drn_d_22_unary", 256, 96, 128, {}), ("disparity_only_pairwise", 512, 64, 64, {})])
+def test_object_lut_entries_against_the_oracle(preset, rows, cols, D, ov):
+    """A4 directly (ComputeObjectLUT, StixelsKernels.cu:236-296, 959-978): every entry of the
+    object data-cost prefix table the prepare kernel leaves in HBM, lutT[v][fn], against the
+    oracle's d_object_lut[fn][v] of the same column -- bit for bit, all columns, two images.  (The
+    DP parity tests see the table only through minima of differences of its entries.)"""
+    from instance_stixels_amd.core import Core
+    case = helpers.build_case(preset, rows, cols, D, seed=5, n_images=2, **ov)
+    cfg, p = case["cfg"], case["params"]
+    core = Core(p, case["lut"], case["odr"], max_batch=2)
+    try:
+        out = core.run(disparity_big=case["disparity"], segmentation=case["segmentation"],
+                       ground_function=case["gf"], normalization_ground=case["ng"],
+                       inv_sigma2_ground=case["ig"], vhor=case["vhor"], pairwise=bool(cfg.pairwise),
+                       median_join=bool(cfg.median_join), want_tables=False)
+        for img in range(2):
+            joined = oracle_mod().join_columns(cfg, case["disparity"][img])
+            assert np.array_equal(helpers.bits(joined), helpers.bits(out["joined"][img]))
+            for c in range(cfg.realcols):
+                want = oracle_mod().object_lut_column(p, joined[c], case["lut"])     # [D][P2 + 1]
+                got = core.read_object_lut(img * cfg.realcols + c)                    # [rows + 1][D]
+                assert np.array_equal(helpers.bits(want[:, : rows + 1].T), helpers.bits(got)), (img, c)
+    finally:
+        core.close()
+
+
 def test_core_rejects_bad_shapes():
     from instance_stixels_amd.core import Core, CoreError
     case = helpers.build_case("drn_d_22_unary", 64, 64, 32, seed=1)
@@ -625,7 +653,30 @@ def test_road_vdisparity_kernels_and_estimation():
     assert np.array_equal(re.GetBinaryVDisparity(), want_b)
     assert abs(re.horizon_point - f.vhor_image) <= 6       # generator: ramp starts at vhor_image
     assert abs(re.slope - f.alpha_ground) < 0.05 * f.alpha_ground + 0.02
+    first = (re.horizon_point, re.pitch, re.camera_height, re.slope)
     re.close()
+
+    # the wrapper's sequence (apps/stixels_wrapper.cu:159-203): SetDisparityImage ->
+    # GetInputDisparityImageOnDevice -> RoadEstimation::Compute(device pointer), both objects
+    # bound to a device with SetDevice (the class runs on ITS device, on its own stream, and puts
+    # the caller's current device back)
+    st = host.Stixels()
+    st.SetConfig(case["cfg"])
+    st.SetDevice(0)
+    st.Initialize()
+    st.SetDisparityImage(disp)
+    re = host.RoadEstimation()
+    re.SetDevice(0)
+    re.Initialize(case["cfg"].camera_center_y * 256 / 1024, case["cfg"].baseline, case["cfg"].focal,
+                  256, 512, 64)
+    assert re.GetActiveDevice() == 0
+    ptr = st.GetInputDisparityImageOnDevice()
+    assert ptr != 0 and re.ComputeOnDevice(ptr)
+    assert np.array_equal(re.GetBinaryVDisparity(), want_b)
+    assert (re.horizon_point, re.pitch, re.camera_height, re.slope) == first
+    assert torch.cuda.current_device() == 0
+    re.close()
+    st.close()
 
 
 def test_plain_cpp_caller_runs():
@@ -643,6 +694,28 @@ def test_plain_cpp_caller_runs():
         assert "stixels" in out.stdout and "horizon row" in out.stdout
         hor = int(out.stdout.split("horizon row")[1].split()[0])
         assert abs(hor - int(0.45 * 256)) <= 8
+
+
+@pytest.mark.parametrize("gather", ["compact", "fixed"])
+def test_bench_force_dist_child_process_runs_the_rccl_gather(gather):
+    """bench.py --force-dist in a FRESH child process (never a re-exec of this one): RCCL (backend
+    "nccl") initialises with one rank, the pipelined gather of either payload runs inside the timed
+    region, rank 0's gathered copy equals what it computed, and the timed output equals the
+    oracle's."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--force-dist", "--gather", gather,
+                          "--steps", "2", "--warmup", "1", "--batch", "8", "--min-seconds", "0",
+                          "--no-variants", "--no-cpu-baseline", "--no-single", "--no-d2h",
+                          "--no-prune-stats"], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0
+    assert line["verify"]["ok"] and line["verify"]["rccl_gather"]["rank0_copy_equals_local"]
+    assert line["gather"]["kind"] == gather and line["gather"]["bytes_per_rank_per_step"]
 
 
 def test_pack_sections_kernels_match_host_logic():
@@ -690,6 +763,19 @@ def test_set_device_guard_with_two_gpus():
         assert helpers.sections_equal(ref["sections"], data.sections)
         assert len(st.GetInstanceStixels()) == int(ref["inst_per_class"].sum())
         assert torch.cuda.current_device() == 0
+    # RoadEstimation bound to the same device: the wrapper's device-pointer call (stixels_wrapper.cu:187)
+    re0, re1 = host.RoadEstimation(), host.RoadEstimation()
+    args = (cfg.camera_center_y * 128 / 1024, cfg.baseline, cfg.focal, 128, 256, 32)
+    re0.Initialize(*args)                       # current device 0, host-vector path
+    assert re0.Compute(f.disparity)
+    re1.SetDevice(1)
+    re1.Initialize(*args)
+    assert re1.GetActiveDevice() == 1 and torch.cuda.current_device() == 0
+    assert re1.ComputeOnDevice(st.GetInputDisparityImageOnDevice())
+    assert torch.cuda.current_device() == 0
+    assert np.array_equal(re0.GetBinaryVDisparity(), re1.GetBinaryVDisparity())
+    assert (re0.horizon_point, re0.slope) == (re1.horizon_point, re1.slope)
+    re0.close(); re1.close()
     st.close()
 
 
@@ -697,14 +783,14 @@ def test_set_device_guard_with_two_gpus():
 # The exact branch-and-bound: proof-of-exactness tests AT the bounds
 # ---------------------------------------------------------------------------------------------
 ADV_FAMILIES = ["negative_data_costs", "ties", "constant_centres", "weight_cutoffs",
-                "horizon_in_tile", "confident_scene"]
+                "horizon_in_tile", "confident_scene", "separable_bound"]
 
 
 def _adversarial_case(family, k):
     """Small seeded cases built so that the slack terms of the bounds matter (lemmas L1-L6 of
     DESIGN.md section 5).  Returns a helpers case."""
     rng = np.random.default_rng(40000 + 97 * ADV_FAMILIES.index(family) + k)
-    pairwise = bool(k % 2)
+    pairwise = bool(k % 2) or family == "separable_bound"
     preset = ["drn_d_22_unary", "drn_d_38_pairwise"][pairwise]
     rows = int(rng.choice([128, 136, 192, 256]))
     cols = int(rng.choice([64, 96]))
@@ -712,6 +798,16 @@ def _adversarial_case(family, k):
     ov = {}
     if k % 4 >= 2:
         ov["invalid_disparity"] = 0.0
+    if family == "separable_bound":
+        # lemma L7 (separable block bounds of the pairwise phase 1): several 64-row blocks of
+        # candidates, homogeneous regions in which every split costs the same up to the transition
+        # prior -- or exactly the same (pw = 0: whole blocks of exact ties, the smallest vB must win)
+        rows = int(rng.choice([192, 256, 320, 384, 448]))
+        cols, D = 64, 32
+        ov.update(prior_weight=float(rng.choice([1.0, 1.0, 0.25, 0.0])),
+                  disparity_weight=float(rng.choice([0.0, 1e-4, 1e-2, 1.0])),
+                  segmentation_weight=float(rng.choice([1.0, 4.7095, 0.5])),
+                  instance_weight=float(rng.choice([0.0, 0.003131])))
     if family == "negative_data_costs":
         # the narrowest Gaussians the reference's FastLog domain allows ((1 - pout) / (sigma *
         # sqrt(2 pi)) <= 1, Stixels.cu:79-84, 786-788): where the Gaussian's mass inside [0, D) is
@@ -760,6 +856,36 @@ def _adversarial_case(family, k):
         seg[:, :, 20, :Hs] = big                                   # mx = 8 col + 4 + big: constant
         seg[:, :, 19, :Hs] = 8 * np.arange(Hs)[None, None, :] - big  # my = big + (v mod 8)
         seg[:, ::2, 19, :Hs] += rng.integers(-1, 2, seg[:, ::2, 19, :Hs].shape)
+    elif family == "separable_bound":
+        # constant class values per region (road below the horizon, sky above, one object slab in
+        # some columns), constant offsets, a noise-free ground ramp or a constant disparity: the
+        # ground / sky costs are separable up to rounding; the horizon anywhere, also inside a block
+        f = case["frames"][0]
+        vhor_image = int(rng.integers(8, rows - 8))
+        alpha = float(rng.choice([0.0, 0.8 * D / max(1, rows - vhor_image)]))
+        g = oracle_mod().host_ground(cfg, vhor_image, f.camera_tilt, f.camera_height, alpha)
+        case["gf"][0], case["ng"][0], case["ig"][0], case["vhor"][0] = g
+        r = np.arange(rows, dtype=np.float32)[:, None]
+        ramp = np.where(r > vhor_image, np.float32(alpha) * (r - vhor_image), 0.0).astype(np.float32)
+        disp[0] = np.clip(ramp + np.float32(rng.choice([0.0, 0.25, 3.5])), 0.0, D - 1.01)
+        if cfg.invalid_disparity >= 0:
+            disp[0][rng.random(disp[0].shape) < 0.03] = np.float32(cfg.invalid_disparity)
+        hs_hor = (rows - vhor_image) // 8            # 1/8-resolution rows (from the bottom) below the horizon
+        lo_v, hi_v = int(rng.choice([0, 1, 2])), int(rng.choice([3, 20, 40]))
+        seg[:, :, :19, :Hs] = hi_v
+        seg[:, :, 0, :hs_hor] = lo_v                  # road
+        seg[:, : cols // 16, 0, :hs_hor] = hi_v       # a sidewalk strip in the first columns
+        seg[:, : cols // 16, 1, :hs_hor] = lo_v
+        seg[:, :, 10, hs_hor:Hs] = lo_v               # sky
+        for c in range(0, seg.shape[1], 3):           # an object slab in every third column
+            a = int(rng.integers(0, Hs - 2)); b = int(rng.integers(a + 1, Hs))
+            cls = int(rng.choice([2, 5, 11, 13, 18]))
+            seg[:, c, :19, a:b] = hi_v
+            seg[:, c, cls, a:b] = lo_v
+        off = int(rng.choice([0, 0, 3, -5]))
+        seg[:, :, 19:, :Hs] = off
+        if k % 3 == 0:                                # a little noise: near-ties instead of exact ones
+            seg[:, :, :19, :Hs] += rng.integers(0, 2, seg[:, :, :19, :Hs].shape)
     elif family == "horizon_in_tile":
         f = case["frames"][0]
         vhor_image = int(rng.choice([1, 5, 63, 64, 65, rows - 70, rows - 64, rows - 2]))
@@ -798,7 +924,8 @@ def _run_counted(case, env, monkeypatch):
 @pytest.mark.parametrize("family", ADV_FAMILIES)
 def test_branch_and_bound_is_exact_at_the_bounds(family, monkeypatch):
     """36 seeded cases per family (216 in all), each run pruned and with IS_NO_PRUNE=1 (every pair
-    evaluated, the reference's walk, StixelsKernels.cu:600-839): the complete cost_table,
+    evaluated, the reference's walk, StixelsKernels.cu:600-839; "separable_bound": lemma L7 of
+    the pairwise phase 1, all 36 cases pairwise): the complete cost_table,
     index_table and all Sections must agree bit for bit; every sixth case is also compared with
     the oracle.  The families put the inputs AT the bounds: negative per-row data costs (LUT
     minima < 0), exact ties between pruned and winning vB, constant instance centres (E2
