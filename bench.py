@@ -142,8 +142,16 @@ def committed_traffic(cfg, B, H, W, D):
     """HBM bytes per step of the DP kernels from the committed PMC passes (profiles/rNN_traffic.json,
     newest round first; counters cannot be read from inside the timed run), or None when no profile
     was taken on this mode / shape / batch.  Returns (bytes, file name)."""
+    t, name = committed_profile(cfg, B, H, W, D)
+    if t is None:
+        return None, None
+    return (2.0 * t["fetch_size_kb"] + t["write_size_kb"]) * 1024.0, name
+
+
+def committed_profile(cfg, B, H, W, D):
+    """The newest profiles/rNN_traffic.json entry of this mode / shape / batch (or None)."""
     prof = os.path.join(ROOT, "profiles")
-    for name in ("r03_traffic.json", "r02_traffic.json"):
+    for name in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json"):
         try:
             with open(os.path.join(prof, name)) as fh:
                 t = json.load(fh).get("pairwise" if cfg.pairwise else "unary")
@@ -151,8 +159,23 @@ def committed_traffic(cfg, B, H, W, D):
             continue
         if not t or (t["batch"], t["rows"], t["cols"], t["max_dis"]) != (B, H, W, D):
             continue
-        return (2.0 * t["fetch_size_kb"] + t["write_size_kb"]) * 1024.0, name
+        return t, name
     return None, None
+
+
+def committed_valu(cfg, B, H, W, D):
+    """VALU issue fraction of the dominant DP kernel from the committed PMC passes:
+    the path's true roofline -- it is bound by vector issue, not by HBM."""
+    t, name = committed_profile(cfg, B, H, W, D)
+    v = (t or {}).get("valu")
+    if not v:
+        return None
+    return {"issue_frac": v.get("issue_frac"), "issue_frac_pmc_upper": v["issue_frac_pmc_upper"],
+            "kernel": v["kernel"], "sq_insts_valu": v["sq_insts_valu"],
+            "sq_active_inst_valu_quadcycles": v["sq_active_inst_valu_quadcycles"],
+            "kernel_cycles": v["kernel_cycles_grbm_gui_active_over_8"],
+            "isa_cycles_per_valu_inst": v["isa_cycles_per_valu_inst"], "formula": v["formula"],
+            "source": f"profiles/{name}"}
 
 
 class Workload:
@@ -314,7 +337,7 @@ def dp_kernel_name(cfg):
             else "k_dp_unary_fast (FAST columns; k_dp_unary takes generic columns: none here)")
 
 
-def measure_mode(wl, steps=3, with_pruning_off=True, with_verify=True, with_prune=True):
+def measure_mode(wl, steps=3, with_pruning_off=True, with_verify=True, with_prune=True, with_single=False):
     """images/s, DP time, roofline, pruning statistics, pruning-off figure and oracle check of one
     workload -- the fields a non-default mode / shape reports under `variants`."""
     core = wl.make_core()
@@ -324,11 +347,23 @@ def measure_mode(wl, steps=3, with_pruning_off=True, with_verify=True, with_prun
     traffic, tfile = committed_traffic(wl.cfg, wl.B, wl.H, wl.W, wl.D)
     out = {"preset_pairwise": bool(wl.cfg.pairwise), "batch": wl.B, "images_per_s": wl.B / dt,
            "ms_per_step": dt * 1e3, "dp_ms": kt["dp_ms"], "kernel_ms": kt, "steps": steps,
-           "roofline": wl.roofline(kt["dp_ms"], dp_kernel_name(wl.cfg), traffic, tfile)}
+           "roofline": wl.roofline(kt["dp_ms"], dp_kernel_name(wl.cfg), traffic, tfile),
+           "valu": committed_valu(wl.cfg, wl.B, wl.H, wl.W, wl.D)}
     if with_verify:
         out["verify"] = wl.verify(wl.d_sections, images=[0, wl.B - 1] if wl.B > 1 else [0])
     if with_prune:
         out["prune"] = wl.prune_stats(core)
+    if with_single and wl.B > 1:   # BASELINE configs[1]: ONE frame per call, the latency a per-frame caller sees
+        for _ in range(5):
+            wl.step(core, n=1)
+        wl.torch.cuda.synchronize(wl.dev)
+        t1 = time.perf_counter()
+        for _ in range(50):
+            wl.step(core, n=1)
+        wl.torch.cuda.synchronize(wl.dev)
+        single = (time.perf_counter() - t1) / 50
+        out["single_frame"] = {"workload": "BASELINE configs[1]: one frame per call (batch 1), device-resident "
+                                           "in/out", "images_per_s": 1.0 / single, "ms_per_frame": single * 1e3}
     core.close()
     if with_pruning_off:
         core = wl.make_core(env={"IS_NO_PRUNE": "1"})
@@ -337,6 +372,41 @@ def measure_mode(wl, steps=3, with_pruning_off=True, with_verify=True, with_prun
         out["pruning_off"] = {"images_per_s": wl.B / dt0, "dp_ms": core.kernel_times_ms()["dp_ms"]}
         core.close()
     return out
+
+
+EXTRA_FAMILIES = ("iid_noise", "low_confidence", "flat_disparity", "homogeneous", "many_thin_objects",
+                  "noisy_disparity")
+
+
+def measure_families(preset, H, W, D, B, dev, local_rank):
+    """images/s and what the branch-and-bound evaluated on the other input families of
+    synthetic.make_frame (the headline family is "scene"), same preset, shape and batch."""
+    import torch
+    fam = {}
+    for name in EXTRA_FAMILIES:
+        wf = Workload(preset, H, W, D, B, 2, dev, local_rank, family=name)
+        core = wf.make_core()
+        dtf = wf.time_steps(core, 3)
+        ps = wf.prune_stats(core)
+        fam[name] = {"images_per_s": B / dtf, "evaluated_frac": ps["evaluated_frac"],
+                     "full_eval_frac": ps["full_eval_frac"]}
+        core.close(); wf.free(); del wf
+        torch.cuda.empty_cache()
+    fam["what"] = ("synthetic.make_frame(family=...): iid_noise = every class logit N(0,1), no scene in "
+                   "the segmentation; low_confidence = true-class logit +1..2 instead of +4..5; "
+                   "flat_disparity = the scene's segmentation over constant + U(0,1) disparity; "
+                   "homogeneous = road below the horizon, sky above, no object, confident CNN (logit +8..9); "
+                   "many_thin_objects = sixty slabs 8..24 px wide; noisy_disparity = the scene with N(0,3) "
+                   "disparity noise; 2 distinct frames repeated to the batch")
+    return fam
+
+
+def floor_over_families(scene_value, fam):
+    """The smallest images/s over every measured input family (the headline family included)."""
+    vals = {"scene": scene_value}
+    vals.update({k: v["images_per_s"] for k, v in fam.items() if isinstance(v, dict)})
+    worst = min(vals, key=vals.get)
+    return {"images_per_s": vals[worst], "family": worst, "families_measured": sorted(vals)}
 
 
 def measure_variants(args, wl, dev, local_rank):
@@ -380,22 +450,8 @@ def measure_variants(args, wl, dev, local_rank):
     core.close(); wi.free(); del wi
     torch.cuda.empty_cache()
 
-    # ---- other input families (SURVEY.md 8d generator + three harder ones)
-    fam = {}
-    for name in ("iid_noise", "low_confidence", "flat_disparity"):
-        wf = Workload(args.preset, H, W, D, B, 2, dev, local_rank, family=name)
-        core = wf.make_core()
-        dtf = wf.time_steps(core, 3)
-        ps = wf.prune_stats(core)
-        fam[name] = {"images_per_s": B / dtf, "evaluated_frac": ps["evaluated_frac"],
-                     "full_eval_frac": ps["full_eval_frac"]}
-        core.close(); wf.free(); del wf
-        torch.cuda.empty_cache()
-    fam["what"] = ("synthetic.make_frame(family=...): iid_noise = every class logit N(0,1), no scene in "
-                   "the segmentation; low_confidence = true-class logit +1..2 instead of +4..5; "
-                   "flat_disparity = the scene's segmentation over constant + U(0,1) disparity; "
-                   "2 distinct frames repeated to the batch")
-    out["families"] = fam
+    # ---- other input families (SURVEY.md 8d generator + six harder / different ones)
+    out["families"] = measure_families(args.preset, H, W, D, B, dev, local_rank)
 
     # ---- every column in the generic encoding: one negative class value per column
     wg = Workload(args.preset, H, W, D, B, args.distinct, dev, local_rank)
@@ -413,10 +469,12 @@ def measure_variants(args, wl, dev, local_rank):
     if other:
         wo = Workload(other, H, W, D, B, args.distinct, dev, local_rank)
         key = ("pairwise" if wo.cfg.pairwise else "unary") + f"_batch{B}"
-        out[key] = measure_mode(wo, steps=3)
+        out[key] = measure_mode(wo, steps=3, with_single=True)
         out[key]["preset"] = other
         wo.free(); del wo
         torch.cuda.empty_cache()
+        out[key]["families"] = measure_families(other, H, W, D, B, dev, local_rank)
+        out[key]["value_floor_families"] = floor_over_families(out[key]["images_per_s"], out[key]["families"])
 
     # ---- BASELINE configs[4]: 1024x4096 frames, 256 disparity bins, both models
     c5 = {}
@@ -694,7 +752,8 @@ def main():
                                        "sections to rank 0, overlapped with the next step")
                                       if world > 1 else "single GPU"},
             "roofline": roof,
-            "valu": {"pair_evals_per_s": (pairs_img * B * prune["evaluated_frac"] / dp_s) if prune else None,
+            "valu": {**(committed_valu(cfg, B, H, W, D) or {"issue_frac": None}),
+                     "pair_evals_per_s": (pairs_img * B * prune["evaluated_frac"] / dp_s) if prune else None,
                      "pair_evals_per_s_nominal": pairs_img * B / dp_s,
                      "pair_evals_per_image_nominal": pairs_img,
                      "lane_ops_peak_per_s": VALU_PEAK_LANEOPS,
@@ -722,6 +781,10 @@ def main():
         if variants is not None:
             out["variants"] = variants
             out["value_incl_instances"] = variants["with_instances"]["images_per_s"]
+            # how far the headline can fall on inputs unlike the generator's: the slowest of the seven
+            # input families, and the data-independent floor (pruning off), side by side with `value`
+            out["value_floor_families"] = floor_over_families(value, variants["families"])
+            out["value_pruning_off"] = variants["pruning_off"]["images_per_s"]
         if cpu is not None:
             out["cpu_baseline"] = cpu
     else:

@@ -38,7 +38,8 @@ def rows_power2_segmentation(rows: int) -> int:  # Stixels.cu:132-133
     return int(2 ** math.ceil(math.log2(rows // 8 + 1)))
 
 
-FAMILIES = ("scene", "iid_noise", "low_confidence", "flat_disparity")
+FAMILIES = ("scene", "iid_noise", "low_confidence", "flat_disparity", "homogeneous", "many_thin_objects",
+            "noisy_disparity")
 
 
 def make_frame(cfg: StixelConfig, seed: int = 0, n_slabs: int = 6, hole_fraction: float = 0.05,
@@ -49,8 +50,14 @@ def make_frame(cfg: StixelConfig, seed: int = 0, n_slabs: int = 6, hole_fraction
     scene at all; "low_confidence" -- the true class's logit is only 1 .. 2 above the N(0, 1)
     rest (a hesitant CNN: class sums separate slowly, the branch-and-bound prunes late);
     "flat_disparity" -- the scene's segmentation over a disparity image without structure
-    (constant + U(0, 1) everywhere).  The value range of the class channels is that of the
-    reference's CNN wrapper, 8 * -log_softmax (wrappers.py:50-60).
+    (constant + U(0, 1) everywhere); "homogeneous" -- road below the horizon, sky above, no object
+    at all and a confident CNN (true-class logit +8 .. 9: the class values are 0 almost
+    everywhere), the long uniform stretches in which every split is a near-optimal candidate;
+    "many_thin_objects" -- about sixty object slabs 8 .. 24 px wide (a crowd / pole scene: hardly a
+    column without an object, many short segments); "noisy_disparity" -- the scene with
+    N(0, 3) disparity noise on every pixel (a poor stereo matcher: the data terms carry little).
+    The value range of the class channels is that of the reference's CNN wrapper,
+    8 * -log_softmax (wrappers.py:50-60).
 
     offset_scale: the offset channels hold int(offset_scale * offset in full-resolution
     pixels).  The kernel adds the channel value to the pixel position as it is
@@ -84,8 +91,17 @@ def make_frame(cfg: StixelConfig, seed: int = 0, n_slabs: int = 6, hole_fraction
     centre_y = np.zeros((H, W), np.float32)
     has_obj = np.zeros((H, W), bool)
     obj_classes = [2, 5, 8, 11, 13, 12, 17, 18, 14, 3]
+    if family not in FAMILIES:
+        raise ValueError(f"unknown input family {family!r}")
+    if family == "homogeneous":
+        n_slabs = 0
+    elif family == "many_thin_objects":
+        n_slabs = 60
     for s in range(n_slabs):
-        w = int(rng.integers(max(8, W // 40), max(9, W // 8)))
+        if family == "many_thin_objects":
+            w = int(rng.integers(8, 25))
+        else:
+            w = int(rng.integers(max(8, W // 40), max(9, W // 8)))
         x0 = int(rng.integers(0, max(1, W - w)))
         foot = int(rng.integers(vhor_img + max(2, H // 16), H))          # image row of the foot
         top = int(rng.integers(max(0, vhor_img - H // 3), max(1, foot - H // 16)))
@@ -96,10 +112,10 @@ def make_frame(cfg: StixelConfig, seed: int = 0, n_slabs: int = 6, hole_fraction
         has_obj[top:foot, x0:x0 + w] = cls >= 11
         centre_x[top:foot, x0:x0 + w] = x0 + 0.5 * w
         centre_y[top:foot, x0:x0 + w] = 0.5 * (top + foot)
-    if family not in FAMILIES:
-        raise ValueError(f"unknown input family {family!r}")
     if family == "flat_disparity":   # keep only the U(0, 1) part of every pixel
         disp = np.float32(D // 3) + (disp - np.floor(disp))
+    if family == "noisy_disparity":
+        disp = disp + rng.normal(0.0, 3.0, (H, W)).astype(np.float32)
     disp = np.clip(disp, 0.0, D - 1.01).astype(np.float32)
     if cfg.invalid_disparity >= 0 and hole_fraction > 0:
         holes = rng.random((H, W)) < hole_fraction
@@ -115,7 +131,7 @@ def make_frame(cfg: StixelConfig, seed: int = 0, n_slabs: int = 6, hole_fraction
         lab = label[np.ix_(ys, xs)]                                     # [Hs][C]
         logits = rng.normal(0.0, 1.0, (Hs, C, K)).astype(np.float32)
         if family != "iid_noise":
-            true_logit = 1.0 if family == "low_confidence" else 4.0
+            true_logit = {"low_confidence": 1.0, "homogeneous": 8.0}.get(family, 4.0)
             np.put_along_axis(logits, lab[..., None],
                               np.float32(true_logit) + rng.random((Hs, C, 1), dtype=np.float32), axis=2)
         logits -= logits.max(axis=2, keepdims=True)
