@@ -618,7 +618,7 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
     const RowRec my = load_rec(rcol + vTc + 1);
 #endif
 #endif
-    const float* my_tile = s_tile + lane * DP;
+    const float* my_tile = s_tile + IS_TILE_ROW(lane) * DP;
     const bool live = vT < H;
     /* lemma L7: per-lane thresholds (order-preserving keys, +inf) and the two survive masks */
     unsigned* s_thr = (unsigned*)(s_scr + 8 * nwl); /* [2][64] + [4] */

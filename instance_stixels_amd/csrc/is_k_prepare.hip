@@ -6,6 +6,9 @@
 /* A4-A6  per-column preparation                                                           */
 /* ====================================================================================== */
 #define PREP_THREADS 256
+#ifndef PREP_STORE_LATE
+#define PREP_STORE_LATE 1
+#endif
 
 /* LDS stride of a segmentation channel: H/8 + 1 prefix entries, rounded up to 16 bytes */
 __host__ __device__ static inline int prep_seg_stride(int H) { return (((H >> 3) + 1) + 3) & ~3; }
@@ -254,23 +257,35 @@ __device__ __forceinline__ void prepare_columns_body(
     int64_t base_mx2 = block_excl_scan_i64(sum_mx2, s_wave);
     int64_t base_my2 = block_excl_scan_i64(sum_my2, s_wave);
     /* the owner of rows [r_lo, r_lo+R) writes the exclusive prefix at those indices; the owner
-     * of row H-1 also writes index H (the total) */
-    for (int r = r_lo; r < r_lo + R && r < H; r++) {
-        store_instance_prefix(rcol + r, slow, base_mx, base_my, base_mx2, base_my2);
-        const double fx = ((double)(P.column_step * col) + 0.5 * ((double)P.column_step - 1.0)) +
-                          (double)offx[r >> 3] + 0.5;
-        const int64_t mx = (int64_t)fx;
-        const int32_t n32 = (int32_t)((uint32_t)r - (uint32_t)offy[r >> 3]);
-        const int64_t my = (int64_t)((double)n32 + 0.5);
-        base_mx += mx;
-        base_my += my;
-        base_mx2 = (int64_t)((uint64_t)base_mx2 + (uint64_t)mx * (uint64_t)mx);
-        base_my2 = (int64_t)((uint64_t)base_my2 + (uint64_t)my * (uint64_t)my);
-    }
-    if (r_lo <= H - 1 && H - 1 < r_lo + R) {
-        store_instance_prefix(rcol + H, slow, base_mx, base_my, base_mx2, base_my2);
-        s_tot[0] = (float)((double)base_mx2 + (double)base_my2); /* column totals (PruneRec.E2) */
-    }
+     * of row H-1 also writes index H (the total).  PREP_STORE_LATE: every piece of a 128-byte record
+     * (instance prefixes, class chunks, the four fp32 prefixes) is stored at the END of the kernel,
+     * back to back, so that the pieces of a line meet in the L2 instead of reaching the memory as
+     * eight partial writes spread over the workgroup's life. */
+    /* (the raw offsets from the input tensor: the LDS copies are squared in place further down) */
+    auto offx_raw = [&](int i) -> int32_t { return scol[(K + 1) * P2S + i]; };
+    auto offy_raw = [&](int i) -> int32_t { return scol[K * P2S + i]; };
+    auto instance_rows = [&](bool store) {
+        int64_t bx = base_mx, by = base_my, bx2 = base_mx2, by2 = base_my2;
+        for (int r = r_lo; r < r_lo + R && r < H; r++) {
+#ifndef PREP_ABL_NOSTORE_INST
+            if (store) store_instance_prefix(rcol + r, slow, bx, by, bx2, by2);
+#endif
+            const double fx = ((double)(P.column_step * col) + 0.5 * ((double)P.column_step - 1.0)) +
+                              (double)offx_raw(r >> 3) + 0.5;
+            const int64_t mx = (int64_t)fx;
+            const int32_t n32 = (int32_t)((uint32_t)r - (uint32_t)offy_raw(r >> 3));
+            const int64_t my = (int64_t)((double)n32 + 0.5);
+            bx += mx;
+            by += my;
+            bx2 = (int64_t)((uint64_t)bx2 + (uint64_t)mx * (uint64_t)mx);
+            by2 = (int64_t)((uint64_t)by2 + (uint64_t)my * (uint64_t)my);
+        }
+        if (r_lo <= H - 1 && H - 1 < r_lo + R) {
+            if (store) store_instance_prefix(rcol + H, slow, bx, by, bx2, by2);
+            s_tot[0] = (float)((double)bx2 + (double)by2); /* column totals (PruneRec.E2) */
+        }
+    };
+    instance_rows(!PREP_STORE_LATE);
     __syncthreads();
 
     /* ---- square the offset channels in place (StixelsKernels.cu:411-416), then exclusive
@@ -328,6 +343,7 @@ __device__ __forceinline__ void prepare_columns_body(
         }
     }
     __syncthreads();
+    auto class_chunks = [&]() {
     /* dwords 0..19 of every record (class prefixes + squared-offset prefix) as five 16-byte
      * chunks.  A thread owns one chunk of the EIGHT rows of a 1/8-resolution block: the full-resolution
      * prefix at row 8 kb + m is ps[kb] * 8 + (ps[kb + 1] - ps[kb]) * m (full_prefix, wrapping
@@ -369,11 +385,15 @@ __device__ __forceinline__ void prepare_columns_body(
                         x[j] = (slow || (is_count && j == 3)) ? f : __float_as_int((float)f);
                         cur[j] += dif[j];
                     }
+#ifndef PREP_ABL_NOSTORE_CLASS
                     reinterpret_cast<int4*>(rcol + v)[q] = make_int4(x[0], x[1], x[2], x[3]);
+#endif
                 }
             }
         }
     }
+    };
+    if (!PREP_STORE_LATE) class_chunks();
 
     /* ---- fp32 prefixes with the reference's block-scan association (:452-461).  A thread keeps
      * the four prefixes of its rows (v = tid + k * PREP_THREADS) and writes dwords 20..23 of the
@@ -501,11 +521,17 @@ __device__ __forceinline__ void prepare_columns_body(
             const int v = tid + k * PREP_THREADS;
             if (v <= H) {
                 pK[k] = prefix_at(v);
+#ifndef PREP_ABL_NOSTORE_F4
                 reinterpret_cast<float4*>(rcol + v)[5] = make_float4(pG[k], pK[k], pS[k], pV[k]);
+#endif
             }
         }
     } else {
         for (int v = tid; v <= H; v += PREP_THREADS) rcol[v].K = prefix_at(v);
+    }
+    if (PREP_STORE_LATE) {
+        class_chunks();
+        instance_rows(true);
     }
 }
 

@@ -298,7 +298,7 @@ __global__ __launch_bounds__(ISF_THREADS, HAS_INVALID ? ISF_OCC_INV : ISF_OCC) v
         b.g = cost_table[o + 0]; b.o = cost_table[o + 1]; b.s = cost_table[o + 2];
         b.vg = index_table[o + 0]; b.vo = index_table[o + 1]; b.vs = index_table[o + 2];
     }
-    const float* my_tile = s_tile + lane * DP;
+    const float* my_tile = s_tile + IS_TILE_ROW(lane) * DP;
     const bool nog = IS_SKIP_GROUND_ABOVE_HORIZON && tile_lo >= vhor;
     __syncthreads(); /* the tile and the 1/h table: the only data the waves share */
     ISF_MARK(0);

@@ -195,6 +195,17 @@ __device__ __forceinline__ RowRec load_rec(const RowRec* p) {
     return r;
 }
 
+/* LDS row of the vT-side tile that holds lutT row tile_lo + 1 + r.  A lane l reads column fni of ITS
+ * row, i.e. bank (row(l) * (D + 1) + fni) mod 64 = (row(l) + fni) mod 64 when D is a multiple of 64.
+ * On a ground ramp fni FALLS as the row rises, so with row(l) = l the sum l + fni is nearly constant
+ * across the lanes: the padding skews the wrong way (38 % of the unary kernel's LDS cycles were
+ * conflict cycles).  IS_TILE_FLIP stores the rows in reverse order, row(l) = 63 - l: the bank becomes
+ * fni - l, which spreads. */
+#ifndef IS_TILE_FLIP
+#define IS_TILE_FLIP 0 /* measured (round 4): SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE 0.376 flipped vs 0.381, same DP time: the lanes' fni differ by far less than one per row, either skew spreads them */
+#endif
+#define IS_TILE_ROW(r) (IS_TILE_FLIP ? (IS_TILE - 1 - (r)) : (r))
+
 /* lutT rows tile_lo+1 .. tile_lo+64 of a column into the LDS tile (row stride D+1).  When the
  * workgroup covers whole rows per sweep (nthreads a multiple of D) a thread keeps its column and
  * walks the rows: no per-element division.  QUADS: 16-byte loads (needs D % 4 == 0 and
@@ -223,7 +234,7 @@ __device__ __forceinline__ void stage_lut_tile(float* s_tile, const float* __res
             for (int k = 0; k < 4; k++) {
                 const int r = rb + k * dr;
                 if (r < IS_TILE) {
-                    float* d = s_tile + r * DP + f;
+                    float* d = s_tile + IS_TILE_ROW(r) * DP + f;
                     d[0] = x[k].x; d[1] = x[k].y; d[2] = x[k].z; d[3] = x[k].w;
                 }
             }
@@ -241,14 +252,14 @@ __device__ __forceinline__ void stage_lut_tile(float* s_tile, const float* __res
 #pragma unroll
             for (int k = 0; k < 8; k++) {
                 const int r = rb + k * dr;
-                if (r < IS_TILE) s_tile[r * DP + f] = x[k];
+                if (r < IS_TILE) s_tile[IS_TILE_ROW(r) * DP + f] = x[k];
             }
         }
     } else {
         for (int i = tid; i < IS_TILE * D; i += nthreads) {
             const int r = i / D, f = i - r * D;
             const int v = min(tile_lo + 1 + r, H);
-            s_tile[r * DP + f] = lcol[(size_t)v * D + f];
+            s_tile[IS_TILE_ROW(r) * DP + f] = lcol[(size_t)v * D + f];
         }
     }
 }
@@ -275,11 +286,12 @@ __device__ __forceinline__ void gen_lut_tile(float* s_tile, const float* __restr
         const bool fn_ok = fn < D;
         const int fnc = fn_ok ? fn : D - 1;
         const int i = tile_lo + LB * blk; /* the block's first row */
-        float* dst = s_tile + (size_t)(LB * blk) * DP + fn;
+        float* dst = s_tile + fn; /* row LB * blk + l at IS_TILE_ROW(LB * blk + l) */
+        const int row0 = LB * blk;
         const float vH = (i + LB > H) ? lcol[(size_t)H * D + fnc] : 0.0f; /* rows beyond the image */
         if (i >= H) {
             if (fn_ok)
-                for (int l = 0; l < LB; l++) dst[l * DP] = vH;
+                for (int l = 0; l < LB; l++) dst[IS_TILE_ROW(row0 + l) * DP] = vH;
             continue;
         }
         const int rl = i + (lane & (LB - 1));
@@ -300,7 +312,7 @@ __device__ __forceinline__ void gen_lut_tile(float* s_tile, const float* __restr
         }
         if (fn_ok) {
 #pragma unroll
-            for (int l = 0; l < LB; l++) dst[l * DP] = (i + l < H) ? c[l] : vH;
+            for (int l = 0; l < LB; l++) dst[IS_TILE_ROW(row0 + l) * DP] = (i + l < H) ? c[l] : vH;
         }
     }
 }
@@ -318,6 +330,9 @@ __device__ __forceinline__ void stage_rcp(float* s_rcp, const float* __restrict_
     }
 }
 
+#ifndef IS_STAGE_SPREAD
+#define IS_STAGE_SPREAD 1
+#endif
 /* The tile and the 1/h table behind ONE memory round trip: staged one after the other, the
  * second one's loads are only issued after the first one's vmcnt(0) wait (measured in the unary
  * ring kernel: 19 % + 15 % of a workgroup's life for the two).  Common shapes (16-byte path of
@@ -335,15 +350,27 @@ __device__ __forceinline__ void stage_tile_and_rcp(float* s_tile, float* s_rcp,
         return;
     }
     const int DP = D + 1;
-    const int r0 = tid / quads, f = (tid - r0 * quads) * 4;
-    const int dr = nthreads / quads;
     float rc[4];
     float4 x[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) rc[k] = rcp[min(tid + k * nthreads, H)];
+#if IS_STAGE_SPREAD
+    /* D = 128, 512 threads: a group of 8 lanes takes one 128-byte line, a wave 8 ROWS x 8 chunks, its four
+     * loads the four quarters of those rows: the dword stores below then hit banks (row + 4 chunk + j)
+     * mod 32 -- 8 rows x 8 chunks spread over all of them -- instead of one row's 32 chunks at a stride
+     * of four dwords (4-way conflicts on every staging store) */
+    const bool spread = quads == 32 && nthreads == 8 * IS_TILE;
+    const int sr = (tid >> 6) * 8 + ((tid & 63) >> 3), sq = tid & 7;
+#else
+    const bool spread = false;
+    const int sr = 0, sq = 0;
+#endif
+    const int r0 = tid / quads, f0 = (tid - r0 * quads) * 4;
+    const int dr = nthreads / quads;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        const int r = min(r0 + k * dr, IS_TILE - 1);
+        const int r = spread ? sr : min(r0 + k * dr, IS_TILE - 1);
+        const int f = spread ? (sq + 8 * k) * 4 : f0;
         x[k] = *reinterpret_cast<const float4*>(lcol + (size_t)min(tile_lo + 1 + r, H) * D + f);
     }
 #pragma unroll
@@ -351,9 +378,10 @@ __device__ __forceinline__ void stage_tile_and_rcp(float* s_tile, float* s_rcp,
         if (tid + k * nthreads <= H) s_rcp[tid + k * nthreads] = rc[k];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        const int r = r0 + k * dr;
+        const int r = spread ? sr : r0 + k * dr;
+        const int f = spread ? (sq + 8 * k) * 4 : f0;
         if (r < IS_TILE) {
-            float* d = s_tile + r * DP + f;
+            float* d = s_tile + IS_TILE_ROW(r) * DP + f;
             d[0] = x[k].x; d[1] = x[k].y; d[2] = x[k].z; d[3] = x[k].w;
         }
     }
