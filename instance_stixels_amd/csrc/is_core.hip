@@ -137,7 +137,7 @@ struct is_ctx {
     float* d_part_cost;      /* [max_batch*C][3][64] merged partial minima of the current tile */
     int* d_part_idx;         /* [max_batch*C][3][64] */
     float* d_sv;             /* [max_batch*C][2][H+1] compact S / V prefixes */
-    float* d_blksum;         /* [max_batch*C][ntiles+1][8] block summaries of the pairwise DP (lemma L7) */
+    float* d_blksum;         /* [max_batch*C][ntiles*IS_QPT+1][8] bound-block summaries of the pairwise DP (lemma L7) */
     float* d_cost_table;     /* [max_batch*C][H][3] */
     int32_t* d_index_table;  /* [max_batch*C][H][3] */
     size_t scratch_bytes;
@@ -370,7 +370,7 @@ static int ctx_init(is_ctx* c, const is_stixel_params* p, const float* obj_cost_
     ALLOC(c->d_part_cost, sizeof(float) * part_slots * 3 * 64);
     ALLOC(c->d_part_idx, sizeof(int) * part_slots * 3 * 64);
     ALLOC(c->d_sv, sizeof(float) * B * C * 2 * (H + 1));
-    ALLOC(c->d_blksum, sizeof(float) * B * C * ((size_t)d.ntiles + 1) * 8);
+    ALLOC(c->d_blksum, sizeof(float) * B * C * ((size_t)d.ntiles * IS_QPT + 1) * 8);
     ALLOC(c->d_cost_table, sizeof(float) * B * C * H * 3);
     ALLOC(c->d_index_table, sizeof(int32_t) * B * C * H * 3);
     ALLOC(c->d_cluster_scratch, sizeof(int32_t) * B * IS_INSTANCE_CLASSES * 2 * C * (size_t)d.S);

@@ -31,6 +31,17 @@
 #define IS_SKIP_GROUND_ABOVE_HORIZON 1 /* tiles above the horizon: ground candidates cost +inf, skip them */
 #endif
 #define IS_TILE 64
+/* Rows per BOUND BLOCK of the pairwise branch-and-bound (lemmas L6 / L7): the running
+ * minima q of the StepRecs restart, the pre-pass of phase 1 evaluates a block top, and phase 2 leaves
+ * a separable summary every IS_QB candidate rows.  A bound loses up to one block of accumulated path
+ * cost, so smaller blocks close a type sooner but cost more block tops per tile (64: the tile, round
+ * 3; 32 measured best in round 4).  Block j >= 1 = the candidate rows IS_QB (j - 1) + 1 .. IS_QB j,
+ * block 0 = the first segment vB = 0. */
+#ifndef IS_QB_LOG
+#define IS_QB_LOG 5
+#endif
+#define IS_QB (1 << IS_QB_LOG)
+#define IS_QPT (IS_TILE / IS_QB) /* bound blocks per tile */
 #define IS_PW_MAX_SPLIT 4            /* phase-1 workgroups per (column, tile) at small batches */
 #define IS_PW_SPLIT_TARGET_WGS 1024 /* partial-minima slots reserved for the split phase 1 */
 #ifndef IS_PW_SPLIT_MAX_COLS

@@ -312,7 +312,11 @@ __device__ __forceinline__ L7Row l7_never() {
 #ifndef IS_P1_L7
 #define IS_P1_L7 1
 #endif
-#define IS_P1_L7_WORDS 136 /* LDS words of the exchange: [2][64] threshold keys + 2 masks, padded */
+#define IS_P1_L7_WORDS 136 /* LDS words of the exchange: [2][64] threshold keys + 2 x 64-bit masks, padded */
+/* LDS words per bound block of a phase-1 launch: 64 object bounds + the 32-dword record at its top + q_o + the
+ * 8-float summary (+ 3 for the alignment of the arrays) */
+#define IS_P1_BLK_WORDS (64 + 32 + 1 + 8 + 1)
+static_assert(IS_QB_LOG >= 3 && IS_QB_LOG <= 5, "bound blocks: 8 .. 32 rows (a phase of k_pw_phase2x holds 32 rows)");
 struct L7B { float lo_g0, lo_g1, lo_s, hi_g0, hi_g1, hi_s; };
 __device__ __forceinline__ void l7_b(float dterm, float fterm, float* lo, float* hi) {
     const float b = dterm + fterm;
@@ -330,7 +334,7 @@ __device__ __forceinline__ L7B l7_lane_bounds(const DevParams& P, const RowRec& 
     l7_b(dk, P.sw * (my.Fsky + n), &b.lo_s, &b.hi_s);
     return b;
 }
-/* summary of block k (wave-uniform, scalar loads); block 0 = the first segment: a ground candidate
+/* summary of block k (wave-uniform); block 0 = the first segment: a ground candidate
  * with T = pw * first_g and every prefix 0 (:196-199, :481-594) */
 __device__ __forceinline__ L7Row l7_block_summary(const DevParams& P, const float* bcol, int k) {
     L7Row m;
@@ -338,11 +342,11 @@ __device__ __forceinline__ L7Row l7_block_summary(const DevParams& P, const floa
         l7_ab(P.pw * P.first_g, 0.0f, 0.0f, &m.lo_g0, &m.hi_g0);
         m.lo_g1 = m.lo_g0; m.hi_g1 = m.hi_g0;
         m.lo_s = m.hi_s = IS_INF;
-    } else {
-        typedef const __attribute__((address_space(4))) float* cflt_t;
-        cflt_t q = (cflt_t)(bcol + (size_t)k * IS_L7_F);
-        m.lo_g0 = q[0]; m.lo_g1 = q[1]; m.lo_s = q[2];
-        m.hi_g0 = q[4]; m.hi_g1 = q[5]; m.hi_s = q[6];
+    } else { /* (bcol: the LDS copy of the column's summaries: broadcast reads) */
+        const float4 a = *reinterpret_cast<const float4*>(bcol + (size_t)k * IS_L7_F);
+        const float4 c = *reinterpret_cast<const float4*>(bcol + (size_t)k * IS_L7_F + 4);
+        m.lo_g0 = a.x; m.lo_g1 = a.y; m.lo_s = a.z;
+        m.hi_g0 = c.x; m.hi_g1 = c.y; m.hi_s = c.z;
     }
     return m;
 }
@@ -610,6 +614,31 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
     const RowRec my = load_rec(rcol + vTc + 1);
     stage_rcp(s_rcp, rcp, H, tid, (int)blockDim.x);
 #else
+    /* What the pre-pass of the branch-and-bound reads -- the records at the tops of the lower bound
+     * blocks, their running minima q_o and the separable block summaries (lemma L7) -- is requested
+     * HERE, in front of the tile staging, and lands in LDS with it: one memory round trip for the
+     * whole prologue instead of one per block top and summary (each wave used to chase its tops
+     * through scalar loads one after the other: the 0.25 ms floor of a launch is a chain of such
+     * round trips). */
+    const int NLB = tile * IS_QPT + 1; /* bound blocks 0 .. tile * IS_QPT of this tile's candidates */
+    float* s_lb = s_scr + 8 * nwl + IS_P1_L7_WORDS;   /* [NLB][64 lanes] object block bounds      */
+    float* s_pre = s_lb + NLB * 64;                   /* [NLB][32] records at the block tops       */
+    float* s_preq = s_pre + NLB * 32;                 /* [NLB -> x4] q_o at the block tops         */
+    float* s_sum = s_preq + ((NLB + 3) & ~3);         /* [NLB][8] block summaries                  */
+    const float* bcol = blksum + (size_t)colg * (P.ntiles * IS_QPT + 1) * IS_L7_F;
+    constexpr int PRE_N = 2; /* record dwords per thread and round: (NLB - 1) * 32 <= PRE_N * nthreads at 1024 rows */
+    float pre_v[PRE_N], pre_q = 0.0f, pre_s = 0.0f;
+    const int nthr = (int)blockDim.x;
+    const bool pre_regs = FAST && IS_PRUNE && (NLB - 1) * 32 <= PRE_N * nthr && NLB * 8 <= nthr;
+    if (pre_regs) {
+#pragma unroll
+        for (int j = 0; j < PRE_N; j++) {
+            const int i = tid + j * nthr;
+            pre_v[j] = (i < (NLB - 1) * 32) ? ((const float*)(rcol + (size_t)(i >> 5) * IS_QB))[i & 31] : 0.0f;
+        }
+        if (tid >= 1 && tid < NLB - 1) pre_q = ((const float*)(scol + (size_t)tid * IS_QB))[14]; /* StepRec.q_o */
+        if (tid >= 8 && tid < NLB * 8) pre_s = bcol[tid];
+    }
 #if IS_P1_MY_FIRST
     const RowRec my = load_rec(rcol + vTc + 1); /* requested with the tile: one memory round trip, not two */
     stage_tile_and_rcp(s_tile, s_rcp, lcol, rcp, tile_lo, H, D, tid, (int)blockDim.x);
@@ -617,6 +646,20 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
     stage_tile_and_rcp(s_tile, s_rcp, lcol, rcp, tile_lo, H, D, tid, (int)blockDim.x);
     const RowRec my = load_rec(rcol + vTc + 1);
 #endif
+    if (pre_regs) {
+#pragma unroll
+        for (int j = 0; j < PRE_N; j++) {
+            const int i = tid + j * nthr;
+            if (i < (NLB - 1) * 32) s_pre[i] = pre_v[j];
+        }
+        if (tid < NLB - 1) s_preq[tid] = pre_q;
+        if (tid < NLB * 8) s_sum[tid] = pre_s;
+    } else if (FAST && IS_PRUNE) { /* tall frames: plain loops */
+        for (int i = tid; i < (NLB - 1) * 32; i += nthr)
+            s_pre[i] = ((const float*)(rcol + (size_t)(i >> 5) * IS_QB))[i & 31];
+        for (int i = tid; i < NLB - 1; i += nthr) s_preq[i] = i >= 1 ? ((const float*)(scol + (size_t)i * IS_QB))[14] : 0.0f;
+        for (int i = tid; i < NLB * 8; i += nthr) s_sum[i] = i >= 8 ? bcol[i] : 0.0f;
+    }
 #endif
     const float* my_tile = s_tile + IS_TILE_ROW(lane) * DP;
     const bool live = vT < H;
@@ -654,15 +697,18 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
          * tile values of vB, no LUT access, no update) and leave, per type and block k, the
          * smallest bound of the blocks BELOW k in LDS (s_lb); the walk closes a type for good when
          * the bound of its own block and that entry both exceed the lane's best cost. */
-        float* s_lb = s_scr + 8 * nwl + IS_P1_L7_WORDS; /* [3 types][tile + 1][64 lanes] */
-        const int NLB = tile + 1;
+        /* (round 4: the BOUND blocks are IS_QB = 32 rows, half a tile -- see is_device.h; "64 k" above
+         * reads IS_QB k.  Only the OBJECT type keeps the per-block array s_lb; the ground / sky types
+         * close when their own block's bound holds and the separable summaries (lemma L7) leave no
+         * surviving block below.) */
         const unsigned long long dead = ~__builtin_amdgcn_ballot_w64(live);
         const unsigned long long gdead = dead | __builtin_amdgcn_ballot_w64(my.G == IS_INF);
         /* Separable block bounds of the ground / sky candidates (lemma L7, see l7_row_bounds): bit k
          * of mask_g / mask_s = block k may hold the winning ground / sky candidate of some lane of
          * this tile; the walk below never enters the other blocks.  Off (all ones) when the column's
-         * pruning is off or the column has more blocks than the masks have bits. */
-        unsigned mask_g = ~0u, mask_s = ~0u;
+         * pruning is off or the column has more blocks than the masks have bits (then the ground /
+         * sky types only close in block 0: slower, never wrong). */
+        unsigned long long mask_g = ~0ull, mask_s = ~0ull;
         L7B bl7;
         bool l7 = false;
         {
@@ -670,13 +716,12 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
             const float pE1o = pq0->E1o, pE2 = 3.0f * pq0->E2;
             const float pE1gs = __builtin_fmaxf(pq0->E1g, pq0->E1s);
             const bool pnog = IS_SKIP_GROUND_ABOVE_HORIZON && tile_lo >= vhor;
-            l7 = IS_P1_L7 && (pE1gs < IS_INF) && tile < 31;
-            const float* bcol = blksum + (size_t)colg * (P.ntiles + 1) * IS_L7_F;
+            l7 = IS_P1_L7 && (pE1gs < IS_INF) && NLB <= 63;
             if (l7) {
                 bl7 = l7_lane_bounds(P, my);
                 float thr_g = IS_INF, thr_s = IS_INF;
-                for (int k = wl; k <= tile; k += nwl) {
-                    const L7Row m = l7_block_summary(P, bcol, k);
+                for (int k = wl; k < NLB; k += nwl) {
+                    const L7Row m = l7_block_summary(P, s_sum, k);
                     float lbg, ubg, lbs, ubs;
                     l7_combine(m, bl7, &lbg, &ubg, &lbs, &ubs);
                     thr_g = __builtin_fminf(thr_g, ubg);
@@ -685,67 +730,60 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
                 if (!pnog && thr_g == thr_g) atomicMin(&s_thr[lane], l7_key(thr_g));
                 if (thr_s == thr_s) atomicMin(&s_thr[64 + lane], l7_key(thr_s));
             }
-            for (int k = wl; k < tile; k += nwl) { /* top of block k: vB = 64 k */
-                const int vBk = k * IS_TILE;
-                const RowRec rb = sload_rec(rcol + vBk);
+            for (int k = wl; k < NLB - 1; k += nwl) { /* top of block k: vB = IS_QB k */
+                const int vBk = k * IS_QB;
                 const int h = vTc + 1 - vBk;
-                const SegTerms t = eval_segment<true, HAS_INVALID>(my, rb, (float)h, s_rcp[h], D, P.iw);
-                float q_o, q_gs;
-                if (k == 0) { /* the first segment's priors, :189-199 */
+                /* (the record of vBk from its LDS copy, as DPP operands: eval_segment_dpp == eval_segment<true>;
+                 * only the object terms are needed) */
+                const float pR0 = s_pre[k * 32 + (lane & 15)], pR1 = s_pre[k * 32 + 16 + (lane & 15)];
+                const SegTerms t = eval_segment_dpp<HAS_INVALID, 0>(my, pR0, pR1, (float)h, s_rcp[h], D, P.iw);
+                float q_o;
+                if (k == 0) /* the first segment's priors, :189-199 */
                     q_o = P.pw * __builtin_fminf(P.first_o_below, P.first_o_above);
-                    q_gs = P.pw * P.first_g;
-                } else {
-                    cstep_t sq = (cstep_t)(scol + vBk);
-                    q_o = sq->q_o;
-                    q_gs = sq->q_gs;
-                }
-                /* ground candidates: rows with vB - 1 < vhor, sky candidates: vB - 1 >= vhor */
-                const bool has_g = !pnog && (k == 0 || vBk - IS_TILE < vhor);
-                const bool has_s = k >= 1 && vBk >= vhor + 1;
+                else
+                    q_o = s_preq[k];
                 float lb_o = (q_o - pE1o) + P.sw * seg_o_lower_bound(t, pE2);
-                float lb_g = has_g ? (q_gs - pE1gs) + P.sw * t.seg_g : IS_INF;
-                float lb_s = has_s ? (q_gs - pE1gs) + P.sw * t.seg_s : IS_INF;
                 /* a NaN bound (inf - inf with the pruning switched off, NaN inputs) must never
                  * close anything: -inf */
                 lb_o = (lb_o == lb_o) ? lb_o : -IS_INF;
-                lb_g = (lb_g == lb_g) ? lb_g : -IS_INF;
-                lb_s = (lb_s == lb_s) ? lb_s : -IS_INF;
-                s_lb[(0 * NLB + k) * 64 + lane] = lb_o;
-                s_lb[(1 * NLB + k) * 64 + lane] = lb_g;
-                s_lb[(2 * NLB + k) * 64 + lane] = lb_s;
+                s_lb[k * 64 + lane] = lb_o;
             }
             __syncthreads();
-            if (tid < 3 * 64) { /* entry k <- smallest bound of the blocks below k */
-                float* q = s_lb + (size_t)(tid >> 6) * NLB * 64 + lane;
+            if (tid < 64) { /* entry k <- smallest bound of the blocks below k */
+                float* q = s_lb + lane;
                 float run = IS_INF;
-                for (int k = 0; k < tile; k++) {
+                for (int k = 0; k < NLB - 1; k++) {
                     const float v = q[k * 64];
                     q[k * 64] = run;
                     run = (v < run) ? v : run;
                 }
-                q[tile * 64] = run;
+                q[(NLB - 1) * 64] = run;
             }
             if (l7) { /* a block survives when its lower bound reaches the threshold in some lane */
                 const float thr_g = l7_unkey(s_thr[lane]), thr_s = l7_unkey(s_thr[64 + lane]);
-                unsigned mg = 0u, ms = 0u;
-                for (int k = wl; k <= tile; k += nwl) {
-                    const L7Row m = l7_block_summary(P, bcol, k);
+                unsigned long long mg = 0ull, ms = 0ull;
+                for (int k = wl; k < NLB; k += nwl) {
+                    const L7Row m = l7_block_summary(P, s_sum, k);
                     float lbg, ubg, lbs, ubs;
                     l7_combine(m, bl7, &lbg, &ubg, &lbs, &ubs);
                     const bool has_g = !pnog && (m.lo_g0 < IS_INF || m.lo_g1 < IS_INF);
                     const bool has_s = m.lo_s < IS_INF;
-                    if (has_g && (__builtin_amdgcn_ballot_w64(lbg > thr_g) | gdead) != ~0ull) mg |= 1u << k;
-                    if (has_s && (__builtin_amdgcn_ballot_w64(lbs > thr_s) | dead) != ~0ull) ms |= 1u << k;
+                    if (has_g && (__builtin_amdgcn_ballot_w64(lbg > thr_g) | gdead) != ~0ull) mg |= 1ull << k;
+                    if (has_s && (__builtin_amdgcn_ballot_w64(lbs > thr_s) | dead) != ~0ull) ms |= 1ull << k;
                 }
                 if (lane == 0) {
-                    atomicOr(&s_thr[2 * 64 + 0], mg);
-                    atomicOr(&s_thr[2 * 64 + 1], ms);
+                    atomicOr(&s_thr[2 * 64 + 0], (unsigned)mg);
+                    atomicOr(&s_thr[2 * 64 + 1], (unsigned)(mg >> 32));
+                    atomicOr(&s_thr[2 * 64 + 2], (unsigned)ms);
+                    atomicOr(&s_thr[2 * 64 + 3], (unsigned)(ms >> 32));
                 }
             }
             __syncthreads();
             if (l7) {
-                mask_g = __builtin_amdgcn_readfirstlane(s_thr[2 * 64 + 0]);
-                mask_s = __builtin_amdgcn_readfirstlane(s_thr[2 * 64 + 1]);
+                mask_g = (unsigned long long)__builtin_amdgcn_readfirstlane(s_thr[2 * 64 + 0]) |
+                         ((unsigned long long)__builtin_amdgcn_readfirstlane(s_thr[2 * 64 + 1]) << 32);
+                mask_s = (unsigned long long)__builtin_amdgcn_readfirstlane(s_thr[2 * 64 + 2]) |
+                         ((unsigned long long)__builtin_amdgcn_readfirstlane(s_thr[2 * 64 + 3]) << 32);
             }
             ISP1_MARK(6); /* (debug build: the pre-pass) */
         }
@@ -815,21 +853,6 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
                 st_next = IS_P1_SREC_LATE ? sload_step_raw(sn) : sload_step(sn);                   \
                 if (!IS_P1_SREC_FIRST) srec_request_next(S, rcol + vn);                            \
             }
-            /* ---- one step = the three candidates that start at vB, TRANSITION FIRST (IS_P1_LAZY).
-             * The object bound of the walk takes the smallest transition term of a block (q_o); the
-             * candidate's own term pw * min(p1, p2, p3) needs only the segment's mean disparity (one
-             * DPP subtraction + the exact division) and the step's StepRec, and it is often far larger:
-             * inside a homogeneous object the object -> object transition is forbidden (the means
-             * agree: p2 = +inf, :159-171) and the ground / sky paths into the object are expensive.
-             * So a step computes mean and transition term first and tests
-             *     fl(fl(pw mp - E1o) + fl(sw lbseg)) > best_o          in every live lane,
-             * lbseg = seg_o_lower_bound of the last fully evaluated step of this wave, a lower bound
-             * of seg_o(vB', vT) for every vB' below it (lemmas L2, L4; the data term >= -E1o, L3; L1
-             * carries the roundings: the cost is fl(fl(fl(dw od) + fl(pw mp)) + fl(sw seg_o))).  When
-             * the test holds the object candidate of vB cannot win or tie in any lane: the sixteen
-             * class differences, the instance term and the two LUT values are not computed; the
-             * ground / sky candidate of vB is evaluated only when its block can hold a winner of its
-             * type (lemma L7).  The type-closing bounds are evaluated on full steps only. */
 #define IS_P1_STEP(SKY, NOG)                                                                       \
             ISP1_COUNT(4);                                                                         \
             const LutRow<NR> row = next_row;                                                       \
@@ -837,81 +860,10 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
                 touch_step(rcol, scol, max(vB - IS_P1_TOUCH_AHEAD * nw, 0), lane, scr);            \
             IS_P1_NEXT_ROW();                                                                      \
             const int h = vTc + 1 - vB;                                                            \
-            const int kb = min((vB + 63) >> 6, 30); /* the block of vB (lemma L7 masks) */         \
-            const float* lbp = s_lb + ((vB + 63) >> 6) * 64 + lane; /* (vB >= 1) */                \
+            const int kb = (vB + IS_QB - 1) >> IS_QB_LOG; /* the bound block of vB (>= 1) */        \
+            const float* lbp = s_lb + kb * 64 + lane;                                              \
             bool ok_o = false, ok_x = (NOG);                                                       \
-            if (USE_DPP && IS_P1_SREC && IS_P1_LAZY) {                                             \
-                const float r1 = c_r1;                                                             \
-                StepVals st = st_next;                                                             \
-                c_r1 = n_r1;                                                                       \
-                n_r1 = ((const float*)(rcol + max(vB - 2 * nw, 0)))[16 + l15];                     \
-                constexpr int WANT = (SKY) ? IS_WANT_SKY : ((NOG) ? 0 : IS_WANT_GROUND);           \
-                if (IS_P1_SREC_LATE) pin_step(st);                                                 \
-                srec_arrived(S);                                                                   \
-                const float mean_raw = fast_div(dpp_sub_first<6>(my.S, r1), (float)h, s_rcp[h]);   \
-                const float fn = __builtin_fmaxf(mean_raw, 0.0f);                                  \
-                const float p1 = (fn > st.g_hi_thr) ? st.p1_hi : ((fn < st.g_lo_thr) ? st.p1_lo : st.p1_mid); \
-                const float p2 = (fn > st.o_hi_thr) ? st.p2_hi : ((fn < st.o_lo_thr) ? st.p2_lo : st.p2_mid); \
-                const float p3 = (fn > P.epsilon) ? st.p3_yes : st.p3_no;                          \
-                const float m12 = min_raw(p1, p2);                                                 \
-                const float pwmp_o = P.pw * min_raw(m12, p3);                                      \
-                int base3 = vB * 3;                                                                \
-                asm volatile("" : "+s"(base3));                                                    \
-                int sel = (p1 < p2) ? IS_GROUND : IS_OBJECT;                                       \
-                sel = (p3 < m12) ? IS_SKY : sel;                                                   \
-                const float lbc = (pwmp_o - E1o) + P.sw * lbseg;                                   \
-                const bool x_open = !(NOG) && ((((SKY) ? mask_s : mask_g) >> kb) & 1u);            \
-                /* (a candidate whose bound is +inf costs +inf: it never wins either -- rows whose     \
-                 * final cost is +inf keep the initial index, see the merge -- and above the horizon   \
-                 * that is every object candidate of a sky lane until the walk reaches the ground)    \
-                 */                                                                                \
-                if ((__builtin_amdgcn_ballot_w64(lbc > b.o || lbc == IS_INF) | dead) != ~0ull) {   \
-                    n_full++;                                                                      \
-                    const SegTerms t = eval_segment_mix<HAS_INVALID, WANT, true>(                  \
-                        my, S, r1, (float)h, s_rcp[h], D, P.iw, mean_raw);                         \
-                    const float od = my_tile[t.fni] - pick_lut<NR>(row, t.fni);                    \
-                    if (SKY) {                                                                     \
-                        take_if_le(b.s, b.is, P.dw * t.sd + st.pwmp + P.sw * t.seg_s, st.idx_gs);  \
-                    } else if (!(NOG)) {                                                           \
-                        take_if_le(b.g, b.ig, P.dw * t.gd + st.pwmp + P.sw * t.seg_g, st.idx_gs);  \
-                    }                                                                              \
-                    take_if_le_v(b.o, b.io, P.dw * od + pwmp_o + P.sw * t.seg_o, base3 + sel);     \
-                    lbseg = seg_o_lower_bound(t, E2);                                              \
-                    const float lb_o = min_raw((st.q_o - E1o) + P.sw * lbseg, lbp[0]);             \
-                    ok_o = (__builtin_amdgcn_ballot_w64(lb_o > b.o) | dead) == ~0ull;              \
-                    if (SKY) {                                                                     \
-                        const float lb_s = min_raw((st.q_gs - E1gs) + P.sw * t.seg_s, lbp[2 * NLB * 64]); \
-                        ok_x = (__builtin_amdgcn_ballot_w64(lb_s > b.s) | dead) == ~0ull;          \
-                    } else if (!(NOG)) {                                                           \
-                        const float lb_g = min_raw((st.q_gs - E1gs) + P.sw * t.seg_g, lbp[NLB * 64]); \
-                        ok_x = (__builtin_amdgcn_ballot_w64(lb_g > b.g) | gdead) == ~0ull;         \
-                    }                                                                              \
-                } else {                                                                           \
-                    n_lazy++;                                                                      \
-                    if (x_open) { /* the ground / sky candidate alone (the terms of IS_P1_GS4) */  \
-                        const float nic = P.iw * (float)dpp_sub_i_first<3>(my.Fnic, r1);           \
-                        float f_x, data;                                                           \
-                        if (SKY) {                                                                 \
-                            f_x = dpp_sub<2>(my.Fsky, r1);                                         \
-                            data = dpp_sub<5>(my.K, r1);                                           \
-                        } else {                                                                   \
-                            f_x = __builtin_fminf(my.Fg0 - S[0], my.Fg1 - S[1]);                   \
-                            data = dpp_sub<4>(my.G, r1);                                           \
-                        }                                                                          \
-                        f_x += nic;                                                                \
-                        const float cost_x = P.dw * data + st.pwmp + P.sw * f_x;                   \
-                        const float lb_x = min_raw((st.q_gs - E1gs) + P.sw * f_x,                  \
-                                                   lbp[((SKY) ? 2 : 1) * NLB * 64]);               \
-                        if (SKY) {                                                                 \
-                            take_if_le(b.s, b.is, cost_x, st.idx_gs);                              \
-                            ok_x = (__builtin_amdgcn_ballot_w64(lb_x > b.s) | dead) == ~0ull;      \
-                        } else {                                                                   \
-                            take_if_le(b.g, b.ig, cost_x, st.idx_gs);                              \
-                            ok_x = (__builtin_amdgcn_ballot_w64(lb_x > b.g) | gdead) == ~0ull;     \
-                        }                                                                          \
-                    }                                                                              \
-                }                                                                                  \
-            } else {                                                                               \
+            {                                                                                      \
                 n_full++;                                                                          \
                 SegTerms t;                                                                        \
                 StepVals st;                                                                       \
@@ -951,11 +903,13 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
                 const float lb_o = min_raw((st.q_o - E1o) + P.sw * seg_o_lower_bound(t, E2), lbp[0]); \
                 ok_o = (__builtin_amdgcn_ballot_w64(lb_o > b.o) | dead) == ~0ull;                  \
                 if (SKY) {                                                                         \
-                    const float lb_s = min_raw((st.q_gs - E1gs) + P.sw * t.seg_s, lbp[2 * NLB * 64]); \
-                    ok_x = (__builtin_amdgcn_ballot_w64(lb_s > b.s) | dead) == ~0ull;              \
+                    const float lb_s = (st.q_gs - E1gs) + P.sw * t.seg_s;                          \
+                    ok_x = (__builtin_amdgcn_ballot_w64(lb_s > b.s) | dead) == ~0ull &&            \
+                           IS_L7_NONE_BELOW(mask_s, kb);                                           \
                 } else if (!(NOG)) {                                                               \
-                    const float lb_g = min_raw((st.q_gs - E1gs) + P.sw * t.seg_g, lbp[NLB * 64]);  \
-                    ok_x = (__builtin_amdgcn_ballot_w64(lb_g > b.g) | gdead) == ~0ull;             \
+                    const float lb_g = (st.q_gs - E1gs) + P.sw * t.seg_g;                          \
+                    ok_x = (__builtin_amdgcn_ballot_w64(lb_g > b.g) | gdead) == ~0ull &&           \
+                           IS_L7_NONE_BELOW(mask_g, kb);                                           \
                 }                                                                                  \
             }                                                                                      \
             if (!(NOG)) ok_x = ok_x || IS_L7_NONE_LE((SKY) ? mask_s : mask_g, kb)
@@ -992,24 +946,26 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
                     }                                                                              \
                 }                                                                                  \
                 const int vb_l = vB - (n_here - 1) * nw; /* the lowest vB just evaluated */      \
-                const float lb_x = min_raw((q_last - E1gs) + P.sw * f_last,                        \
-                                           s_lb[(((SKY) ? 2 : 1) * NLB + ((vb_l + 63) >> 6)) * 64 + lane]); \
-                if ((__builtin_amdgcn_ballot_w64(lb_x > ((SKY) ? b.s : b.g)) | (x_dead)) == ~0ull) \
+                const float lb_x = (q_last - E1gs) + P.sw * f_last;                                \
+                if ((__builtin_amdgcn_ballot_w64(lb_x > ((SKY) ? b.s : b.g)) | (x_dead)) == ~0ull && \
+                    IS_L7_NONE_BELOW((SKY) ? mask_s : mask_g, (vb_l + IS_QB - 1) >> IS_QB_LOG))    \
                     x_closed = true;                                                               \
                 vB -= n_here * nw;                                                                 \
             }
             /* lemma L7: no block at or below block k holds a possible winner */
-#define IS_L7_NONE_LE(mask, k) (((mask) & ((2u << min((k), 30)) - 1u)) == 0u)
+#define IS_L7_NONE_LE(mask, k) (((mask) & ((2ull << min((k), 62)) - 1ull)) == 0ull)
+            /* ... strictly below block k */
+#define IS_L7_NONE_BELOW(mask, k) (((mask) & ((1ull << min((k), 63)) - 1ull)) == 0ull)
             /* in front of a ground / sky round: close the type when no surviving block is left at or
              * below the block of vB; jump over the blocks that cannot hold the winner to this wave's
              * largest vB in the next surviving block (block 0 = the first segment, vB = 0) */
 #define IS_P1_L7_SKIP(mask, x_closed)                                                              \
             {                                                                                      \
-                const int kb = min((vB + 63) >> 6, 30);                                            \
-                const unsigned at_or_below = (mask) & ((2u << kb) - 1u);                           \
-                if (at_or_below == 0u) { x_closed = true; break; }                                 \
-                if (!(((mask) >> kb) & 1u)) {                                                      \
-                    const int top = (31 - __builtin_clz(at_or_below)) << 6;                        \
+                const int kb = min((vB + IS_QB - 1) >> IS_QB_LOG, 62);                             \
+                const unsigned long long at_or_below = (mask) & ((2ull << kb) - 1ull);             \
+                if (at_or_below == 0ull) { x_closed = true; break; }                               \
+                if (!(((mask) >> kb) & 1ull)) {                                                    \
+                    const int top = (63 - __builtin_clzll(at_or_below)) << IS_QB_LOG;              \
                     int dd = (top - w) % nw;                                                       \
                     dd = dd < 0 ? dd + nw : dd;                                                    \
                     vB = top - dd;                                                                 \
@@ -1063,6 +1019,7 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
 #undef IS_P1_GS4
 #undef IS_P1_L7_SKIP
 #undef IS_L7_NONE_LE
+#undef IS_L7_NONE_BELOW
 #undef IS_P1_DRAIN
 #undef IS_P1_REQUEST_NEXT
             if (!done && vB == 0) { /* first segment, :481-594 */
@@ -1428,6 +1385,7 @@ __device__ __forceinline__ void pw_phase2_body(const DevParams& P, char* smem, i
             /* fminf skips NaN fields: a candidate that selects one costs NaN and never wins */
             const float m8 = min_raw(min3_raw(st.p1_hi, st.p1_lo, st.p1_mid),
                                      min3_raw(min3_raw(st.p2_hi, st.p2_lo, st.p2_mid), st.p3_yes, st.p3_no));
+            if ((s & (IS_QB - 1)) == 0) q_o = q_gs = IS_INF; /* vB = r + 1 starts a bound block */
             q_o = min_raw(q_o, P.pw * m8);
             q_gs = min_raw(q_gs, st.pwmp);
             st.q_o = q_o; st.q_gs = q_gs;
@@ -1445,16 +1403,18 @@ __device__ __forceinline__ void pw_phase2_body(const DevParams& P, char* smem, i
         cost_table[o + 0] = b.g; cost_table[o + 1] = b.o; cost_table[o + 2] = b.s;
         index_table[o + 0] = b.ig; index_table[o + 1] = b.io; index_table[o + 2] = b.is;
     }
-    { /* block summary of the candidate rows vB = tile_lo + 1 .. tile_lo + 64 (block tile + 1, lemma L7):
-       * lane s holds the record of vB = vT + 1 (`my`) and its pwmp */
+    { /* summaries of the bound blocks of the candidate rows vB = tile_lo + 1 .. tile_lo + 64 (lemma L7):
+       * lane s holds the record of vB = vT + 1 (`my`) and its pwmp; IS_QB lanes = one block */
         L7Row sum;
         if (FAST) {
             sum = l7_row_bounds(P, pw_keep, my.G, my.K, my.Fg0, my.Fg1, my.Fsky, my.Fnic, vT < vhor, vT + 1 < H);
-            sum = l7_group_min_row<6>(sum);
+            sum = l7_group_min_row<IS_QB_LOG>(sum);
         } else {
             sum = l7_never();
         }
-        if (lane == 0) l7_store(blksum + ((size_t)colg * (P.ntiles + 1) + tile + 1) * IS_L7_F, sum);
+        if ((lane & (IS_QB - 1)) == 0)
+            l7_store(blksum + ((size_t)colg * (P.ntiles * IS_QPT + 1) + tile * IS_QPT + (lane >> IS_QB_LOG) + 1) * IS_L7_F,
+                     sum);
     }
 }
 
@@ -1618,7 +1578,10 @@ __device__ __forceinline__ void pw_phase2x_body(const DevParams& P, char* smem, 
     int ob_cached = -1;
     float S_obc = 0.0f, V_obc = 0.0f;
     float pw_keep = IS_INF; /* pwmp of the StepRec of vB = (this lane's vT) + 1: block summary, lemma L7 */
-    float* const my_blk = blksum + ((size_t)colg * (P.ntiles + 1) + tile + 1) * IS_L7_F;
+    /* summary slot of the bound block that starts with this lane's candidate row, rows `base` .. of the tile */
+    auto blk_slot = [&](int base) -> float* {
+        return blksum + ((size_t)colg * (P.ntiles * IS_QPT + 1) + tile * IS_QPT + ((base + li) >> IS_QB_LOG) + 1) * IS_L7_F;
+    };
 
     /* partial minima of phase 1 for the rows base + li (its nsplit workgroups merged) */
     auto load_best = [&](int row_off, PairBest& b) {
@@ -1687,6 +1650,7 @@ __device__ __forceinline__ void pw_phase2x_body(const DevParams& P, char* smem, 
                                           cO, cS, ob);
         const float m8 = min_raw(min3_raw(st.p1_hi, st.p1_lo, st.p1_mid),
                                  min3_raw(min3_raw(st.p2_hi, st.p2_lo, st.p2_mid), st.p3_yes, st.p3_no));
+        if (((r - tile_lo) & (IS_QB - 1)) == 0) q_o = q_gs = IS_INF; /* vB = r + 1 starts a bound block */
         q_o = min_raw(q_o, P.pw * m8);
         q_gs = min_raw(q_gs, st.pwmp);
         st.q_o = q_o; st.q_gs = q_gs;
@@ -1699,7 +1663,6 @@ __device__ __forceinline__ void pw_phase2x_body(const DevParams& P, char* smem, 
         R1 = q[16 + l15];
     };
 
-    L7Row sumL; /* block summary of the rows of phase L (uniform per half) */
     /* ================= phase L: rows tile_lo .. tile_lo + 31 ================= */
     {
         const int vT = tile_lo + li, vTc = min(vT, H - 1);
@@ -1720,8 +1683,11 @@ __device__ __forceinline__ void pw_phase2x_body(const DevParams& P, char* smem, 
             finalize(r, s, b, my.S, my.V);
         }
         store_rows(vT, b);
-        sumL = l7_group_min_row<5>(l7_row_bounds(P, pw_keep, my.G, my.K, my.Fg0, my.Fg1, my.Fsky, my.Fnic,
-                                                 vT < vhor, vT + 1 < H));
+        {
+            const L7Row sumL = l7_group_min_row<IS_QB_LOG>(l7_row_bounds(P, pw_keep, my.G, my.K, my.Fg0, my.Fg1,
+                                                                         my.Fsky, my.Fnic, vT < vhor, vT + 1 < H));
+            if ((li & (IS_QB - 1)) == 0) l7_store(blk_slot(0), sumL);
+        }
         pw_keep = IS_INF;
         if (li == 0) { /* StepRec(tile_lo + 32) for phase U */
             float* d = s_st + half * 16;
@@ -1731,10 +1697,7 @@ __device__ __forceinline__ void pw_phase2x_body(const DevParams& P, char* smem, 
             d[14] = st.q_o; d[15] = st.q_gs;
         }
     }
-    if (n_rows <= 32) {
-        if (li == 0) l7_store(my_blk, sumL);
-        return;
-    }
+    if (n_rows <= 32) return;
     /* this wave's StepRec stores of phase L must have reached the L2 before phase S reads them */
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
@@ -1780,16 +1743,9 @@ __device__ __forceinline__ void pw_phase2x_body(const DevParams& P, char* smem, 
             finalize(r, s - 32, b, my.S, my.V);
         }
         store_rows(vT, b);
-        const L7Row sumU = l7_group_min_row<5>(l7_row_bounds(P, pw_keep, my.G, my.K, my.Fg0, my.Fg1, my.Fsky,
-                                                             my.Fnic, vT < vhor, vT + 1 < H));
-        if (li == 0) {
-            L7Row sum;
-            sum.lo_g0 = __builtin_fminf(sumL.lo_g0, sumU.lo_g0); sum.lo_g1 = __builtin_fminf(sumL.lo_g1, sumU.lo_g1);
-            sum.lo_s = __builtin_fminf(sumL.lo_s, sumU.lo_s);
-            sum.hi_g0 = __builtin_fminf(sumL.hi_g0, sumU.hi_g0); sum.hi_g1 = __builtin_fminf(sumL.hi_g1, sumU.hi_g1);
-            sum.hi_s = __builtin_fminf(sumL.hi_s, sumU.hi_s);
-            l7_store(my_blk, sum);
-        }
+        const L7Row sumU = l7_group_min_row<IS_QB_LOG>(l7_row_bounds(P, pw_keep, my.G, my.K, my.Fg0, my.Fg1,
+                                                                     my.Fsky, my.Fnic, vT < vhor, vT + 1 < H));
+        if ((li & (IS_QB - 1)) == 0) l7_store(blk_slot(32), sumU);
     }
 }
 
@@ -2062,6 +2018,7 @@ __device__ __forceinline__ void pw_phase2s_body(const DevParams& P, char* smem, 
                                             cG, cO, cS, ob);
                 const float m8 = min_raw(min3_raw(st.p1_hi, st.p1_lo, st.p1_mid),
                                          min3_raw(min3_raw(st.p2_hi, st.p2_lo, st.p2_mid), st.p3_yes, st.p3_no));
+                if ((s & (IS_QB - 1)) == 0) q_o = q_gs = IS_INF; /* vB = r + 1 starts a bound block */
                 q_o = min_raw(q_o, P.pw * m8);
                 q_gs = min_raw(q_gs, st.pwmp);
                 st.q_o = q_o; st.q_gs = q_gs;
@@ -2080,11 +2037,13 @@ __device__ __forceinline__ void pw_phase2s_body(const DevParams& P, char* smem, 
                 const RowRec* mr = rcol + vTc + 1;
                 sum = l7_row_bounds(P, pw_keep, mr->G, mr->K, mr->Fg0, mr->Fg1, mr->Fsky, mr->Fnic, vT < vhor,
                                     vT + 1 < H);
-                sum = l7_group_min_row<6>(sum);
+                sum = l7_group_min_row<IS_QB_LOG>(sum);
             } else {
                 sum = l7_never();
             }
-            if (lane == 0) l7_store(blksum + ((size_t)colg * (P.ntiles + 1) + tile + 1) * IS_L7_F, sum);
+            if ((lane & (IS_QB - 1)) == 0)
+                l7_store(blksum + ((size_t)colg * (P.ntiles * IS_QPT + 1) + tile * IS_QPT + (lane >> IS_QB_LOG) + 1) *
+                                      IS_L7_F, sum);
         }
     } else {
         /* ================================ evaluator waves ================================ */
@@ -2154,9 +2113,10 @@ size_t isk_pairwise_lds_bytes(const DevParams* P, int nwaves) {
     const size_t rcp = sizeof(float) * (((size_t)P->H + 1 + 3) & ~(size_t)3);
     const size_t tile = sizeof(float) * (size_t)IS_TILE * (P->D + 1);
     const size_t merge = (size_t)nwaves * 3 * 64 * 8; /* aliases the tile after the loop */
-    /* + the block bounds of the pre-pass: [3][ntiles + 1][64] (a launch of tile t uses t + 1 entries) */
+    /* + the object block bounds of the pre-pass: [ntiles * IS_QPT + 1][64] (a launch of tile t uses
+     * t * IS_QPT + 1 entries) */
     return (tile > merge ? tile : merge) + rcp + sizeof(float) * 8 * (size_t)nwaves +
-           sizeof(float) * IS_P1_L7_WORDS + sizeof(float) * 3 * 64 * ((size_t)P->ntiles + 1) + 16;
+           sizeof(float) * IS_P1_L7_WORDS + sizeof(float) * IS_P1_BLK_WORDS * ((size_t)P->ntiles * IS_QPT + 1) + 32;
 }
 size_t isk_phase2_lds_bytes(const DevParams* P) {
     size_t need = sizeof(double) * 2 * IS_LOG_TABLE_SIZE +
@@ -2270,7 +2230,7 @@ hipError_t isk_launch_dp_pairwise(const DevParams* P, int ncols, int nwaves, con
     }
     for (int tile = 0; tile < P->ntiles; tile++) {
         /* (the block bounds of tile t need t + 1 of the ntiles + 1 entries lds1 has room for) */
-        const size_t lds1_t = lds1 - sizeof(float) * 3 * 64 * (size_t)(P->ntiles - tile);
+        const size_t lds1_t = lds1 - sizeof(float) * IS_P1_BLK_WORDS * (size_t)IS_QPT * (size_t)(P->ntiles - tile);
         for (int g = 0; g < groups; g++) {
             const int c0 = (int)((long long)ncols * g / groups) & ~1; /* (even: column pairs) */
             const int c1 = g + 1 == groups ? ncols : ((int)((long long)ncols * (g + 1) / groups) & ~1);
