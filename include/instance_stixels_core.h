@@ -242,6 +242,10 @@ int is_device_synchronize(void);
  * d_object_lut[fn][v] (Stixels.cu:159-160, StixelsKernels.cu:959-978).  Synchronises the device. */
 int is_debug_read_object_lut(is_ctx* ctx, int column, float* h_out);
 
+/* Test hook: the bound-block summaries the pairwise DP of the last is_compute call left for one stixel
+ * column (lemmas L7 / L8): h_out[n_blocks][24], returns n_blocks through *n_blocks. */
+int is_debug_read_block_summaries(is_ctx* ctx, int column, float* h_out, int cap_floats, int* n_blocks);
+
 /* Introspection used by bench.py / tests. */
 const char* is_last_error(void);
 const char* is_version(void);

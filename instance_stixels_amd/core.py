@@ -23,7 +23,7 @@ EXPORTS = [
     "is_cluster_instances", "is_host_malloc", "is_host_free", "is_get_device", "is_set_device",
     "is_ctx_device", "is_set_eval_counters", "is_get_eval_counters",
     "is_pack_sections", "is_unpack_sections", "is_stream_create", "is_stream_destroy",
-    "is_debug_read_object_lut",
+    "is_debug_read_object_lut", "is_debug_read_block_summaries",
 ]
 
 
@@ -86,6 +86,10 @@ def lib():
         L.is_scratch_bytes.argtypes = [vp]
         L.is_scratch_bytes.restype = ctypes.c_size_t
         L.is_debug_read_object_lut.argtypes = [vp, ci, vp]
+        try:   # (an experiment library built from an older tree may lack the newest test hook)
+            L.is_debug_read_block_summaries.argtypes = [vp, ci, vp, ci, ctypes.POINTER(ci)]
+        except AttributeError:
+            pass
         _LIB = L
     return _LIB
 
@@ -149,6 +153,14 @@ class Core:
         out = np.zeros((self.params.rows + 1, self.params.max_dis), np.float32)
         _check(lib().is_debug_read_object_lut(self._ctx, int(column), _hp(out)), "is_debug_read_object_lut")
         return out
+
+    def read_block_summaries(self, column):
+        """[n_blocks][24] bound-block summaries of one column after a pairwise call (test hook)."""
+        out = np.zeros(4096 * 24, np.float32)
+        n = ctypes.c_int(0)
+        _check(lib().is_debug_read_block_summaries(self._ctx, int(column), _hp(out), out.size, ctypes.byref(n)),
+               "is_debug_read_block_summaries")
+        return out[: n.value * 24].reshape(n.value, 24).copy()
 
     def kernel_times_ms(self):
         a, b, c = ctypes.c_float(), ctypes.c_float(), ctypes.c_float()

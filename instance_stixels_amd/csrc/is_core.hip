@@ -33,7 +33,7 @@ hipError_t isk_launch_dp_unary(const DevParams*, int, int, const RowRec*, const 
 hipError_t isk_launch_dp_pairwise(const DevParams*, int, int, const RowRec*, const float*,
                                   const float*, const PriorRec*, const float*, const float*, const float*,
                                   const int*, const int*, const PruneRec*, StepRec*, float*, int*,
-                                  float*, int32_t*, unsigned long long*, const float*, const int*, float*,
+                                  float*, int32_t*, unsigned long long*, const float*, const int*, float*, float*,
                                   hipStream_t, hipStream_t*, int, hipEvent_t, hipEvent_t*);
 hipError_t isk_launch_backtrace(const DevParams*, int, int, const RowRec*, const float*,
                                 const int32_t*, const int*, is_section*, int*, int*, hipStream_t);
@@ -137,7 +137,8 @@ struct is_ctx {
     float* d_part_cost;      /* [max_batch*C][3][64] merged partial minima of the current tile */
     int* d_part_idx;         /* [max_batch*C][3][64] */
     float* d_sv;             /* [max_batch*C][2][H+1] compact S / V prefixes */
-    float* d_blksum;         /* [max_batch*C][ntiles*IS_QPT+1][8] bound-block summaries of the pairwise DP (lemma L7) */
+    float* d_t8row;          /* [max_batch*C][H] pw * (smallest p field) of every StepRec (lemma L8) */
+    float* d_blksum;         /* [max_batch*C][ntiles*IS_QPT+1][24] bound-block summaries of the pairwise DP (lemmas L7, L8) */
     float* d_cost_table;     /* [max_batch*C][H][3] */
     int32_t* d_index_table;  /* [max_batch*C][H][3] */
     size_t scratch_bytes;
@@ -370,7 +371,8 @@ static int ctx_init(is_ctx* c, const is_stixel_params* p, const float* obj_cost_
     ALLOC(c->d_part_cost, sizeof(float) * part_slots * 3 * 64);
     ALLOC(c->d_part_idx, sizeof(int) * part_slots * 3 * 64);
     ALLOC(c->d_sv, sizeof(float) * B * C * 2 * (H + 1));
-    ALLOC(c->d_blksum, sizeof(float) * B * C * ((size_t)d.ntiles * IS_QPT + 1) * 8);
+    ALLOC(c->d_t8row, sizeof(float) * B * C * H);
+    ALLOC(c->d_blksum, sizeof(float) * B * C * ((size_t)d.ntiles * IS_QPT + 1) * 24);
     ALLOC(c->d_cost_table, sizeof(float) * B * C * H * 3);
     ALLOC(c->d_index_table, sizeof(int32_t) * B * C * H * 3);
     ALLOC(c->d_cluster_scratch, sizeof(int32_t) * B * IS_INSTANCE_CLASSES * 2 * C * (size_t)d.S);
@@ -441,7 +443,7 @@ int is_ctx_destroy(is_ctx* c) {
         free(c->graph_cache);
     }
     (void)hipFree(c->d_obj_cost_lut); (void)hipFree(c->d_odr); (void)hipFree(c->d_rcp); (void)hipFree(c->d_col_flags); (void)hipFree(c->d_prune); (void)hipFree(c->d_n_generic); (void)hipFree(c->d_stage);
-    (void)hipFree(c->d_recs); (void)hipFree(c->d_lutT); (void)hipFree(c->d_priors); (void)hipFree(c->d_steps); (void)hipFree(c->d_part_cost); (void)hipFree(c->d_part_idx); (void)hipFree(c->d_sv); (void)hipFree(c->d_blksum);
+    (void)hipFree(c->d_recs); (void)hipFree(c->d_lutT); (void)hipFree(c->d_priors); (void)hipFree(c->d_steps); (void)hipFree(c->d_part_cost); (void)hipFree(c->d_part_idx); (void)hipFree(c->d_sv); (void)hipFree(c->d_blksum); (void)hipFree(c->d_t8row);
     (void)hipFree(c->d_cost_table); (void)hipFree(c->d_index_table); (void)hipFree(c->d_cluster_scratch);
     (void)hipFree(c->d_inst_cnt); (void)hipFree(c->d_counters);
     for (int i = 0; i < IS_STAGE_SLOTS; i++) {
@@ -555,6 +557,18 @@ int is_debug_read_object_lut(is_ctx* c, int column, float* h_out) {
     return IS_OK;
 }
 
+int is_debug_read_block_summaries(is_ctx* c, int column, float* h_out, int cap_floats, int* n_blocks) {
+    if (!c || !h_out || !n_blocks) return fail_arg("null pointer");
+    if (column < 0 || column >= c->max_batch * c->dp.C) return fail_arg("column outside the context's scratch");
+    const int nb = c->dp.ntiles * IS_QPT + 1;
+    if (cap_floats < nb * 24) return fail_arg("h_out too small");
+    ON_CTX_DEVICE(c);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(h_out, c->d_blksum + (size_t)column * nb * 24, sizeof(float) * nb * 24, hipMemcpyDeviceToHost));
+    *n_blocks = nb;
+    return IS_OK;
+}
+
 int is_set_kernel_timing(is_ctx* c, int enabled) {
     if (!c) return fail_arg("null ctx");
     c->timing = enabled != 0;
@@ -623,7 +637,7 @@ static int compute_enqueue(is_ctx* c, const float* d_joined, const int32_t* d_se
                                        d_joined, c->d_priors, c->d_odr, c->d_rcp, c->d_sv, c->d_vhor,
                                        c->d_col_flags, c->d_prune, c->d_steps, c->d_part_cost,
                                        c->d_part_idx, ct, it, c->counting ? c->d_counters : nullptr,
-                                       c->d_obj_cost_lut, c->d_n_generic, c->d_blksum, stream, c->aux_streams,
+                                       c->d_obj_cost_lut, c->d_n_generic, c->d_blksum, c->d_t8row, stream, c->aux_streams,
                                        IS_AUX_STREAMS, c->ev_fork, c->ev_joins));
     else
         HIP_TRY(isk_launch_dp_unary(&P, ncols, c->nwaves_unary, c->d_recs, c->d_lutT, c->d_rcp,

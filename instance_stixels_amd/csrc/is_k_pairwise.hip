@@ -297,7 +297,114 @@ __device__ __forceinline__ L7Row l7_never() {
     r.hi_g0 = r.hi_g1 = r.hi_s = IS_INF;
     return r;
 }
-#define IS_L7_F 8 /* floats per block summary */
+#define IS_L7_F 24 /* floats per block summary: 8 of lemma L7 (ground / sky) + 16 of lemma L8 (object classes) */
+
+/* ---- lemma L8: separable block bounds of the OBJECT candidates ------------------------------------
+ * cost_o(vB, vT) = fl(fl(fl(dw od) + fl(pw mp)) + fl(sw seg_o)),  seg_o = min(on, oi),  on = fl(nic + f_on),
+ * oi = fl(ic + f_oi)  (pairwise_step, eval_segment).  By L1 (monotone rounding) with fl(dw od) >= -E1o (L3),
+ * mp >= m8(vB) = the smallest of the eight p fields of StepRec(vB), the computed ic >= -E2 (L4) and
+ * nic, f >= 0:
+ *     cost_o >= min_c [ T8(vB) - sw (F_c[vB] + n_c[vB]) ]  +  [ sw (F_c[vT+1] + n_c[vT+1]) - e_c ]  -  roundings,
+ * c over the sixteen object classes, T8 = fl(pw m8), n_c = iw N for the non-instance classes 2..9 and 0
+ * for the instance classes 11..18, e_c = E1o (+ sw E2 for an instance class): per class the SAME
+ * separable form as lemma L7, with the same slack rule (2^-20 of the magnitudes + 2^-90 on either side,
+ * 2^-22 on the sum).  Phase 2 leaves min over the block's rows of alo_c = fl(a^_c - slack) for the
+ * sixteen classes; the pre-pass of phase 1 turns them into the lower bound of every object candidate
+ * of a lower block, per lane -- what the sticky closure of the object type compares with the lane's
+ * best cost (s_lb).  Where round 3 evaluated the block's TOP row (the smallest transition term of the
+ * block + the smallest semantic term of the block: a chain of short objects, every split near-optimal,
+ * lost a whole block of accumulated path cost), the per-class form loses nothing but the instance term. */
+/* Per lane the sixteen alo_c of its candidate row (record `rec`, T8 = pw * m8 of its StepRec; `ok`: the row
+ * is a candidate, 1 <= vB <= H - 1), then the minima over a group of 2^LOG lanes (LOG = 4 or 5) as a
+ * reduce-scatter, eight classes at a time (the kernels that call this have no registers to spare):
+ * every exchange halves the classes a lane is responsible for, 4 + 2 + 1 shuffles + the full-minimum
+ * steps of the remaining strides instead of eight full butterflies; the lanes that end up with a class
+ * store it.  dst: the group's 16 floats. */
+template <int LOG>
+__device__ __forceinline__ void l8_group_min_store(const DevParams& P, float T8, const RowRec* rec /* global */,
+                                                   bool ok, float* dst) {
+    static_assert(LOG == 4 || LOG == 5, "groups of 16 or 32 lanes");
+    const int lane = threadIdx.x;
+    /* the class prefixes are RE-READ from the record in memory (an L2 hit), eight at a time: the lane's
+     * register copy would have to stay alive across the whole walk of the calling kernel, which has no
+     * registers to spare (k_pw_phase2x: 124 of 128) */
+    asm volatile("" ::: "memory");
+    const float4* r4 = reinterpret_cast<const float4*>(rec);
+    const float n = P.iw * (float)__float_as_int(r4[4].w); /* Fnic, dword 19 */
+#pragma unroll
+    for (int bq = 0; bq < 2; bq++) { /* the non-instance classes 2..9, then the instance classes 11..18 */
+        float f[8];
+        if (bq == 0) { /* Fon[0..7] = dwords 2..9 */
+            const float4 a = r4[0], b = r4[1], c = r4[2];
+            f[0] = a.z; f[1] = a.w; f[2] = b.x; f[3] = b.y; f[4] = b.z; f[5] = b.w; f[6] = c.x; f[7] = c.y;
+        } else { /* Foi[0..7] = dwords 10..17 */
+            const float4 a = r4[2], b = r4[3], c = r4[4];
+            f[0] = a.z; f[1] = a.w; f[2] = b.x; f[3] = b.y; f[4] = b.z; f[5] = b.w; f[6] = c.x; f[7] = c.y;
+        }
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const float ft = P.sw * (bq == 0 ? f[j] + n : f[j]);
+            const float a = T8 - ft;
+            const float mu = __builtin_fabsf(T8) + ft;
+            const float lo = a - (mu * IS_L7_REL + IS_L7_ABS);
+            /* (a NaN bound -- NaN / infinite T8: the candidates cost NaN / +inf -- counts as +inf) */
+            v[j] = ok ? __builtin_fminf(lo, IS_INF) : IS_INF;
+        }
+        int base = 0;
+#pragma unroll
+        for (int step = 0; step < 3; step++) { /* 8 -> 4 -> 2 -> 1 classes per lane */
+            const int m = 1 << (LOG - 1 - step);
+            const int half = 4 >> step;
+            const bool up = (lane & m) != 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (j < half) {
+                    const float send = up ? v[j] : v[j + half];
+                    const float keep = up ? v[j + half] : v[j];
+                    v[j] = __builtin_fminf(keep, __shfl_xor(send, m, 64));
+                }
+            }
+            base += up ? half : 0;
+        }
+#pragma unroll
+        for (int m = 1 << (LOG - 4); m >= 1; m >>= 1) v[0] = __builtin_fminf(v[0], __shfl_xor(v[0], m, 64));
+        if ((lane & ((1 << (LOG - 3)) - 1)) == 0) dst[bq * 8 + base] = v[0];
+    }
+}
+/* The summaries (lemmas L7, L8) of the bound blocks of the candidate rows vB = tile_lo + base + g + 1, g = this
+ * lane's index in its group of 2^LOG lanes (one lane per row, one group per block).  Called at the END of
+ * a phase-2 walk, when nothing else is alive: the per-row transition terms -- pwmp = StepRec field 0 and
+ * T8 = pw * m8 from the side array t8col -- are read back from memory (this wave stored them during
+ * the walk; the caller has waited for its stores), the record fields from the record. */
+template <int LOG>
+__device__ __forceinline__ void l78_block_summaries(const DevParams& P, const RowRec* rcol, const StepRec* scol,
+                                                    const float* t8col, float* bsum_col /* the column's summaries */,
+                                                    int tile_lo, int row /* of the tile: base + g */, int vhor) {
+    const int H = P.H;
+    const int vB = tile_lo + row + 1;
+    const bool ok = vB < H;
+    const int vBc = min(vB, H - 1);
+    const float T = ((const float*)(scol + vBc))[0];
+    const float T8 = t8col[vBc];
+    const RowRec* rec = rcol + vBc;
+    const float4* r4 = reinterpret_cast<const float4*>(rec);
+    const float4 c0 = r4[0], c4 = r4[4];      /* Fg0 Fg1 . . | Foi6 Foi7 Fsky Fnic */
+    const float2 gk = *reinterpret_cast<const float2*>((const float*)rec + 20); /* G K */
+    L7Row sum = l7_row_bounds(P, T, gk.x, gk.y, c0.x, c0.y, c4.z, __float_as_int(c4.w), vB - 1 < vhor, ok);
+    sum = l7_group_min_row<LOG>(sum);
+    float* const slot = bsum_col + (size_t)(((tile_lo >> 6) * IS_QPT) + (row >> IS_QB_LOG) + 1) * IS_L7_F;
+    if ((threadIdx.x & ((1 << LOG) - 1)) == 0) l7_store(slot, sum);
+    l8_group_min_store<LOG>(P, T8, rec, ok, slot + 8);
+}
+/* (generic columns: never a bound) */
+__device__ __forceinline__ void l8_store_never(float* dst, bool writer) {
+    if (writer) {
+        float4* d = reinterpret_cast<float4*>(dst);
+#pragma unroll
+        for (int q = 0; q < 4; q++) d[q] = make_float4(-IS_INF, -IS_INF, -IS_INF, -IS_INF);
+    }
+}
 
 /* ---- phase-1 side of lemma L7 ----------------------------------------------------------------
  * Per lane (vT) and class: blo_c / bhi_c from the lane's own record; per block k and type: a lower
@@ -313,9 +420,10 @@ __device__ __forceinline__ L7Row l7_never() {
 #define IS_P1_L7 1
 #endif
 #define IS_P1_L7_WORDS 136 /* LDS words of the exchange: [2][64] threshold keys + 2 x 64-bit masks, padded */
-/* LDS words per bound block of a phase-1 launch: 64 object bounds + the 32-dword record at its top + q_o + the
- * 8-float summary (+ 3 for the alignment of the arrays) */
-#define IS_P1_BLK_WORDS (64 + 32 + 1 + 8 + 1)
+/* LDS words per bound block of a phase-1 launch: 64 object bounds (one per lane) + its 24-float summary + the
+ * 8 instance-prefix dwords of the record at its top row */
+#define IS_P1_SUM_F (IS_L7_F + 8)
+#define IS_P1_BLK_WORDS (64 + IS_P1_SUM_F)
 static_assert(IS_QB_LOG >= 3 && IS_QB_LOG <= 5, "bound blocks: 8 .. 32 rows (a phase of k_pw_phase2x holds 32 rows)");
 struct L7B { float lo_g0, lo_g1, lo_s, hi_g0, hi_g1, hi_s; };
 __device__ __forceinline__ void l7_b(float dterm, float fterm, float* lo, float* hi) {
@@ -336,15 +444,15 @@ __device__ __forceinline__ L7B l7_lane_bounds(const DevParams& P, const RowRec& 
 }
 /* summary of block k (wave-uniform); block 0 = the first segment: a ground candidate
  * with T = pw * first_g and every prefix 0 (:196-199, :481-594) */
-__device__ __forceinline__ L7Row l7_block_summary(const DevParams& P, const float* bcol, int k) {
+__device__ __forceinline__ L7Row l7_block_summary(const DevParams& P, const float* entry /* of block k */, int k) {
     L7Row m;
     if (k == 0) {
         l7_ab(P.pw * P.first_g, 0.0f, 0.0f, &m.lo_g0, &m.hi_g0);
         m.lo_g1 = m.lo_g0; m.hi_g1 = m.hi_g0;
         m.lo_s = m.hi_s = IS_INF;
-    } else { /* (bcol: the LDS copy of the column's summaries: broadcast reads) */
-        const float4 a = *reinterpret_cast<const float4*>(bcol + (size_t)k * IS_L7_F);
-        const float4 c = *reinterpret_cast<const float4*>(bcol + (size_t)k * IS_L7_F + 4);
+    } else { /* (the LDS copy of the block's summary: broadcast reads) */
+        const float4 a = *reinterpret_cast<const float4*>(entry);
+        const float4 c = *reinterpret_cast<const float4*>(entry + 4);
         m.lo_g0 = a.x; m.lo_g1 = a.y; m.lo_s = a.z;
         m.hi_g0 = c.x; m.hi_g1 = c.y; m.hi_s = c.z;
     }
@@ -614,30 +722,31 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
     const RowRec my = load_rec(rcol + vTc + 1);
     stage_rcp(s_rcp, rcp, H, tid, (int)blockDim.x);
 #else
-    /* What the pre-pass of the branch-and-bound reads -- the records at the tops of the lower bound
-     * blocks, their running minima q_o and the separable block summaries (lemma L7) -- is requested
-     * HERE, in front of the tile staging, and lands in LDS with it: one memory round trip for the
-     * whole prologue instead of one per block top and summary (each wave used to chase its tops
-     * through scalar loads one after the other: the 0.25 ms floor of a launch is a chain of such
-     * round trips). */
+    /* What the pre-pass of the branch-and-bound reads -- the separable summaries of the lower bound
+     * blocks (lemmas L7, L8: 24 floats per block) -- is requested HERE, in front of the tile staging, and
+     * lands in LDS with it: one memory round trip for the whole prologue (round 3 chased a record and a
+     * StepRec per block top through scalar loads, one after the other: the 0.25 ms floor of a launch is
+     * a chain of such round trips). */
     const int NLB = tile * IS_QPT + 1; /* bound blocks 0 .. tile * IS_QPT of this tile's candidates */
     float* s_lb = s_scr + 8 * nwl + IS_P1_L7_WORDS;   /* [NLB][64 lanes] object block bounds      */
-    float* s_pre = s_lb + NLB * 64;                   /* [NLB][32] records at the block tops       */
-    float* s_preq = s_pre + NLB * 32;                 /* [NLB -> x4] q_o at the block tops         */
-    float* s_sum = s_preq + ((NLB + 3) & ~3);         /* [NLB][8] block summaries                  */
+    float* s_sum = s_lb + NLB * 64;                   /* [NLB][IS_P1_SUM_F]: 24 summary floats + the instance
+                                                       * prefixes (dwords 24..31) of the record at the block's TOP row */
     const float* bcol = blksum + (size_t)colg * (P.ntiles * IS_QPT + 1) * IS_L7_F;
-    constexpr int PRE_N = 2; /* record dwords per thread and round: (NLB - 1) * 32 <= PRE_N * nthreads at 1024 rows */
-    float pre_v[PRE_N], pre_q = 0.0f, pre_s = 0.0f;
+    constexpr int PRE_N = 2; /* floats per thread: NLB * 32 <= PRE_N * nthreads at 1024 rows */
+    float pre_v[PRE_N];
     const int nthr = (int)blockDim.x;
-    const bool pre_regs = FAST && IS_PRUNE && (NLB - 1) * 32 <= PRE_N * nthr && NLB * 8 <= nthr;
+    const bool pre_regs = FAST && IS_PRUNE && NLB * IS_P1_SUM_F <= PRE_N * nthr;
+    auto pre_load = [&](int i) -> float { /* entry i of s_sum */
+        const int k = i / IS_P1_SUM_F, j = i - k * IS_P1_SUM_F;
+        if (j >= IS_L7_F) return ((const float*)(rcol + (size_t)k * IS_QB))[24 + (j - IS_L7_F)];
+        return k >= 1 ? bcol[k * IS_L7_F + j] : 0.0f; /* (the summary of block 0 is analytic) */
+    };
     if (pre_regs) {
 #pragma unroll
         for (int j = 0; j < PRE_N; j++) {
             const int i = tid + j * nthr;
-            pre_v[j] = (i < (NLB - 1) * 32) ? ((const float*)(rcol + (size_t)(i >> 5) * IS_QB))[i & 31] : 0.0f;
+            pre_v[j] = i < NLB * IS_P1_SUM_F ? pre_load(i) : 0.0f;
         }
-        if (tid >= 1 && tid < NLB - 1) pre_q = ((const float*)(scol + (size_t)tid * IS_QB))[14]; /* StepRec.q_o */
-        if (tid >= 8 && tid < NLB * 8) pre_s = bcol[tid];
     }
 #if IS_P1_MY_FIRST
     const RowRec my = load_rec(rcol + vTc + 1); /* requested with the tile: one memory round trip, not two */
@@ -650,15 +759,10 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
 #pragma unroll
         for (int j = 0; j < PRE_N; j++) {
             const int i = tid + j * nthr;
-            if (i < (NLB - 1) * 32) s_pre[i] = pre_v[j];
+            if (i < NLB * IS_P1_SUM_F) s_sum[i] = pre_v[j];
         }
-        if (tid < NLB - 1) s_preq[tid] = pre_q;
-        if (tid < NLB * 8) s_sum[tid] = pre_s;
-    } else if (FAST && IS_PRUNE) { /* tall frames: plain loops */
-        for (int i = tid; i < (NLB - 1) * 32; i += nthr)
-            s_pre[i] = ((const float*)(rcol + (size_t)(i >> 5) * IS_QB))[i & 31];
-        for (int i = tid; i < NLB - 1; i += nthr) s_preq[i] = i >= 1 ? ((const float*)(scol + (size_t)i * IS_QB))[14] : 0.0f;
-        for (int i = tid; i < NLB * 8; i += nthr) s_sum[i] = i >= 8 ? bcol[i] : 0.0f;
+    } else if (FAST && IS_PRUNE) { /* tall frames: a plain loop */
+        for (int i = tid; i < NLB * IS_P1_SUM_F; i += nthr) s_sum[i] = pre_load(i);
     }
 #endif
     const float* my_tile = s_tile + IS_TILE_ROW(lane) * DP;
@@ -713,7 +817,7 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
         bool l7 = false;
         {
             cprune_t pq0 = (cprune_t)prec;
-            const float pE1o = pq0->E1o, pE2 = 3.0f * pq0->E2;
+            const float pE1o = pq0->E1o;
             const float pE1gs = __builtin_fmaxf(pq0->E1g, pq0->E1s);
             const bool pnog = IS_SKIP_GROUND_ABOVE_HORIZON && tile_lo >= vhor;
             l7 = IS_P1_L7 && (pE1gs < IS_INF) && NLB <= 63;
@@ -721,7 +825,7 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
                 bl7 = l7_lane_bounds(P, my);
                 float thr_g = IS_INF, thr_s = IS_INF;
                 for (int k = wl; k < NLB; k += nwl) {
-                    const L7Row m = l7_block_summary(P, s_sum, k);
+                    const L7Row m = l7_block_summary(P, s_sum + (size_t)k * IS_P1_SUM_F, k);
                     float lbg, ubg, lbs, ubs;
                     l7_combine(m, bl7, &lbg, &ubg, &lbs, &ubs);
                     thr_g = __builtin_fminf(thr_g, ubg);
@@ -730,19 +834,60 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
                 if (!pnog && thr_g == thr_g) atomicMin(&s_thr[lane], l7_key(thr_g));
                 if (thr_s == thr_s) atomicMin(&s_thr[64 + lane], l7_key(thr_s));
             }
-            for (int k = wl; k < NLB - 1; k += nwl) { /* top of block k: vB = IS_QB k */
-                const int vBk = k * IS_QB;
-                const int h = vTc + 1 - vBk;
-                /* (the record of vBk from its LDS copy, as DPP operands: eval_segment_dpp == eval_segment<true>;
-                 * only the object terms are needed) */
-                const float pR0 = s_pre[k * 32 + (lane & 15)], pR1 = s_pre[k * 32 + 16 + (lane & 15)];
-                const SegTerms t = eval_segment_dpp<HAS_INVALID, 0>(my, pR0, pR1, (float)h, s_rcp[h], D, P.iw);
-                float q_o;
-                if (k == 0) /* the first segment's priors, :189-199 */
-                    q_o = P.pw * __builtin_fminf(P.first_o_below, P.first_o_above);
-                else
-                    q_o = s_preq[k];
-                float lb_o = (q_o - pE1o) + P.sw * seg_o_lower_bound(t, pE2);
+            /* lemma L8: the lower bound of every OBJECT candidate of the lower block k, per lane */
+            float bo[16]; /* sw (F_c[vT+1] + n_c[vT+1]) - e_c - slack, per object class */
+            {
+                const float n1 = P.iw * (float)my.Fnic;
+#pragma unroll
+                for (int c = 0; c < 16; c++) {
+                    const float ft = P.sw * (c < IS_N_ON ? my.Fon[c] + n1 : my.Foi[c - IS_N_ON]);
+                    bo[c] = (ft - pE1o) - ((ft + pE1o) * IS_L7_REL + IS_L7_ABS);
+                }
+            }
+            /* the instance classes also keep lemma L4's term of the block's TOP row: the computed
+             * ic(vB', vT) >= ic(top, vT) - 2 E2 for every vB' <= top (a sum of squared deviations only grows
+             * with the segment), so oi' >= fl(fl(ic_top - 3 E2) + f_oi') like in seg_o_lower_bound; it is
+             * what makes a candidate that starts inside an instance object and ends in the sky above it
+             * expensive.  ic_top: the expression of eval_segment on the staged prefixes of the top row. */
+            const float E2x3 = 3.0f * pq0->E2;
+            const float t0 = P.pw * __builtin_fminf(P.first_o_below, P.first_o_above); /* block 0: the first segment, :189-199 */
+            for (int k = wl; k < NLB - 1; k += nwl) {
+                float lb_n, lb_i; /* non-instance / instance classes */
+                if (k == 0) {
+                    const float a0 = t0 - (__builtin_fabsf(t0) * IS_L7_REL + IS_L7_ABS); /* every prefix is 0 at vB = 0 */
+                    lb_n = a0 + bo[0];
+                    lb_i = a0 + bo[IS_N_ON];
+#pragma unroll
+                    for (int c = 1; c < IS_N_ON; c++) {
+                        lb_n = __builtin_fminf(lb_n, a0 + bo[c]);
+                        lb_i = __builtin_fminf(lb_i, a0 + bo[IS_N_ON + c]);
+                    }
+                } else {
+                    const float4* m4 = reinterpret_cast<const float4*>(s_sum + k * IS_P1_SUM_F + 8);
+                    const float4 m0 = m4[0], m1 = m4[1], m2 = m4[2], m3 = m4[3];
+                    const float mm[16] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w,
+                                          m2.x, m2.y, m2.z, m2.w, m3.x, m3.y, m3.z, m3.w};
+                    lb_n = mm[0] + bo[0];
+                    lb_i = mm[IS_N_ON] + bo[IS_N_ON];
+#pragma unroll
+                    for (int c = 1; c < IS_N_ON; c++) {
+                        lb_n = __builtin_fminf(lb_n, mm[c] + bo[c]);
+                        lb_i = __builtin_fminf(lb_i, mm[IS_N_ON + c] + bo[IS_N_ON + c]);
+                    }
+                }
+                { /* ic(top, vT), top = IS_QB k (FAST encoding, eval_segment's expression and order) */
+                    const float4 t0i = *reinterpret_cast<const float4*>(s_sum + k * IS_P1_SUM_F + IS_L7_F);     /* MX MY MX2h MX2l */
+                    const float2 t1i = *reinterpret_cast<const float2*>(s_sum + k * IS_P1_SUM_F + IS_L7_F + 4); /* MY2h MY2l */
+                    const int h = vTc + 1 - k * IS_QB;
+                    const float rh = s_rcp[h];
+                    const float meanx = my.MX - t0i.x, meany = my.MY - t0i.y;
+                    const float meanx2 = (my.MX2h - t0i.z) + (my.MX2l - t0i.w);
+                    const float meany2 = (my.MY2h - t1i.x) + (my.MY2l - t1i.y);
+                    const float ic = P.iw * (meanx2 - fast_div(meanx * meanx, (float)h, rh) + meany2 -
+                                             fast_div(meany * meany, (float)h, rh));
+                    lb_i = lb_i + P.sw * (ic - E2x3);
+                }
+                float lb_o = l7_dn(__builtin_fminf(lb_n, lb_i));
                 /* a NaN bound (inf - inf with the pruning switched off, NaN inputs) must never
                  * close anything: -inf */
                 lb_o = (lb_o == lb_o) ? lb_o : -IS_INF;
@@ -763,7 +908,7 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
                 const float thr_g = l7_unkey(s_thr[lane]), thr_s = l7_unkey(s_thr[64 + lane]);
                 unsigned long long mg = 0ull, ms = 0ull;
                 for (int k = wl; k < NLB; k += nwl) {
-                    const L7Row m = l7_block_summary(P, s_sum, k);
+                    const L7Row m = l7_block_summary(P, s_sum + (size_t)k * IS_P1_SUM_F, k);
                     float lbg, ubg, lbs, ubs;
                     l7_combine(m, bl7, &lbg, &ubg, &lbs, &ubs);
                     const bool has_g = !pnog && (m.lo_g0 < IS_INF || m.lo_g1 < IS_INF);
@@ -1228,7 +1373,7 @@ __device__ __forceinline__ void pw_phase2_body(const DevParams& P, char* smem, i
                                                StepRec* __restrict__ steps,
                                                float* __restrict__ cost_table,
                                                int32_t* __restrict__ index_table,
-                                               float* __restrict__ blksum) {
+                                               float* __restrict__ blksum, float* __restrict__ t8row) {
     const int H = P.H, D = P.D;
     const int lane = threadIdx.x;
     double* s_invc = (double*)smem;                    /* [32] */
@@ -1318,7 +1463,6 @@ __device__ __forceinline__ void pw_phase2_body(const DevParams& P, char* smem, i
     st.q_o = q_o; st.q_gs = q_gs;
     int ob_cached = -1;
     float S_obc = 0.0f, V_obc = 0.0f;
-    float pw_keep = IS_INF; /* lane s: pwmp of the StepRec of vB = tile_lo + s + 1 (block summary, lemma L7) */
 #ifdef IS_ABL_P2PHASES
     unsigned long long acc_p2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
@@ -1386,11 +1530,14 @@ __device__ __forceinline__ void pw_phase2_body(const DevParams& P, char* smem, i
             const float m8 = min_raw(min3_raw(st.p1_hi, st.p1_lo, st.p1_mid),
                                      min3_raw(min3_raw(st.p2_hi, st.p2_lo, st.p2_mid), st.p3_yes, st.p3_no));
             if ((s & (IS_QB - 1)) == 0) q_o = q_gs = IS_INF; /* vB = r + 1 starts a bound block */
-            q_o = min_raw(q_o, P.pw * m8);
+            const float pwm8 = P.pw * m8;
+            q_o = min_raw(q_o, pwm8);
             q_gs = min_raw(q_gs, st.pwmp);
             st.q_o = q_o; st.q_gs = q_gs;
-            pw_keep = (lane == s) ? st.pwmp : pw_keep;
-            if (lane == 0 && r + 1 < H) store_step(scol + r + 1, st);
+            if (lane == 0 && r + 1 < H) {
+                store_step(scol + r + 1, st);
+                t8row[(size_t)colg * H + r + 1] = pwm8; /* (lemma L8: the row's own transition bound) */
+            }
             ISP2_MARK(7); /* running minima + store */
         }
     }
@@ -1403,18 +1550,17 @@ __device__ __forceinline__ void pw_phase2_body(const DevParams& P, char* smem, i
         cost_table[o + 0] = b.g; cost_table[o + 1] = b.o; cost_table[o + 2] = b.s;
         index_table[o + 0] = b.ig; index_table[o + 1] = b.io; index_table[o + 2] = b.is;
     }
-    { /* summaries of the bound blocks of the candidate rows vB = tile_lo + 1 .. tile_lo + 64 (lemma L7):
-       * lane s holds the record of vB = vT + 1 (`my`) and its pwmp; IS_QB lanes = one block */
-        L7Row sum;
+    { /* summaries of the bound blocks of the candidate rows vB = tile_lo + 1 .. tile_lo + 64 (lemmas L7, L8) */
+        float* const bcolw = blksum + (size_t)colg * (P.ntiles * IS_QPT + 1) * IS_L7_F;
         if (FAST) {
-            sum = l7_row_bounds(P, pw_keep, my.G, my.K, my.Fg0, my.Fg1, my.Fsky, my.Fnic, vT < vhor, vT + 1 < H);
-            sum = l7_group_min_row<IS_QB_LOG>(sum);
+            __builtin_amdgcn_s_waitcnt(0); /* this wave's StepRec / T8 stores have reached the L2 */
+            l78_block_summaries<IS_QB_LOG>(P, rcol, scol, t8row + (size_t)colg * H, bcolw, tile_lo, lane, vhor);
         } else {
-            sum = l7_never();
+            float* const slot = bcolw + (size_t)(tile * IS_QPT + (lane >> IS_QB_LOG) + 1) * IS_L7_F;
+            const bool writer = (lane & (IS_QB - 1)) == 0;
+            if (writer) l7_store(slot, l7_never());
+            l8_store_never(slot + 8, writer);
         }
-        if ((lane & (IS_QB - 1)) == 0)
-            l7_store(blksum + ((size_t)colg * (P.ntiles * IS_QPT + 1) + tile * IS_QPT + (lane >> IS_QB_LOG) + 1) * IS_L7_F,
-                     sum);
     }
 }
 
@@ -1430,17 +1576,17 @@ __global__ __launch_bounds__(64, ISP2_OCC) void k_pw_phase2(
     const float* __restrict__ sv_arr, const int* __restrict__ vhor_arr,
     const int* __restrict__ col_flags, const float* __restrict__ part_cost,
     const int* __restrict__ part_idx, StepRec* __restrict__ steps, float* __restrict__ cost_table,
-    int32_t* __restrict__ index_table, float* __restrict__ blksum) {
+    int32_t* __restrict__ index_table, float* __restrict__ blksum, float* __restrict__ t8row) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int colg = col_base + blockIdx.x;
     if (colg >= ncols) return;
     const int vhor = __builtin_amdgcn_readfirstlane(vhor_arr[colg / P.C]);
     if (__builtin_amdgcn_readfirstlane(col_flags[colg]) == 0)
         pw_phase2_body<true, HAS_INVALID>(P, smem, colg, tile, recs, lutT, joined, priors, odr, rcp, sv_arr, vhor,
-                                          nsplit, part_cost, part_idx, steps, cost_table, index_table, blksum);
+                                          nsplit, part_cost, part_idx, steps, cost_table, index_table, blksum, t8row);
     else
         pw_phase2_body<false, HAS_INVALID>(P, smem, colg, tile, recs, lutT, joined, priors, odr, rcp, sv_arr, vhor,
-                                           nsplit, part_cost, part_idx, steps, cost_table, index_table, blksum);
+                                           nsplit, part_cost, part_idx, steps, cost_table, index_table, blksum, t8row);
 }
 
 /* ====================================================================================== */
@@ -1501,7 +1647,7 @@ __device__ __forceinline__ void pw_phase2x_body(const DevParams& P, char* smem, 
                                                 StepRec* __restrict__ steps,
                                                 float* __restrict__ cost_table,
                                                 int32_t* __restrict__ index_table,
-                                                float* __restrict__ blksum) {
+                                                float* __restrict__ blksum, float* __restrict__ t8row) {
     const int H = P.H, D = P.D;
     const int lane = threadIdx.x, li = lane & 31, l15 = lane & 15, hbase = lane & 32;
     const int half = lane >> 5;
@@ -1577,12 +1723,6 @@ __device__ __forceinline__ void pw_phase2x_body(const DevParams& P, char* smem, 
     st.q_o = q_o; st.q_gs = q_gs;
     int ob_cached = -1;
     float S_obc = 0.0f, V_obc = 0.0f;
-    float pw_keep = IS_INF; /* pwmp of the StepRec of vB = (this lane's vT) + 1: block summary, lemma L7 */
-    /* summary slot of the bound block that starts with this lane's candidate row, rows `base` .. of the tile */
-    auto blk_slot = [&](int base) -> float* {
-        return blksum + ((size_t)colg * (P.ntiles * IS_QPT + 1) + tile * IS_QPT + ((base + li) >> IS_QB_LOG) + 1) * IS_L7_F;
-    };
-
     /* partial minima of phase 1 for the rows base + li (its nsplit workgroups merged) */
     auto load_best = [&](int row_off, PairBest& b) {
         const size_t o = (size_t)colg * nsplit * 3 * 64 + row_off + li;
@@ -1651,11 +1791,14 @@ __device__ __forceinline__ void pw_phase2x_body(const DevParams& P, char* smem, 
         const float m8 = min_raw(min3_raw(st.p1_hi, st.p1_lo, st.p1_mid),
                                  min3_raw(min3_raw(st.p2_hi, st.p2_lo, st.p2_mid), st.p3_yes, st.p3_no));
         if (((r - tile_lo) & (IS_QB - 1)) == 0) q_o = q_gs = IS_INF; /* vB = r + 1 starts a bound block */
-        q_o = min_raw(q_o, P.pw * m8);
+        const float pwm8 = P.pw * m8;
+        q_o = min_raw(q_o, pwm8);
         q_gs = min_raw(q_gs, st.pwmp);
         st.q_o = q_o; st.q_gs = q_gs;
-        pw_keep = (li == src) ? st.pwmp : pw_keep;
-        if (li == 0 && r + 1 < H) store_step(scol + r + 1, st);
+        if (li == 0 && r + 1 < H) {
+            store_step(scol + r + 1, st);
+            t8row[(size_t)colg * H + r + 1] = pwm8; /* (lemma L8: the row's own transition bound) */
+        }
     };
     auto rec_dpp = [&](int v, float& R0, float& R1) { /* the record of v of this lane's column, DPP layout */
         const float* q = (const float*)(rcol + min(v, H));
@@ -1683,12 +1826,6 @@ __device__ __forceinline__ void pw_phase2x_body(const DevParams& P, char* smem, 
             finalize(r, s, b, my.S, my.V);
         }
         store_rows(vT, b);
-        {
-            const L7Row sumL = l7_group_min_row<IS_QB_LOG>(l7_row_bounds(P, pw_keep, my.G, my.K, my.Fg0, my.Fg1,
-                                                                         my.Fsky, my.Fnic, vT < vhor, vT + 1 < H));
-            if ((li & (IS_QB - 1)) == 0) l7_store(blk_slot(0), sumL);
-        }
-        pw_keep = IS_INF;
         if (li == 0) { /* StepRec(tile_lo + 32) for phase U */
             float* d = s_st + half * 16;
             d[0] = st.pwmp; d[1] = __builtin_bit_cast(float, st.idx_gs); d[2] = st.g_hi_thr; d[3] = st.g_lo_thr;
@@ -1697,7 +1834,18 @@ __device__ __forceinline__ void pw_phase2x_body(const DevParams& P, char* smem, 
             d[14] = st.q_o; d[15] = st.q_gs;
         }
     }
-    if (n_rows <= 32) return;
+    /* the summaries of the bound blocks (lemmas L7, L8) of both phases' rows, at the very end: nothing of
+     * the walk is alive any more (computed inside the phases they cost the walk registers it does not have) */
+    auto summaries = [&](int rows_done) {
+        __builtin_amdgcn_s_waitcnt(0); /* this wave's StepRec / T8 stores have reached the L2 */
+        float* const bcolw = blksum + (size_t)colg * (P.ntiles * IS_QPT + 1) * IS_L7_F;
+        for (int base = 0; base < rows_done; base += 32)
+            l78_block_summaries<IS_QB_LOG>(P, rcol, scol, t8row + (size_t)colg * H, bcolw, tile_lo, base + li, vhor);
+    };
+    if (n_rows <= 32) {
+        summaries(32);
+        return;
+    }
     /* this wave's StepRec stores of phase L must have reached the L2 before phase S reads them */
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
@@ -1743,10 +1891,8 @@ __device__ __forceinline__ void pw_phase2x_body(const DevParams& P, char* smem, 
             finalize(r, s - 32, b, my.S, my.V);
         }
         store_rows(vT, b);
-        const L7Row sumU = l7_group_min_row<IS_QB_LOG>(l7_row_bounds(P, pw_keep, my.G, my.K, my.Fg0, my.Fg1,
-                                                                     my.Fsky, my.Fnic, vT < vhor, vT + 1 < H));
-        if ((li & (IS_QB - 1)) == 0) l7_store(blk_slot(32), sumU);
     }
+    summaries(64);
 }
 
 template <bool HAS_INVALID>
@@ -1758,7 +1904,7 @@ __global__ __launch_bounds__(64, ISP2X_OCC) void k_pw_phase2x(
     const float* __restrict__ sv_arr, const int* __restrict__ vhor_arr,
     const int* __restrict__ col_flags, const float* __restrict__ part_cost,
     const int* __restrict__ part_idx, StepRec* __restrict__ steps, float* __restrict__ cost_table,
-    int32_t* __restrict__ index_table, float* __restrict__ blksum) {
+    int32_t* __restrict__ index_table, float* __restrict__ blksum, float* __restrict__ t8row) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int col0 = col_base + 2 * (int)blockIdx.x; /* col_base even, P.C even: one image per pair */
     if (col0 >= ncols) return;
@@ -1767,7 +1913,7 @@ __global__ __launch_bounds__(64, ISP2X_OCC) void k_pw_phase2x(
     const int f1 = col0 + 1 < ncols ? __builtin_amdgcn_readfirstlane(col_flags[col0 + 1]) : 1;
     if (f0 == 0 && f1 == 0)
         pw_phase2x_body<HAS_INVALID>(P, smem, col0, tile, recs, lutT, joined, priors, odr, rcp, sv_arr, vhor, nsplit,
-                                     part_cost, part_idx, steps, cost_table, index_table, blksum);
+                                     part_cost, part_idx, steps, cost_table, index_table, blksum, t8row);
     /* (a pair with a generic column: k_pw_phase2_generic walks it, column by column) */
 }
 
@@ -1782,7 +1928,7 @@ __global__ __launch_bounds__(64, 2) void k_pw_phase2_generic(
     const float* __restrict__ sv_arr, const int* __restrict__ vhor_arr,
     const int* __restrict__ col_flags, const float* __restrict__ part_cost,
     const int* __restrict__ part_idx, StepRec* __restrict__ steps, float* __restrict__ cost_table,
-    int32_t* __restrict__ index_table, const int* __restrict__ n_generic, float* __restrict__ blksum) {
+    int32_t* __restrict__ index_table, const int* __restrict__ n_generic, float* __restrict__ blksum, float* __restrict__ t8row) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (__builtin_amdgcn_readfirstlane(*n_generic) == 0) return;
     for (int colg = col_base + (int)blockIdx.x; colg < ncols; colg += (int)gridDim.x) {
@@ -1792,10 +1938,10 @@ __global__ __launch_bounds__(64, 2) void k_pw_phase2_generic(
         const int vhor = __builtin_amdgcn_readfirstlane(vhor_arr[colg / P.C]);
         if (__builtin_amdgcn_readfirstlane(col_flags[colg]) == 0)
             pw_phase2_body<true, HAS_INVALID>(P, smem, colg, tile, recs, lutT, joined, priors, odr, rcp, sv_arr, vhor,
-                                              nsplit, part_cost, part_idx, steps, cost_table, index_table, blksum);
+                                              nsplit, part_cost, part_idx, steps, cost_table, index_table, blksum, t8row);
         else
             pw_phase2_body<false, HAS_INVALID>(P, smem, colg, tile, recs, lutT, joined, priors, odr, rcp, sv_arr, vhor,
-                                               nsplit, part_cost, part_idx, steps, cost_table, index_table, blksum);
+                                               nsplit, part_cost, part_idx, steps, cost_table, index_table, blksum, t8row);
         __syncthreads();
     }
 }
@@ -1878,7 +2024,7 @@ __device__ __forceinline__ void pw_phase2s_body(const DevParams& P, char* smem, 
                                                 StepRec* __restrict__ steps,
                                                 float* __restrict__ cost_table,
                                                 int32_t* __restrict__ index_table,
-                                                float* __restrict__ blksum) {
+                                                float* __restrict__ blksum, float* __restrict__ t8row) {
     const int H = P.H, D = P.D;
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1972,7 +2118,6 @@ __device__ __forceinline__ void pw_phase2s_body(const DevParams& P, char* smem, 
         st.q_o = q_o; st.q_gs = q_gs;
         int ob_cached = -1;
         float S_obc = 0.0f, V_obc = 0.0f;
-        float pw_keep = IS_INF; /* (block summary, see pw_phase2_body) */
         for (int s = 0; s < n_rows; s++) {
             const int r = tile_lo + s;
             PriorVals pv;
@@ -2019,11 +2164,14 @@ __device__ __forceinline__ void pw_phase2s_body(const DevParams& P, char* smem, 
                 const float m8 = min_raw(min3_raw(st.p1_hi, st.p1_lo, st.p1_mid),
                                          min3_raw(min3_raw(st.p2_hi, st.p2_lo, st.p2_mid), st.p3_yes, st.p3_no));
                 if ((s & (IS_QB - 1)) == 0) q_o = q_gs = IS_INF; /* vB = r + 1 starts a bound block */
-                q_o = min_raw(q_o, P.pw * m8);
+                const float pwm8 = P.pw * m8;
+                q_o = min_raw(q_o, pwm8);
                 q_gs = min_raw(q_gs, st.pwmp);
                 st.q_o = q_o; st.q_gs = q_gs;
-                pw_keep = (lane == s) ? st.pwmp : pw_keep;
-                if (lane == 0 && r + 1 < H) store_step(scol + r + 1, st);
+                if (lane == 0 && r + 1 < H) {
+                    store_step(scol + r + 1, st);
+                    t8row[(size_t)colg * H + r + 1] = pwm8;
+                }
             }
         }
         if (vT < H) {
@@ -2031,19 +2179,17 @@ __device__ __forceinline__ void pw_phase2s_body(const DevParams& P, char* smem, 
             cost_table[o + 0] = b.g; cost_table[o + 1] = b.o; cost_table[o + 2] = b.s;
             index_table[o + 0] = b.ig; index_table[o + 1] = b.io; index_table[o + 2] = b.is;
         }
-        { /* block summary (lemma L7, see pw_phase2_body); the chain wave fetches the record fields here */
-            L7Row sum;
+        { /* block summaries (lemmas L7, L8, see pw_phase2_body) */
+            float* const bcolw = blksum + (size_t)colg * (P.ntiles * IS_QPT + 1) * IS_L7_F;
             if (FAST) {
-                const RowRec* mr = rcol + vTc + 1;
-                sum = l7_row_bounds(P, pw_keep, mr->G, mr->K, mr->Fg0, mr->Fg1, mr->Fsky, mr->Fnic, vT < vhor,
-                                    vT + 1 < H);
-                sum = l7_group_min_row<IS_QB_LOG>(sum);
+                __builtin_amdgcn_s_waitcnt(0);
+                l78_block_summaries<IS_QB_LOG>(P, rcol, scol, t8row + (size_t)colg * H, bcolw, tile_lo, lane, vhor);
             } else {
-                sum = l7_never();
+                float* const slot = bcolw + (size_t)(tile * IS_QPT + (lane >> IS_QB_LOG) + 1) * IS_L7_F;
+                const bool writer = (lane & (IS_QB - 1)) == 0;
+                if (writer) l7_store(slot, l7_never());
+                l8_store_never(slot + 8, writer);
             }
-            if ((lane & (IS_QB - 1)) == 0)
-                l7_store(blksum + ((size_t)colg * (P.ntiles * IS_QPT + 1) + tile * IS_QPT + (lane >> IS_QB_LOG) + 1) *
-                                      IS_L7_F, sum);
         }
     } else {
         /* ================================ evaluator waves ================================ */
@@ -2094,17 +2240,17 @@ __global__ __launch_bounds__(ISP2S_WAVES * 64, 5) void k_pw_phase2s(
     const float* __restrict__ sv_arr, const int* __restrict__ vhor_arr,
     const int* __restrict__ col_flags, const float* __restrict__ part_cost,
     const int* __restrict__ part_idx, StepRec* __restrict__ steps, float* __restrict__ cost_table,
-    int32_t* __restrict__ index_table, float* __restrict__ blksum) {
+    int32_t* __restrict__ index_table, float* __restrict__ blksum, float* __restrict__ t8row) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int colg = col_base + blockIdx.x;
     if (colg >= ncols) return;
     const int vhor = __builtin_amdgcn_readfirstlane(vhor_arr[colg / P.C]);
     if (__builtin_amdgcn_readfirstlane(col_flags[colg]) == 0)
         pw_phase2s_body<true, HAS_INVALID>(P, smem, colg, tile, recs, lutT, joined, priors, odr, rcp, sv_arr,
-                                           vhor, nsplit, part_cost, part_idx, steps, cost_table, index_table, blksum);
+                                           vhor, nsplit, part_cost, part_idx, steps, cost_table, index_table, blksum, t8row);
     else
         pw_phase2s_body<false, HAS_INVALID>(P, smem, colg, tile, recs, lutT, joined, priors, odr, rcp, sv_arr,
-                                            vhor, nsplit, part_cost, part_idx, steps, cost_table, index_table, blksum);
+                                            vhor, nsplit, part_cost, part_idx, steps, cost_table, index_table, blksum, t8row);
 }
 
 extern "C" {
@@ -2148,7 +2294,7 @@ hipError_t isk_launch_dp_pairwise(const DevParams* P, int ncols, int nwaves, con
                                   const int* col_flags, const PruneRec* prune, StepRec* steps,
                                   float* part_cost, int* part_idx, float* cost_table,
                                   int32_t* index_table, unsigned long long* counters,
-                                  const float* cost_T, const int* n_generic, float* blksum,
+                                  const float* cost_T, const int* n_generic, float* blksum, float* t8row,
                                   hipStream_t stream, hipStream_t* aux, int n_aux,
                                   hipEvent_t ev_fork, hipEvent_t* ev_join) {
     const size_t lds1 = isk_pairwise_lds_bytes(P, nwaves);
@@ -2196,21 +2342,21 @@ hipError_t isk_launch_dp_pairwise(const DevParams* P, int ncols, int nwaves, con
     hipLaunchKernelGGL(k_pw_phase2<INV>, dim3((c1) - (c0)), dim3(64), lds2, st, *P, c0, c1, tile,  \
                        nsplit, recs, lutT, joined, priors, odr, rcp, sv_arr, vhor, col_flags,      \
                        part_cost,                                                                  \
-                       part_idx, steps, cost_table, index_table, blksum)
+                       part_idx, steps, cost_table, index_table, blksum, t8row)
 #define IS_LAUNCH_P2X(INV, c0, c1, st)                                                             \
     do {                                                                                           \
         hipLaunchKernelGGL(k_pw_phase2x<INV>, dim3(((c1) - (c0) + 1) / 2), dim3(64), lds2x, st, *P, c0, \
                            c1, tile, nsplit, recs, lutT, joined, priors, odr, rcp, sv_arr, vhor,   \
-                           col_flags, part_cost, part_idx, steps, cost_table, index_table, blksum); \
+                           col_flags, part_cost, part_idx, steps, cost_table, index_table, blksum, t8row); \
         hipLaunchKernelGGL(k_pw_phase2_generic<INV>, dim3(min((c1) - (c0), 512)), dim3(64), lds2, st, \
                            *P, c0, c1, tile, nsplit, recs, lutT, joined, priors, odr, rcp, sv_arr, \
                            vhor, col_flags, part_cost, part_idx, steps, cost_table, index_table,   \
-                           n_generic, blksum);                                                     \
+                           n_generic, blksum, t8row);                                                     \
     } while (0)
 #define IS_LAUNCH_P2S(INV, c0, c1, st)                                                             \
     hipLaunchKernelGGL(k_pw_phase2s<INV>, dim3((c1) - (c0)), dim3(ISP2S_WAVES * 64), lds2s, st, *P, \
                        c0, c1, tile, nsplit, recs, lutT, joined, priors, odr, rcp, sv_arr, vhor,   \
-                       col_flags, part_cost, part_idx, steps, cost_table, index_table, blksum)
+                       col_flags, part_cost, part_idx, steps, cost_table, index_table, blksum, t8row)
     const bool inv = P->invalid >= 0;
     /* phase 2 split over four waves per column (k_pw_phase2s) while the columns are too few to fill
      * the chip with one wave each: it shortens the serial chain of a column (one frame: 82 -> 74 us
