@@ -372,6 +372,90 @@ __device__ __forceinline__ void l8_group_min_store(const DevParams& P, float T8,
         if ((lane & ((1 << (LOG - 3)) - 1)) == 0) dst[bq * 8 + base] = v[0];
     }
 }
+/* ---- the same minima on the DPP / permlane path (IS_L78_DPP, groups of 32 lanes) --------------------
+ * __shfl_xor is a ds_bpermute (LDS crossbar, an address VGPR, an lgkmcnt wait) and __builtin_fminf
+ * re-quiets a value that went through a bitcast (v_max x, x): 3 instructions and a round trip per
+ * exchange.  Here an exchange is v_permlane16_swap (distance 16: the rows of TWO values swapped by one
+ * instruction, so that one minimum reduces both -- each lands in its own row parity) or a v_mov_b32_dpp
+ * (row_ror / quad_perm, bank-masked where the two halves of a pair go different ways) + a bare v_min_f32.
+ * The results are the minima of the same numbers: bit-identical to the shuffle version. */
+#ifndef IS_L78_DPP
+#define IS_L78_DPP 1
+#endif
+template <int CTRL, int BANK = 0xf>
+__device__ __forceinline__ float dpp_mov(float old, float src) {
+    return __uint_as_float(__builtin_amdgcn_update_dpp(__float_as_uint(old), __float_as_uint(src), CTRL, 0xf, BANK, false));
+}
+#define IS_DPP_ROR4 0x124
+#define IS_DPP_ROR8 0x128
+#define IS_DPP_ROR12 0x12C
+#define IS_DPP_XOR1 0xB1 /* quad_perm:[1,0,3,2] */
+#define IS_DPP_XOR2 0x4E /* quad_perm:[2,3,0,1] */
+#define IS_DPP_ID 0xE4   /* quad_perm:[0,1,2,3] */
+/* rows 0 / 2 of the result: min of a over lanes 0..31 / 32..63, rows 1 / 3: min of b (quiet-NaN-free inputs) */
+__device__ __forceinline__ float pair_min32(float a, float b) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    float x = min_raw(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    x = min_raw(x, dpp_mov<IS_DPP_ROR8>(x, x));
+    x = min_raw(x, dpp_mov<IS_DPP_ROR4>(x, x));
+    x = min_raw(x, dpp_mov<IS_DPP_XOR2>(x, x));
+    x = min_raw(x, dpp_mov<IS_DPP_XOR1>(x, x));
+    return x;
+}
+/* sixteen values per lane -> lane l of a 32-lane group holds the group's minimum of value (l & 31) >> 1 */
+__device__ __forceinline__ float scatter_min32x16(const float (&v)[16], int lane) {
+    float w[8], x[4], y[2];
+#pragma unroll
+    for (int j = 0; j < 8; j++) { /* distance 16: odd rows take value j + 8 */
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[j]), __float_as_uint(v[j + 8]), false, false);
+        w[j] = min_raw(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) { /* distance 8: lanes 8..15 of a row (banks 2, 3) take value j + 4 */
+        const float keep = dpp_mov<IS_DPP_ID, 0xC>(w[j], w[j + 4]);
+        float recv = dpp_mov<IS_DPP_ROR8, 0x3>(w[j], w[j]);
+        recv = dpp_mov<IS_DPP_ROR8, 0xC>(recv, w[j + 4]);
+        x[j] = min_raw(keep, recv);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; j++) { /* distance 4: banks 1, 3 take value j + 2 (row_ror:n: lane l reads lane l - n) */
+        const float keep = dpp_mov<IS_DPP_ID, 0xA>(x[j], x[j + 2]);
+        float recv = dpp_mov<IS_DPP_ROR12, 0x5>(x[j], x[j]);
+        recv = dpp_mov<IS_DPP_ROR4, 0xA>(recv, x[j + 2]);
+        y[j] = min_raw(keep, recv);
+    }
+    const bool up = (lane & 2) != 0; /* distance 2 */
+    const float keep = up ? y[1] : y[0], send = up ? y[0] : y[1];
+    float z = min_raw(keep, dpp_mov<IS_DPP_XOR2>(send, send));
+    return min_raw(z, dpp_mov<IS_DPP_XOR1>(z, z));
+}
+/* l7_row_bounds + l7_group_min_row + l7_store and l8_group_min_store for groups of 32 lanes */
+__device__ __forceinline__ void l78_store32(const DevParams& P, float T, float T8, const RowRec* rec /* global */,
+                                            bool ground_row, bool ok, float* slot, int lane) {
+    const float4* r4 = reinterpret_cast<const float4*>(rec);
+    const float4 c0 = r4[0], c1 = r4[1], c2 = r4[2], c3 = r4[3], c4 = r4[4]; /* Fg0 Fg1 Fon0..7 Foi0..7 Fsky Fnic */
+    const float2 gk = *reinterpret_cast<const float2*>((const float*)rec + 20); /* G K */
+    L7Row r = l7_row_bounds(P, T, gk.x, gk.y, c0.x, c0.y, c4.z, __float_as_int(c4.w), ground_row, ok);
+    r.lo_g0 = min_raw(r.lo_g0, IS_INF); r.lo_g1 = min_raw(r.lo_g1, IS_INF); r.lo_s = min_raw(r.lo_s, IS_INF); /* NaN -> +inf */
+    r.hi_g0 = min_raw(r.hi_g0, IS_INF); r.hi_g1 = min_raw(r.hi_g1, IS_INF); r.hi_s = min_raw(r.hi_s, IS_INF);
+    const float m0 = pair_min32(r.lo_g0, r.hi_g0), m1 = pair_min32(r.lo_g1, r.hi_g1), m2 = pair_min32(r.lo_s, r.hi_s);
+    if ((lane & 15) == 0) /* lane 0 of the group: the lo minima (floats 0..3), lane 16: the hi minima (floats 4..7) */
+        reinterpret_cast<float4*>(slot)[(lane >> 4) & 1] = make_float4(m0, m1, m2, 0.0f);
+    const float n = P.iw * (float)__float_as_int(c4.w);
+    const float f[16] = {c0.z, c0.w, c1.x, c1.y, c1.z, c1.w, c2.x, c2.y, c2.z, c2.w, c3.x, c3.y, c3.z, c3.w, c4.x, c4.y};
+    const float t8 = ok ? T8 : IS_INF; /* not a candidate row: inf - inf = NaN -> +inf below */
+    float v[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const float ft = P.sw * (j < 8 ? f[j] + n : f[j]);
+        const float a = t8 - ft;
+        const float mu = __builtin_fabsf(t8) + ft;
+        v[j] = min_raw(a - (mu * IS_L7_REL + IS_L7_ABS), IS_INF);
+    }
+    const float z = scatter_min32x16(v, lane);
+    if ((lane & 1) == 0) slot[8 + ((lane & 31) >> 1)] = z;
+}
+
 /* The summaries (lemmas L7, L8) of the bound blocks of the candidate rows vB = tile_lo + base + g + 1, g = this
  * lane's index in its group of 2^LOG lanes (one lane per row, one group per block).  Called at the END of
  * a phase-2 walk, when nothing else is alive: the per-row transition terms -- pwmp = StepRec field 0 and
@@ -388,12 +472,16 @@ __device__ __forceinline__ void l78_block_summaries(const DevParams& P, const Ro
     const float T = ((const float*)(scol + vBc))[0];
     const float T8 = t8col[vBc];
     const RowRec* rec = rcol + vBc;
+    float* const slot = bsum_col + (size_t)(((tile_lo >> 6) * IS_QPT) + (row >> IS_QB_LOG) + 1) * IS_L7_F;
+    if (IS_L78_DPP && LOG == 5) {
+        l78_store32(P, T, T8, rec, vB - 1 < vhor, ok, slot, (int)(threadIdx.x & 63));
+        return;
+    }
     const float4* r4 = reinterpret_cast<const float4*>(rec);
     const float4 c0 = r4[0], c4 = r4[4];      /* Fg0 Fg1 . . | Foi6 Foi7 Fsky Fnic */
     const float2 gk = *reinterpret_cast<const float2*>((const float*)rec + 20); /* G K */
     L7Row sum = l7_row_bounds(P, T, gk.x, gk.y, c0.x, c0.y, c4.z, __float_as_int(c4.w), vB - 1 < vhor, ok);
     sum = l7_group_min_row<LOG>(sum);
-    float* const slot = bsum_col + (size_t)(((tile_lo >> 6) * IS_QPT) + (row >> IS_QB_LOG) + 1) * IS_L7_F;
     if ((threadIdx.x & ((1 << LOG) - 1)) == 0) l7_store(slot, sum);
     l8_group_min_store<LOG>(P, T8, rec, ok, slot + 8);
 }
