@@ -264,11 +264,12 @@ __device__ __forceinline__ void prepare_columns_body(
     /* (the raw offsets from the input tensor: the LDS copies are squared in place further down) */
     auto offx_raw = [&](int i) -> int32_t { return scol[(K + 1) * P2S + i]; };
     auto offy_raw = [&](int i) -> int32_t { return scol[K * P2S + i]; };
-    auto instance_rows = [&](bool store) {
+    /* (dst_row(r): where the record of row r goes) */
+    auto instance_rows = [&](bool store, auto dst_row) {
         int64_t bx = base_mx, by = base_my, bx2 = base_mx2, by2 = base_my2;
         for (int r = r_lo; r < r_lo + R && r < H; r++) {
 #ifndef PREP_ABL_NOSTORE_INST
-            if (store) store_instance_prefix(rcol + r, slow, bx, by, bx2, by2);
+            if (store) store_instance_prefix(dst_row(r), slow, bx, by, bx2, by2);
 #endif
             const double fx = ((double)(P.column_step * col) + 0.5 * ((double)P.column_step - 1.0)) +
                               (double)offx_raw(r >> 3) + 0.5;
@@ -281,11 +282,12 @@ __device__ __forceinline__ void prepare_columns_body(
             by2 = (int64_t)((uint64_t)by2 + (uint64_t)my * (uint64_t)my);
         }
         if (r_lo <= H - 1 && H - 1 < r_lo + R) {
-            if (store) store_instance_prefix(rcol + H, slow, bx, by, bx2, by2);
+            if (store) store_instance_prefix(dst_row(H), slow, bx, by, bx2, by2);
             s_tot[0] = (float)((double)bx2 + (double)by2); /* column totals (PruneRec.E2) */
         }
     };
-    instance_rows(!PREP_STORE_LATE);
+    auto rec_row = [&](int r) -> RowRec* { return rcol + r; };
+    instance_rows(!PREP_STORE_LATE, rec_row);
     __syncthreads();
 
     /* ---- square the offset channels in place (StixelsKernels.cu:411-416), then exclusive
@@ -343,6 +345,43 @@ __device__ __forceinline__ void prepare_columns_body(
         }
     }
     __syncthreads();
+    /* one (1/8-resolution block kb, chunk q) item of the class prefixes: emit(v, q, chunk) for its rows */
+    auto class_item = [&](int kb, int q, auto emit) {
+        const int kn = min(kb + 1, SS - 1); /* (the last block has one row: its increment is never used) */
+        uint32_t cur[4], dif[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int dw = q * 4 + j; /* dword of RowRec: Fg0 Fg1 Fon[8] Foi[8] Fsky Fnic */
+            if (dw == 19) {
+                const int32_t* px = s_seg + (K + 1) * SS;
+                const int32_t* py = s_seg + K * SS;
+                const uint32_t ax = (uint32_t)px[kb], ay = (uint32_t)py[kb];
+                cur[j] = ax * 8u + ay * 8u;
+                dif[j] = ((uint32_t)px[kn] - ax) + ((uint32_t)py[kn] - ay);
+            } else {
+                const int chn = dw < 10 ? dw : (dw < 18 ? dw + 1 : 10);
+                const int32_t* ps = s_seg + chn * SS;
+                const uint32_t a = (uint32_t)ps[kb];
+                cur[j] = a * 8u;
+                dif[j] = (uint32_t)ps[kn] - a;
+            }
+        }
+        const bool is_count = (q == 4); /* dword 19 (Fnic) stays an integer in both encodings */
+#pragma unroll
+        for (int m = 0; m < 8; m++) {
+            const int v = kb * 8 + m;
+            if (v <= H) {
+                int32_t x[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int32_t f = (int32_t)cur[j];
+                    x[j] = (slow || (is_count && j == 3)) ? f : __float_as_int((float)f);
+                    cur[j] += dif[j];
+                }
+                emit(v, q, make_int4(x[0], x[1], x[2], x[3]));
+            }
+        }
+    };
     auto class_chunks = [&]() {
     /* dwords 0..19 of every record (class prefixes + squared-offset prefix) as five 16-byte
      * chunks.  A thread owns one chunk of the EIGHT rows of a 1/8-resolution block: the full-resolution
@@ -354,42 +393,11 @@ __device__ __forceinline__ void prepare_columns_body(
         const int NB = (H >> 3) + 1; /* blocks; the last one holds row H only */
         for (int it = tid; it < NB * 5; it += PREP_THREADS) {
             const int kb = it / 5, q = it - kb * 5;
-            const int kn = min(kb + 1, SS - 1); /* (the last block has one row: its increment is never used) */
-            uint32_t cur[4], dif[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int dw = q * 4 + j; /* dword of RowRec: Fg0 Fg1 Fon[8] Foi[8] Fsky Fnic */
-                if (dw == 19) {
-                    const int32_t* px = s_seg + (K + 1) * SS;
-                    const int32_t* py = s_seg + K * SS;
-                    const uint32_t ax = (uint32_t)px[kb], ay = (uint32_t)py[kb];
-                    cur[j] = ax * 8u + ay * 8u;
-                    dif[j] = ((uint32_t)px[kn] - ax) + ((uint32_t)py[kn] - ay);
-                } else {
-                    const int chn = dw < 10 ? dw : (dw < 18 ? dw + 1 : 10);
-                    const int32_t* ps = s_seg + chn * SS;
-                    const uint32_t a = (uint32_t)ps[kb];
-                    cur[j] = a * 8u;
-                    dif[j] = (uint32_t)ps[kn] - a;
-                }
-            }
-            const bool is_count = (q == 4); /* dword 19 (Fnic) stays an integer in both encodings */
-#pragma unroll
-            for (int m = 0; m < 8; m++) {
-                const int v = kb * 8 + m;
-                if (v <= H) {
-                    int32_t x[4];
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        const int32_t f = (int32_t)cur[j];
-                        x[j] = (slow || (is_count && j == 3)) ? f : __float_as_int((float)f);
-                        cur[j] += dif[j];
-                    }
+            class_item(kb, q, [&](int v, int qq, int4 x) {
 #ifndef PREP_ABL_NOSTORE_CLASS
-                    reinterpret_cast<int4*>(rcol + v)[q] = make_int4(x[0], x[1], x[2], x[3]);
+                reinterpret_cast<int4*>(rcol + v)[qq] = x;
 #endif
-                }
-            }
+            });
         }
     }
     };
@@ -529,9 +537,13 @@ __device__ __forceinline__ void prepare_columns_body(
     } else {
         for (int v = tid; v <= H; v += PREP_THREADS) rcol[v].K = prefix_at(v);
     }
+    /* (round 4, measured and removed: the records staged 64 rows at a time in LDS and stored as whole
+     * 128-byte lines, eight lanes per record -- 1.53 instead of 1.21 ms for the column blocks of a batch of
+     * 64: the 34 extra barriers cost more than the partial lines do; the kernel is bound by its LDS /
+     * VALU work, not by its 2.15 GB of stores) */
     if (PREP_STORE_LATE) {
         class_chunks();
-        instance_rows(true);
+        instance_rows(true, rec_row);
     }
 }
 
@@ -557,14 +569,28 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_columns(
  * cross-lane traffic); the 64 lanes of a wave are 64 consecutive fn, so every load of the
  * transposed cost table and every store of a lutT row is one fully coalesced 256-byte access. */
 #define LUT_BLOCK 32
+/* The table is 8.6 GB for a batch of 64 (1024 x 2048 x 128): its stores ARE the kernel.  Measured (batch 64,
+ * k_object_lut alone, tools/abl_prep.sh): 1.78 ms = 4.8 TB/s with plain stores; the same instruction stream
+ * with the stores wrapped into 8 rows per column (absorbed by the L2, PREP_ABL_WRAP) 0.48 ms; non-temporal
+ * stores (full 256-byte rows that nothing reads before the whole table is written: no reason to keep them in
+ * the L2 / MALL) 1.59 ms = 5.4 TB/s.  Storing fewer fn per row only pays in whole 128-byte lines
+ * (PREP_ABL_FNMAX=105: 2.37 ms, partial lines are read-modify-write). */
+#ifndef PREP_LUT_NT
+#define PREP_LUT_NT 1
+#endif
 __device__ __forceinline__ void object_lut_body(const DevParams& P, const int colg, const int fn_block,
                                                 const int lane, const float* __restrict__ joined,
                                                 const float* __restrict__ cost_T /*[dis][fn]*/,
                                                 float* __restrict__ lutT) {
     const int H = P.H, D = P.D;
     const int fn = fn_block * 64 + lane;
+#ifdef PREP_ABL_FNMAX /* ablation: how much of the LUT blocks' time is their store bytes */
+    const bool fn_ok = fn < PREP_ABL_FNMAX;
+    const int fnc = fn_ok ? fn : PREP_ABL_FNMAX - 1;
+#else
     const bool fn_ok = fn < D;
     const int fnc = fn_ok ? fn : D - 1;
+#endif
     const float* dcol = joined + (size_t)colg * H;
     float* lcol = lutT + (size_t)colg * (H + 1) * D;
     if (fn_ok) lcol[fn] = 0.0f; /* arr[0] = 0, :283-285 */
@@ -615,7 +641,13 @@ __device__ __forceinline__ void object_lut_body(const DevParams& P, const int co
         }
         if (full) {
 #pragma unroll
+#ifdef PREP_ABL_WRAP /* ablation: the same stores into 8 rows per column (absorbed by the L2): what do the HBM bytes cost */
+            for (int l = 0; l < LUT_BLOCK; l++) lcol[(size_t)((i + l + 1) & 7) * D + fnc] = c[l];
+#elif PREP_LUT_NT
+            for (int l = 0; l < LUT_BLOCK; l++) __builtin_nontemporal_store(c[l], &lcol[(size_t)(i + l + 1) * D + fnc]);
+#else
             for (int l = 0; l < LUT_BLOCK; l++) lcol[(size_t)(i + l + 1) * D + fnc] = c[l]; /* :266 */
+#endif
         } else if (fn_ok) {
 #pragma unroll
             for (int l = 0; l < LUT_BLOCK; l++)
@@ -652,6 +684,9 @@ __global__ __launch_bounds__(64) void k_object_lut(const DevParams P,
 #ifndef IS_FUSED_LUT_FIRST
 #define IS_FUSED_LUT_FIRST 0
 #endif
+#ifndef IS_FUSED_INTERLEAVE
+#define IS_FUSED_INTERLEAVE 0
+#endif
 __global__ __launch_bounds__(PREP_THREADS) void k_prepare_fused(
     const DevParams P, int ncols, int n_lut, const float* __restrict__ joined, const int32_t* __restrict__ seg,
     const float* __restrict__ ground, const int* __restrict__ vhor_arr, const float* __restrict__ cost_T,
@@ -659,14 +694,38 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_fused(
     float* __restrict__ sv_arr, PruneRec* __restrict__ prune, int* __restrict__ n_generic) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int b = (int)blockIdx.x;
-    const bool is_lut = IS_FUSED_LUT_FIRST ? b < n_lut : b >= ncols;
+    bool is_lut;
+    int lut_b, col_b;
+#if IS_FUSED_INTERLEAVE
+    /* block order: IS_FUSED_INTERLEAVE column blocks, one LUT block, ... while both kinds last */
+    {
+        constexpr int G = IS_FUSED_INTERLEAVE + 1;
+        const int groups = min(ncols / IS_FUSED_INTERLEAVE, n_lut); /* full groups */
+        if (b < groups * G) {
+            const int g = b / G, r = b - g * G;
+            is_lut = r == IS_FUSED_INTERLEAVE;
+            lut_b = g;
+            col_b = g * IS_FUSED_INTERLEAVE + r;
+        } else { /* the rest of the longer kind */
+            const int rest = b - groups * G;
+            const int cols_left = ncols - groups * IS_FUSED_INTERLEAVE;
+            is_lut = rest >= cols_left;
+            col_b = groups * IS_FUSED_INTERLEAVE + rest;
+            lut_b = groups + (rest - cols_left);
+        }
+    }
+#else
+    is_lut = IS_FUSED_LUT_FIRST ? b < n_lut : b >= ncols;
+    lut_b = IS_FUSED_LUT_FIRST ? b : b - ncols;
+    col_b = IS_FUSED_LUT_FIRST ? b - n_lut : b;
+#endif
     if (is_lut) {
         const int fn_blocks = (P.D + 63) / 64;
-        const int unit = (IS_FUSED_LUT_FIRST ? b : b - ncols) * (PREP_THREADS / 64) + (int)(threadIdx.x >> 6);
+        const int unit = lut_b * (PREP_THREADS / 64) + (int)(threadIdx.x >> 6);
         if (unit < ncols * fn_blocks)
             object_lut_body(P, unit / fn_blocks, unit % fn_blocks, (int)(threadIdx.x & 63), joined, cost_T, lutT);
     } else {
-        prepare_columns_body(P, IS_FUSED_LUT_FIRST ? b - n_lut : b, smem, joined, seg, ground, vhor_arr, recs,
+        prepare_columns_body(P, col_b, smem, joined, seg, ground, vhor_arr, recs,
                              col_flags, sv_arr, prune, n_generic);
     }
 }

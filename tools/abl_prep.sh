@@ -3,7 +3,7 @@
 set -u
 export TMPDIR=/tmp
 cd instance_stixels_amd/csrc
-for v in base "-DPREP_STORE_LATE=0"; do
+for v in ${ABL_VARIANTS:-base "-DPREP_STORE_LATE=0"}; do
   if [ "$v" = base ]; then A=""; else A="$v"; fi
   make abl ABL="$A" > /dev/null 2>&1 || { echo build failed $v; continue; }
   cd ../..
