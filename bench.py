@@ -374,6 +374,42 @@ def measure_mode(wl, steps=3, with_pruning_off=True, with_verify=True, with_prun
     return out
 
 
+def measure_in_flight(wl, counts, steps=12):
+    """The headline step with several contexts in flight (tools/two_ctx.py): context k on its own stream
+    takes every k-th batch; all results are compared with the single-context output."""
+    torch = wl.torch
+    res = {"what": "N contexts on N streams, batches alternate between them; images/s over all of them "
+                   "(the headline `value` is ONE context, one batch at a time)"}
+    for n in counts:
+        cores = [wl.make_core() for _ in range(n)]
+        streams = [torch.cuda.Stream(wl.dev) for _ in range(n)]
+        joined = [torch.empty_like(wl.d_joined) for _ in range(n)]
+        outs = [torch.empty_like(wl.d_sections) for _ in range(n)]
+
+        def step(i):
+            k = i % n
+            sp = streams[k].cuda_stream
+            cores[k].join_columns_ptr(wl.d_big.data_ptr(), wl.W, wl.cfg.median_join, joined[k].data_ptr(), wl.B, sp)
+            cores[k].compute_ptr(joined[k].data_ptr(), wl.d_seg.data_ptr(), wl.gf, wl.ng, wl.ig, wl.vh,
+                                 wl.cfg.pairwise, wl.B, outs[k].data_ptr(), None, None, None, sp)
+
+        for i in range(2 * n):
+            step(i)
+        torch.cuda.synchronize(wl.dev)
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(i)
+        torch.cuda.synchronize(wl.dev)
+        dt = (time.perf_counter() - t0) / steps
+        res[str(n)] = {"images_per_s": wl.B / dt, "ms_per_step": dt * 1e3, "steps": steps,
+                       "outputs_equal_single_context": bool(all(torch.equal(wl.d_sections, o) for o in outs))}
+        for c in cores:
+            c.close()
+        del cores, streams, joined, outs
+        torch.cuda.empty_cache()
+    return res
+
+
 EXTRA_FAMILIES = ("iid_noise", "low_confidence", "flat_disparity", "homogeneous", "many_thin_objects",
                   "noisy_disparity")
 
@@ -439,6 +475,11 @@ def measure_variants(args, wl, dev, local_rank):
         "what": "the same step with the instance candidates (StixelsKernels.cu:926-942) and their "
                 "size-filtered DBSCAN (Stixels.cu:613) for every frame: two more launches per batch"}
     del keep, ibs
+    core.close()
+
+    # ---- two / three batches in flight: one context and one stream each, batches alternate (what a
+    # double-buffered caller does; the kernels of one batch fill the launch gaps and tails of another)
+    out["in_flight"] = measure_in_flight(wl, (2, 3))
 
     # ---- invalid-disparity value 0 with 5 % holes: the HAS_INVALID kernel variants
     wl.free()

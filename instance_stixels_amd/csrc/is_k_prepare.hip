@@ -9,6 +9,9 @@
 #ifndef PREP_STORE_LATE
 #define PREP_STORE_LATE 1
 #endif
+#ifndef PREP_EPI_ROWS
+#define PREP_EPI_ROWS 256 /* rows per block of the record epilogue (0 = piece by piece) */
+#endif
 
 /* LDS stride of a segmentation channel: H/8 + 1 prefix entries, rounded up to 16 bytes */
 __host__ __device__ static inline int prep_seg_stride(int H) { return (((H >> 3) + 1) + 3) & ~3; }
@@ -106,6 +109,19 @@ __device__ __forceinline__ int32_t full_prefix(const int32_t* ps, int v) {
     return r;
 }
 
+#ifndef PREP_REC_NT
+#define PREP_REC_NT 0
+#endif
+/* one 16-byte piece of a record */
+__device__ __forceinline__ void prep_store16(int4* dst, int4 x) {
+#if PREP_REC_NT
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    v4i y = {x.x, x.y, x.z, x.w};
+    __builtin_nontemporal_store(y, reinterpret_cast<v4i*>(dst));
+#else
+    *dst = x;
+#endif
+}
 __device__ __forceinline__ void store_instance_prefix(RowRec* o, int slow, int64_t mx, int64_t my,
                                                       int64_t mx2, int64_t my2) {
     /* dwords 24..31 of the record as two 16-byte stores */
@@ -123,8 +139,8 @@ __device__ __forceinline__ void store_instance_prefix(RowRec* o, int slow, int64
                       0, 0);
     }
     int4* d = reinterpret_cast<int4*>(o);
-    d[6] = a;
-    d[7] = b;
+    prep_store16(d + 6, a);
+    prep_store16(d + 7, b);
 }
 
 __device__ __forceinline__ void prepare_columns_body(
@@ -286,7 +302,15 @@ __device__ __forceinline__ void prepare_columns_body(
             s_tot[0] = (float)((double)bx2 + (double)by2); /* column totals (PruneRec.E2) */
         }
     };
-    auto rec_row = [&](int r) -> RowRec* { return rcol + r; };
+#ifndef PREP_REC_NT
+#define PREP_REC_NT 0
+#endif
+#ifdef PREP_ABL_RECWRAP /* ablation: the same record stores into 8 rows per column (absorbed by the L2) */
+#define PREP_RROW(v) ((v) & 7)
+#else
+#define PREP_RROW(v) (v)
+#endif
+    auto rec_row = [&](int r) -> RowRec* { return rcol + PREP_RROW(r); };
     instance_rows(!PREP_STORE_LATE, rec_row);
     __syncthreads();
 
@@ -395,7 +419,7 @@ __device__ __forceinline__ void prepare_columns_body(
             const int kb = it / 5, q = it - kb * 5;
             class_item(kb, q, [&](int v, int qq, int4 x) {
 #ifndef PREP_ABL_NOSTORE_CLASS
-                reinterpret_cast<int4*>(rcol + v)[qq] = x;
+                prep_store16(reinterpret_cast<int4*>(rcol + PREP_RROW(v)) + qq, x);
 #endif
             });
         }
@@ -408,6 +432,7 @@ __device__ __forceinline__ void prepare_columns_body(
      * record {G, K, S, V} as ONE 16-byte store per row at the end. */
     constexpr int MAXR = 9; /* rows per thread held in registers: H + 1 <= 9 * 256 */
     const bool regs = (H + 1) <= MAXR * PREP_THREADS;
+    const bool epi = PREP_EPI_ROWS > 0 && PREP_STORE_LATE && regs && R > 0 && (PREP_EPI_ROWS % (R > 0 ? R : 1)) == 0;
     float pS[MAXR], pV[MAXR], pG[MAXR], pK[MAXR];
 #pragma unroll
     for (int k = 0; k < MAXR; k++) pS[k] = pV[k] = pG[k] = pK[k] = 0.0f;
@@ -530,7 +555,7 @@ __device__ __forceinline__ void prepare_columns_body(
             if (v <= H) {
                 pK[k] = prefix_at(v);
 #ifndef PREP_ABL_NOSTORE_F4
-                reinterpret_cast<float4*>(rcol + v)[5] = make_float4(pG[k], pK[k], pS[k], pV[k]);
+                if (!epi) prep_store16(reinterpret_cast<int4*>(rcol + PREP_RROW(v)) + 5, make_int4(__float_as_int(pG[k]), __float_as_int(pK[k]), __float_as_int(pS[k]), __float_as_int(pV[k])));
 #endif
             }
         }
@@ -541,7 +566,47 @@ __device__ __forceinline__ void prepare_columns_body(
      * 128-byte lines, eight lanes per record -- 1.53 instead of 1.21 ms for the column blocks of a batch of
      * 64: the 34 extra barriers cost more than the partial lines do; the kernel is bound by its LDS /
      * VALU work, not by its 2.15 GB of stores) */
-    if (PREP_STORE_LATE) {
+    if (epi) {
+        /* PREP_EPI_ROWS: the epilogue walks the column in blocks of rows and every producer stores its
+         * pieces of the block's records before anyone goes on to the next block -- no barrier, the waves
+         * only have to stay roughly together: the partial lines a workgroup has in flight are
+         * PREP_EPI_ROWS x 128 bytes instead of the whole column's 131 KB (x 128 workgroups per XCD: 16.8 MB
+         * against 4 MB of L2 -- lines left the L2 before their last piece arrived). */
+        constexpr int ER = PREP_EPI_ROWS > 0 ? PREP_EPI_ROWS : PREP_THREADS;
+        constexpr int M = ER >= PREP_THREADS ? ER / PREP_THREADS : 1; /* register slots per block */
+        constexpr int SUBS = ER >= PREP_THREADS ? 1 : PREP_THREADS / ER; /* blocks per register slot */
+        static_assert(ER % 8 == 0 && (ER >= PREP_THREADS ? ER % PREP_THREADS == 0 : PREP_THREADS % ER == 0),
+                      "PREP_EPI_ROWS: a multiple of 8 that divides PREP_THREADS or is a multiple of it");
+#pragma unroll
+        for (int kk = 0; kk < (MAXR + M - 1) / M; kk++) {
+            for (int sub = 0; sub < SUBS; sub++) {
+                const int row0 = kk * M * PREP_THREADS + sub * ER;
+                if (row0 <= H) {
+#pragma unroll
+                    for (int j = 0; j < M; j++) { /* {G, K, S, V}: row k * PREP_THREADS + tid is this thread's slot k */
+                        const int k = kk * M + j;
+                        if (k < MAXR) {
+                            const int v = k * PREP_THREADS + tid;
+                            if ((SUBS == 1 || tid / ER == sub) && v <= H)
+                                prep_store16(reinterpret_cast<int4*>(rcol + PREP_RROW(v)) + 5,
+                                             make_int4(__float_as_int(pG[k]), __float_as_int(pK[k]),
+                                                       __float_as_int(pS[k]), __float_as_int(pV[k])));
+                        }
+                    }
+                    for (int it = tid; it < (ER / 8) * 5; it += PREP_THREADS) { /* class chunks: 1/8-resolution blocks x 5 */
+                        const int kbl = it / 5, q = it - kbl * 5, kb = (row0 >> 3) + kbl;
+                        if (kb * 8 <= H)
+                            class_item(kb, q, [&](int v, int qq, int4 x) {
+                                prep_store16(reinterpret_cast<int4*>(rcol + PREP_RROW(v)) + qq, x);
+                            });
+                    }
+                    if (r_lo >= row0 && r_lo < row0 + ER) instance_rows(true, rec_row);
+                }
+            }
+        }
+        /* (row H when it starts a block of its own -- H a multiple of PREP_EPI_ROWS: its class chunk and
+         * {G, K, S, V} went out with that block above, its instance piece with row H - 1's owner) */
+    } else if (PREP_STORE_LATE) {
         class_chunks();
         instance_rows(true, rec_row);
     }
