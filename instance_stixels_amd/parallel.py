@@ -375,4 +375,8 @@ class PipelinedCompactGather:
                 "ratio_vs_fixed": (sum(per_rank) / len(per_rank) / fixed) if per_rank else None,
                 "lag_steps": self.lag, "depth": self.depth, "landing_buffer_bytes_on_dst": landing,
                 "host_seconds_in_size_read_and_posting": self.host_seconds["post"],
-                "host_seconds_in_waits": self.host_seconds["wait"]}
+                "host_seconds_in_waits": self.host_seconds["wait"],
+                "host_seconds_note": "the size read of step k - lag blocks the host until the device has "
+                                     "packed that step -- with steps k - lag + 1 .. k already queued behind it: "
+                                     "back-pressure of a host that runs `lag` steps ahead, not a device stall "
+                                     "(see exposed_ms_per_step)"}

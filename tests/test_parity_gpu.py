@@ -923,7 +923,7 @@ def _run_counted(case, env, monkeypatch):
 
 @pytest.mark.parametrize("family", ADV_FAMILIES)
 def test_branch_and_bound_is_exact_at_the_bounds(family, monkeypatch):
-    """36 seeded cases per family (216 in all), each run pruned and with IS_NO_PRUNE=1 (every pair
+    """36 seeded cases per family (252 in all), each run pruned and with IS_NO_PRUNE=1 (every pair
     evaluated, the reference's walk, StixelsKernels.cu:600-839; "separable_bound": lemma L7 of
     the pairwise phase 1, all 36 cases pairwise): the complete cost_table,
     index_table and all Sections must agree bit for bit; every sixth case is also compared with
