@@ -708,18 +708,18 @@ __device__ __forceinline__ void touch_round(const RowRec* rcol, const StepRec* s
 #ifdef IS_ABL_P1PHASES
 /* debug build only: s_memtime cycles of wave 0 of every phase-1 workgroup in prologue / walk /
  * waiting for the other waves / merge, plus the number of full and ground-sky rounds of wave 0 */
-__device__ unsigned long long g_p1phase[8];
+__device__ unsigned long long g_p1phase[16 * 8]; /* [min(tile, 15)][counter] */
 #define ISP1_MARK(k)                                                              \
     do {                                                                          \
         const unsigned long long now__ = __builtin_readcyclecounter();            \
-        if (threadIdx.x == 0) atomicAdd(&g_p1phase[k], now__ - t_p1);             \
+        if (threadIdx.x == 0) atomicAdd(&g_p1phase[min(tile, 15) * 8 + (k)], now__ - t_p1); \
         t_p1 = now__;                                                             \
     } while (0)
-#define ISP1_COUNT(k) do { if (threadIdx.x == 0) atomicAdd(&g_p1phase[k], 1ull); } while (0)
+#define ISP1_COUNT(k) do { if (threadIdx.x == 0) atomicAdd(&g_p1phase[min(tile, 15) * 8 + (k)], 1ull); } while (0)
 extern "C" void isk_debug_p1phases(unsigned long long* out, int reset) {
     (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_p1phase), sizeof(g_p1phase));
     if (reset) {
-        unsigned long long z[8] = {0};
+        unsigned long long z[16 * 8] = {0};
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_p1phase), z, sizeof(z));
     }
 }

@@ -7,15 +7,16 @@ sys.argv = ["bench.py", "--preset", "drn_d_38_pairwise", "--steps", "3", "--warm
             "--no-single", "--no-d2h", "--no-variants", "--min-seconds", "0"] + sys.argv[1:]
 from instance_stixels_amd import core
 L = core.lib()
-out = (ctypes.c_ulonglong * 8)()
+out = (ctypes.c_ulonglong * 128)()
 try:
     runpy.run_path("bench.py", run_name="__main__")
 finally:
     L.isk_debug_p1phases(out, 1)
-    v = list(out)
-    tot = (sum(v[:4]) + v[6]) or 1
-    for n, x in zip(["prologue", "pre-pass (block bounds)", "walk", "wait for the other waves", "merge"],
-                    [v[0], v[6], v[1], v[2], v[3]]):
-        print("  %-26s %14d  %5.1f%%" % (n, x, 100.0 * x / tot))
-    print("  wave 0: %d full steps, %d ground/sky rounds; ticks per round trip of the walk: %.0f"
-          % (v[4], v[5], v[1] / max(1, v[4] + v[5])))
+    names = ["prologue", "pre-pass", "walk", "wait others", "merge"]
+    print("per tile, ticks of wave 0 per workgroup launch (s_memtime), share of the workgroup's life")
+    for t in range(16):
+        v = list(out[t * 8:(t + 1) * 8])
+        parts = [v[0], v[6], v[1], v[2], v[3]]
+        tot = sum(parts) or 1
+        print("  tile %2d: " % t + "  ".join("%s %4.1f%%" % (n, 100.0 * x / tot) for n, x in zip(names, parts)) +
+              "   total %.3g   full steps %d  gs rounds %d" % (tot, v[4], v[5]))
