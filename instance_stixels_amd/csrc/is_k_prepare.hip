@@ -593,6 +593,24 @@ __device__ __forceinline__ void prepare_columns_body(
                                                        __float_as_int(pS[k]), __float_as_int(pV[k])));
                         }
                     }
+#ifdef PREP_ABL_WAVEROWS /* timing-only: every wave stores ALL pieces of its own 64 rows (instance pieces: dummies) */
+                    {
+                        const int v = kk * M * PREP_THREADS + tid;
+                        if (v <= H) {
+                            prep_store16(reinterpret_cast<int4*>(rcol + v) + 6, make_int4(v, tid, 0, 0));
+                            prep_store16(reinterpret_cast<int4*>(rcol + v) + 7, make_int4(v, tid, 1, 0));
+                        }
+                        const int ln = tid & 63, wv = tid >> 6;
+                        if (ln < 40) {
+                            const int kbl = ln / 5, q = ln - kbl * 5, kb = ((row0 + 64 * wv) >> 3) + kbl;
+                            if (kb * 8 <= H)
+                                class_item(kb, q, [&](int vv, int qq, int4 x) {
+                                    prep_store16(reinterpret_cast<int4*>(rcol + PREP_RROW(vv)) + qq, x);
+                                });
+                        }
+                    }
+                    if (false)
+#endif
                     for (int it = tid; it < (ER / 8) * 5; it += PREP_THREADS) { /* class chunks: 1/8-resolution blocks x 5 */
                         const int kbl = it / 5, q = it - kbl * 5, kb = (row0 >> 3) + kbl;
                         if (kb * 8 <= H)
@@ -600,7 +618,9 @@ __device__ __forceinline__ void prepare_columns_body(
                                 prep_store16(reinterpret_cast<int4*>(rcol + PREP_RROW(v)) + qq, x);
                             });
                     }
+#ifndef PREP_ABL_WAVEROWS
                     if (r_lo >= row0 && r_lo < row0 + ER) instance_rows(true, rec_row);
+#endif
                 }
             }
         }
