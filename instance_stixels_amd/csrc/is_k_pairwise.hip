@@ -632,6 +632,9 @@ __device__ __forceinline__ void pairwise_step(const DevParams& P, const StepVals
  * instruction (two lanes, no VGPR, destination a scratch word nobody reads), issued just before
  * the step's own row prefetch so that it never lengthens a vmcnt wait; when the scalar loads come
  * they hit the L2. */
+#ifndef IS_P2_GATHER_MASKED
+#define IS_P2_GATHER_MASKED 1
+#endif
 #ifndef IS_P1_ROW_AHEAD
 #define IS_P1_ROW_AHEAD 1 /* steps the vB-side lutT row is fetched ahead of its use (1 or 2) */
 #endif
@@ -1572,8 +1575,12 @@ __device__ __forceinline__ void pw_phase2_body(const DevParams& P, char* smem, i
             const int foc = inwin ? fo : 0;
             float od = my_win[foc] - s_win[s * ISP2_WS + foc];
             if (__builtin_amdgcn_ballot_w64(live && !inwin) != 0ull) { /* outside the window: rare */
-                const float og = my_row[(unsigned)t.fni] - (lcol + (size_t)r * D)[(unsigned)t.fni];
-                od = inwin ? od : og;
+                /* (only the lanes outside fetch: with every lane gathering, a step of this kind pulled up to
+                 * 128 lines -- 16 KB -- for the few values it needed) */
+                if (IS_P2_GATHER_MASKED ? (live && !inwin) : true) {
+                    const float og = my_row[(unsigned)t.fni] - (lcol + (size_t)r * D)[(unsigned)t.fni];
+                    od = inwin ? od : og;
+                }
             }
             ISP2_MARK(3); /* LUT values */
             if (r - 1 < vhor)
@@ -1848,8 +1855,10 @@ __device__ __forceinline__ void pw_phase2x_body(const DevParams& P, char* smem, 
         const int foc = inwin ? fo : 0;
         float od = my_win[foc] - my_winbase[(r - tile_lo) * ISP2_WS + foc];
         if (__builtin_amdgcn_ballot_w64(live && !inwin) != 0ull) { /* outside the window: rare */
-            const float og = (lcol + (size_t)(vTc + 1) * D)[(unsigned)t.fni] - (lcol + (size_t)r * D)[(unsigned)t.fni];
-            od = inwin ? od : og;
+            if (IS_P2_GATHER_MASKED ? (live && !inwin) : true) { /* (only the lanes outside fetch, see pw_phase2_body) */
+                const float og = (lcol + (size_t)(vTc + 1) * D)[(unsigned)t.fni] - (lcol + (size_t)r * D)[(unsigned)t.fni];
+                od = inwin ? od : og;
+            }
         }
         if (sky) pairwise_step<true>(P, stv, r, live, od, t, b);
         else pairwise_step<false>(P, stv, r, live, od, t, b);
@@ -2296,8 +2305,12 @@ __device__ __forceinline__ void pw_phase2s_body(const DevParams& P, char* smem, 
             const int foc = inwin ? fo : 0;
             float od = my_win[foc] - s_win[s * ISP2_WS + foc];
             if (__builtin_amdgcn_ballot_w64(live && !inwin) != 0ull) { /* outside the window: rare */
-                const float og = my_row[(unsigned)t.fni] - (lcol + (size_t)r * D)[(unsigned)t.fni];
-                od = inwin ? od : og;
+                /* (only the lanes outside fetch: with every lane gathering, a step of this kind pulled up to
+                 * 128 lines -- 16 KB -- for the few values it needed) */
+                if (IS_P2_GATHER_MASKED ? (live && !inwin) : true) {
+                    const float og = my_row[(unsigned)t.fni] - (lcol + (size_t)r * D)[(unsigned)t.fni];
+                    od = inwin ? od : og;
+                }
             }
             const bool ground = r - 1 < vhor; /* :687 / :729 */
             const float a_gs = live ? P.dw * (ground ? t.gd : t.sd) : IS_INF;
