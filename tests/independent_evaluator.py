@@ -82,8 +82,9 @@ def i32(x):
     return ((np.asarray(x, np.int64) + 2 ** 31) % 2 ** 32 - 2 ** 31)
 
 
-def evaluate_column(p, col, d, seg, gf, ng, ig, vhor, cost_lut, odr, pairwise):
-    """One stixel column -> (cost_table [H][3] f32, index_table [H][3] i32, sections list)."""
+def evaluate_column(p, col, d, seg, gf, ng, ig, vhor, cost_lut, odr, pairwise, trace=None):
+    """One stixel column -> (cost_table [H][3] f32, index_table [H][3] i32, sections list).  trace: a dict
+    that receives the prefix arrays and, per vB >= 1, (type, vT, ground- or sky cost, object cost)."""
     H, D, P2, P2S, K = p.rows, p.max_dis, p.rows_power2, p.rows_power2_segmentation, p.segmentation_classes
     dw, pw, sw, iw = F(p.disparity_weight), F(p.prior_weight), F(p.segmentation_weight), F(p.instance_weight)
     inv = F(p.invalid_disparity)
@@ -123,6 +124,8 @@ def evaluate_column(p, col, d, seg, gf, ng, ig, vhor, cost_lut, odr, pairwise):
             x = i32(x * x)
         ps[c] = i32(block_scan(x))                 # (int32 additions wrap; any association is exact)
     lut = object_lut(p, d, cost_lut)
+    if trace is not None:
+        trace.update(Gps=Gps, Kps=Kps, ps=ps, MX=MX, MY=MY, MX2=MX2, MY2=MY2, pair={})
 
     def mean(vB, vT):                              # ComputeMean, :47-60
         with np.errstate(invalid="ignore", divide="ignore"):
@@ -214,6 +217,7 @@ def evaluate_column(p, col, d, seg, gf, ng, ig, vhor, cost_lut, odr, pairwise):
                     cost = dw * data + pw * ih + sw * s
                 typ = SKY
             u = cost < ct[t, typ]
+            cgs = cost
             ct[t[u], typ] = cost[u]
             it[t[u], typ] = b * 3 + (GROUND if p1 < p2 else OBJECT)
             # object (:777-837)
@@ -233,6 +237,8 @@ def evaluate_column(p, col, d, seg, gf, ng, ig, vhor, cost_lut, odr, pairwise):
                 cost = dw * od + pw * np.fmin(np.fmin(q1, q2), q3) + sw * o
             else:
                 cost = dw * od + pw * ih + sw * o
+            if trace is not None:
+                trace["pair"][b] = (typ, t, cgs, cost)
             u = cost < ct[t, OBJECT]
             prev = np.where(q1 < q2, GROUND, OBJECT)
             prev = np.where(q3 < np.fmin(q1, q2), SKY, prev)

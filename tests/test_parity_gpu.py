@@ -584,6 +584,117 @@ def test_object_lut_entries_against_the_oracle(preset, rows, cols, D, ov):
         core.close()
 
 
+@pytest.mark.parametrize("seed,ov", [(3, {}), (4, dict(invalid_disparity=0.0)), (9, dict(instance_weight=0.0))])
+def test_separable_block_bounds_hold_numerically(seed, ov):
+    """Lemmas L7 / L8 checked as inequalities, not through their effect: the block
+    summaries the device leaves behind (is_debug_read_block_summaries), combined per lane the way
+    phase 1 does it (fp32, numpy restatement of l7_lane_bounds / l7_combine / the L8 loop), against
+    EVERY pairwise candidate cost of tests/independent_evaluator.py: for each 32-row block k and each
+    row vT above it  LB_k <= min over the block's candidates <= UB_k  (ground, sky) and
+    lb_o <= min over the block's object candidates."""
+    import independent_evaluator as ie
+    from instance_stixels_amd.core import Core
+    rows, cols, D = 192, 64, 32
+    case = helpers.build_case("drn_d_38_pairwise", rows, cols, D, seed=seed, **ov)
+    cfg, p = case["cfg"], case["params"]
+    F32, QB = np.float32, 32
+    dw, pw, sw, iw = (F32(p.disparity_weight), F32(p.prior_weight), F32(p.segmentation_weight),
+                      F32(p.instance_weight))
+    REL, ABS, U22 = F32(2.0 ** -20), F32(2.0 ** -90), F32(2.0 ** -22)
+    dn = lambda x: (x - np.abs(x) * U22).astype(F32)   # noqa: E731
+    up = lambda x: (x + np.abs(x) * U22).astype(F32)   # noqa: E731
+    # PruneRec constants (is_core.hip: sigma_od; is_k_prepare.hip: E1o, E2)
+    P2 = int(p.rows_power2)
+    gamma = 1.01 * (2.0 * np.log2(P2) + rows / 32.0 + 8.0) * 2.0 ** -24
+    lut64 = np.asarray(case["lut"], np.float64)
+    sigma_od = F32(((0.0 - min(lut64.min(), 0.0)) * rows + 2.0 * gamma * rows * np.abs(lut64).max()) * 1.001)
+    E1o = F32(dw * sigma_od)
+    core = Core(p, case["lut"], case["odr"], max_batch=1)
+    checked = 0
+    try:
+        out = core.run(disparity_big=case["disparity"], segmentation=case["segmentation"],
+                       ground_function=case["gf"], normalization_ground=case["ng"],
+                       inv_sigma2_ground=case["ig"], vhor=case["vhor"], pairwise=True,
+                       median_join=bool(cfg.median_join), want_tables=False)
+        joined, vhor, K = out["joined"][0], int(case["vhor"][0]), int(p.segmentation_classes)
+        for c in range(cfg.realcols):
+            summ = core.read_block_summaries(c)                      # [n_blocks][24]
+            tr = {}
+            ie.evaluate_column(p, c, joined[c], case["segmentation"][0][c], case["gf"][0].astype(F32),
+                               case["ng"][0].astype(F32), case["ig"][0].astype(F32), vhor,
+                               np.asarray(case["lut"], F32), np.asarray(case["odr"], F32), True, trace=tr)
+            H = rows
+            cg = np.full((H, H), np.inf, F32); cs = cg.copy(); co = cg.copy()   # [vB][vT]
+            for b, (typ, t, cgs, cob) in tr["pair"].items():
+                (cg if typ == ie.GROUND else cs)[b, t] = cgs
+                co[b, t] = cob
+            v1 = np.arange(1, H + 1)                                 # the record of lane vT: prefixes at vT + 1
+
+            def full(ps):                                            # full-resolution prefix at v1
+                kb, m = v1 // 8, v1 % 8
+                return (ps[kb] * 8 + (ps[np.minimum(kb + 1, len(ps) - 1)] - ps[kb]) * m)
+            ps = tr["ps"]
+            n1 = (iw * (full(ps[K]) + full(ps[K + 1])).astype(F32)).astype(F32)
+            G1, K1 = tr["Gps"][v1].astype(F32), tr["Kps"][v1].astype(F32)
+
+            def lane_b(dterm, fterm):                                # l7_b
+                b = (dterm + fterm).astype(F32)
+                sl = ((np.abs(dterm) + fterm) * REL + ABS).astype(F32)
+                return (b - sl).astype(F32), (b + sl).astype(F32)
+            with np.errstate(invalid="ignore", over="ignore"):
+                fg0 = (sw * (full(ps[0]).astype(F32) + n1)).astype(F32)
+                fg1 = (sw * (full(ps[1]).astype(F32) + n1)).astype(F32)
+                fsk = (sw * (full(ps[10]).astype(F32) + n1)).astype(F32)
+                lo_g0, hi_g0 = lane_b((dw * G1).astype(F32), fg0)
+                lo_g1, hi_g1 = lane_b((dw * G1).astype(F32), fg1)
+                lo_s, hi_s = lane_b((dw * K1).astype(F32), fsk)
+                obj = [cl for cl in range(2, 19) if cl != 10]           # 2..9: n_c = iw N, 11..18: 0
+                bo = []
+                for cl in obj:
+                    ft = (sw * (full(ps[cl]).astype(F32) + (n1 if cl < 10 else F32(0)))).astype(F32)
+                    bo.append(((ft - E1o) - ((ft + E1o) * REL + ABS)).astype(F32))
+                tot2 = float(tr["MX2"][H] + tr["MY2"][H])
+                E2 = float(iw) * 2.0 ** -21 * (1 + 2.0 ** -10) * tot2
+                for k in range(1, summ.shape[0]):
+                    lo_row, hi_row = QB * (k - 1) + 1, min(QB * k, H - 1)
+                    if lo_row > hi_row:
+                        continue
+                    lanes = np.arange(QB * k, H)                     # vT >= the block's top row
+                    if lanes.size == 0:
+                        continue
+                    m = summ[k].astype(F32)
+                    blk = slice(lo_row, hi_row + 1)
+                    act_g, act_s, act_o = (x[blk][:, lanes].min(axis=0) for x in (cg, cs, co))
+                    lbg = np.fmin(dn(m[0] + lo_g0[lanes]), dn(m[1] + lo_g1[lanes]))
+                    ubg = np.fmin(up(m[4] + hi_g0[lanes]), up(m[5] + hi_g1[lanes]))
+                    lbs, ubs = dn(m[2] + lo_s[lanes]), up(m[6] + hi_s[lanes])
+                    gl = np.isfinite(G1[lanes])                      # (+inf ground prefix: the lane is dead for the type)
+                    # (a block without rows of the type has +inf summaries: phase 1 leaves it out, has_g / has_s)
+                    if np.isfinite(m[0]) or np.isfinite(m[1]):
+                        assert np.all(lbg[gl] <= act_g[gl]), (c, k, "ground lower bound")
+                        assert np.all(ubg[gl] >= act_g[gl]), (c, k, "ground upper bound")
+                    else:
+                        assert not np.isfinite(act_g).any(), (c, k, "ground candidates in a block without summary")
+                    if np.isfinite(m[2]):
+                        assert np.all(lbs <= act_s), (c, k, "sky lower bound")
+                        assert np.all(ubs >= act_s), (c, k, "sky upper bound")
+                    else:
+                        assert not np.isfinite(act_s).any(), (c, k, "sky candidates in a block without summary")
+                    lb_n = np.min([m[8 + j] + bo[j][lanes] for j in range(8)], axis=0).astype(F32)
+                    lb_i = np.min([m[16 + j] + bo[8 + j][lanes] for j in range(8)], axis=0).astype(F32)
+                    top, h = QB * k, (lanes + 1 - QB * k).astype(np.float64)   # L4's term of the block's top row
+                    sx, sy = (tr[a][lanes + 1] - tr[a][top] for a in ("MX", "MY"))
+                    sx2, sy2 = (tr[a][lanes + 1] - tr[a][top] for a in ("MX2", "MY2"))
+                    ic = float(iw) * (sx2 - sx * sx / h + sy2 - sy * sy / h)   # the real value, binary64
+                    lb_o = np.fmin(lb_n, lb_i + float(sw) * (ic - 4.0 * E2))   # (computed ic <= real + E2)
+                    tol = 1e-5 * np.abs(act_o[np.isfinite(act_o)]).max(initial=1.0)
+                    assert np.all(dn(lb_o.astype(F32)) <= act_o + tol), (c, k, "object lower bound")
+                    checked += int(lanes.size)
+    finally:
+        core.close()
+    assert checked > 2000
+
+
 def test_core_rejects_bad_shapes():
     from instance_stixels_amd.core import Core, CoreError
     case = helpers.build_case("drn_d_22_unary", 64, 64, 32, seed=1)
