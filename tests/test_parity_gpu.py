@@ -207,6 +207,41 @@ def test_pruning_changes_nothing_at_full_size(preset, monkeypatch):
             assert np.all(col["cost"] <= np.float32(1e4)) and np.all(col["cost"] >= best)
 
 
+@pytest.mark.parametrize("family", ["homogeneous", "many_thin_objects", "iid_noise", "low_confidence",
+                                    "flat_disparity", "noisy_disparity"])
+def test_pruning_changes_nothing_on_the_input_families(family, monkeypatch):
+    """The same property on the other input families of bench.py (synthetic.make_frame(family=...)), pairwise
+    model, 9 full frames = 2304 columns (the two-column phase 2 and the unsplit phase 1 of large batches):
+    the separable block bounds (lemmas L7 / L8) bite hardest where the scene is homogeneous or the CNN
+    hesitant, i.e. exactly where the headline family exercises them least."""
+    from instance_stixels_amd import synthetic
+    base = helpers.build_case("drn_d_38_pairwise", 1024, 2048, 128, seed=7, n_images=1)
+    cfg = base["cfg"]
+    frames = [synthetic.make_frame(cfg, seed=300 + i, family=family) for i in range(3)]
+    ground = [oracle_mod().host_ground(cfg, f.vhor_image, f.camera_tilt, f.camera_height, f.alpha_ground)
+              for f in frames]
+    pick = [i % 3 for i in range(9)]
+    case = dict(base)
+    case["frames"] = [frames[k] for k in pick]
+    case["gf"] = np.stack([ground[k][0] for k in pick]); case["ng"] = np.stack([ground[k][1] for k in pick])
+    case["ig"] = np.stack([ground[k][2] for k in pick])
+    case["vhor"] = np.array([ground[k][3] for k in pick], np.int32)
+    case["disparity"] = np.stack([frames[k].disparity for k in pick])
+    case["segmentation"] = np.stack([frames[k].segmentation for k in pick])
+    pruned = helpers.run_core(case, want_tables=True)
+    monkeypatch.setenv("IS_NO_PRUNE", "1")
+    full = helpers.run_core(case, want_tables=True)
+    assert np.array_equal(pruned["cost_table"].view(np.uint32), full["cost_table"].view(np.uint32))
+    assert np.array_equal(pruned["index_table"], full["index_table"])
+    for img in range(9):
+        assert helpers.sections_equal(pruned["sections"][img], full["sections"][img])
+    # one column of the first frame against the oracle as well (the oracle needs ~1 s per column here)
+    ref = oracle_mod().compute(case["params"], case["lut"], case["odr"], pruned["joined"][0],
+                               case["segmentation"][0], case["gf"][0], case["ng"][0], case["ig"][0],
+                               int(case["vhor"][0]), True, col_range=(100, 101))
+    assert np.array_equal(ref["cost_table"][100].view(np.uint32), pruned["cost_table"][0][100].view(np.uint32))
+
+
 @pytest.mark.parametrize("preset", ["drn_d_22_unary", "drn_d_38_pairwise"])
 def test_batch64_launch_geometry(preset):
     """BASELINE configs[2] / the per-GPU share of configs[3]: 64 full 1024x2048x128 frames in ONE
