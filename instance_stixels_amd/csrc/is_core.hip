@@ -306,6 +306,8 @@ static int ctx_init(is_ctx* c, const is_stixel_params* p, const float* obj_cost_
         d.knob_p2_split = knob("IS_P2_SPLIT");
         d.knob_p2x = knob("IS_P2X");
         d.knob_unary_diag = knob("IS_UNARY_DIAG") == 1; /* (experiment: off unless asked for) */
+        d.knob_win_tiles = knob("IS_P1_WIN_TILES");
+        d.knob_pw_waves = knob("IS_PW_WAVES");
     }
     {
         /* branch-and-bound constants (PruneRec, is_device.h).  gamma_d bounds the relative error of
@@ -333,6 +335,8 @@ static int ctx_init(is_ctx* c, const is_stixel_params* p, const float* obj_cost_
     /* waves per DP workgroup: the LUT tile is 64*(D+1) floats; keep >= 16 waves per CU */
     c->nwaves_unary = IS_UNARY_WAVES;
     c->nwaves_pairwise = IS_UNARY_WAVES;
+    if (d.knob_pw_waves >= 1 && d.knob_pw_waves <= IS_UNARY_WAVES) c->nwaves_pairwise = d.knob_pw_waves;
+    else d.knob_pw_waves = -1;
     if (sizeof(int) * (6 * (size_t)d.H + 3 * (size_t)d.S + 4) > 160 * 1024 ||
         isk_unary_lds_bytes(&d) > 160 * 1024 || isk_pairwise_lds_bytes(&d, c->nwaves_pairwise) > 160 * 1024 ||
         isk_prepare_lds_bytes(&d) > 160 * 1024 || isk_phase2_lds_bytes(&d) > 64 * 1024 ||
@@ -372,6 +376,8 @@ static int ctx_init(is_ctx* c, const is_stixel_params* p, const float* obj_cost_
     ALLOC(c->d_part_idx, sizeof(int) * part_slots * 3 * 64);
     ALLOC(c->d_sv, sizeof(float) * B * C * 2 * (H + 1));
     ALLOC(c->d_t8row, sizeof(float) * B * C * H);
+    ALLOC(c->dp.win_lo, sizeof(int) * B * C * (size_t)c->dp.ntiles);
+    HIP_TRY(hipMemset(c->dp.win_lo, 0, sizeof(int) * B * C * (size_t)c->dp.ntiles));
     ALLOC(c->d_blksum, sizeof(float) * B * C * ((size_t)d.ntiles * IS_QPT + 1) * 24);
     ALLOC(c->d_cost_table, sizeof(float) * B * C * H * 3);
     ALLOC(c->d_index_table, sizeof(int32_t) * B * C * H * 3);
@@ -443,7 +449,7 @@ int is_ctx_destroy(is_ctx* c) {
         free(c->graph_cache);
     }
     (void)hipFree(c->d_obj_cost_lut); (void)hipFree(c->d_odr); (void)hipFree(c->d_rcp); (void)hipFree(c->d_col_flags); (void)hipFree(c->d_prune); (void)hipFree(c->d_n_generic); (void)hipFree(c->d_stage);
-    (void)hipFree(c->d_recs); (void)hipFree(c->d_lutT); (void)hipFree(c->d_priors); (void)hipFree(c->d_steps); (void)hipFree(c->d_part_cost); (void)hipFree(c->d_part_idx); (void)hipFree(c->d_sv); (void)hipFree(c->d_blksum); (void)hipFree(c->d_t8row);
+    (void)hipFree(c->d_recs); (void)hipFree(c->d_lutT); (void)hipFree(c->d_priors); (void)hipFree(c->d_steps); (void)hipFree(c->d_part_cost); (void)hipFree(c->d_part_idx); (void)hipFree(c->d_sv); (void)hipFree(c->d_blksum); (void)hipFree(c->d_t8row); (void)hipFree(c->dp.win_lo);
     (void)hipFree(c->d_cost_table); (void)hipFree(c->d_index_table); (void)hipFree(c->d_cluster_scratch);
     (void)hipFree(c->d_inst_cnt); (void)hipFree(c->d_counters);
     for (int i = 0; i < IS_STAGE_SLOTS; i++) {
@@ -632,8 +638,19 @@ static int compute_enqueue(is_ctx* c, const float* d_joined, const int32_t* d_se
                                c->d_prune, c->d_n_generic, stream, c->aux_stream, c->ev_fork, c->ev_join));
     if (pairwise) HIP_TRY(isk_launch_priors(&P, c->d_ground, c->d_priors, n_images, stream));
     if (timing) HIP_TRY(hipEventRecord(c->ev[1], stream));
+    /* fn windows in phase 1 (is_device.h, IS_P1_WIN) for the tiles that start below the horizon of every image
+     * of the call: ground and what stands on it span few disparities within 64 rows, while a tile above the
+     * horizon mixes sky (d ~ 0) with objects of any disparity -- measured: 3.6 % of the steps of tile 7 read
+     * outside the window, 22-35 % of tiles 12-13, and a step with a lane outside pays a memory round trip */
+    DevParams Pw = P;
+    {
+        int vmin = P.H;
+        for (int i = 0; i < n_images; i++) vmin = c->h_vhor_pinned[slot][i] < vmin ? c->h_vhor_pinned[slot][i] : vmin;
+        Pw.win_tiles = (IS_P1_WINDOWED(P.D) && P.win_lo != nullptr && vmin > 0) ? (vmin + IS_TILE - 1) / IS_TILE : 0;
+        if (P.knob_win_tiles >= 0) Pw.win_tiles = P.knob_win_tiles; /* (experiments) */
+    }
     if (pairwise)
-        HIP_TRY(isk_launch_dp_pairwise(&P, ncols, c->nwaves_pairwise, c->d_recs, c->d_lutT,
+        HIP_TRY(isk_launch_dp_pairwise(&Pw, ncols, c->nwaves_pairwise, c->d_recs, c->d_lutT,
                                        d_joined, c->d_priors, c->d_odr, c->d_rcp, c->d_sv, c->d_vhor,
                                        c->d_col_flags, c->d_prune, c->d_steps, c->d_part_cost,
                                        c->d_part_idx, ct, it, c->counting ? c->d_counters : nullptr,

@@ -141,8 +141,8 @@ static_assert(sizeof(PruneRec) == 32, "PruneRec must be 32 bytes");
 #define IS_CNT_UNARY_GS 1   /* k_dp_unary_fast: ground- / sky-only steps               */
 #define IS_CNT_P1_FULL 2    /* k_pw_phase1: full steps (incl. the first segment vB = 0) */
 #define IS_CNT_P1_GS 3      /* k_pw_phase1: ground- / sky-only candidates               */
-#define IS_CNT_P1_LAZY 4    /* k_pw_phase1: steps that stopped after the transition term */
-#define IS_CNT_TILE0 8    /* + 3 * tile + {0 full, 1 lazy, 2 ground / sky-only}: per phase-1 launch, tile < 64 */
+#define IS_CNT_P1_LAZY 4    /* k_pw_phase1: steps in which some lane read outside its fn window (IS_P1_WIN; the slot of the lazy-step experiment) */
+#define IS_CNT_TILE0 8    /* + 3 * tile + {0 full, 1 window misses, 2 ground / sky-only}: per phase-1 launch, tile < 64 */
 #define IS_CNT_N 200
 
 struct DevParams {
@@ -176,7 +176,23 @@ struct DevParams {
     int knob_pw_groups;       /* IS_PW_GROUPS: column groups (streams) of the pairwise DP */
     int knob_p2_split;        /* IS_P2_SPLIT: 1 = k_pw_phase2s, 0 = k_pw_phase2 */
     int knob_p2x;             /* IS_P2X=0: large batches walk phase 2 with k_pw_phase2 (one column per wave) */
+    int knob_win_tiles;       /* IS_P1_WIN_TILES: number of phase-1 tiles that stage an fn window (-1: those below the horizon) */
+    int knob_pw_waves;        /* IS_PW_WAVES: waves per phase-1 workgroup for every tile (-1: 8, windowed tiles IS_P1_WIN_WAVES) */
     int knob_unary_diag;      /* IS_UNARY_DIAG=1: the diagonal blocks of the unary DP in k_dp_unary_diag (two columns per wave) */
+    /* fn windows of the pairwise phase 1 (IS_P1_WIN): [n_columns][ntiles] first lutT column of the window a
+     * (column, tile) stages in LDS; written by the prepare kernel, device memory of the context */
+    int* win_lo;
+    int win_tiles; /* the tiles 0 .. win_tiles - 1 of this call stage a window (set per call: the tiles that start below every horizon of the batch) */
 };
+
+/* Pairwise phase 1 stages IS_P1_WIN lutT columns of its 64 vT rows instead of all D when D is larger (and a
+ * multiple of 4): 16.6 instead of 33 KB of LDS per workgroup at D = 128 -- more, smaller workgroups per CU.
+ * The segments of a lane start BELOW its row (nearer to the camera: larger or equal disparities on a road
+ * scene), so the window starts at the tile's smallest disparity; a lane whose floor(mean) falls outside
+ * reads global memory (exactness does not rest on the window). */
+#ifndef IS_P1_WIN
+#define IS_P1_WIN 32
+#endif
+#define IS_P1_WINDOWED(D) (IS_P1_WIN > 0 && (D) > IS_P1_WIN && ((D) & 3) == 0)
 
 #endif /* IS_DEVICE_H_ */

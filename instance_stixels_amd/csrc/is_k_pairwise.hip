@@ -632,6 +632,12 @@ __device__ __forceinline__ void pairwise_step(const DevParams& P, const StepVals
  * instruction (two lanes, no VGPR, destination a scratch word nobody reads), issued just before
  * the step's own row prefetch so that it never lengthens a vmcnt wait; when the scalar loads come
  * they hit the L2. */
+#ifndef IS_P1_WIN_MIN_COLS
+#define IS_P1_WIN_MIN_COLS 4096
+#endif
+#ifndef IS_P1_WIN_WAVES
+#define IS_P1_WIN_WAVES 4
+#endif
 #ifndef IS_P2_GATHER_MASKED
 #define IS_P2_GATHER_MASKED 1
 #endif
@@ -731,7 +737,7 @@ extern "C" void isk_debug_p1phases(unsigned long long* out, int reset) {
 #define ISP1_COUNT(k)
 #endif
 
-template <bool FAST, bool HAS_INVALID, int NR>
+template <bool FAST, bool HAS_INVALID, int NR, bool WIN>
 __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, int colg, int tile,
                                                const RowRec* __restrict__ recs,
                                                const float* __restrict__ lutT,
@@ -746,8 +752,12 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
                                                const float* __restrict__ cost_T,
                                                const float* __restrict__ blksum) {
     const int H = P.H, D = P.D;
-    const int DP = D + 1;
-    float* s_tile = (float*)smem;             /* [64][D+1] */
+    /* the vT-side tile: all D lutT columns of the 64 rows, or the fn window [win_lo, win_lo + IS_P1_WIN) of
+     * wide tables (is_device.h) */
+    constexpr bool windowed = WIN && !IS_P1_GEN_TILE; /* (the launch picks the instantiation: tile < P.win_tiles) */
+    const int win_w = windowed ? IS_P1_WIN : D;
+    const int DP = win_w + 1;
+    float* s_tile = (float*)smem;             /* [64][win_w + 1] */
     float* s_rcp = s_tile + IS_TILE * DP;     /* [H+1]     */
     float* s_scr = s_rcp + ((H + 1 + 3) & ~3); /* [8 per wave] landing area of the L2-warming DMAs */
     const int tid = threadIdx.x, lane = tid & 63;
@@ -839,11 +849,14 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
             pre_v[j] = i < NLB * IS_P1_SUM_F ? pre_load(i) : 0.0f;
         }
     }
+    const int win_lo = windowed ? __builtin_amdgcn_readfirstlane(P.win_lo[(size_t)colg * P.ntiles + tile]) : 0;
 #if IS_P1_MY_FIRST
     const RowRec my = load_rec(rcol + vTc + 1); /* requested with the tile: one memory round trip, not two */
-    stage_tile_and_rcp(s_tile, s_rcp, lcol, rcp, tile_lo, H, D, tid, (int)blockDim.x);
+    if (windowed) stage_window_and_rcp(s_tile, s_rcp, lcol, rcp, tile_lo, H, D, win_lo, tid, (int)blockDim.x);
+    else stage_tile_and_rcp(s_tile, s_rcp, lcol, rcp, tile_lo, H, D, tid, (int)blockDim.x);
 #else
-    stage_tile_and_rcp(s_tile, s_rcp, lcol, rcp, tile_lo, H, D, tid, (int)blockDim.x);
+    if (windowed) stage_window_and_rcp(s_tile, s_rcp, lcol, rcp, tile_lo, H, D, win_lo, tid, (int)blockDim.x);
+    else stage_tile_and_rcp(s_tile, s_rcp, lcol, rcp, tile_lo, H, D, tid, (int)blockDim.x);
     const RowRec my = load_rec(rcol + vTc + 1);
 #endif
     if (pre_regs) {
@@ -873,6 +886,19 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
         (void*)lcol, 0, (H + 1) * D * (int)sizeof(float), 0x00020000);
     const int lane4 = lane * 4;
     const unsigned scr = lds_addr(s_scr + 8 * wl);
+    /* lutT[vT + 1][fni] of this lane: from the staged tile / window; outside the window from global memory */
+    int n_winmiss = 0; /* steps in which some lane read outside the window (evaluation counters) */
+    auto vt_value = [&](int fni) -> float {
+        if (!windowed) return my_tile[fni];
+        const int fo = fni - win_lo;
+        const bool inw = (unsigned)fo < (unsigned)win_w;
+        float v = my_tile[inw ? fo : 0];
+        if (__builtin_amdgcn_ballot_w64(!inw) != 0ull) { /* (never without a window: fni < D) */
+            n_winmiss++;
+            if (!inw) v = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(lrsrc, ((vTc + 1) * D + fni) * 4, 0, 0));
+        }
+        return v;
+    };
     if (FAST && IS_PRUNE) {
         /* FAST columns: vB downwards with the exact branch-and-bound of DESIGN.md "Pruning".  The
          * candidates of a tile fall into BLOCKS: block k >= 1 = the vB values 64 (k-1) + 1 .. 64 k
@@ -1121,7 +1147,7 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
                     } else {                                                                       \
                         t = eval_segment_dpp<HAS_INVALID, WANT>(my, r0, r1, (float)h, s_rcp[h], D, P.iw); \
                     }                                                                              \
-                    od = my_tile[t.fni] - pick_lut<NR>(row, t.fni);                                \
+                    od = vt_value(t.fni) - pick_lut<NR>(row, t.fni);                                \
                     if (!IS_P1_SREC) {                                                             \
                         /* the next StepRec: requested only now -- every LDS wait is an lgkmcnt(0) \
                          * wait and would wait for this scalar load too (SMEM returns out of order) */ \
@@ -1133,7 +1159,7 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
                     const RowRec rb = sload_rec(rcol + vB);                                        \
                     st = sload_step(scol + vB);                                                    \
                     t = eval_segment<true, HAS_INVALID>(my, rb, (float)h, s_rcp[h], D, P.iw);      \
-                    od = my_tile[t.fni] - pick_lut<NR>(row, t.fni);                                \
+                    od = vt_value(t.fni) - pick_lut<NR>(row, t.fni);                                \
                 }                                                                                  \
                 pairwise_step<SKY, true, NOG, true>(P, st, vB, live, od, t, b);                    \
                 const float lb_o = min_raw((st.q_o - E1o) + P.sw * seg_o_lower_bound(t, E2), lbp[0]); \
@@ -1263,7 +1289,7 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
                 const RowRec rb = sload_rec(rcol);
                 const int h = vTc + 1;
                 const SegTerms t = eval_segment<true, HAS_INVALID>(my, rb, (float)h, s_rcp[h], D, P.iw);
-                const float od = my_tile[t.fni] - lcol[(unsigned)t.fni];
+                const float od = vt_value(t.fni) - lcol[(unsigned)t.fni];
                 const bool below = vT <= vhor;
                 const float cost_g = P.dw * t.gd + P.pw * P.first_g + P.sw * t.seg_g;
                 const bool ug = live && below && (cost_g <= b.g);
@@ -1278,10 +1304,10 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
             if (counters != nullptr && lane == 0) {
                 atomicAdd(counters + IS_CNT_P1_FULL, (unsigned long long)n_full);
                 atomicAdd(counters + IS_CNT_P1_GS, (unsigned long long)n_gs);
-                atomicAdd(counters + IS_CNT_P1_LAZY, (unsigned long long)n_lazy);
+                atomicAdd(counters + IS_CNT_P1_LAZY, (unsigned long long)(n_lazy + n_winmiss));
                 unsigned long long* ct = counters + IS_CNT_TILE0 + 3 * min(tile, 63);
                 atomicAdd(ct + 0, (unsigned long long)n_full);
-                atomicAdd(ct + 1, (unsigned long long)n_lazy);
+                atomicAdd(ct + 1, (unsigned long long)(n_lazy + n_winmiss));
                 atomicAdd(ct + 2, (unsigned long long)n_gs);
             }
         }
@@ -1293,7 +1319,7 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
             const RowRec rb = sload_rec(rcol);
             const int h = vTc + 1;
             const SegTerms t = eval_segment<FAST, HAS_INVALID>(my, rb, (float)h, s_rcp[h], D, P.iw);
-            const float od = my_tile[t.fni] - lcol[(unsigned)t.fni];
+            const float od = vt_value(t.fni) - lcol[(unsigned)t.fni];
             const bool below = vT <= vhor;
             const float cost_g = P.dw * t.gd + P.pw * P.first_g + P.sw * t.seg_g;
             const bool ug = live && below && (cost_g < b.g);
@@ -1312,7 +1338,7 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
                 load_lut_row<NR>(next_row, lrsrc, lcol, min(vB + nw, H), D, lane4);
                 const int h = vTc + 1 - vB;
                 const SegTerms t = eval_segment<FAST, HAS_INVALID>(my, rb, (float)h, s_rcp[h], D, P.iw);
-                const float od = my_tile[t.fni] - pick_lut<NR>(row, t.fni);
+                const float od = vt_value(t.fni) - pick_lut<NR>(row, t.fni);
                 pairwise_step<false, true, true>(P, st, vB, live, od, t, b);
             }
         }
@@ -1323,7 +1349,7 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
             load_lut_row<NR>(next_row, lrsrc, lcol, min(vB + nw, H), D, lane4);
             const int h = vTc + 1 - vB;
             const SegTerms t = eval_segment<FAST, HAS_INVALID>(my, rb, (float)h, s_rcp[h], D, P.iw);
-            const float od = my_tile[t.fni] - pick_lut<NR>(row, t.fni);
+            const float od = vt_value(t.fni) - pick_lut<NR>(row, t.fni);
             pairwise_step<false, true>(P, st, vB, live, od, t, b);
         }
         for (; vB <= vB_last; vB += nw) { /* sky range */
@@ -1333,7 +1359,7 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
             load_lut_row<NR>(next_row, lrsrc, lcol, min(vB + nw, H), D, lane4);
             const int h = vTc + 1 - vB;
             const SegTerms t = eval_segment<FAST, HAS_INVALID>(my, rb, (float)h, s_rcp[h], D, P.iw);
-            const float od = my_tile[t.fni] - pick_lut<NR>(row, t.fni);
+            const float od = vt_value(t.fni) - pick_lut<NR>(row, t.fni);
             pairwise_step<true, true>(P, st, vB, live, od, t, b);
         }
     }
@@ -1376,8 +1402,11 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
 #ifndef ISP1_OCC
 #define ISP1_OCC 6 /* waves per SIMD phase 1 is compiled for: 80 VGPRs, no spills (8: 64 VGPRs + spills) */
 #endif
-template <bool HAS_INVALID, int NR>
-__global__ __launch_bounds__(IS_UNARY_WAVES * 64, HAS_INVALID ? ISP1_OCC_INV : ISP1_OCC) void k_pw_phase1(
+#ifndef ISP1_OCC_WIN
+#define ISP1_OCC_WIN ISP1_OCC /* the windowed instantiation (4-wave workgroups, 8-26 KB of LDS) */
+#endif
+template <bool HAS_INVALID, int NR, bool WIN = false>
+__global__ __launch_bounds__(IS_UNARY_WAVES * 64, HAS_INVALID ? ISP1_OCC_INV : (WIN ? ISP1_OCC_WIN : ISP1_OCC)) void k_pw_phase1(
     const DevParams P, int col_base, int ncols, int tile, int nsplit,
     const RowRec* __restrict__ recs, const float* __restrict__ lutT,
     const StepRec* __restrict__ steps, const float* __restrict__ rcp,
@@ -1391,11 +1420,11 @@ __global__ __launch_bounds__(IS_UNARY_WAVES * 64, HAS_INVALID ? ISP1_OCC_INV : I
     if (colg >= ncols) return;
     const int vhor = __builtin_amdgcn_readfirstlane(vhor_arr[colg / P.C]);
     if (__builtin_amdgcn_readfirstlane(col_flags[colg]) == 0)
-        pw_phase1_body<true, HAS_INVALID, NR>(P, smem, colg, tile, recs, lutT, steps, rcp, vhor, split,
+        pw_phase1_body<true, HAS_INVALID, NR, WIN>(P, smem, colg, tile, recs, lutT, steps, rcp, vhor, split,
                                               nsplit, prune + colg, part_cost, part_idx, counters, joined, cost_T,
                                               blksum);
     else
-        pw_phase1_body<false, HAS_INVALID, NR>(P, smem, colg, tile, recs, lutT, steps, rcp, vhor, split,
+        pw_phase1_body<false, HAS_INVALID, NR, WIN>(P, smem, colg, tile, recs, lutT, steps, rcp, vhor, split,
                                                nsplit, prune + colg, part_cost, part_idx, counters, joined, cost_T,
                                                blksum);
 }
@@ -2356,15 +2385,16 @@ __global__ __launch_bounds__(ISP2S_WAVES * 64, 5) void k_pw_phase2s(
 
 extern "C" {
 
-size_t isk_pairwise_lds_bytes(const DevParams* P, int nwaves) {
+static size_t p1_lds_bytes(const DevParams* P, int nwaves, bool windowed) {
     const size_t rcp = sizeof(float) * (((size_t)P->H + 1 + 3) & ~(size_t)3);
-    const size_t tile = sizeof(float) * (size_t)IS_TILE * (P->D + 1);
+    const size_t tile = sizeof(float) * (size_t)IS_TILE * ((windowed ? IS_P1_WIN : P->D) + 1);
     const size_t merge = (size_t)nwaves * 3 * 64 * 8; /* aliases the tile after the loop */
     /* + the object block bounds of the pre-pass: [ntiles * IS_QPT + 1][64] (a launch of tile t uses
      * t * IS_QPT + 1 entries) */
     return (tile > merge ? tile : merge) + rcp + sizeof(float) * 8 * (size_t)nwaves +
            sizeof(float) * IS_P1_L7_WORDS + sizeof(float) * IS_P1_BLK_WORDS * ((size_t)P->ntiles * IS_QPT + 1) + 32;
 }
+size_t isk_pairwise_lds_bytes(const DevParams* P, int nwaves) { return p1_lds_bytes(P, nwaves, false); }
 size_t isk_phase2_lds_bytes(const DevParams* P) {
     size_t need = sizeof(double) * 2 * IS_LOG_TABLE_SIZE +
                   sizeof(float) * (P->D + (IS_TILE + 1) + (size_t)ISP2_ROWS * ISP2_WS) + 16;
@@ -2398,7 +2428,10 @@ hipError_t isk_launch_dp_pairwise(const DevParams* P, int ncols, int nwaves, con
                                   const float* cost_T, const int* n_generic, float* blksum, float* t8row,
                                   hipStream_t stream, hipStream_t* aux, int n_aux,
                                   hipEvent_t ev_fork, hipEvent_t* ev_join) {
-    const size_t lds1 = isk_pairwise_lds_bytes(P, nwaves);
+    /* windowed tiles (P->win_tiles): IS_P1_WIN_WAVES waves per workgroup -- the smaller LDS footprint lets a CU
+     * hold more, smaller workgroups (measured at D = 64: 4 waves x 4 workgroups beat 8 x 3 on every tile) */
+    int nwaves_win = IS_P1_WIN_WAVES < nwaves ? IS_P1_WIN_WAVES : nwaves;
+    if (P->knob_pw_waves > 0) nwaves_win = nwaves; /* (experiments: one wave count for all tiles) */
     const size_t lds2 = isk_phase2_lds_bytes(P);
     /* Columns are independent: with enough of them the batch is cut into groups whose
      * phase-1 / phase-2 chains (2 x ntiles dependent launches each) run on their own streams, so
@@ -2428,14 +2461,19 @@ hipError_t isk_launch_dp_pairwise(const DevParams* P, int ncols, int nwaves, con
 #endif
 #define IS_LAUNCH_P1(INV, c0, c1, st)                                                              \
     do {                                                                                           \
-        if (IS_PW_PHASE1_ROW_REGS && P->D <= 128)                                                  \
+        if (win_t)                                                                                 \
+            hipLaunchKernelGGL((k_pw_phase1<INV, 2, true>), dim3(((c1) - (c0)) * nsplit),          \
+                               dim3(nw_t * 64), lds1_t, st, *P, c0, c1, tile, nsplit, recs, lutT,  \
+                               steps, rcp, vhor, col_flags, prune, part_cost, part_idx, counters, \
+                               joined, cost_T, blksum);                                            \
+        else if (IS_PW_PHASE1_ROW_REGS && P->D <= 128)                                             \
             hipLaunchKernelGGL((k_pw_phase1<INV, 2>), dim3(((c1) - (c0)) * nsplit),                \
-                               dim3(nwaves * 64), lds1_t, st, *P, c0, c1, tile, nsplit, recs, lutT,  \
+                               dim3(nw_t * 64), lds1_t, st, *P, c0, c1, tile, nsplit, recs, lutT,  \
                                steps, rcp, vhor, col_flags, prune, part_cost, part_idx, counters, \
                                joined, cost_T, blksum);                                            \
         else                                                                                       \
             hipLaunchKernelGGL((k_pw_phase1<INV, 0>), dim3(((c1) - (c0)) * nsplit),                \
-                               dim3(nwaves * 64), lds1_t, st, *P, c0, c1, tile, nsplit, recs, lutT,  \
+                               dim3(nw_t * 64), lds1_t, st, *P, c0, c1, tile, nsplit, recs, lutT,  \
                                steps, rcp, vhor, col_flags, prune, part_cost, part_idx, counters,  \
                                joined, cost_T, blksum);                                            \
     } while (0)
@@ -2477,7 +2515,16 @@ hipError_t isk_launch_dp_pairwise(const DevParams* P, int ncols, int nwaves, con
     }
     for (int tile = 0; tile < P->ntiles; tile++) {
         /* (the block bounds of tile t need t + 1 of the ntiles + 1 entries lds1 has room for) */
-        const size_t lds1_t = lds1 - sizeof(float) * IS_P1_BLK_WORDS * (size_t)IS_QPT * (size_t)(P->ntiles - tile);
+        /* (large batches only: a call of a few frames does not fill the chip, there the eight waves per
+         * column are the parallelism: one frame 1.57 ms classic, 1.63 ms windowed; frames/s at batch 4 / 8 /
+         * 16 / 32: 1461 / 2068 / 2795 / 3178 classic, 1424 / 2010 / 2798 / 3269 windowed.  IS_P1_WIN_TILES
+         * forces the window for that many tiles at any batch: tests) */
+        const bool win_t = !IS_P1_GEN_TILE && IS_P1_WINDOWED(P->D) && IS_PW_PHASE1_ROW_REGS && P->D <= 128 &&
+                           P->win_lo != nullptr && tile < P->win_tiles &&
+                           (P->knob_win_tiles >= 0 || ncols >= IS_P1_WIN_MIN_COLS);
+        const int nw_t = win_t ? nwaves_win : nwaves;
+        const size_t lds1_t = p1_lds_bytes(P, nw_t, win_t) -
+                              sizeof(float) * IS_P1_BLK_WORDS * (size_t)IS_QPT * (size_t)(P->ntiles - tile);
         for (int g = 0; g < groups; g++) {
             const int c0 = (int)((long long)ncols * g / groups) & ~1; /* (even: column pairs) */
             const int c1 = g + 1 == groups ? ncols : ((int)((long long)ncols * (g + 1) / groups) & ~1);
@@ -2509,6 +2556,10 @@ hipError_t isk_set_lds_pairwise(const DevParams* P, int nwaves_pair) {
     e = hipFuncSetAttribute((const void*)k_pw_phase1<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, c);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void*)k_pw_phase1<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, c);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void*)k_pw_phase1<true, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, c);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void*)k_pw_phase1<false, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, c);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void*)k_pw_phase1<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, c);
     if (e != hipSuccess) return e;

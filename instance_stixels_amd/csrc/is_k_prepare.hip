@@ -208,6 +208,29 @@ __device__ __forceinline__ void prepare_columns_body(
     }
     __syncthreads();
 
+    /* ---- fn windows of the pairwise phase 1 (is_device.h, IS_P1_WIN): per 64-row tile the smallest valid
+     * disparity, rounded down to a multiple of 4 columns (16-byte loads), one below for the rounding of
+     * the prefix sums a mean is computed from */
+    if (IS_P1_WINDOWED(P.D) && P.win_lo != nullptr) {
+        const int lane = tid & 63, wv = tid >> 6;
+        for (int t = wv; t < P.ntiles; t += PREP_THREADS / 64) {
+            const int r = t * 64 + lane;
+            float d = IS_INF;
+            if (r < H) {
+                const float x = s_d[r];
+                if (!(P.invalid >= 0 && x == P.invalid)) d = x;
+            }
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) d = __builtin_fminf(d, __shfl_xor(d, m, 64));
+            if (lane == 0) {
+                int lo = 0;
+                if (d < IS_INF) lo = (int)__builtin_fminf(__builtin_fmaxf(d, 1.0f), (float)P.D) - 1;
+                lo = min(max(lo, 0) & ~3, P.D - IS_P1_WIN);
+                P.win_lo[(size_t)colg * P.ntiles + t] = lo;
+            }
+        }
+    }
+
     /* ---- instance-centre values per row from the RAW offsets (StixelsKernels.cu:401-409);
      * thread t owns rows [t*R, t*R+R).  mx = 8*col + 3.5 + offx + 0.5 is an exact integer;
      * my = trunc(row - offy + 0.5): n for n >= 0, n + 1 for n < 0 (truncation toward zero). */

@@ -387,6 +387,49 @@ __device__ __forceinline__ void stage_tile_and_rcp(float* s_tile, float* s_rcp,
     }
 }
 
+/* The fn window [lo, lo + IS_P1_WIN) of lutT rows tile_lo + 1 .. tile_lo + 64 (row stride IS_P1_WIN + 1) and the
+ * 1/h table behind one memory round trip.  lo is a multiple of 4: sixteen lanes fetch the 256 bytes of one
+ * row's window with 16-byte loads, a wave four rows; the dword stores of a wave then hit banks
+ * (row + 4 q + j) mod 64, q = 0 .. 15, four consecutive rows: all different. */
+__device__ __forceinline__ void stage_window_and_rcp(float* s_tile, float* s_rcp, const float* __restrict__ lcol,
+                                                     const float* __restrict__ rcp, int tile_lo, int H, int D,
+                                                     int lo, int tid, int nthreads) {
+    constexpr int WQ = IS_P1_WIN / 4; /* 16-byte chunks per row */
+    constexpr int WPs = IS_P1_WIN + 1;
+    constexpr int NX = 4;             /* chunks per thread and batch */
+    constexpr int NR = 5;             /* 1/h entries per thread: 1025 <= 5 * 256 */
+    const bool one_trip = H + 1 <= NR * nthreads;
+    float rc[NR];
+    if (one_trip) {
+#pragma unroll
+        for (int k = 0; k < NR; k++) rc[k] = rcp[min(tid + k * nthreads, H)];
+    }
+    const int q = tid & (WQ - 1), r0 = tid / WQ, dr = nthreads / WQ; /* (nthreads: a multiple of 64) */
+    for (int rb = r0; rb < IS_TILE; rb += NX * dr) {
+        float4 x[NX];
+#pragma unroll
+        for (int k = 0; k < NX; k++) {
+            const int r = min(rb + k * dr, IS_TILE - 1);
+            x[k] = *reinterpret_cast<const float4*>(lcol + (size_t)min(tile_lo + 1 + r, H) * D + lo + 4 * q);
+        }
+#pragma unroll
+        for (int k = 0; k < NX; k++) {
+            const int r = rb + k * dr;
+            if (r < IS_TILE) {
+                float* d = s_tile + IS_TILE_ROW(r) * WPs + 4 * q;
+                d[0] = x[k].x; d[1] = x[k].y; d[2] = x[k].z; d[3] = x[k].w;
+            }
+        }
+    }
+    if (one_trip) {
+#pragma unroll
+        for (int k = 0; k < NR; k++)
+            if (tid + k * nthreads <= H) s_rcp[tid + k * nthreads] = rc[k];
+    } else {
+        stage_rcp(s_rcp, rcp, H, tid, nthreads);
+    }
+}
+
 /* vB-side row of lutT.  NR > 0: the wave holds the whole row in NR registers per lane (element
  * j*64 + lane), fetched with coalesced loads one step AHEAD of its use -- the address does not
  * depend on the segment -- and a lane picks its element fni with ds_bpermute (no memory access on

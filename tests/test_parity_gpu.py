@@ -1099,6 +1099,47 @@ def test_branch_and_bound_is_exact_at_the_bounds(family, monkeypatch):
         assert pruned_steps < 0.8 * full_steps, (family, pruned_steps, full_steps)
 
 
+@pytest.mark.parametrize("rows,cols,D,family,inv", [(256, 256, 64, "scene", -1.0), (512, 512, 128, "noisy_disparity", -1.0),
+                                                  (512, 256, 128, "many_thin_objects", 0.0),
+                                                  (1024, 1024, 128, "scene", -1.0)])
+def test_phase1_fn_windows_change_nothing(rows, cols, D, family, inv, monkeypatch):
+    """The fn windows of the pairwise phase 1 (is_device.h, IS_P1_WIN: a (column, tile) stages 32 lutT columns of
+    its 64 rows instead of all D; lanes whose floor(mean) falls outside read global memory) forced for EVERY
+    tile at any batch (IS_P1_WIN_TILES=99; the default takes the tiles below the horizon of batches >= 16
+    frames) against the classic tile (IS_P1_WIN_TILES=0): complete tables and Sections bit for bit, the classic
+    run against the oracle, and the counters prove that the forced run did read outside its windows."""
+    from instance_stixels_amd import synthetic
+    from instance_stixels_amd.core import Core
+    ov = dict(invalid_disparity=inv) if inv >= 0 else {}
+    base = helpers.build_case("drn_d_38_pairwise", rows, cols, D, seed=11, **ov)
+    cfg = base["cfg"]
+    f = synthetic.make_frame(cfg, seed=41, family=family)
+    g = oracle_mod().host_ground(cfg, f.vhor_image, f.camera_tilt, f.camera_height, f.alpha_ground)
+    case = dict(base)
+    case.update(frames=[f], gf=g[0][None], ng=g[1][None], ig=g[2][None], vhor=np.array([g[3]], np.int32),
+                disparity=f.disparity[None], segmentation=f.segmentation[None])
+    outs, misses = {}, {}
+    for tiles in ("99", "0"):
+        monkeypatch.setenv("IS_P1_WIN_TILES", tiles)
+        core = Core(case["params"], case["lut"], case["odr"], max_batch=1)
+        try:
+            core.set_eval_counters(True)
+            outs[tiles] = core.run(disparity_big=case["disparity"], segmentation=case["segmentation"],
+                                   ground_function=case["gf"], normalization_ground=case["ng"],
+                                   inv_sigma2_ground=case["ig"], vhor=case["vhor"], pairwise=True,
+                                   median_join=bool(cfg.median_join), want_tables=True)
+            misses[tiles] = core.eval_counters()["p1_window_miss"]
+        finally:
+            core.close()
+    a, b = outs["99"], outs["0"]
+    assert np.array_equal(a["cost_table"].view(np.uint32), b["cost_table"].view(np.uint32))
+    assert np.array_equal(a["index_table"], b["index_table"])
+    assert helpers.sections_equal(a["sections"][0], b["sections"][0])
+    assert misses["0"] == 0 and misses["99"] > 0, misses
+    if rows <= 512:
+        _assert_parity(case, b)
+
+
 @pytest.mark.parametrize("knob,value", [("IS_GRAPH", "1"), ("IS_PREPARE_OVERLAP", "0"),
                                          ("IS_PREPARE_OVERLAP", "1"), ("IS_UNARY_DIAG", "1")])
 @pytest.mark.parametrize("preset", ["drn_d_22_unary", "drn_d_38_pairwise"])
