@@ -145,7 +145,7 @@ class Core:
         out = np.zeros(200, np.uint64)   # IS_EVAL_COUNTERS
         _check(lib().is_get_eval_counters(self._ctx, _hp(out), 200), "is_get_eval_counters")
         return dict(unary_full=int(out[0]), unary_gs=int(out[1]), p1_full=int(out[2]), p1_gs=int(out[3]),
-                    p1_lazy=int(out[4]), p1_window_miss=int(out[4]),
+                    p1_lazy=int(out[4]), p1_window_miss=int(out[4]), unary_window_miss=int(out[5]),
                     p1_per_tile=[[int(out[8 + 3 * t + j]) for j in range(3)] for t in range(64)])
 
     def read_object_lut(self, column):

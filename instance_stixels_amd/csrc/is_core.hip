@@ -638,7 +638,7 @@ static int compute_enqueue(is_ctx* c, const float* d_joined, const int32_t* d_se
                                c->d_prune, c->d_n_generic, stream, c->aux_stream, c->ev_fork, c->ev_join));
     if (pairwise) HIP_TRY(isk_launch_priors(&P, c->d_ground, c->d_priors, n_images, stream));
     if (timing) HIP_TRY(hipEventRecord(c->ev[1], stream));
-    /* fn windows in phase 1 (is_device.h, IS_P1_WIN) for the tiles that start below the horizon of every image
+    /* fn windows of the DP kernels (is_device.h, IS_P1_WIN) for the tiles that start below the horizon of every image
      * of the call: ground and what stands on it span few disparities within 64 rows, while a tile above the
      * horizon mixes sky (d ~ 0) with objects of any disparity -- measured: 3.6 % of the steps of tile 7 read
      * outside the window, 22-35 % of tiles 12-13, and a step with a lane outside pays a memory round trip */
@@ -647,6 +647,11 @@ static int compute_enqueue(is_ctx* c, const float* d_joined, const int32_t* d_se
         int vmin = P.H;
         for (int i = 0; i < n_images; i++) vmin = c->h_vhor_pinned[slot][i] < vmin ? c->h_vhor_pinned[slot][i] : vmin;
         Pw.win_tiles = (IS_P1_WINDOWED(P.D) && P.win_lo != nullptr && vmin > 0) ? (vmin + IS_TILE - 1) / IS_TILE : 0;
+        /* the unary kernel windows EVERY tile: a lane outside costs it an L2 gather (2.8 % of its steps on the
+         * synthetic scene), not the HBM round trip on a latency-bound chain it costs phase 1 -- measured at
+         * batch 64: 9 windowed tiles 7450, all 16: 7760 frames/s (pairwise 3780 / 3810, but its unpruned
+         * floor 1720 / 1630) */
+        if (!pairwise && IS_P1_WINDOWED(P.D) && P.win_lo != nullptr) Pw.win_tiles = P.ntiles;
         if (P.knob_win_tiles >= 0) Pw.win_tiles = P.knob_win_tiles; /* (experiments) */
     }
     if (pairwise)
@@ -657,7 +662,7 @@ static int compute_enqueue(is_ctx* c, const float* d_joined, const int32_t* d_se
                                        c->d_obj_cost_lut, c->d_n_generic, c->d_blksum, c->d_t8row, stream, c->aux_streams,
                                        IS_AUX_STREAMS, c->ev_fork, c->ev_joins));
     else
-        HIP_TRY(isk_launch_dp_unary(&P, ncols, c->nwaves_unary, c->d_recs, c->d_lutT, c->d_rcp,
+        HIP_TRY(isk_launch_dp_unary(&Pw, ncols, c->nwaves_unary, c->d_recs, c->d_lutT, c->d_rcp,
                                     c->d_vhor, c->d_col_flags, c->d_prune, ct, it, c->d_n_generic,
                                     c->counting ? c->d_counters : nullptr, d_joined, c->d_obj_cost_lut,
                                     stream));

@@ -215,19 +215,32 @@ __device__ __forceinline__ void prepare_columns_body(
         const int lane = tid & 63, wv = tid >> 6;
         for (int t = wv; t < P.ntiles; t += PREP_THREADS / 64) {
             const int r = t * 64 + lane;
-            float d = IS_INF;
+            float d = IS_INF, dx = -IS_INF;
+            bool ok = false;
             if (r < H) {
                 const float x = s_d[r];
-                if (!(P.invalid >= 0 && x == P.invalid)) d = x;
+                if (!(P.invalid >= 0 && x == P.invalid) && x == x) { d = dx = x; ok = true; }
             }
+            const float mine = d;
 #pragma unroll
-            for (int m = 32; m >= 1; m >>= 1) d = __builtin_fminf(d, __shfl_xor(d, m, 64));
-            if (lane == 0) {
-                int lo = 0;
-                if (d < IS_INF) lo = (int)__builtin_fminf(__builtin_fmaxf(d, 1.0f), (float)P.D) - 1;
-                lo = min(max(lo, 0) & ~3, P.D - IS_P1_WIN);
-                P.win_lo[(size_t)colg * P.ntiles + t] = lo;
+            for (int m = 32; m >= 1; m >>= 1) {
+                d = __builtin_fminf(d, __shfl_xor(d, m, 64));
+                dx = __builtin_fmaxf(dx, __shfl_xor(dx, m, 64));
             }
+            /* two candidates: the window that starts at the tile's smallest disparity (the segments of a lane
+             * start below its row -- nearer, larger disparities) and the one that ends at its largest; a tile
+             * above the horizon can hold sky (d ~ 0) AND an object: the window goes where more of its rows are */
+            int lo_a = 0, lo_b = 0;
+            if (d < IS_INF) {
+                lo_a = (int)__builtin_fminf(__builtin_fmaxf(d, 1.0f), (float)P.D) - 1;
+                lo_b = (int)__builtin_fminf(__builtin_fmaxf(dx, 0.0f), (float)(P.D - 1)) + 2 - IS_P1_WIN;
+            }
+            lo_a = min(max(lo_a, 0) & ~3, P.D - IS_P1_WIN);
+            lo_b = min(max(lo_b, 0) & ~3, P.D - IS_P1_WIN);
+            const int fl = (int)__builtin_fminf(__builtin_fmaxf(mine, 0.0f), (float)(P.D - 1));
+            const int n_a = __builtin_popcountll(__builtin_amdgcn_ballot_w64(ok && (unsigned)(fl - lo_a) < (unsigned)IS_P1_WIN));
+            const int n_b = __builtin_popcountll(__builtin_amdgcn_ballot_w64(ok && (unsigned)(fl - lo_b) < (unsigned)IS_P1_WIN));
+            if (lane == 0) P.win_lo[(size_t)colg * P.ntiles + t] = n_b > n_a ? lo_b : lo_a;
         }
     }
 

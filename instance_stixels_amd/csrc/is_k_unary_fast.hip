@@ -49,6 +49,12 @@
 #define ISF_GEN_TILE 0 /* 1: the vT-side lutT rows rebuilt in LDS (gen_lut_tile) instead of read back: -8.6 GB of HBM reads per 64 frames, but +9 % DP time (measured, round 3) */
 #endif
 #define ISF_THREADS (ISF_WAVES * 64)
+#ifndef ISF_WIN_WAVES
+#define ISF_WIN_WAVES 4 /* waves per workgroup of the windowed tiles */
+#endif
+#ifndef ISF_WIN_MIN_COLS
+#define ISF_WIN_MIN_COLS 2048 /* columns per call from which the windowed launch is used (frames/s windowed | classic at batch 2: 6470 | 6050, 4: 6090 | 6350, 8: 6890 | 6680, 16: 7480 | 7010, 32: 7860 | 7200) */
+#endif
 
 struct UnaryBestF {
     float g, o, s;
@@ -57,11 +63,20 @@ struct UnaryBestF {
 
 /* One (vB, vT) evaluation; semantics of unary_step (is_k_unary.hip) with the `<=` update of a
  * descending walk.  lrow: the lutT row of vB in LDS. */
-template <bool HAS_INVALID, bool SKY, bool DIAG, bool FIRST, bool NOGROUND>
+/* WIN: my_tile holds the fn window [win.lo, win.lo + IS_P1_WIN) of the lane's lutT row (is_device.h); a lane
+ * outside it reads global memory -- the one access of the loop that waits for memory (the compiler's
+ * vmcnt(0) for it also drains the ring's prefetches: correct, and rare below the horizon). */
+struct FastWin {
+    int lo;
+    const float* grow; /* lutT row vT + 1 of this lane in global memory */
+    int* misses;       /* wave-uniform count of steps with a lane outside */
+};
+template <bool HAS_INVALID, bool SKY, bool DIAG, bool FIRST, bool NOGROUND, bool WIN = false>
 __device__ __forceinline__ SegTerms fast_step(const DevParams& P, const RowRec& my, const float* srec,
                                               const float* lrow, const float* my_tile,
                                               const float* s_rcp, int vT, int vTc, int vhor, int vB,
-                                              bool row_ok, UnaryBestF& b, const isk_f16v& S) {
+                                              bool row_ok, UnaryBestF& b, const isk_f16v& S,
+                                              const FastWin win = FastWin()) {
     const int h = vTc + 1 - vB;
     const bool live = DIAG ? ((h > 0) && row_ok) : row_ok;
     const int hc = DIAG ? max(h, 1) : h;
@@ -80,7 +95,19 @@ __device__ __forceinline__ SegTerms fast_step(const DevParams& P, const RowRec& 
     const RowRec rb = lds_rec(srec);
     const SegTerms t = eval_segment<true, HAS_INVALID>(my, rb, (float)hc, r, P.D, P.iw);
 #endif
-    const float od = my_tile[t.fni] - lrow[t.fni];
+    float vtv;
+    if (WIN) {
+        const int fo = t.fni - win.lo;
+        const bool inw = (unsigned)fo < (unsigned)IS_P1_WIN;
+        vtv = my_tile[inw ? fo : 0];
+        if (__builtin_amdgcn_ballot_w64(live && !inw) != 0ull) { /* (the dead lanes of a diagonal step hold no segment) */
+            if (live && !inw) vtv = win.grow[(unsigned)t.fni];
+            (*win.misses)++;
+        }
+    } else {
+        vtv = my_tile[t.fni];
+    }
+    const float od = vtv - lrow[t.fni];
     const float pwih = P.pw * r;
     /* cost = dw*data + pw*(1/h) + sw*seg, left to right (:716-719, 762-765, 820-823) */
     const float cost_o = P.dw * od + pwih + P.sw * t.seg_o;
@@ -211,7 +238,7 @@ __device__ __forceinline__ void ring_prefetch(const float* __restrict__ lcol,
 
 /* PRE_DIAG: the instantiation that starts from the minima k_dp_unary_diag left in the tables (an
  * instantiation of its own: as a run-time flag the path cost the unpruned walk 1.8 %) */
-template <bool HAS_INVALID, int NVR, bool PRE_DIAG = false>
+template <bool HAS_INVALID, int NVR, bool PRE_DIAG = false, bool WIN = false>
 __global__ __launch_bounds__(ISF_THREADS, HAS_INVALID ? ISF_OCC_INV : ISF_OCC) void k_dp_unary_fast(
     const DevParams P, int ncols, const RowRec* __restrict__ recs, const float* __restrict__ lutT,
     const float* __restrict__ rcp, const int* __restrict__ vhor_arr,
@@ -219,26 +246,28 @@ __global__ __launch_bounds__(ISF_THREADS, HAS_INVALID ? ISF_OCC_INV : ISF_OCC) v
     float* __restrict__ cost_table, int32_t* __restrict__ index_table,
     unsigned long long* __restrict__ counters /* null, or the evaluation counters (is_device.h) */,
     const float* __restrict__ joined, const float* __restrict__ cost_T,
-    int pre_diag /* k_dp_unary_diag has run: the tables hold the minima over the vB inside the tiles */) {
+    int pre_diag /* k_dp_unary_diag has run: the tables hold the minima over the vB inside the tiles */,
+    int tile0, int ntl /* this launch walks the tiles tile0 .. tile0 + ntl - 1 */) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int H = P.H, D = P.D;
-    const int DP = D + 1;
+    const int DP = (WIN ? IS_P1_WIN : D) + 1; /* WIN: the tile holds an fn window of its rows (is_device.h) */
+    const int nwv = (int)(blockDim.x >> 6);   /* waves of the workgroup: 8, or 4 for the windowed tiles */
     constexpr int K = ISF_RING;
     constexpr int ROWF = 64 * NVR;             /* floats of a row slot */
     constexpr int SLOT = ROWF + ISF_REC_F;     /* floats of a ring slot */
     float* s_rcp = (float*)smem;                        /* [H+1 -> x4]                       */
     float* s_tile = s_rcp + ((H + 1 + 3) & ~3);         /* [64][D+1] lutT rows tile_lo+1 ..   */
     /* (the tile's space also holds the merge area after the walk: at least ISF_MERGE_F floats) */
-    constexpr int ISF_MERGE_F = 2 * ISF_WAVES * 3 * 64 + 2 * 3 * 64;
-    const int tile_f = max((IS_TILE * DP + 3) & ~3, ISF_MERGE_F);
+    const int merge_f = 2 * nwv * 3 * 64 + 2 * 3 * 64;
+    const int tile_f = max((IS_TILE * DP + 3) & ~3, merge_f);
     float* s_ring = s_tile + tile_f;                    /* [8 waves][K][SLOT]                */
 
     /* XCD-aware order: blocks b, b+8, ... share an XCD/L2; the tiles of a column stay on one XCD
      * (they fetch the same lutT rows) and the tallest tiles start first */
     const int nxcd = 8;
     const int xcd = blockIdx.x % nxcd, q = blockIdx.x / nxcd;
-    const int tile = __builtin_amdgcn_readfirstlane(P.ntiles - 1 - q % P.ntiles);
-    const int colg = __builtin_amdgcn_readfirstlane((q / P.ntiles) * nxcd + xcd);
+    const int tile = __builtin_amdgcn_readfirstlane(tile0 + ntl - 1 - q % ntl);
+    const int colg = __builtin_amdgcn_readfirstlane((q / ntl) * nxcd + xcd);
     if (colg >= ncols) return;
     if (__builtin_amdgcn_readfirstlane(col_flags[colg]) != 0) return; /* generic column: k_dp_unary */
     const int vhor = __builtin_amdgcn_readfirstlane(vhor_arr[colg / P.C]);
@@ -264,7 +293,7 @@ __global__ __launch_bounds__(ISF_THREADS, HAS_INVALID ? ISF_OCC_INV : ISF_OCC) v
     const int vB_top = (pre ? tile_lo : vB_end) - w; /* (pre: may be negative = no step for this wave) */
 #pragma unroll
     for (int i = 0; i < K; i++)
-        ring_prefetch<NVR>(lcol, rcol, max(vB_top - ISF_WAVES * i, 0), D, my_ring + i * SLOT,
+        ring_prefetch<NVR>(lcol, rcol, max(vB_top - nwv * i, 0), D, my_ring + i * SLOT,
                            my_ring + i * SLOT + ROWF, lane);
     ISF_MARK(4); /* (debug build: ring requests issued) */
 #if ISF_GEN_TILE
@@ -275,11 +304,19 @@ __global__ __launch_bounds__(ISF_THREADS, HAS_INVALID ? ISF_OCC_INV : ISF_OCC) v
     const RowRec my = load_rec(rcol + vTc + 1);
     ISF_MARK(5); /* (debug build: record requested) */
     stage_rcp(s_rcp, rcp, H, tid, ISF_THREADS);
+    const int win_lo = 0;
 #else
     const RowRec my = load_rec(rcol + vTc + 1);
     ISF_MARK(5); /* (debug build: record requested) */
-    stage_tile_and_rcp(s_tile, s_rcp, lcol, rcp, tile_lo, H, D, tid, ISF_THREADS);
+    const int win_lo = WIN ? __builtin_amdgcn_readfirstlane(P.win_lo[(size_t)colg * P.ntiles + tile]) : 0;
+    if (WIN) stage_window_and_rcp(s_tile, s_rcp, lcol, rcp, tile_lo, H, D, win_lo, tid, (int)blockDim.x);
+    else stage_tile_and_rcp(s_tile, s_rcp, lcol, rcp, tile_lo, H, D, tid, (int)blockDim.x);
 #endif
+    int n_winmiss = 0;
+    FastWin fwin;
+    fwin.lo = win_lo;
+    fwin.grow = lcol + (size_t)(vTc + 1) * D;
+    fwin.misses = &n_winmiss;
     ISF_MARK(6); /* (debug build: tile + 1/h table staged; mark 0 then = the barrier) */
 
     PruneValsF pv;
@@ -311,7 +348,7 @@ __global__ __launch_bounds__(ISF_THREADS, HAS_INVALID ? ISF_OCC_INV : ISF_OCC) v
 #if ISF_SREC
     srec_request(S, rcol + max(vB_top, 0));
 #endif
-    for (int vB = vB_top; vB >= 0; vB -= ISF_WAVES) {
+    for (int vB = vB_top; vB >= 0; vB -= nwv) {
         wait_vmcnt<(NVR + 1) * (K - 1)>(); /* this step's slot has landed; K - 1 prefetches in flight */
 #if ISF_SREC
         srec_arrived(S);
@@ -334,31 +371,31 @@ __global__ __launch_bounds__(ISF_THREADS, HAS_INVALID ? ISF_OCC_INV : ISF_OCC) v
         n_full += diag ? 0 : 1;
         if (vB == 0) { /* first segment (:481-594): ground + object */
             if (diag)
-                fast_step<HAS_INVALID, false, true, true, false>(P, my, rb, lrow, my_tile, s_rcp, vT, vTc, vhor,
-                                                                 0, row_ok, b, S);
+                fast_step<HAS_INVALID, false, true, true, false, WIN>(P, my, rb, lrow, my_tile, s_rcp, vT, vTc, vhor,
+                                                                      0, row_ok, b, S, fwin);
             else
-                fast_step<HAS_INVALID, false, false, true, false>(P, my, rb, lrow, my_tile, s_rcp, vT, vTc,
-                                                                  vhor, 0, row_ok, b, S);
+                fast_step<HAS_INVALID, false, false, true, false, WIN>(P, my, rb, lrow, my_tile, s_rcp, vT, vTc,
+                                                                       vhor, 0, row_ok, b, S, fwin);
         } else if (vB > vhor) { /* vB - 1 >= vhor: sky + object (:729) */
             if (diag) {
-                fast_step<HAS_INVALID, true, true, false, false>(P, my, rb, lrow, my_tile, s_rcp, vT, vTc, vhor,
-                                                                 vB, row_ok, b, S);
+                fast_step<HAS_INVALID, true, true, false, false, WIN>(P, my, rb, lrow, my_tile, s_rcp, vT, vTc, vhor,
+                                                                      vB, row_ok, b, S, fwin);
             } else {
-                const SegTerms t = fast_step<HAS_INVALID, true, false, false, false>(
-                    P, my, rb, lrow, my_tile, s_rcp, vT, vTc, vhor, vB, row_ok, b, S);
+                const SegTerms t = fast_step<HAS_INVALID, true, false, false, false, WIN>(
+                    P, my, rb, lrow, my_tile, s_rcp, vT, vTc, vhor, vB, row_ok, b, S, fwin);
                 if (IS_PRUNE) ok = fast_bounds<true, false>(P, pv, t, b);
             }
         } else { /* ground + object (:687) */
             if (diag) {
-                fast_step<HAS_INVALID, false, true, false, false>(P, my, rb, lrow, my_tile, s_rcp, vT, vTc, vhor,
-                                                                  vB, row_ok, b, S);
+                fast_step<HAS_INVALID, false, true, false, false, WIN>(P, my, rb, lrow, my_tile, s_rcp, vT, vTc, vhor,
+                                                                       vB, row_ok, b, S, fwin);
             } else if (nog) {
-                const SegTerms t = fast_step<HAS_INVALID, false, false, false, true>(
-                    P, my, rb, lrow, my_tile, s_rcp, vT, vTc, vhor, vB, row_ok, b, S);
+                const SegTerms t = fast_step<HAS_INVALID, false, false, false, true, WIN>(
+                    P, my, rb, lrow, my_tile, s_rcp, vT, vTc, vhor, vB, row_ok, b, S, fwin);
                 if (IS_PRUNE) ok = fast_bounds<false, true>(P, pv, t, b);
             } else {
-                const SegTerms t = fast_step<HAS_INVALID, false, false, false, false>(
-                    P, my, rb, lrow, my_tile, s_rcp, vT, vTc, vhor, vB, row_ok, b, S);
+                const SegTerms t = fast_step<HAS_INVALID, false, false, false, false, WIN>(
+                    P, my, rb, lrow, my_tile, s_rcp, vT, vTc, vhor, vB, row_ok, b, S, fwin);
                 if (IS_PRUNE) ok = fast_bounds<false, false>(P, pv, t, b);
             }
         }
@@ -369,9 +406,9 @@ __global__ __launch_bounds__(ISF_THREADS, HAS_INVALID ? ISF_OCC_INV : ISF_OCC) v
         if (done) break; /* nothing below can win any more */
         /* refill the slot just consumed (its reads have returned: their values were used) */
         asm volatile("" ::: "memory");
-        ring_prefetch<NVR>(lcol, rcol, max(vB - ISF_WAVES * K, 0), D, s_row, s_row + ROWF, lane);
+        ring_prefetch<NVR>(lcol, rcol, max(vB - nwv * K, 0), D, s_row, s_row + ROWF, lane);
 #if ISF_SREC
-        srec_request(S, rcol + max(vB - ISF_WAVES, 0));
+        srec_request(S, rcol + max(vB - nwv, 0));
 #endif
         slot = (slot + 1 == K) ? 0 : slot + 1;
     }
@@ -383,6 +420,7 @@ __global__ __launch_bounds__(ISF_THREADS, HAS_INVALID ? ISF_OCC_INV : ISF_OCC) v
     if (counters != nullptr && lane == 0) {
         atomicAdd(counters + IS_CNT_UNARY_FULL, (unsigned long long)n_full);
         atomicAdd(counters + IS_CNT_UNARY_GS, (unsigned long long)n_gs);
+        if (WIN) atomicAdd(counters + IS_CNT_UNARY_WINMISS, (unsigned long long)n_winmiss);
     }
 
     /* ---- merge the waves' partial minima: min cost, ties -> smallest vB.  After the barrier no
@@ -393,8 +431,8 @@ __global__ __launch_bounds__(ISF_THREADS, HAS_INVALID ? ISF_OCC_INV : ISF_OCC) v
     __syncthreads();
     ISF_MARK(2);
     float* m_cost = s_tile;                              /* [8][3][64] */
-    int* m_vb = (int*)(m_cost + ISF_WAVES * 3 * 64);     /* [8][3][64] */
-    float* f_cost = m_cost + 2 * ISF_WAVES * 3 * 64;     /* [3][64] final values */
+    int* m_vb = (int*)(m_cost + nwv * 3 * 64);           /* [8][3][64] */
+    float* f_cost = m_cost + 2 * nwv * 3 * 64;           /* [3][64] final values */
     int* f_vb = (int*)(f_cost + 3 * 64);                 /* [3][64] */
     m_cost[(w * 3 + 0) * 64 + lane] = b.g; m_vb[(w * 3 + 0) * 64 + lane] = b.vg;
     m_cost[(w * 3 + 1) * 64 + lane] = b.o; m_vb[(w * 3 + 1) * 64 + lane] = b.vo;
@@ -404,7 +442,7 @@ __global__ __launch_bounds__(ISF_THREADS, HAS_INVALID ? ISF_OCC_INV : ISF_OCC) v
         const int type = tid >> 6;
         float c = m_cost[(0 * 3 + type) * 64 + lane];
         int vb = m_vb[(0 * 3 + type) * 64 + lane];
-        for (int ww = 1; ww < ISF_WAVES; ww++) {
+        for (int ww = 1; ww < nwv; ww++) {
             const float c2 = m_cost[(ww * 3 + type) * 64 + lane];
             const int vb2 = m_vb[(ww * 3 + type) * 64 + lane];
             const bool take = (c2 < c) || (c2 == c && vb2 >= 0 && (vb < 0 || vb2 < vb));
@@ -605,15 +643,16 @@ static int isf_nvr(const DevParams* P) {
     return 0;
 }
 
-size_t isk_unary_fast_lds_bytes(const DevParams* P, int nvr) {
-    const size_t DP = (size_t)P->D + 1;
+static size_t isf_lds_bytes(const DevParams* P, int nvr, int nwaves, bool windowed) {
+    const size_t DP = (size_t)(windowed ? IS_P1_WIN : P->D) + 1;
     const size_t rcp = ((size_t)P->H + 1 + 3) & ~(size_t)3;
     size_t tile = ((size_t)IS_TILE * DP + 3) & ~(size_t)3;
-    const size_t ring = (size_t)ISF_WAVES * ISF_RING * (64 * (size_t)nvr + ISF_REC_F);
-    const size_t merge = (size_t)ISF_WAVES * 3 * 64 * 2 + 2 * 3 * 64; /* lives in the tile's space */
+    const size_t ring = (size_t)nwaves * ISF_RING * (64 * (size_t)nvr + ISF_REC_F);
+    const size_t merge = (size_t)nwaves * 3 * 64 * 2 + 2 * 3 * 64; /* lives in the tile's space */
     if (tile < merge) tile = merge;
     return sizeof(float) * (rcp + tile + ring) + 16;
 }
+size_t isk_unary_fast_lds_bytes(const DevParams* P, int nvr) { return isf_lds_bytes(P, nvr, ISF_WAVES, false); }
 
 /* nonzero (the row-load count) when the shape can use the kernel: a workgroup must fit the CU's
  * 160 KiB of LDS */
@@ -634,6 +673,9 @@ hipError_t isk_set_lds_unary_fast(const DevParams* P) {
                             hipFuncAttributeMaxDynamicSharedMemorySize, b);                       \
     if (e == hipSuccess)                                                                          \
     e = hipFuncSetAttribute((const void*)k_dp_unary_fast<INV, NVR, true>,                         \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, b);                       \
+    if (e == hipSuccess)                                                                          \
+    e = hipFuncSetAttribute((const void*)k_dp_unary_fast<INV, NVR, false, true>,                  \
                             hipFuncAttributeMaxDynamicSharedMemorySize, b)
     if (nvr == 2) { ISF_SET(true, 2); ISF_SET(false, 2); } else { ISF_SET(true, 4); ISF_SET(false, 4); }
 #undef ISF_SET
@@ -661,18 +703,36 @@ hipError_t isk_launch_dp_unary_fast(const DevParams* P, int ncols, const RowRec*
                                rcp, vhor, col_flags, cost_table, index_table);
     }
     const int groups = (ncols + 7) / 8;
-    const dim3 grid(groups * 8 * P->ntiles);
+    /* The tiles 0 .. wt - 1 (P->win_tiles: those that start below every horizon of the batch) stage an fn window of
+     * IS_P1_WIN lutT columns instead of all D and run as ISF_WIN_WAVES-wave workgroups in a launch of their own:
+     * 20 instead of 52 KB of LDS per workgroup, seven 4-wave workgroups per CU instead of three 8-wave ones.  The
+     * tiles do not depend on each other: the taller (classic) ones go first. */
+    int wt = 0;
+    if (!pre_diag && !ISF_GEN_TILE && IS_P1_WINDOWED(P->D) && P->win_lo != nullptr && nvr == 2 &&
+        (P->knob_win_tiles >= 0 || ncols >= ISF_WIN_MIN_COLS))
+        wt = P->win_tiles < P->ntiles ? P->win_tiles : P->ntiles;
+    const int nw_win = ISF_WIN_WAVES;
     const size_t lds = isk_unary_fast_lds_bytes(P, nvr);
+    const size_t lds_win = isf_lds_bytes(P, nvr, nw_win, true);
 #define ISF_LAUNCH(INV, NVR)                                                                      \
     do {                                                                                          \
         if (pre_diag)                                                                             \
-            hipLaunchKernelGGL((k_dp_unary_fast<INV, NVR, true>), grid, dim3(ISF_THREADS), lds, stream, *P, \
+            hipLaunchKernelGGL((k_dp_unary_fast<INV, NVR, true>), dim3(groups * 8 * P->ntiles), dim3(ISF_THREADS), \
+                               lds, stream, *P,                                                    \
                                ncols, recs, lutT, rcp, vhor, col_flags, prune, cost_table, index_table, \
-                               counters, joined, cost_T, pre_diag);                                \
-        else                                                                                      \
-            hipLaunchKernelGGL((k_dp_unary_fast<INV, NVR, false>), grid, dim3(ISF_THREADS), lds, stream, *P, \
-                               ncols, recs, lutT, rcp, vhor, col_flags, prune, cost_table, index_table, \
-                               counters, joined, cost_T, pre_diag);                                \
+                               counters, joined, cost_T, pre_diag, 0, P->ntiles);                  \
+        else {                                                                                    \
+            if (wt < P->ntiles)                                                                   \
+                hipLaunchKernelGGL((k_dp_unary_fast<INV, NVR, false>), dim3(groups * 8 * (P->ntiles - wt)), \
+                                   dim3(ISF_THREADS), lds, stream, *P,                             \
+                                   ncols, recs, lutT, rcp, vhor, col_flags, prune, cost_table, index_table, \
+                                   counters, joined, cost_T, pre_diag, wt, P->ntiles - wt);        \
+            if (wt > 0)                                                                           \
+                hipLaunchKernelGGL((k_dp_unary_fast<INV, NVR, false, true>), dim3(groups * 8 * wt), \
+                                   dim3(nw_win * 64), lds_win, stream, *P,                         \
+                                   ncols, recs, lutT, rcp, vhor, col_flags, prune, cost_table, index_table, \
+                                   counters, joined, cost_T, pre_diag, 0, wt);                     \
+        }                                                                                         \
     } while (0)
     if (P->invalid >= 0) {
         if (nvr == 2) ISF_LAUNCH(true, 2); else ISF_LAUNCH(true, 4);
