@@ -69,6 +69,7 @@ struct UnaryBestF {
 struct FastWin {
     int lo;
     const float* grow; /* lutT row vT + 1 of this lane in global memory */
+    const float* gcol; /* lutT of the column (row vB: gcol + vB * D) */
     int* misses;       /* wave-uniform count of steps with a lane outside */
 };
 template <bool HAS_INVALID, bool SKY, bool DIAG, bool FIRST, bool NOGROUND, bool WIN = false>
@@ -95,19 +96,26 @@ __device__ __forceinline__ SegTerms fast_step(const DevParams& P, const RowRec& 
     const RowRec rb = lds_rec(srec);
     const SegTerms t = eval_segment<true, HAS_INVALID>(my, rb, (float)hc, r, P.D, P.iw);
 #endif
-    float vtv;
+    float vtv, vbv;
     if (WIN) {
         const int fo = t.fni - win.lo;
         const bool inw = (unsigned)fo < (unsigned)IS_P1_WIN;
+        /* both ends from the windows: the lane's row in the tile, the row of vB in the ring slot (the ring
+         * fetches the SAME window of every vB row: 128 instead of 512 bytes per step) */
         vtv = my_tile[inw ? fo : 0];
+        vbv = lrow[inw ? fo : 0];
         if (__builtin_amdgcn_ballot_w64(live && !inw) != 0ull) { /* (the dead lanes of a diagonal step hold no segment) */
-            if (live && !inw) vtv = win.grow[(unsigned)t.fni];
+            if (live && !inw) {
+                vtv = win.grow[(unsigned)t.fni];
+                vbv = (win.gcol + (size_t)vB * P.D)[(unsigned)t.fni];
+            }
             (*win.misses)++;
         }
     } else {
         vtv = my_tile[t.fni];
+        vbv = lrow[t.fni];
     }
-    const float od = vtv - lrow[t.fni];
+    const float od = vtv - vbv;
     const float pwih = P.pw * r;
     /* cost = dw*data + pw*(1/h) + sw*seg, left to right (:716-719, 762-765, 820-823) */
     const float cost_o = P.dw * od + pwih + P.sw * t.seg_o;
@@ -236,6 +244,15 @@ __device__ __forceinline__ void ring_prefetch(const float* __restrict__ lcol,
         dma_dword((const float*)(rcol + vB) + lane, lds_addr(slot_rec));
 }
 
+/* The windowed ring slot: [IS_P1_WIN floats of lutT row vB from column lo][the 32 dwords of the record of vB] --
+ * ONE LDS-DMA instruction, lanes 0-31 the row window, lanes 32-63 the record. */
+__device__ __forceinline__ void ring_prefetch_win(const float* __restrict__ lcol, const RowRec* __restrict__ rcol,
+                                                  int vB, int D, int lo, float* slot, int lane) {
+    static_assert(IS_P1_WIN == 32 && ISF_REC_F == 32, "one 64-lane DMA = window + record");
+    const float* g = lane < 32 ? lcol + (size_t)vB * D + lo + lane : (const float*)(rcol + vB) + (lane - 32);
+    dma_dword(g, lds_addr(slot));
+}
+
 /* PRE_DIAG: the instantiation that starts from the minima k_dp_unary_diag left in the tables (an
  * instantiation of its own: as a run-time flag the path cost the unpruned walk 1.8 %) */
 template <bool HAS_INVALID, int NVR, bool PRE_DIAG = false, bool WIN = false>
@@ -253,7 +270,8 @@ __global__ __launch_bounds__(ISF_THREADS, HAS_INVALID ? ISF_OCC_INV : ISF_OCC) v
     const int DP = (WIN ? IS_P1_WIN : D) + 1; /* WIN: the tile holds an fn window of its rows (is_device.h) */
     const int nwv = (int)(blockDim.x >> 6);   /* waves of the workgroup: 8, or 4 for the windowed tiles */
     constexpr int K = ISF_RING;
-    constexpr int ROWF = 64 * NVR;             /* floats of a row slot */
+    constexpr int ROWF = WIN ? IS_P1_WIN : 64 * NVR; /* floats of a row slot (WIN: the fn window of the row) */
+    constexpr int NV = WIN ? 1 : NVR + 1;            /* VMEM instructions per slot fill */
     constexpr int SLOT = ROWF + ISF_REC_F;     /* floats of a ring slot */
     float* s_rcp = (float*)smem;                        /* [H+1 -> x4]                       */
     float* s_tile = s_rcp + ((H + 1 + 3) & ~3);         /* [64][D+1] lutT rows tile_lo+1 ..   */
@@ -271,6 +289,8 @@ __global__ __launch_bounds__(ISF_THREADS, HAS_INVALID ? ISF_OCC_INV : ISF_OCC) v
     if (colg >= ncols) return;
     if (__builtin_amdgcn_readfirstlane(col_flags[colg]) != 0) return; /* generic column: k_dp_unary */
     const int vhor = __builtin_amdgcn_readfirstlane(vhor_arr[colg / P.C]);
+    /* WIN: first lutT column of the fn window of this (column, tile) (k_prepare writes it; requested with the flags) */
+    const int win_lo = WIN ? __builtin_amdgcn_readfirstlane(P.win_lo[(size_t)colg * P.ntiles + tile]) : 0;
     /* (pairs with a generic-encoding column are skipped by the diagonal kernel) */
     const bool pre = PRE_DIAG && pre_diag != 0 && (colg | 1) < ncols &&
                      (__builtin_amdgcn_readfirstlane(col_flags[colg ^ 1]) == 0);
@@ -293,8 +313,11 @@ __global__ __launch_bounds__(ISF_THREADS, HAS_INVALID ? ISF_OCC_INV : ISF_OCC) v
     const int vB_top = (pre ? tile_lo : vB_end) - w; /* (pre: may be negative = no step for this wave) */
 #pragma unroll
     for (int i = 0; i < K; i++)
-        ring_prefetch<NVR>(lcol, rcol, max(vB_top - nwv * i, 0), D, my_ring + i * SLOT,
-                           my_ring + i * SLOT + ROWF, lane);
+    {
+        const int vq = max(vB_top - nwv * i, 0);
+        if (WIN) ring_prefetch_win(lcol, rcol, vq, D, win_lo, my_ring + i * SLOT, lane);
+        else ring_prefetch<NVR>(lcol, rcol, vq, D, my_ring + i * SLOT, my_ring + i * SLOT + ROWF, lane);
+    }
     ISF_MARK(4); /* (debug build: ring requests issued) */
 #if ISF_GEN_TILE
     /* (before this lane's record is requested: the 32 values of a block and the 32 dwords of the
@@ -304,11 +327,9 @@ __global__ __launch_bounds__(ISF_THREADS, HAS_INVALID ? ISF_OCC_INV : ISF_OCC) v
     const RowRec my = load_rec(rcol + vTc + 1);
     ISF_MARK(5); /* (debug build: record requested) */
     stage_rcp(s_rcp, rcp, H, tid, ISF_THREADS);
-    const int win_lo = 0;
 #else
     const RowRec my = load_rec(rcol + vTc + 1);
     ISF_MARK(5); /* (debug build: record requested) */
-    const int win_lo = WIN ? __builtin_amdgcn_readfirstlane(P.win_lo[(size_t)colg * P.ntiles + tile]) : 0;
     if (WIN) stage_window_and_rcp(s_tile, s_rcp, lcol, rcp, tile_lo, H, D, win_lo, tid, (int)blockDim.x);
     else stage_tile_and_rcp(s_tile, s_rcp, lcol, rcp, tile_lo, H, D, tid, (int)blockDim.x);
 #endif
@@ -316,6 +337,7 @@ __global__ __launch_bounds__(ISF_THREADS, HAS_INVALID ? ISF_OCC_INV : ISF_OCC) v
     FastWin fwin;
     fwin.lo = win_lo;
     fwin.grow = lcol + (size_t)(vTc + 1) * D;
+    fwin.gcol = lcol;
     fwin.misses = &n_winmiss;
     ISF_MARK(6); /* (debug build: tile + 1/h table staged; mark 0 then = the barrier) */
 
@@ -349,7 +371,7 @@ __global__ __launch_bounds__(ISF_THREADS, HAS_INVALID ? ISF_OCC_INV : ISF_OCC) v
     srec_request(S, rcol + max(vB_top, 0));
 #endif
     for (int vB = vB_top; vB >= 0; vB -= nwv) {
-        wait_vmcnt<(NVR + 1) * (K - 1)>(); /* this step's slot has landed; K - 1 prefetches in flight */
+        wait_vmcnt<NV * (K - 1)>(); /* this step's slot has landed; K - 1 prefetches in flight */
 #if ISF_SREC
         srec_arrived(S);
 #endif
@@ -406,7 +428,8 @@ __global__ __launch_bounds__(ISF_THREADS, HAS_INVALID ? ISF_OCC_INV : ISF_OCC) v
         if (done) break; /* nothing below can win any more */
         /* refill the slot just consumed (its reads have returned: their values were used) */
         asm volatile("" ::: "memory");
-        ring_prefetch<NVR>(lcol, rcol, max(vB - nwv * K, 0), D, s_row, s_row + ROWF, lane);
+        if (WIN) ring_prefetch_win(lcol, rcol, max(vB - nwv * K, 0), D, win_lo, s_row, lane);
+        else ring_prefetch<NVR>(lcol, rcol, max(vB - nwv * K, 0), D, s_row, s_row + ROWF, lane);
 #if ISF_SREC
         srec_request(S, rcol + max(vB - nwv, 0));
 #endif
@@ -647,7 +670,7 @@ static size_t isf_lds_bytes(const DevParams* P, int nvr, int nwaves, bool window
     const size_t DP = (size_t)(windowed ? IS_P1_WIN : P->D) + 1;
     const size_t rcp = ((size_t)P->H + 1 + 3) & ~(size_t)3;
     size_t tile = ((size_t)IS_TILE * DP + 3) & ~(size_t)3;
-    const size_t ring = (size_t)nwaves * ISF_RING * (64 * (size_t)nvr + ISF_REC_F);
+    const size_t ring = (size_t)nwaves * ISF_RING * ((windowed ? (size_t)IS_P1_WIN : 64 * (size_t)nvr) + ISF_REC_F);
     const size_t merge = (size_t)nwaves * 3 * 64 * 2 + 2 * 3 * 64; /* lives in the tile's space */
     if (tile < merge) tile = merge;
     return sizeof(float) * (rcp + tile + ring) + 16;
