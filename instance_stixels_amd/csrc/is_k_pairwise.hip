@@ -885,6 +885,10 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
     const __amdgpu_buffer_rsrc_t lrsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void*)lcol, 0, (H + 1) * D * (int)sizeof(float), 0x00020000);
     const int lane4 = lane * 4;
+    /* WIN: ONE 64-lane load fetches the 64 lutT columns from win_lo on of a vB row (the row registers cover
+     * twice the tile's window); classic: NR loads, the whole row */
+    constexpr int NRW = windowed ? 1 : NR;
+    const int lane4r = lane4 + (windowed ? win_lo * 4 : 0);
     const unsigned scr = lds_addr(s_scr + 8 * wl);
     /* lutT[vT + 1][fni] of this lane: from the staged tile / window; outside the window from global memory */
     int n_winmiss = 0; /* steps in which some lane read outside the window (evaluation counters) */
@@ -898,6 +902,21 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
             if (!inw) v = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(lrsrc, ((vTc + 1) * D + fni) * 4, 0, 0));
         }
         return v;
+    };
+    /* lutT[vT + 1][fni] - lutT[vB][fni]: `row` = the registers of row vB */
+    auto od_value = [&](const LutRow<NRW>& row, int fni, int vB_row) -> float {
+        if (!windowed) return my_tile[fni] - pick_lut<NRW>(row, fni);
+        const int fo = fni - win_lo;
+        const bool in_t = (unsigned)fo < (unsigned)win_w; /* the tile's window  */
+        const bool in_r = (unsigned)fo < 64u;              /* the row registers */
+        float vt = my_tile[in_t ? fo : 0];
+        float vb = pick_lut<NRW>(row, in_r ? fo : 0);
+        if (__builtin_amdgcn_ballot_w64(!in_t) != 0ull) {
+            n_winmiss++;
+            if (!in_t) vt = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(lrsrc, ((vTc + 1) * D + fni) * 4, 0, 0));
+            if (!in_r) vb = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(lrsrc, (vB_row * D + fni) * 4, 0, 0));
+        }
+        return vt - vb;
     };
     if (FAST && IS_PRUNE) {
         /* FAST columns: vB downwards with the exact branch-and-bound of DESIGN.md "Pruning".  The
@@ -1055,11 +1074,11 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
             const float E1gs = __builtin_fmaxf(pq->E1g, pq->E1s);
             const bool nog = IS_SKIP_GROUND_ABOVE_HORIZON && tile_lo >= vhor;
             int vB = vB_last - (vB_last - w) % nw; /* the wave's largest vB */
-            LutRow<NR> next_row;
-            load_lut_row<NR>(next_row, lrsrc, lcol, vB, D, lane4);
+            LutRow<NRW> next_row;
+            load_lut_row<NRW>(next_row, lrsrc, lcol, vB, D, lane4r);
 #if IS_P1_ROW_AHEAD == 2
-            LutRow<NR> next2_row; /* the row of the step after next: two rows in flight */
-            load_lut_row<NR>(next2_row, lrsrc, lcol, max(vB - nw, 0), D, lane4);
+            LutRow<NRW> next2_row; /* the row of the step after next: two rows in flight */
+            load_lut_row<NRW>(next2_row, lrsrc, lcol, max(vB - nw, 0), D, lane4r);
 #endif
             /* The bounds are sticky per type (a bound that holds at vB holds at every smaller vB:
              * the class minima only grow, the running minima q only grow, the best cost cannot
@@ -1079,9 +1098,9 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
 #if IS_P1_ROW_AHEAD == 2
 #define IS_P1_NEXT_ROW()                                                                           \
             next_row = next2_row;                                                                  \
-            load_lut_row<NR>(next2_row, lrsrc, lcol, max(vB - 2 * nw, 0), D, lane4)
+            load_lut_row<NRW>(next2_row, lrsrc, lcol, max(vB - 2 * nw, 0), D, lane4r)
 #else
-#define IS_P1_NEXT_ROW() load_lut_row<NR>(next_row, lrsrc, lcol, max(vB - nw, 0), D, lane4)
+#define IS_P1_NEXT_ROW() load_lut_row<NRW>(next_row, lrsrc, lcol, max(vB - nw, 0), D, lane4r)
 #endif
             /* DPP record operands without an invalid-disparity value; with one (valid-count operands
              * and an IEEE division per step: 90+ VGPRs) the scalar-load form at 8 waves per SIMD is
@@ -1117,7 +1136,7 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
             }
 #define IS_P1_STEP(SKY, NOG)                                                                       \
             ISP1_COUNT(4);                                                                         \
-            const LutRow<NR> row = next_row;                                                       \
+            const LutRow<NRW> row = next_row;                                                       \
             if (IS_P1_TOUCH_AHEAD > 0)                                                             \
                 touch_step(rcol, scol, max(vB - IS_P1_TOUCH_AHEAD * nw, 0), lane, scr);            \
             IS_P1_NEXT_ROW();                                                                      \
@@ -1147,7 +1166,7 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
                     } else {                                                                       \
                         t = eval_segment_dpp<HAS_INVALID, WANT>(my, r0, r1, (float)h, s_rcp[h], D, P.iw); \
                     }                                                                              \
-                    od = vt_value(t.fni) - pick_lut<NR>(row, t.fni);                                \
+                    od = od_value(row, t.fni, vB);                                \
                     if (!IS_P1_SREC) {                                                             \
                         /* the next StepRec: requested only now -- every LDS wait is an lgkmcnt(0) \
                          * wait and would wait for this scalar load too (SMEM returns out of order) */ \
@@ -1159,7 +1178,7 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
                     const RowRec rb = sload_rec(rcol + vB);                                        \
                     st = sload_step(scol + vB);                                                    \
                     t = eval_segment<true, HAS_INVALID>(my, rb, (float)h, s_rcp[h], D, P.iw);      \
-                    od = vt_value(t.fni) - pick_lut<NR>(row, t.fni);                                \
+                    od = od_value(row, t.fni, vB);                                \
                 }                                                                                  \
                 pairwise_step<SKY, true, NOG, true>(P, st, vB, live, od, t, b);                    \
                 const float lb_o = min_raw((st.q_o - E1o) + P.sw * seg_o_lower_bound(t, E2), lbp[0]); \
@@ -1313,8 +1332,8 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
         }
     } else {
         int vB = w;
-        LutRow<NR> next_row;
-        if (vB <= vB_last) load_lut_row<NR>(next_row, lrsrc, lcol, vB == 0 ? min(nw, H) : vB, D, lane4);
+        LutRow<NRW> next_row;
+        if (vB <= vB_last) load_lut_row<NRW>(next_row, lrsrc, lcol, vB == 0 ? min(nw, H) : vB, D, lane4r);
         if (vB == 0) { /* first segment, :481-594 */
             const RowRec rb = sload_rec(rcol);
             const int h = vTc + 1;
@@ -1334,32 +1353,32 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
             for (; vB <= min(vhor, vB_last); vB += nw) { /* ground range, ground candidate = +inf */
                 const RowRec rb = sload_rec(rcol + vB);
                 const StepVals st = sload_step(scol + vB);
-                const LutRow<NR> row = next_row;
-                load_lut_row<NR>(next_row, lrsrc, lcol, min(vB + nw, H), D, lane4);
+                const LutRow<NRW> row = next_row;
+                load_lut_row<NRW>(next_row, lrsrc, lcol, min(vB + nw, H), D, lane4r);
                 const int h = vTc + 1 - vB;
                 const SegTerms t = eval_segment<FAST, HAS_INVALID>(my, rb, (float)h, s_rcp[h], D, P.iw);
-                const float od = vt_value(t.fni) - pick_lut<NR>(row, t.fni);
+                const float od = od_value(row, t.fni, vB);
                 pairwise_step<false, true, true>(P, st, vB, live, od, t, b);
             }
         }
         for (; vB <= min(vhor, vB_last); vB += nw) { /* ground range: vB-1 < vhor */
             const RowRec rb = sload_rec(rcol + vB);
             const StepVals st = sload_step(scol + vB);
-            const LutRow<NR> row = next_row;
-            load_lut_row<NR>(next_row, lrsrc, lcol, min(vB + nw, H), D, lane4);
+            const LutRow<NRW> row = next_row;
+            load_lut_row<NRW>(next_row, lrsrc, lcol, min(vB + nw, H), D, lane4r);
             const int h = vTc + 1 - vB;
             const SegTerms t = eval_segment<FAST, HAS_INVALID>(my, rb, (float)h, s_rcp[h], D, P.iw);
-            const float od = vt_value(t.fni) - pick_lut<NR>(row, t.fni);
+            const float od = od_value(row, t.fni, vB);
             pairwise_step<false, true>(P, st, vB, live, od, t, b);
         }
         for (; vB <= vB_last; vB += nw) { /* sky range */
             const RowRec rb = sload_rec(rcol + vB);
             const StepVals st = sload_step(scol + vB);
-            const LutRow<NR> row = next_row;
-            load_lut_row<NR>(next_row, lrsrc, lcol, min(vB + nw, H), D, lane4);
+            const LutRow<NRW> row = next_row;
+            load_lut_row<NRW>(next_row, lrsrc, lcol, min(vB + nw, H), D, lane4r);
             const int h = vTc + 1 - vB;
             const SegTerms t = eval_segment<FAST, HAS_INVALID>(my, rb, (float)h, s_rcp[h], D, P.iw);
-            const float od = vt_value(t.fni) - pick_lut<NR>(row, t.fni);
+            const float od = od_value(row, t.fni, vB);
             pairwise_step<true, true>(P, st, vB, live, od, t, b);
         }
     }
