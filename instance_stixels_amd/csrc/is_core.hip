@@ -652,7 +652,7 @@ static int compute_enqueue(is_ctx* c, const float* d_joined, const int32_t* d_se
          * batch 64: 9 windowed tiles 7450, all 16: 7760 frames/s (pairwise 3780 / 3810, but its unpruned
          * floor 1720 / 1630) */
         if (!pairwise && IS_P1_WINDOWED(P.D) && P.win_lo != nullptr) Pw.win_tiles = P.ntiles;
-        if (P.knob_win_tiles >= 0) Pw.win_tiles = P.knob_win_tiles; /* (experiments) */
+        if (P.knob_win_tiles >= 0) Pw.win_tiles = P.knob_win_tiles; /* (experiments, tests) */
     }
     if (pairwise)
         HIP_TRY(isk_launch_dp_pairwise(&Pw, ncols, c->nwaves_pairwise, c->d_recs, c->d_lutT,

@@ -2538,7 +2538,8 @@ hipError_t isk_launch_dp_pairwise(const DevParams* P, int ncols, int nwaves, con
          * column are the parallelism: one frame 1.57 ms classic, 1.63 ms windowed; frames/s at batch 4 / 8 /
          * 16 / 32: 1461 / 2068 / 2795 / 3178 classic, 1424 / 2010 / 2798 / 3269 windowed.  IS_P1_WIN_TILES
          * forces the window for that many tiles at any batch: tests) */
-        const bool win_t = !IS_P1_GEN_TILE && IS_P1_WINDOWED(P->D) && IS_PW_PHASE1_ROW_REGS && P->D <= 128 &&
+        /* (any D: the windowed instantiation keeps 64 columns of a vB row in one register per lane) */
+        const bool win_t = !IS_P1_GEN_TILE && IS_P1_WINDOWED(P->D) &&
                            P->win_lo != nullptr && tile < P->win_tiles &&
                            (P->knob_win_tiles >= 0 || ncols >= IS_P1_WIN_MIN_COLS);
         const int nw_t = win_t ? nwaves_win : nwaves;

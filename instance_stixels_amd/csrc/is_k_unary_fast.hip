@@ -731,7 +731,7 @@ hipError_t isk_launch_dp_unary_fast(const DevParams* P, int ncols, const RowRec*
      * 20 instead of 52 KB of LDS per workgroup, seven 4-wave workgroups per CU instead of three 8-wave ones.  The
      * tiles do not depend on each other: the taller (classic) ones go first. */
     int wt = 0;
-    if (!pre_diag && !ISF_GEN_TILE && IS_P1_WINDOWED(P->D) && P->win_lo != nullptr && nvr == 2 &&
+    if (!pre_diag && !ISF_GEN_TILE && IS_P1_WINDOWED(P->D) && P->win_lo != nullptr &&
         (P->knob_win_tiles >= 0 || ncols >= ISF_WIN_MIN_COLS))
         wt = P->win_tiles < P->ntiles ? P->win_tiles : P->ntiles;
     const int nw_win = ISF_WIN_WAVES;

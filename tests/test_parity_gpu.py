@@ -1099,20 +1099,24 @@ def test_branch_and_bound_is_exact_at_the_bounds(family, monkeypatch):
         assert pruned_steps < 0.8 * full_steps, (family, pruned_steps, full_steps)
 
 
+@pytest.mark.parametrize("preset", ["drn_d_38_pairwise", "drn_d_22_unary"])
 @pytest.mark.parametrize("rows,cols,D,family,inv", [(256, 256, 64, "scene", -1.0), (512, 512, 128, "noisy_disparity", -1.0),
                                                   (512, 256, 128, "many_thin_objects", 0.0),
+                                                  (256, 512, 256, "scene", -1.0),
                                                   (1024, 1024, 128, "scene", -1.0)])
-def test_phase1_fn_windows_change_nothing(rows, cols, D, family, inv, monkeypatch):
-    """The fn windows of the pairwise phase 1 (is_device.h, IS_P1_WIN: a (column, tile) stages 32 lutT columns of
-    its 64 rows instead of all D; lanes whose floor(mean) falls outside read global memory) forced for EVERY
-    tile at any batch (IS_P1_WIN_TILES=99; the default takes the tiles below the horizon of batches >= 16
-    frames) against the classic tile (IS_P1_WIN_TILES=0): complete tables and Sections bit for bit, the classic
-    run against the oracle, and the counters prove that the forced run did read outside its windows."""
+def test_phase1_fn_windows_change_nothing(preset, rows, cols, D, family, inv, monkeypatch):
+    """The fn windows of the DP kernels (is_device.h, IS_P1_WIN: a (column, tile) stages 32 lutT columns of
+    its 64 rows instead of all D; lanes whose floor(mean) falls outside read global memory; k_dp_unary_fast
+    and k_pw_phase1) forced for EVERY tile at any batch (IS_P1_WIN_TILES=99; by default the unary kernel
+    windows every tile of calls of >= 8 frames, phase 1 the tiles below the horizon of >= 16 frames) against
+    the classic tiles (IS_P1_WIN_TILES=0): complete tables and Sections bit for bit, the classic run against
+    the oracle, and the counters prove that the forced run did read outside its windows."""
     from instance_stixels_amd import synthetic
     from instance_stixels_amd.core import Core
     ov = dict(invalid_disparity=inv) if inv >= 0 else {}
-    base = helpers.build_case("drn_d_38_pairwise", rows, cols, D, seed=11, **ov)
+    base = helpers.build_case(preset, rows, cols, D, seed=11, **ov)
     cfg = base["cfg"]
+    pairwise = bool(cfg.pairwise)
     f = synthetic.make_frame(cfg, seed=41, family=family)
     g = oracle_mod().host_ground(cfg, f.vhor_image, f.camera_tilt, f.camera_height, f.alpha_ground)
     case = dict(base)
@@ -1126,9 +1130,9 @@ def test_phase1_fn_windows_change_nothing(rows, cols, D, family, inv, monkeypatc
             core.set_eval_counters(True)
             outs[tiles] = core.run(disparity_big=case["disparity"], segmentation=case["segmentation"],
                                    ground_function=case["gf"], normalization_ground=case["ng"],
-                                   inv_sigma2_ground=case["ig"], vhor=case["vhor"], pairwise=True,
+                                   inv_sigma2_ground=case["ig"], vhor=case["vhor"], pairwise=pairwise,
                                    median_join=bool(cfg.median_join), want_tables=True)
-            misses[tiles] = core.eval_counters()["p1_window_miss"]
+            misses[tiles] = core.eval_counters()["p1_window_miss" if pairwise else "unary_window_miss"]
         finally:
             core.close()
     a, b = outs["99"], outs["0"]
