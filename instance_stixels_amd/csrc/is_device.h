@@ -180,17 +180,24 @@ struct DevParams {
     int knob_win_tiles;       /* IS_P1_WIN_TILES: number of phase-1 tiles that stage an fn window (-1: those below the horizon) */
     int knob_pw_waves;        /* IS_PW_WAVES: waves per phase-1 workgroup for every tile (-1: 8, windowed tiles IS_P1_WIN_WAVES) */
     int knob_unary_diag;      /* IS_UNARY_DIAG=1: the diagonal blocks of the unary DP in k_dp_unary_diag (two columns per wave) */
-    /* fn windows of the pairwise phase 1 (IS_P1_WIN): [n_columns][ntiles] first lutT column of the window a
+    /* fn windows of the DP kernels (IS_P1_WIN): [n_columns][ntiles] first lutT column of the window a
      * (column, tile) stages in LDS; written by the prepare kernel, device memory of the context */
     int* win_lo;
-    int win_tiles; /* the tiles 0 .. win_tiles - 1 of this call stage a window (set per call: the tiles that start below every horizon of the batch) */
+    int win_tiles; /* the tiles 0 .. win_tiles - 1 of this call stage a window (set per call: unary every tile,
+                    * pairwise phase 1 the tiles that start below every horizon of the batch) */
 };
 
-/* Pairwise phase 1 stages IS_P1_WIN lutT columns of its 64 vT rows instead of all D when D is larger (and a
- * multiple of 4): 16.6 instead of 33 KB of LDS per workgroup at D = 128 -- more, smaller workgroups per CU.
- * The segments of a lane start BELOW its row (nearer to the camera: larger or equal disparities on a road
- * scene), so the window starts at the tile's smallest disparity; a lane whose floor(mean) falls outside
- * reads global memory (exactness does not rest on the window). */
+/* fn windows (k_dp_unary_fast, k_pw_phase1).  A (column, tile) workgroup keeps lutT[vT + 1][*] of its 64 rows in
+ * LDS: D + 1 floats per row, 33 KB at D = 128 -- which is what limited a CU to three workgroups.  A lane only
+ * reads lutT[vT + 1][floor(mean of its segment)], and the means of the segments a tile evaluates lie close
+ * together (a road ramp moves by ~12 disparities over 64 rows, an object by ~1), so when D is larger than
+ * IS_P1_WIN (and a multiple of 4) the workgroup stages only the IS_P1_WIN columns from win_lo[column][tile] on:
+ * 8.4 KB, small workgroups (4 waves), six or seven per CU.  k_prepare picks the start: the window that begins
+ * at the tile's smallest disparity (the segments of a lane start BELOW its row, nearer to the camera: larger
+ * or equal disparities on a road scene) or the one that ends at its largest, whichever holds more of the
+ * tile's rows.  The vB side uses the same window (unary: ring slots of 32 columns + the record; phase 1: 64
+ * columns in one register per lane).  A lane whose floor(mean) falls outside reads global memory: exactness
+ * never rests on the window. */
 #ifndef IS_P1_WIN
 #define IS_P1_WIN 32
 #endif
