@@ -1757,7 +1757,13 @@ __global__ __launch_bounds__(64, ISP2_OCC) void k_pw_phase2(
 #ifndef ISP2X_OCC
 #define ISP2X_OCC 4 /* waves per SIMD k_pw_phase2x is compiled for (each wave: two columns) */
 #endif
-#define ISP2X_WF (ISP2_ROWS * ISP2_WS)         /* floats of one column's lutT window */
+/* the two-column kernel: windows of at most 15 columns at a row stride of 15 (odd as it is: no padding column) --
+ * with 16 + 1 the wave's LDS was 11.1 KB = 14 waves per CU, now 9.6 KB = 16 (what its 128 VGPRs allow) */
+#ifndef ISP2X_WMAX
+#define ISP2X_WMAX 15
+#endif
+#define ISP2X_WS (ISP2X_WMAX | 1)
+#define ISP2X_WF (ISP2_ROWS * ISP2X_WS)        /* floats of one column's lutT window */
 
 __device__ __forceinline__ float half_bcast_f(float x, int src_lane) { /* src_lane: per lane */
     return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src_lane << 2, __builtin_bit_cast(int, x)));
@@ -1798,9 +1804,10 @@ __device__ __forceinline__ void pw_phase2x_body(const DevParams& P, char* smem, 
     double* s_logc = s_invc + IS_LOG_TABLE_SIZE;         /* [32] */
     float* s_odr = (float*)(s_logc + IS_LOG_TABLE_SIZE); /* [D -> x4] */
     float* s_rcp = s_odr + ((D + 3) & ~3);               /* [IS_TILE+1 -> x4] */
-    float* s_win = s_rcp + ((IS_TILE + 1 + 3) & ~3);     /* [2][65][ISP2_WS] lutT windows */
-    float* s_SV = s_win + 2 * ISP2X_WF;                  /* [2][2][66] S / V prefixes of the tile's rows */
-    float* s_st = s_SV + 2 * 2 * 66;                     /* [2][16] StepRec handed from phase L to phase U */
+    float* s_win = s_rcp + ((IS_TILE + 1 + 3) & ~3);     /* [2][65][ISP2X_WS] lutT windows */
+    constexpr int NSV = HAS_INVALID ? 2 : 1;             /* (the valid-count prefixes only with an invalid value) */
+    float* s_SV = s_win + 2 * ISP2X_WF;                  /* [2][NSV][66] S / V prefixes of the tile's rows */
+    float* s_st = s_SV + 2 * NSV * 66;                   /* [2][16] StepRec handed from phase L to phase U */
     const int tile_lo = tile * IS_TILE;
     const int colg = col0 + half;
     const RowRec* rcol = recs + (size_t)colg * (H + 1);
@@ -1810,8 +1817,8 @@ __device__ __forceinline__ void pw_phase2x_body(const DevParams& P, char* smem, 
     const float* sv = sv_arr + (size_t)colg * 2 * (H + 1);
     const int n_rows = min(IS_TILE, H - tile_lo);
     float* my_winbase = s_win + half * ISP2X_WF;
-    float* my_S = s_SV + half * 2 * 66;
-    float* my_V = my_S + 66;
+    float* my_S = s_SV + half * NSV * 66;
+    float* my_V = my_S + (HAS_INVALID ? 66 : 0); /* (never read without an invalid value) */
 
     /* ---- prologue: per column the fn window [lo, lo + W) of the tile's rows (pw_phase2_body) */
     int lo, W;
@@ -1829,13 +1836,13 @@ __device__ __forceinline__ void pw_phase2x_body(const DevParams& P, char* smem, 
         int l = (int)__builtin_fminf(__builtin_fmaxf(dmin, 1.0f), (float)D) - 1;
         l = min(max(l, 0), D - 1);
         int hh = (int)__builtin_fminf(__builtin_fmaxf(dmax, 0.0f), (float)(D - 1)) + 1;
-        hh = min(max(hh, l), min(D - 1, l + ISP2_WMAX - 1));
+        hh = min(max(hh, l), min(D - 1, l + ISP2X_WMAX - 1));
         lo = l;
         W = hh - l + 1;
     }
     { /* the window rows tile_lo .. tile_lo + 64 of this lane's column: 32 lanes, 16 columns at most */
-        constexpr int NL = (ISP2_ROWS * ISP2_WMAX + 31) / 32;
-        const int f = li & (ISP2_WMAX - 1), j0 = li >> 4; /* two rows per sweep of the half */
+        constexpr int NL = (ISP2_ROWS * 16 + 31) / 32; /* sixteen lanes per row, those beyond the window idle */
+        const int f = li & 15, j0 = li >> 4; /* two rows per sweep of the half */
         float tmp[NL];
 #pragma unroll
         for (int k = 0; k < NL; k++) {
@@ -1845,13 +1852,13 @@ __device__ __forceinline__ void pw_phase2x_body(const DevParams& P, char* smem, 
 #pragma unroll
         for (int k = 0; k < NL; k++) {
             const int j = j0 + 2 * k;
-            if (j < ISP2_ROWS && f < W) my_winbase[j * ISP2_WS + f] = tmp[k];
+            if (j < ISP2_ROWS && f < W) my_winbase[j * ISP2X_WS + f] = tmp[k];
         }
     }
     for (int j = li; j <= IS_TILE; j += 32) { /* S / V prefixes at tile_lo + j */
         const RowRec* q = rcol + min(tile_lo + j, H);
         my_S[j] = q->S;
-        my_V[j] = HAS_INVALID ? q->V : 0.0f;
+        if (HAS_INVALID) my_V[j] = q->V;
     }
     if (lane == 0) is_log_tables(s_invc, s_logc);
     for (int i = lane; i < D; i += 64) s_odr[i] = odr[i];
@@ -1901,7 +1908,7 @@ __device__ __forceinline__ void pw_phase2x_body(const DevParams& P, char* smem, 
         const int fo = t.fni - lo;
         const bool inwin = (unsigned)fo < (unsigned)W;
         const int foc = inwin ? fo : 0;
-        float od = my_win[foc] - my_winbase[(r - tile_lo) * ISP2_WS + foc];
+        float od = my_win[foc] - my_winbase[(r - tile_lo) * ISP2X_WS + foc];
         if (__builtin_amdgcn_ballot_w64(live && !inwin) != 0ull) { /* outside the window: rare */
             if (IS_P2_GATHER_MASKED ? (live && !inwin) : true) { /* (only the lanes outside fetch, see pw_phase2_body) */
                 const float og = (lcol + (size_t)(vTc + 1) * D)[(unsigned)t.fni] - (lcol + (size_t)r * D)[(unsigned)t.fni];
@@ -1955,7 +1962,7 @@ __device__ __forceinline__ void pw_phase2x_body(const DevParams& P, char* smem, 
     {
         const int vT = tile_lo + li, vTc = min(vT, H - 1);
         const RowRec my = load_rec(rcol + vTc + 1);
-        const float* my_win = my_winbase + (vTc + 1 - tile_lo) * ISP2_WS;
+        const float* my_win = my_winbase + (vTc + 1 - tile_lo) * ISP2X_WS;
         PairBest b;
         load_best(0, b);
         float n0, n1;
@@ -1999,7 +2006,7 @@ __device__ __forceinline__ void pw_phase2x_body(const DevParams& P, char* smem, 
     {
         const int vT = tile_lo + 32 + li, vTc = min(vT, H - 1);
         const RowRec my = load_rec(rcol + vTc + 1);
-        const float* my_win = my_winbase + (vTc + 1 - tile_lo) * ISP2_WS;
+        const float* my_win = my_winbase + (vTc + 1 - tile_lo) * ISP2X_WS;
         PairBest b;
         load_best(32, b);
         const bool live_all = vT < H;
@@ -2425,7 +2432,7 @@ size_t isk_phase2_lds_bytes(const DevParams* P) {
 size_t isk_phase2x_lds_bytes(const DevParams* P) {
     const size_t x = sizeof(double) * 2 * IS_LOG_TABLE_SIZE +
                      sizeof(float) * (((P->D + 3) & ~3) + ((IS_TILE + 1 + 3) & ~3) + 2 * (size_t)ISP2X_WF +
-                                      2 * 2 * 66 + 2 * 16) + 32;
+                                      2 * (P->invalid >= 0 ? 2 : 1) * 66 + 2 * 16) + 32;
     const size_t one = isk_phase2_lds_bytes(P); /* the one-column fallback inside the kernel */
     return x > one ? x : one;
 }
