@@ -481,6 +481,17 @@ def measure_variants(args, wl, dev, local_rank):
     del keep, ibs
     core.close()
 
+    # ---- pairwise: the column groups of the DP on three streams of ONE context (IS_PW_GROUPS=3; default 1: beside
+    # an RCCL gather pipeline the groups cost 5 %, and per-kernel durations of overlapping launches say less)
+    if wl.cfg.pairwise:
+        core = wl.make_core(env={"IS_PW_GROUPS": "3"})
+        dt_g = wl.time_steps(core, 3)
+        out["column_groups_3"] = {"images_per_s": B / dt_g, "steps": 3,
+                                  "what": "IS_PW_GROUPS=3: the phase-1 / phase-2 chains of three column groups on "
+                                          "three streams of the context (launch tails and the latency-bound phases "
+                                          "of one group beside the launches of the others)"}
+        core.close()
+
     # ---- two / three batches in flight: one context and one stream each, batches alternate (what a
     # double-buffered caller does; the kernels of one batch fill the launch gaps and tails of another)
     out["in_flight"] = measure_in_flight(wl, (2, 3))
