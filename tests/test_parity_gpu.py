@@ -1102,7 +1102,8 @@ def test_branch_and_bound_is_exact_at_the_bounds(family, monkeypatch):
 @pytest.mark.parametrize("preset", ["drn_d_38_pairwise", "drn_d_22_unary"])
 @pytest.mark.parametrize("rows,cols,D,family,inv", [(256, 256, 64, "scene", -1.0), (512, 512, 128, "noisy_disparity", -1.0),
                                                   (512, 256, 128, "many_thin_objects", 0.0),
-                                                  (256, 512, 256, "scene", -1.0),
+                                                  (256, 512, 256, "scene", -1.0), (192, 256, 48, "scene", 0.0),
+                                                  (128, 256, 36, "noisy_disparity", -1.0),
                                                   (1024, 1024, 128, "scene", -1.0)])
 def test_phase1_fn_windows_change_nothing(preset, rows, cols, D, family, inv, monkeypatch):
     """The fn windows of the DP kernels (is_device.h, IS_P1_WIN: a (column, tile) stages 32 lutT columns of
@@ -1139,7 +1140,9 @@ def test_phase1_fn_windows_change_nothing(preset, rows, cols, D, family, inv, mo
     assert np.array_equal(a["cost_table"].view(np.uint32), b["cost_table"].view(np.uint32))
     assert np.array_equal(a["index_table"], b["index_table"])
     assert helpers.sections_equal(a["sections"][0], b["sections"][0])
-    assert misses["0"] == 0 and misses["99"] > 0, misses
+    assert misses["0"] == 0, misses
+    if D >= 64:   # (a table hardly wider than the window leaves nothing outside it)
+        assert misses["99"] > 0, misses
     if rows <= 512:
         _assert_parity(case, b)
 
