@@ -1104,6 +1104,8 @@ def test_branch_and_bound_is_exact_at_the_bounds(family, monkeypatch):
                                                   (512, 256, 128, "many_thin_objects", 0.0),
                                                   (256, 512, 256, "scene", -1.0), (192, 256, 48, "scene", 0.0),
                                                   (128, 256, 36, "noisy_disparity", -1.0),
+                                                  (200, 256, 128, "many_thin_objects", -1.0),
+                                                  (72, 512, 64, "scene", 0.0),
                                                   (1024, 1024, 128, "scene", -1.0)])
 def test_phase1_fn_windows_change_nothing(preset, rows, cols, D, family, inv, monkeypatch):
     """The fn windows of the DP kernels (is_device.h, IS_P1_WIN: a (column, tile) stages 32 lutT columns of
@@ -1141,7 +1143,7 @@ def test_phase1_fn_windows_change_nothing(preset, rows, cols, D, family, inv, mo
     assert np.array_equal(a["index_table"], b["index_table"])
     assert helpers.sections_equal(a["sections"][0], b["sections"][0])
     assert misses["0"] == 0, misses
-    if D >= 64:   # (a table hardly wider than the window leaves nothing outside it)
+    if D >= 64 and rows >= 192:   # (a table hardly wider than the window, or a frame of two tiles, leaves nothing outside it)
         assert misses["99"] > 0, misses
     if rows <= 512:
         _assert_parity(case, b)
