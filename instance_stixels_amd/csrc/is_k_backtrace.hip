@@ -75,7 +75,10 @@ __device__ __forceinline__ is_section make_section(const DevParams& P, const Row
 /* STAGE (few columns, i.e. latency matters more than waves per CU): the column's two tables are
  * copied into LDS first (coalesced, one round trip) and the chase runs there (~0.1 us per section
  * instead of a dependent global round trip): one frame 28 -> ~8 us. */
-template <bool STAGE>
+/* TWO (large batches): two columns per wavefront -- lanes 0 and 32 chase their chains side by side, each half
+ * builds its column's Sections with its 32 lanes.  A CU holds 32 waves, the chip 8192: 16384 one-column waves
+ * are two rounds of a latency chain (one dependent memory round trip per section), 8192 two-column waves one. */
+template <bool STAGE, bool TWO = false>
 __global__ __launch_bounds__(64) void k_backtrace(const DevParams P, int ncols, int pairwise,
                                                   const RowRec* __restrict__ recs,
                                                   const float* __restrict__ cost_table,
@@ -84,17 +87,22 @@ __global__ __launch_bounds__(64) void k_backtrace(const DevParams P, int ncols, 
                                                   is_section* __restrict__ sections,
                                                   int* __restrict__ inst_cnt /* [ncols][8] or null */,
                                                   int* __restrict__ n_generic /* reset for the next call */) {
+    static_assert(!(STAGE && TWO), "the staged variant is for small calls: one column per wave");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int colg = blockIdx.x;
-    if (colg >= ncols) return;
     const int lane = threadIdx.x;
+    constexpr int LW = TWO ? 32 : 64;          /* lanes per column */
+    const int half = TWO ? (lane >> 5) : 0, li = lane & (LW - 1);
+    const int colq = TWO ? (int)blockIdx.x * 2 + half : (int)blockIdx.x;
+    if ((TWO ? (int)blockIdx.x * 2 : (int)blockIdx.x) >= ncols) return;
+    const bool valid = colq < ncols;           /* (TWO, odd column count: the last wave's second half idles) */
+    const int colg = valid ? colq : ncols - 1;
     /* the count of generic-encoding columns (k_prepare_columns adds to it, the generic DP kernels of
      * this call have read it: they precede this launch in stream order) goes back to zero here --
      * a memset node per call costs a single frame ten microseconds of queue time */
-    if (colg == 0 && lane == 0) *n_generic = 0;
+    if (blockIdx.x == 0 && lane == 0) *n_generic = 0;
     const int H = P.H, S = P.S;
-    int* s_cut = (int*)smem;                /* [S][3]: vT, vB, type */
-    int* s_n = s_cut + 3 * S;               /* [1] */
+    int* s_cut = (int*)smem + half * (3 * S + 8); /* [S][3]: vT, vB, type */
+    int* s_n = s_cut + 3 * S;                     /* [1] */
     const bool wide = col_flags[colg] != 0; /* generic record encoding, see RowRec */
     const RowRec* rcol = recs + (size_t)colg * (H + 1);
     const float* ct = cost_table + (size_t)colg * H * 3;
@@ -113,7 +121,7 @@ __global__ __launch_bounds__(64) void k_backtrace(const DevParams P, int ncols, 
         s_cost = l_cost;
         s_idx = l_idx;
     }
-    if (lane == 0) {
+    if (li == 0) {
         int vT = H - 1;
         const float last_ground = s_cost[vT * 3 + IS_GROUND];
         const float last_object = s_cost[vT * 3 + IS_OBJECT];
@@ -159,9 +167,12 @@ __global__ __launch_bounds__(64) void k_backtrace(const DevParams P, int ncols, 
     }
     __syncthreads();
     const int n = *s_n;
-    int my_cnt = 0; /* lane k < 8: instance candidates of class 11 + k in this column */
-    for (int i0 = 0; i0 <= n; i0 += 64) { /* (wave-uniform trip count: ballots inside) */
-        const int i = i0 + lane;
+    /* (wave-uniform trip count: ballots inside; TWO: the longer of the two columns) */
+    const int n_loop = TWO ? max(__builtin_amdgcn_readlane(n, 0), __builtin_amdgcn_readlane(n, 32)) : n;
+    const unsigned long long half_mask = TWO ? (half ? 0xFFFFFFFF00000000ull : 0x00000000FFFFFFFFull) : ~0ull;
+    int my_cnt = 0; /* lane k < 8 (of the column's lanes): instance candidates of class 11 + k in this column */
+    for (int i0 = 0; i0 <= n_loop; i0 += LW) {
+        const int i = i0 + li;
         is_section sec;
         sec.type = -1; sec.vB = 0; sec.vT = 0; sec.disparity = 0.0f; /* terminator, :952-954 */
         sec.semantic_class = 0; sec.cost = 0.0f; sec.instance_meanx = 0.0f; sec.instance_meany = 0.0f;
@@ -169,18 +180,18 @@ __global__ __launch_bounds__(64) void k_backtrace(const DevParams P, int ncols, 
             const int vT = s_cut[i * 3 + 0], vB = s_cut[i * 3 + 1], type = s_cut[i * 3 + 2];
             sec = make_section(P, rcol, wide, vT, vB, type, s_cost[vT * 3 + type]);
         }
-        if (i <= n) out[i] = sec;
+        if (i <= n && valid) out[i] = sec;
         if (inst_cnt) { /* candidates per instance class, :926-942 (the scatter: k_compact_instances) */
             const bool cand = i < n && sec.type == IS_OBJECT && sec.semantic_class >= IS_FIRST_INSTANCE_CLASS;
             const int k = sec.semantic_class - IS_FIRST_INSTANCE_CLASS;
 #pragma unroll
             for (int kk = 0; kk < IS_INSTANCE_CLASSES; kk++) {
-                const int c = __builtin_popcountll(__builtin_amdgcn_ballot_w64(cand && k == kk));
-                if (lane == kk) my_cnt += c;
+                const int c = __builtin_popcountll(__builtin_amdgcn_ballot_w64(cand && k == kk) & half_mask);
+                if (li == kk) my_cnt += c;
             }
         }
     }
-    if (inst_cnt && lane < IS_INSTANCE_CLASSES) inst_cnt[(size_t)colg * IS_INSTANCE_CLASSES + lane] = my_cnt;
+    if (inst_cnt && li < IS_INSTANCE_CLASSES && valid) inst_cnt[(size_t)colg * IS_INSTANCE_CLASSES + li] = my_cnt;
 }
 
 /* ====================================================================================== */
@@ -269,6 +280,9 @@ __global__ __launch_bounds__(ISC_THREADS) void k_compact_instances(
 
 extern "C" {
 
+#ifndef IS_BACKTRACE_TWO_MIN_COLS
+#define IS_BACKTRACE_TWO_MIN_COLS 8192 /* more one-column waves than the chip holds at once */
+#endif
 hipError_t isk_launch_backtrace(const DevParams* P, int ncols, int pairwise, const RowRec* recs,
                                 const float* cost_table, const int32_t* index_table,
                                 const int* col_flags, is_section* sections, int* inst_cnt,
@@ -278,6 +292,9 @@ hipError_t isk_launch_backtrace(const DevParams* P, int ncols, int pairwise, con
     if (ncols <= IS_BACKTRACE_STAGE_MAX_COLS && lds_staged <= 64 * 1024)
         hipLaunchKernelGGL(k_backtrace<true>, dim3(ncols), dim3(64), lds_staged, stream, *P, ncols, pairwise,
                            recs, cost_table, index_table, col_flags, sections, inst_cnt, n_generic);
+    else if (ncols >= IS_BACKTRACE_TWO_MIN_COLS)
+        hipLaunchKernelGGL((k_backtrace<false, true>), dim3((ncols + 1) / 2), dim3(64), 2 * lds, stream, *P, ncols,
+                           pairwise, recs, cost_table, index_table, col_flags, sections, inst_cnt, n_generic);
     else
         hipLaunchKernelGGL(k_backtrace<false>, dim3(ncols), dim3(64), lds, stream, *P, ncols, pairwise, recs,
                            cost_table, index_table, col_flags, sections, inst_cnt, n_generic);
