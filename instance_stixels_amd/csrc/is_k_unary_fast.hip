@@ -52,6 +52,7 @@
 #ifndef ISF_WIN_WAVES
 #define ISF_WIN_WAVES 4 /* waves per workgroup of the windowed tiles */
 #endif
+static_assert(ISF_WIN_WAVES >= 3 && ISF_WIN_WAVES <= ISF_WAVES, "the merge runs on 3 x 64 threads (one wave per type)");
 #ifndef ISF_WIN_MIN_COLS
 #define ISF_WIN_MIN_COLS 2048 /* columns per call from which the windowed launch is used (frames/s windowed | classic at batch 2: 6470 | 6050, 4: 6090 | 6350, 8: 6890 | 6680, 16: 7480 | 7010, 32: 7860 | 7200) */
 #endif
