@@ -350,7 +350,15 @@ __device__ __forceinline__ void prepare_columns_body(
 #define PREP_RROW(v) (v)
 #endif
     auto rec_row = [&](int r) -> RowRec* { return rcol + PREP_RROW(r); };
-    instance_rows(!PREP_STORE_LATE, rec_row);
+    if (PREP_STORE_LATE) {
+        /* (the records are stored in the epilogue; here only the column totals are needed, and the owner of row
+         * H - 1 has them: its exclusive prefix + its own rows -- the integers instance_rows would end with) */
+        if (r_lo <= H - 1 && H - 1 < r_lo + R)
+            s_tot[0] = (float)((double)(int64_t)((uint64_t)base_mx2 + (uint64_t)sum_mx2) +
+                               (double)(int64_t)((uint64_t)base_my2 + (uint64_t)sum_my2));
+    } else {
+        instance_rows(true, rec_row);
+    }
     __syncthreads();
 
     /* ---- square the offset channels in place (StixelsKernels.cu:411-416), then exclusive
