@@ -1,4 +1,7 @@
 #!/bin/bash
+# NOTE (round 4): `make abl` now goes through the per-object rules + ISA check and takes minutes; on the GPU box prefer
+# variant libraries built beforehand with tools/build_variant.sh and run with tools/run_variants.sh (a silent build of
+# more than 7 minutes is killed by gpurun).
 # usage: ABL_VARIANTS="base -DX=1 ..." tools/abl_fused.sh [bench args]  (GPU box): k_prepare_fused time and images/s per build variant
 set -u
 export TMPDIR=/tmp

@@ -1,4 +1,7 @@
 #!/bin/bash
+# NOTE (round 4): `make abl` now goes through the per-object rules + ISA check and takes minutes; on the GPU box prefer
+# variant libraries built beforehand with tools/build_variant.sh and run with tools/run_variants.sh (a silent build of
+# more than 7 minutes is killed by gpurun).
 # usage: abl_prep.sh  (run on GPU box): builds variants and times k_prepare_columns / k_object_lut separately
 set -u
 export TMPDIR=/tmp
