@@ -30,6 +30,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+VERIFIED = []                  # (what, ok) of every oracle check of this run -> verify_all_ok
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
 VALU_PEAK_LANEOPS = 78.6e12    # 157.3 TFLOP/s fp32 vector = 78.6 T lane-FMA/s
 OTHER_PRESET = {"drn_d_22_unary": "drn_d_38_pairwise", "drn_d_38_unary": "drn_d_38_pairwise",
@@ -47,7 +48,10 @@ def parse():
     ap.add_argument("--cols", type=int, default=2048)
     ap.add_argument("--max-dis", type=int, default=128)
     ap.add_argument("--family", default="scene", help="synthetic input family (synthetic.FAMILIES)")
-    ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic frames per rank")
+    ap.add_argument("--distinct", type=int, default=0,
+                    help="distinct synthetic frames per rank (default 0 = --batch: every frame of the batch is its own scene)")
+    ap.add_argument("--spread-batches", type=int, default=8,
+                    help="disjoint batches of distinct frames behind value_spread (0 = skip)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise RCCL and run the gather pipeline even with one rank (plumbing test)")
     ap.add_argument("--gather", choices=("fixed", "compact"), default="compact",
@@ -178,19 +182,35 @@ def committed_valu(cfg, B, H, W, D):
             "source": f"profiles/{name}"}
 
 
+def gen_frames(cfg, seeds, family="scene", zero_segmentation=False):
+    """synthetic.make_frame for a list of seeds on a thread pool (numpy releases the GIL in the large
+    fills): 64 distinct 1024x2048 frames cost 1-2 s instead of 6.  `family` may be a list (one per seed)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from instance_stixels_amd import synthetic
+    fams = [family] * len(seeds) if isinstance(family, str) else list(family)
+    one = lambda a: synthetic.make_frame(cfg, seed=a[0], family=a[1], zero_segmentation=zero_segmentation)
+    if len(seeds) <= 2:
+        return [one(a) for a in zip(seeds, fams)]
+    with ThreadPoolExecutor(max(1, min(usable_cores(), 16, len(seeds)))) as ex:
+        return list(ex.map(one, zip(seeds, fams)))
+
+
 class Workload:
     """One configuration's batch, resident in HBM: host tables through the C++ Stixels class,
-    `distinct` synthetic frames repeated to `batch`, device inputs and output buffers."""
+    `distinct` synthetic frames repeated to `batch` (or the given `frames`), device inputs and output
+    buffers."""
 
     side_stream = False   # --side-stream: steps on a torch side stream instead of the default stream
 
     def __init__(self, preset, H, W, D, batch, distinct, dev, local_rank, seed0=17, family="scene",
-                 **overrides):
+                 frames=None, **overrides):
         import torch
         from instance_stixels_amd import make_config, synthetic, host
         self.torch = torch
         self.dev, self.local_rank, self.B = dev, local_rank, batch
         self.cfg = cfg = make_config(preset, H, W, D, **overrides)
+        distinct = len(frames) if frames is not None else max(1, min(distinct or batch, batch))
+        self.distinct, self.family = distinct, family
         self.H, self.W, self.D, self.C = int(cfg.rows), int(cfg.cols), int(cfg.max_dis), cfg.realcols
         st = host.Stixels()
         st.SetConfig(cfg)
@@ -198,8 +218,8 @@ class Workload:
         self.params = st.GetParameters()
         self.lut, self.odr = st.GetLUTs()
         zero_seg = preset.startswith("disparity_only")
-        self.frames = [synthetic.make_frame(cfg, seed=seed0 + i, family=family, zero_segmentation=zero_seg)
-                       for i in range(distinct)]
+        self.frames = frames if frames is not None else gen_frames(
+            cfg, [seed0 + i for i in range(distinct)], family, zero_seg)
         g = []
         for f in self.frames:
             st.SetRoadParameters(f.vhor_image, f.camera_tilt, f.camera_height, f.alpha_ground)
@@ -290,15 +310,17 @@ class Workload:
                        "nominal C*H*(H+1)/2 pairs; full = all three candidates, ground_sky_only = the "
                        "cheap steps after the object bound has closed"}
 
-    def verify(self, d_sections, images=None):
-        """Oracle check of frames of a finished step (first, either side of the middle, last)."""
+    def verify(self, d_sections, images=None, fatal=False):
+        """Oracle check of frames of a finished step (first, either side of the middle, last).  A
+        mismatch is reported as ok = False (and collected into the line's verify_all_ok); with `fatal`
+        -- the headline value -- the bench stops instead: a number whose output differs is no number."""
         from oracle import oracle
         from instance_stixels_amd.config import SECTION_DTYPE
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import helpers
         cfg, B = self.cfg, self.B
         params, lut, odr = oracle.host_initialize(cfg)
-        checked = []
+        checked, bad = [], []
         for i in (sorted({0, B // 2 - 1 if B > 1 else 0, B // 2, B - 1}) if images is None else images):
             if i < 0 or i >= B:
                 continue
@@ -310,10 +332,17 @@ class Workload:
                                  want_tables=False)
             got = d_sections[i].cpu().numpy().view(SECTION_DTYPE).reshape(self.C, self.S)
             if not helpers.sections_equal(ref["sections"], got):
-                raise SystemExit(f"bench.py verify: frame {i} of the timed batch "
-                                 f"({cfg.rows}x{cfg.cols}, pairwise={cfg.pairwise}) differs from the oracle")
+                if fatal:
+                    raise SystemExit(f"bench.py verify: frame {i} of the timed batch "
+                                     f"({cfg.rows}x{cfg.cols}, pairwise={cfg.pairwise}) differs from the oracle")
+                bad.append(i)
             checked.append(i)
-        return {"frames_checked": checked, "against": "oracle (bit-exact Section arrays)", "ok": True}
+        out = {"frames_checked": checked, "against": "oracle (bit-exact Section arrays)", "ok": not bad}
+        if bad:
+            out["frames_differing"] = bad
+        VERIFIED.append((f"{cfg.rows}x{cfg.cols}x{cfg.max_dis} {'pairwise' if cfg.pairwise else 'unary'} "
+                         f"batch {B} family {self.family} invalid {cfg.invalid_disparity:g}", not bad))
+        return out
 
     def roofline(self, dp_ms, kernel, traffic=None, traffic_file=None):
         from instance_stixels_amd import synthetic
@@ -389,6 +418,8 @@ def measure_in_flight(wl, counts, steps=12):
         ref = torch.zeros_like(wl.d_sections)
         wl.step(cores[0], out=ref)
         torch.cuda.synchronize(wl.dev)
+        if "verify" not in res:   # the output every context's result is compared with, against the oracle
+            res["verify"] = wl.verify(ref, images=[wl.B - 1])
 
         def step(i):
             k = i % n
@@ -418,18 +449,27 @@ EXTRA_FAMILIES = ("iid_noise", "low_confidence", "flat_disparity", "homogeneous"
                   "noisy_disparity")
 
 
-def measure_families(preset, H, W, D, B, dev, local_rank):
+def measure_families(preset, H, W, D, B, dev, local_rank, distinct=2):
     """images/s and what the branch-and-bound evaluated on the other input families of
-    synthetic.make_frame (the headline family is "scene"), same preset, shape and batch."""
+    synthetic.make_frame (the headline family is "scene"), same preset, shape and batch; one frame of
+    every timed output is compared with the oracle."""
     import torch
     fam = {}
-    for name in EXTRA_FAMILIES:
-        wf = Workload(preset, H, W, D, B, 2, dev, local_rank, family=name)
+    for name in EXTRA_FAMILIES + ("mixed",):
+        if name == "mixed":   # every frame of the batch from another family, distinct seeds: do slow frames gate a batch?
+            from instance_stixels_amd import make_config, synthetic
+            cfg = make_config(preset, H, W, D)
+            frames = gen_frames(cfg, [700 + i for i in range(B)],
+                                [synthetic.FAMILIES[i % len(synthetic.FAMILIES)] for i in range(B)])
+            wf = Workload(preset, H, W, D, B, B, dev, local_rank, family=name, frames=frames)
+        else:
+            wf = Workload(preset, H, W, D, B, distinct, dev, local_rank, family=name)
         core = wf.make_core()
         dtf = wf.time_steps(core, 3)
+        v = wf.verify(wf.d_sections, images=[B - 1])
         ps = wf.prune_stats(core)
         fam[name] = {"images_per_s": B / dtf, "evaluated_frac": ps["evaluated_frac"],
-                     "full_eval_frac": ps["full_eval_frac"]}
+                     "full_eval_frac": ps["full_eval_frac"], "distinct_frames": wf.distinct, "verify": v}
         core.close(); wf.free(); del wf
         torch.cuda.empty_cache()
     fam["what"] = ("synthetic.make_frame(family=...): iid_noise = every class logit N(0,1), no scene in "
@@ -437,14 +477,47 @@ def measure_families(preset, H, W, D, B, dev, local_rank):
                    "flat_disparity = the scene's segmentation over constant + U(0,1) disparity; "
                    "homogeneous = road below the horizon, sky above, no object, confident CNN (logit +8..9); "
                    "many_thin_objects = sixty slabs 8..24 px wide; noisy_disparity = the scene with N(0,3) "
-                   "disparity noise; 2 distinct frames repeated to the batch")
+                   "disparity noise; mixed = frame i of the batch from family i mod 7, every frame its own "
+                   "seed; the others: 2 distinct frames repeated to the batch (value_spread has whole "
+                   "batches of distinct frames for the scene and floor families)")
     return fam
+
+
+def measure_spread(presets, H, W, D, B, dev, local_rank, families, n_batches):
+    """Sampling error of a data-dependent number: `n_batches` DISJOINT batches of B distinct frames per
+    family (frame generation does not depend on the preset, so every batch serves both models): images/s
+    and evaluated_frac of each batch -> min / median / max."""
+    import torch
+    from instance_stixels_amd import make_config
+    out = {}
+    for fam in families:
+        rows = {p: [] for p in presets}
+        for b in range(n_batches):
+            frames = gen_frames(make_config(presets[0], H, W, D), [50000 + 1000 * b + i for i in range(B)], fam)
+            for preset in presets:
+                w = Workload(preset, H, W, D, B, B, dev, local_rank, family=fam, frames=frames)
+                core = w.make_core()
+                dt = w.time_steps(core, 3)
+                ps = w.prune_stats(core)
+                rows[preset].append((B / dt, ps["evaluated_frac"]))
+                core.close(); w.free(); del w
+                torch.cuda.empty_cache()
+            del frames
+        for preset in presets:
+            v = np.array([r[0] for r in rows[preset]]); e = np.array([r[1] for r in rows[preset]])
+            out.setdefault(preset, {})[fam] = {
+                "images_per_s": {"min": float(v.min()), "median": float(np.median(v)), "max": float(v.max())},
+                "evaluated_frac": {"min": float(e.min()), "median": float(np.median(e)), "max": float(e.max())},
+                "batches": n_batches, "frames_per_batch": B, "images_per_s_all": [round(float(x), 1) for x in v]}
+    out["what"] = (f"{n_batches} disjoint batches of {B} distinct frames (seeds 50000 + 1000 b + i) per family, "
+                   "3 timed steps each, wall clock around the steps; the pruning counters from an untimed pass")
+    return out
 
 
 def floor_over_families(scene_value, fam):
     """The smallest images/s over every measured input family (the headline family included)."""
     vals = {"scene": scene_value}
-    vals.update({k: v["images_per_s"] for k, v in fam.items() if isinstance(v, dict)})
+    vals.update({k: v["images_per_s"] for k, v in fam.items() if isinstance(v, dict) and k != "mixed"})
     worst = min(vals, key=vals.get)
     return {"images_per_s": vals[worst], "family": worst, "families_measured": sorted(vals)}
 
@@ -496,24 +569,37 @@ def measure_variants(args, wl, dev, local_rank):
     # double-buffered caller does; the kernels of one batch fill the launch gaps and tails of another)
     out["in_flight"] = measure_in_flight(wl, (2, 3))
 
-    # ---- invalid-disparity value 0 with 5 % holes: the HAS_INVALID kernel variants
+    # ---- invalid-disparity value 0 with 5 % holes: the HAS_INVALID kernel variants (the mode the
+    # reference's own CLI hard-codes, apps/run_cityscapes.cu:188), both models
     wl.free()
     torch.cuda.empty_cache()
-    wi = Workload(args.preset, H, W, D, B, args.distinct, dev, local_rank, invalid_disparity=0.0)
-    core = wi.make_core()
-    out["invalid_disparity_0"] = {"images_per_s": B / wi.time_steps(core, 3), "steps": 3,
-                                  "what": "invalid_disparity = 0, 5 % of the pixels invalid (HAS_INVALID kernels)"}
-    core.close(); wi.free(); del wi
-    torch.cuda.empty_cache()
+    other = OTHER_PRESET.get(args.preset)
+    inv0 = {}
+    for preset in (args.preset, other):
+        if not preset:
+            continue
+        wi = Workload(preset, H, W, D, B, min(wl.distinct, 8), dev, local_rank, invalid_disparity=0.0)
+        core = wi.make_core()
+        core.set_kernel_timing(True)
+        dti = wi.time_steps(core, 3)
+        inv0[preset] = {"images_per_s": B / dti, "steps": 3, "kernel_ms": core.kernel_times_ms(),
+                        "verify": wi.verify(wi.d_sections, images=[0, B - 1]),
+                        "what": "invalid_disparity = 0, 5 % of the pixels invalid (HAS_INVALID kernels)"}
+        core.close(); wi.free(); del wi
+        torch.cuda.empty_cache()
+    out["invalid_disparity_0"] = inv0[args.preset]
 
     # ---- other input families (SURVEY.md 8d generator + six harder / different ones)
     out["families"] = measure_families(args.preset, H, W, D, B, dev, local_rank)
 
     # ---- every column in the generic encoding: one negative class value per column
-    wg = Workload(args.preset, H, W, D, B, args.distinct, dev, local_rank)
+    wg = Workload(args.preset, H, W, D, B, 4, dev, local_rank)
     wg.d_seg[:, :, 0, 0] = -1
+    for f in wg.frames:                  # (the host copies the oracle check reads)
+        f.segmentation[:, 0, 0] = -1
     core = wg.make_core()
     out["generic_encoding"] = {"images_per_s": B / wg.time_steps(core, 2), "steps": 2,
+                               "verify": wg.verify(wg.d_sections, images=[B - 1]),
                                "what": "one negative class value per column: int32 / int64 records, "
                                        "IEEE division, no pruning (the hostile-input path)"}
     core.close(); wg.free(); del wg
@@ -521,12 +607,13 @@ def measure_variants(args, wl, dev, local_rank):
 
     # ---- the OTHER model at the same shape and batch (BASELINE configs[3]'s per-GPU share when
     # the headline is the unary preset): own roofline, pruning statistics, pruning off, verify
-    other = OTHER_PRESET.get(args.preset)
     if other:
         wo = Workload(other, H, W, D, B, args.distinct, dev, local_rank)
         key = ("pairwise" if wo.cfg.pairwise else "unary") + f"_batch{B}"
         out[key] = measure_mode(wo, steps=3, with_single=True)
         out[key]["preset"] = other
+        out[key]["distinct_frames"] = wo.distinct
+        out[key]["invalid_disparity_0"] = inv0[other]
         wo.free(); del wo
         torch.cuda.empty_cache()
         out[key]["families"] = measure_families(other, H, W, D, B, dev, local_rank)
@@ -537,16 +624,55 @@ def measure_variants(args, wl, dev, local_rank):
     for preset in (args.preset, other):
         if not preset:
             continue
-        w5 = Workload(preset, 1024, 4096, 256, 32, 2, dev, local_rank, seed0=91)
-        m = measure_mode(w5, steps=2, with_verify=False)
+        w5 = Workload(preset, 1024, 4096, 256, 32, 4, dev, local_rank, seed0=91)
+        m = measure_mode(w5, steps=2)
         m["preset"] = preset
         c5["pairwise" if w5.cfg.pairwise else "unary"] = m
         w5.free(); del w5
         torch.cuda.empty_cache()
     c5["what"] = ("BASELINE configs[4]: 32 frames of 1024x4096, 256 disparity bins per call (512 stixel "
-                  "columns per frame, 2.2 GB of lutT per frame); parity: tests/test_parity_gpu.py "
-                  "test_config5_*")
+                  "columns per frame, 2.2 GB of lutT per frame; the windowed D = 256 kernels), first and last "
+                  "frame of the timed output against the oracle; parity at this instantiation: "
+                  "tests/test_parity_gpu.py test_config5_batch_of_8_windowed_kernels_as_timed")
     out["c5_1024x4096x256"] = c5
+
+    # ---- the reference's OWN operating point: the 784x1792 crop, 128 disparities, invalid_disparity = 0
+    # (tests/run_test.sh:84, apps/run_cityscapes.cu:129-134 and :188, apps/stixels_node.cu:162-176): batch 64
+    # through the C ABI and one frame per call through Stixels::Compute, both models, verified
+    rs = {}
+    for preset in (args.preset, other):
+        if not preset:
+            continue
+        wr = Workload(preset, 784, 1792, 128, B, min(B, 16), dev, local_rank, seed0=211, invalid_disparity=0.0)
+        m = measure_mode(wr, steps=3, with_pruning_off=False)
+        m["preset"] = preset
+        st = host.Stixels()
+        st.SetConfig(wr.cfg)
+        st.SetDevice(local_rank)
+        st.Initialize()
+        f = wr.frames[0]
+        st.SetDisparityImage(f.disparity)
+        st.SetSegmentation(f.segmentation)
+        st.SetRoadParameters(f.vhor_image, f.camera_tilt, f.camera_height, f.alpha_ground)
+        data = st.Compute(wr.cfg.pairwise)
+        t1 = st.time_compute(wr.cfg.pairwise, 100 if wr.cfg.pairwise else 200, True)
+        st.close()
+        one = Workload(preset, 784, 1792, 128, 1, 1, dev, local_rank, frames=[f], invalid_disparity=0.0)
+        m["stixels_compute_one_frame_per_call"] = {
+            "images_per_s": 1.0 / t1, "ms_per_frame": t1 * 1e3,
+            "stixels_in_frame": int(sum((c["type"] != -1).argmin() for c in data.sections)),
+            "verify": one.verify(torch.from_numpy(data.sections.view(np.int32).reshape(1, one.C, one.S, 8))),
+            "what": "Stixels::Compute + GetInstanceStixels per frame (host ground model, device clustering, "
+                    "D2H of the sections), timed inside the C++ library"}
+        one.free(); del one
+        rs["pairwise" if wr.cfg.pairwise else "unary"] = m
+        wr.free(); del wr
+        torch.cuda.empty_cache()
+    rs["what"] = ("the only shape / mode the reference itself launches: 784x1792 crop (224 stixel columns, 12.25 "
+                  "tiles), 128 disparities, invalid_disparity = 0 with 5 % holes; 16 distinct frames per batch of "
+                  "64.  Context, not a baseline for this metric: BASELINE.md quotes ~19 fps for the reference's "
+                  "WHOLE pipeline (CNN included) at this shape on a Titan V")
+    out["ref_shape_784x1792"] = rs
 
     # ---- BASELINE configs[0]: one 512x1024 frame, 64 bins, disparity only -- CPU path + GPU
     c1 = {}
@@ -711,7 +837,7 @@ def main():
     # ---- verify (default): frames of the TIMED output (the batch geometry the value is measured on)
     verify = None
     if not args.no_verify and rank == 0:
-        verify = wl.verify(timed_out)
+        verify = wl.verify(timed_out, fatal=True)
         if pipe is not None:  # what the RCCL gather delivered to rank 0 is what the ranks computed
             verify["rccl_gather"] = pipe.check_last(S)
             if not verify["rccl_gather"]["rank0_copy_equals_local"]:
@@ -777,8 +903,18 @@ def main():
     # ---- extra figures (N = 1): other kernel variants / families / models / shapes
     variants = None
     core.close()
+    spread = None
     if world == 1 and not args.no_variants:
         variants = measure_variants(args, wl, dev, local_rank)   # (frees wl's device buffers)
+        if args.spread_batches > 0:
+            other = OTHER_PRESET.get(args.preset)
+            floors = {floor_over_families(float("inf"), variants["families"])["family"]}
+            okey = [k for k in variants if k.endswith(f"_batch{B}")]
+            if okey:
+                floors.add(floor_over_families(float("inf"), variants[okey[0]]["families"])["family"])
+            floors.discard("scene")
+            spread = measure_spread([p for p in (args.preset, other) if p], H, W, D, B, dev, local_rank,
+                                    ["scene"] + sorted(floors), args.spread_batches)
 
     if rank == 0:
         images = B * world * args.steps
@@ -834,6 +970,8 @@ def main():
             out["per_rank"] = per_rank
         if verify is not None:
             out["verify"] = verify
+        if spread is not None:
+            out["value_spread"] = spread
         if variants is not None:
             out["variants"] = variants
             out["value_incl_instances"] = variants["with_instances"]["images_per_s"]
@@ -843,6 +981,9 @@ def main():
             out["value_pruning_off"] = variants["pruning_off"]["images_per_s"]
         if cpu is not None:
             out["cpu_baseline"] = cpu
+        out["distinct_frames"] = wl.distinct
+        out["verify_all_ok"] = bool(VERIFIED) and all(ok for _, ok in VERIFIED)
+        out["verified"] = [{"what": w, "ok": ok} for w, ok in VERIFIED]
     else:
         out = None
 

@@ -259,9 +259,10 @@ size_t is_scratch_bytes(const is_ctx* ctx);
  * wave-steps they evaluated below the diagonal blocks to a device array (enabling resets it).
  *   out[0] unary full steps, out[1] unary ground/sky-only steps,
  *   out[2] pairwise phase-1 full steps, out[3] pairwise phase-1 ground/sky-only candidates,
- *   out[4] pairwise phase-1 steps that stopped after the transition term (lazy steps);
- *   out[8 + 3 t + j], t < 64: the phase-1 launch of 64-row tile t alone, j = 0 full, 1 lazy, 2
- *   ground/sky-only.  n <= IS_EVAL_COUNTERS.  Both calls synchronise the device. */
+ *   out[4] pairwise phase-1 steps in which some lane read OUTSIDE its fn window (window misses),
+ *   out[5] the same for the unary ring kernel;
+ *   out[8 + 3 t + j], t < 64: the phase-1 launch of 64-row tile t alone, j = 0 full, 1 window
+ *   misses, 2 ground/sky-only.  n <= IS_EVAL_COUNTERS.  Both calls synchronise the device. */
 #define IS_EVAL_COUNTERS 200
 int is_set_eval_counters(is_ctx* ctx, int enabled);
 int is_get_eval_counters(is_ctx* ctx, unsigned long long* out, int n);

@@ -14,6 +14,7 @@ from .config import StixelParams, SECTION_DTYPE, INSTANCE_CLASSES
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("IS_CORE_LIB", os.path.join(_HERE, "lib", "libis_core.so"))
 _LIB = None
+EVAL_COUNTERS = 200   # IS_EVAL_COUNTERS of include/instance_stixels_core.h (checked by tests/test_host_and_abi.py)
 
 EXPORTS = [
     "is_ctx_create", "is_ctx_destroy", "is_join_columns", "is_compute", "is_device_malloc",
@@ -142,10 +143,13 @@ class Core:
         _check(lib().is_set_eval_counters(self._ctx, int(enabled)), "is_set_eval_counters")
 
     def eval_counters(self):
-        out = np.zeros(200, np.uint64)   # IS_EVAL_COUNTERS
-        _check(lib().is_get_eval_counters(self._ctx, _hp(out), 200), "is_get_eval_counters")
+        out = np.zeros(EVAL_COUNTERS, np.uint64)
+        rc = lib().is_get_eval_counters(self._ctx, _hp(out), EVAL_COUNTERS)
+        if rc != 0:   # (an experiment library built from an older tree only knows the first eight)
+            _check(lib().is_get_eval_counters(self._ctx, _hp(out), 8), "is_get_eval_counters")
         return dict(unary_full=int(out[0]), unary_gs=int(out[1]), p1_full=int(out[2]), p1_gs=int(out[3]),
-                    p1_lazy=int(out[4]), p1_window_miss=int(out[4]), unary_window_miss=int(out[5]),
+                    p1_window_miss=int(out[4]), unary_window_miss=int(out[5]),
+                    # per phase-1 launch (tile): [full, window misses, ground / sky-only]
                     p1_per_tile=[[int(out[8 + 3 * t + j]) for j in range(3)] for t in range(64)])
 
     def read_object_lut(self, column):

@@ -79,6 +79,7 @@ struct is_graph_entry {
     bool valid;
     const void *joined, *seg, *sections, *ct, *it;
     int pairwise, n_images, n_inst;
+    int win_tiles; /* the windowed / classic tile split of the captured launches (a function of the call's horizons) */
     is_instance_buffers inst[IS_GRAPH_MAX_IMAGES];
     int slot; /* the pinned staging slot baked into the copy nodes */
     hipGraphExec_t exec;
@@ -535,6 +536,8 @@ int is_road_vdisparity(const float* d_disparity, int rows, int cols, int max_dis
     return IS_OK;
 }
 
+static_assert(IS_CNT_N == IS_EVAL_COUNTERS, "is_device.h and instance_stixels_core.h disagree on the counter array");
+
 int is_set_eval_counters(is_ctx* c, int enabled) {
     if (!c) return fail_arg("null ctx");
     ON_CTX_DEVICE(c);
@@ -596,6 +599,25 @@ int is_get_kernel_times_ms(is_ctx* c, float* prepare_ms, float* dp_ms, float* ba
     return IS_OK;
 }
 
+/* fn windows of the DP kernels (is_device.h, IS_P1_WIN) for the tiles that start below the horizon of every image
+ * of the call: ground and what stands on it span few disparities within 64 rows, while a tile above the
+ * horizon mixes sky (d ~ 0) with objects of any disparity -- measured: 3.6 % of the steps of tile 7 read
+ * outside the window, 22-35 % of tiles 12-13, and a step with a lane outside pays a memory round trip.
+ * The split decides launch geometry only (workgroup shapes, which kernel instantiation a tile runs), never
+ * results; a hipGraph replays the split it was captured with, so it is part of the graph cache's key. */
+static int call_win_tiles(const DevParams& P, const int* h_vhor, int n_images, int pairwise) {
+    int vmin = P.H;
+    for (int i = 0; i < n_images; i++) vmin = h_vhor[i] < vmin ? h_vhor[i] : vmin;
+    int w = (IS_P1_WINDOWED(P.D) && P.win_lo != nullptr && vmin > 0) ? (vmin + IS_TILE - 1) / IS_TILE : 0;
+    /* the unary kernel windows EVERY tile: a lane outside costs it an L2 gather (2.8 % of its steps on the
+     * synthetic scene), not the HBM round trip on a latency-bound chain it costs phase 1 -- measured at
+     * batch 64: 9 windowed tiles 7450, all 16: 7760 frames/s (pairwise 3780 / 3810, but its unpruned
+     * floor 1720 / 1630) */
+    if (!pairwise && IS_P1_WINDOWED(P.D) && P.win_lo != nullptr) w = P.ntiles;
+    if (P.knob_win_tiles >= 0) w = P.knob_win_tiles; /* (experiments, tests) */
+    return w;
+}
+
 /* Everything is_compute queues on `stream` behind the host-side staging of slot `slot`.
  * `capturing`: the calls are being recorded into a hipGraph -- no timing events, no staging
  * event (the caller records it behind the graph launch). */
@@ -638,22 +660,8 @@ static int compute_enqueue(is_ctx* c, const float* d_joined, const int32_t* d_se
                                c->d_prune, c->d_n_generic, stream, c->aux_stream, c->ev_fork, c->ev_join));
     if (pairwise) HIP_TRY(isk_launch_priors(&P, c->d_ground, c->d_priors, n_images, stream));
     if (timing) HIP_TRY(hipEventRecord(c->ev[1], stream));
-    /* fn windows of the DP kernels (is_device.h, IS_P1_WIN) for the tiles that start below the horizon of every image
-     * of the call: ground and what stands on it span few disparities within 64 rows, while a tile above the
-     * horizon mixes sky (d ~ 0) with objects of any disparity -- measured: 3.6 % of the steps of tile 7 read
-     * outside the window, 22-35 % of tiles 12-13, and a step with a lane outside pays a memory round trip */
-    DevParams Pw = P;
-    {
-        int vmin = P.H;
-        for (int i = 0; i < n_images; i++) vmin = c->h_vhor_pinned[slot][i] < vmin ? c->h_vhor_pinned[slot][i] : vmin;
-        Pw.win_tiles = (IS_P1_WINDOWED(P.D) && P.win_lo != nullptr && vmin > 0) ? (vmin + IS_TILE - 1) / IS_TILE : 0;
-        /* the unary kernel windows EVERY tile: a lane outside costs it an L2 gather (2.8 % of its steps on the
-         * synthetic scene), not the HBM round trip on a latency-bound chain it costs phase 1 -- measured at
-         * batch 64: 9 windowed tiles 7450, all 16: 7760 frames/s (pairwise 3780 / 3810, but its unpruned
-         * floor 1720 / 1630) */
-        if (!pairwise && IS_P1_WINDOWED(P.D) && P.win_lo != nullptr) Pw.win_tiles = P.ntiles;
-        if (P.knob_win_tiles >= 0) Pw.win_tiles = P.knob_win_tiles; /* (experiments, tests) */
-    }
+    DevParams Pw = P; /* (+ this call's windowed / classic tile split) */
+    Pw.win_tiles = call_win_tiles(P, c->h_vhor_pinned[slot], n_images, pairwise);
     if (pairwise)
         HIP_TRY(isk_launch_dp_pairwise(&Pw, ncols, c->nwaves_pairwise, c->d_recs, c->d_lutT,
                                        d_joined, c->d_priors, c->d_odr, c->d_rcp, c->d_sv, c->d_vhor,
@@ -699,8 +707,8 @@ static int compute_enqueue(is_ctx* c, const float* d_joined, const int32_t* d_se
  * serialise on that copy. */
 static bool graph_matches(const is_graph_entry& e, const float* d_joined, const int32_t* d_seg, int pairwise,
                           int n_images, const is_section* d_sections, const is_instance_buffers* instances,
-                          const float* ct, const int32_t* it) {
-    if (!e.valid || e.joined != d_joined || e.seg != d_seg || e.sections != d_sections || e.ct != ct ||
+                          const float* ct, const int32_t* it, int win_tiles) {
+    if (!e.valid || e.win_tiles != win_tiles || e.joined != d_joined || e.seg != d_seg || e.sections != d_sections || e.ct != ct ||
         e.it != it || e.pairwise != pairwise || e.n_images != n_images || e.n_inst != (instances ? n_images : 0))
         return false;
     return !instances || memcmp(e.inst, instances, sizeof(is_instance_buffers) * n_images) == 0;
@@ -728,10 +736,11 @@ int is_compute(is_ctx* c, const float* d_joined, const int32_t* d_seg, const flo
     const bool graph_ok = c->graphs && stream != nullptr && n_images <= IS_GRAPH_MAX_IMAGES && !c->timing &&
                           !c->counting;
     is_graph_entry* ge = nullptr;
+    const int win_tiles = call_win_tiles(c->dp, h_vhor, n_images, pairwise);
     if (graph_ok)
         for (int i = 0; i < IS_GRAPH_ENTRIES; i++)
             if (graph_matches(c->graph_cache[i], d_joined, d_seg, pairwise, n_images, d_sections, instances,
-                              d_cost_table, d_index_table))
+                              d_cost_table, d_index_table, win_tiles))
                 ge = &c->graph_cache[i];
 
     /* stage the per-frame ground model (the reference does 3 blocking cudaMemcpy per frame,
@@ -779,6 +788,7 @@ int is_compute(is_ctx* c, const float* d_joined, const int32_t* d_seg, const flo
                     victim->joined = d_joined; victim->seg = d_seg; victim->sections = d_sections;
                     victim->ct = d_cost_table; victim->it = d_index_table;
                     victim->pairwise = pairwise; victim->n_images = n_images;
+                    victim->win_tiles = win_tiles;
                     victim->n_inst = instances ? n_images : 0;
                     if (instances) memcpy(victim->inst, instances, sizeof(is_instance_buffers) * n_images);
                     victim->slot = slot;

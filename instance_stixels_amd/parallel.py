@@ -3,8 +3,33 @@
 stixel outputs to one rank (RCCL over xGMI on GPUs, gloo in the CPU tests): fixed-stride Section
 tensors (gather_sections / PipelinedGather) or, ~10 x fewer bytes, per-column counts + the used
 sections only (gather_compact / PipelinedCompactGather)."""
+import inspect
+
 import torch
 import torch.distributed as dist
+
+# `group_dst=` / `group_peer=` (ranks of the group instead of global ranks) exist since torch 2.6; older
+# versions get the same call through the global rank of the group member
+_HAS_GROUP_RANKS = "group_dst" in inspect.signature(dist.gather).parameters
+
+
+def _global_rank(group, r):
+    return r if group is None else dist.get_global_rank(group, r)
+
+
+def _gather_to(tensor, gather_list, dst, group, async_op=False):
+    """dist.gather to the GROUP rank `dst`."""
+    if _HAS_GROUP_RANKS:
+        return dist.gather(tensor, gather_list=gather_list, group=group, group_dst=dst, async_op=async_op)
+    return dist.gather(tensor, gather_list=gather_list, group=group, dst=_global_rank(group, dst),
+                       async_op=async_op)
+
+
+def _p2p(op, tensor, peer, group):
+    """dist.P2POp with the GROUP rank `peer`."""
+    if _HAS_GROUP_RANKS:
+        return dist.P2POp(op, tensor, group=group, group_peer=peer)
+    return dist.P2POp(op, tensor, _global_rank(group, peer), group=group)
 
 
 def shard_range(n_items: int, rank: int, world: int):
@@ -20,7 +45,7 @@ def gather_sections(local: torch.Tensor, gathered, dst: int = 0, group=None):
 
     `gathered` is a list of world_size tensors on `dst` and None elsewhere."""
     rank = dist.get_rank(group)
-    dist.gather(local, gather_list=gathered if rank == dst else None, group=group, group_dst=dst)
+    _gather_to(local, gathered if rank == dst else None, dst, group)
     return gathered
 
 
@@ -40,7 +65,7 @@ def gather_variable(local: torch.Tensor, dst: int = 0, group=None):
                           device=local.device)
         padded = torch.cat([local, pad], dim=0)
     out = [torch.empty_like(padded) for _ in range(world)] if rank == dst else None
-    dist.gather(padded.contiguous(), gather_list=out, group=group, group_dst=dst)
+    _gather_to(padded.contiguous(), out, dst, group)
     if rank != dst:
         return None
     return torch.cat([o[:s] for o, s in zip(out, sizes)], dim=0)
@@ -77,9 +102,9 @@ class PipelinedGather:
     def submit(self):
         """Issues the gather of the buffer handed out by the last next_buffer() call."""
         slot = self.step % self.depth
-        self.inflight[slot] = dist.gather(
-            self.buffers[slot], gather_list=self.gathered[slot] if self.rank == self.dst else None,
-            group=self.group, group_dst=self.dst, async_op=True)
+        self.inflight[slot] = _gather_to(
+            self.buffers[slot], self.gathered[slot] if self.rank == self.dst else None, self.dst, self.group,
+            async_op=True)
         self.step += 1
         return slot
 
@@ -178,14 +203,14 @@ def _post_compact(counts, packed, sizes, dst, group, recv=None):
                 c_r = torch.empty(nc, dtype=torch.int32, device=dev)
                 p_r = torch.empty((n, 8), dtype=torch.int32, device=dev)
             # group_peer: ranks of `group` (with a sub-group they differ from the global ranks)
-            ops.append(dist.P2POp(dist.irecv, c_r, group=group, group_peer=r))
+            ops.append(_p2p(dist.irecv, c_r, r, group))
             if n > 0:
-                ops.append(dist.P2POp(dist.irecv, p_r, group=group, group_peer=r))
+                ops.append(_p2p(dist.irecv, p_r, r, group))
             out.append((c_r, p_r))
     else:
-        ops.append(dist.P2POp(dist.isend, counts, group=group, group_peer=dst))
+        ops.append(_p2p(dist.isend, counts, dst, group))
         if packed.shape[0] > 0:
-            ops.append(dist.P2POp(dist.isend, packed, group=group, group_peer=dst))
+            ops.append(_p2p(dist.isend, packed, dst, group))
     works = dist.batch_isend_irecv(ops) if ops else []
     return out, works
 
@@ -214,6 +239,14 @@ def gather_compact(sections: torch.Tensor, dst: int = 0, group=None):
     return out
 
 
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
 class PipelinedCompactGather:
     """PipelinedGather with the compacted payload, without a host wait on recent GPU work.
 
@@ -225,7 +258,9 @@ class PipelinedCompactGather:
     compute stream in front of it), so it never waits for work the GPU has not finished long ago,
     never leaves the GPU without queued work, and no size is ever guessed (no truncation, no
     worst-case transfer).  The transfer of step k overlaps the compute of steps k+2, k+3; its
-    buffers are reused at step k + depth (depth >= lag + 2).  `dst` is a rank of `group`.  The
+    buffers are reused at step k + depth (depth >= lag + 1; with lag + 1 the step that reuses a slot
+    waits for a transfer posted one step earlier, lag + 2 and more leave it a whole step).  `dst` is
+    a rank of `group`.  The
     landing buffers on `dst` grow on demand from what really arrives (not depth x ranks x the
     worst case).  `flush()` finishes what is still pending."""
 
@@ -251,6 +286,7 @@ class PipelinedCompactGather:
         self.events = [torch.cuda.Event() if self.cuda else None for _ in range(depth)]
         self.comm = torch.cuda.Stream(dev) if self.cuda else None
         self.landing = [dict() for _ in range(depth)]   # slot -> {rank: (counts, packed)} grown on demand
+        self.retired = [[] for _ in range(depth)]       # outgrown landing buffers, kept until the slot's next use
         self.works = [[] for _ in range(depth)]
         self.result = [None] * depth
         self.sizes = [None] * depth
@@ -260,12 +296,26 @@ class PipelinedCompactGather:
 
     # ---- landing buffers of rank r in a slot: reused, grown by half when a payload outgrows them
     def _landing(self, slot, r, nc, n):
+        """Allocated on the CONSUMER's stream (the stream that was current when the transfers are posted), not
+        on the communication stream this runs under: the caching allocator ties a block to the stream it was
+        allocated on, and the results are read on the compute stream; the communication stream's use is
+        declared with record_stream.  An outgrown buffer stays alive until the slot is used again, so a reader
+        of the previous result that is still queued never sees its block reused."""
         c_r, p_r = self.landing[slot].get(r, (None, None))
-        if c_r is None or c_r.numel() < nc:
-            c_r = torch.empty(nc, dtype=torch.int32, device=self.dev)
-        if p_r is None or p_r.shape[0] < n:
-            p_r = torch.empty((max(n, int(1.5 * (0 if p_r is None else p_r.shape[0]))), 8),
-                              dtype=torch.int32, device=self.dev)
+        grow_c = c_r is None or c_r.numel() < nc
+        grow_p = p_r is None or p_r.shape[0] < n
+        if grow_c or grow_p:
+            self.retired[slot].append((c_r, p_r))
+            ctx = torch.cuda.stream(self._consumer) if self.cuda else _NullCtx()
+            with ctx:
+                if grow_c:
+                    c_r = torch.empty(nc, dtype=torch.int32, device=self.dev)
+                if grow_p:
+                    p_r = torch.empty((max(n, int(1.5 * (0 if p_r is None else p_r.shape[0]))), 8),
+                                      dtype=torch.int32, device=self.dev)
+            if self.cuda:
+                c_r.record_stream(self.comm)
+                p_r.record_stream(self.comm)
         self.landing[slot][r] = (c_r, p_r)
         return c_r[:nc], p_r[:n]
 
@@ -276,6 +326,7 @@ class PipelinedCompactGather:
 
     def _finish(self, slot):
         import time
+        self.retired[slot].clear()           # (the result of the slot's previous use is out of reach by now)
         while slot in self.pending:          # (only when fewer than `lag` steps follow: flush, tiny runs)
             self._post(self.pending[0])
         t0 = time.perf_counter()
@@ -324,6 +375,7 @@ class PipelinedCompactGather:
                                        lambda r, nc, m: self._landing(slot, r, nc, m))
             return out, works, sizes
         if self.cuda:
+            self._consumer = torch.cuda.current_stream(self.dev)
             with torch.cuda.stream(self.comm):   # nothing of the compute stream in front of the size copy
                 out, works, sizes = go()
         else:

@@ -20,6 +20,10 @@ def test_core_library_exports_every_declared_symbol():
         assert hasattr(L, name), f"libis_core.so does not export {name}"
     assert set(core.EXPORTS) <= declared
     assert b"gfx950" in L.is_version()
+    # the counter array of is_get_eval_counters: one size in the header, the device code and the binding
+    assert int(re.search(r"#define IS_EVAL_COUNTERS (\d+)", text).group(1)) == core.EVAL_COUNTERS
+    dev = open(os.path.join(ROOT, "instance_stixels_amd", "csrc", "is_device.h")).read()
+    assert int(re.search(r"#define IS_CNT_N (\d+)", dev).group(1)) == core.EVAL_COUNTERS
 
 
 def test_host_library_exports():

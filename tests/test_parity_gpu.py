@@ -207,15 +207,18 @@ def test_pruning_changes_nothing_at_full_size(preset, monkeypatch):
             assert np.all(col["cost"] <= np.float32(1e4)) and np.all(col["cost"] >= best)
 
 
+@pytest.mark.parametrize("preset", ["drn_d_38_pairwise", "drn_d_22_unary"])
 @pytest.mark.parametrize("family", ["homogeneous", "many_thin_objects", "iid_noise", "low_confidence",
                                     "flat_disparity", "noisy_disparity"])
-def test_pruning_changes_nothing_on_the_input_families(family, monkeypatch):
-    """The same property on the other input families of bench.py (synthetic.make_frame(family=...)), pairwise
-    model, 9 full frames = 2304 columns (the two-column phase 2 and the unsplit phase 1 of large batches):
-    the separable block bounds (lemmas L7 / L8) bite hardest where the scene is homogeneous or the CNN
-    hesitant, i.e. exactly where the headline family exercises them least."""
+def test_pruning_changes_nothing_on_the_input_families(family, preset, monkeypatch):
+    """The same property on the other input families of bench.py (synthetic.make_frame(family=...)), both
+    models, 9 full frames = 2304 columns (the two-column phase 2 and the unsplit phase 1 of large batches;
+    the windowed unary ring kernel): the separable block bounds (lemmas L7 / L8) bite hardest where the
+    scene is homogeneous or the CNN hesitant, i.e. exactly where the headline family exercises them least;
+    the unary model has its floor on the homogeneous family.  Eight columns of two distinct frames go
+    against the oracle with their complete tables (StixelsKernels.cu:600-839)."""
     from instance_stixels_amd import synthetic
-    base = helpers.build_case("drn_d_38_pairwise", 1024, 2048, 128, seed=7, n_images=1)
+    base = helpers.build_case(preset, 1024, 2048, 128, seed=7, n_images=1)
     cfg = base["cfg"]
     frames = [synthetic.make_frame(cfg, seed=300 + i, family=family) for i in range(3)]
     ground = [oracle_mod().host_ground(cfg, f.vhor_image, f.camera_tilt, f.camera_height, f.alpha_ground)
@@ -235,11 +238,12 @@ def test_pruning_changes_nothing_on_the_input_families(family, monkeypatch):
     assert np.array_equal(pruned["index_table"], full["index_table"])
     for img in range(9):
         assert helpers.sections_equal(pruned["sections"][img], full["sections"][img])
-    # one column of the first frame against the oracle as well (the oracle needs ~1 s per column here)
-    ref = oracle_mod().compute(case["params"], case["lut"], case["odr"], pruned["joined"][0],
-                               case["segmentation"][0], case["gf"][0], case["ng"][0], case["ig"][0],
-                               int(case["vhor"][0]), True, col_range=(100, 101))
-    assert np.array_equal(ref["cost_table"][100].view(np.uint32), pruned["cost_table"][0][100].view(np.uint32))
+    # eight columns spread over two distinct frames against the oracle: Sections and complete tables
+    for img, cols in ((0, (3, 100, 171, 255)), (4, (0, 64, 130, 222))):
+        for c in cols:
+            ref = helpers.run_oracle(case, image=img, col_range=(c, c + 1), joined=pruned["joined"][img])
+            errs = helpers.compare(ref, pruned, img, cfg, cols=[c])
+            assert not errs, f"{family} image {img} column {c}:\n" + "\n".join(errs[:5])
 
 
 @pytest.mark.parametrize("preset", ["drn_d_22_unary", "drn_d_38_pairwise"])
@@ -312,6 +316,120 @@ def test_config5_ultrawide_1024x4096x256_column_subset():
         assert not errs, "\n".join(errs[:5])
     for c in range(cfg.realcols):
         check_column_structure(got["sections"][0][c], 1024)
+
+
+def _run_with_counters(case, want_tables=True):
+    """One is_compute call of the whole case with the evaluation counters on: (outputs, counters)."""
+    from instance_stixels_amd.core import Core
+    cfg = case["cfg"]
+    core = Core(case["params"], case["lut"], case["odr"], max_batch=len(case["frames"]))
+    try:
+        core.set_eval_counters(True)
+        out = core.run(disparity_big=case["disparity"], segmentation=case["segmentation"],
+                       ground_function=case["gf"], normalization_ground=case["ng"],
+                       inv_sigma2_ground=case["ig"], vhor=case["vhor"], pairwise=bool(cfg.pairwise),
+                       median_join=bool(cfg.median_join), want_tables=want_tables, want_instances=False)
+        return out, core.eval_counters()
+    finally:
+        core.close()
+
+
+@pytest.mark.parametrize("preset", ["drn_d_22_unary", "drn_d_38_pairwise"])
+def test_config5_batch_of_8_windowed_kernels_as_timed(preset, monkeypatch):
+    """BASELINE configs[4] at the instantiation bench.py TIMES it on: eight 1024x4096x256 frames per call =
+    4096 stixel columns, which is where the library switches the D = 256 kernels to their fn windows BY
+    DEFAULT (k_dp_unary_fast from 2048 columns, k_pw_phase1 from 4096; a single frame = 512 columns runs
+    the classic tiles, which is what the one-frame tests above exercise).  Two distinct frames, repeated;
+    of one copy of each: every 16th column (Sections + complete tables) and the complete tables of eight
+    more columns against the oracle (StixelsKernels.cu:600-839); the counters prove that the window path
+    ran and that lanes did read outside their windows."""
+    for k in ("IS_P1_WIN_TILES", "IS_NO_PRUNE"):
+        monkeypatch.delenv(k, raising=False)
+    case2 = helpers.build_case(preset, 1024, 4096, 256, seed=23, n_images=2)
+    case = helpers.sub_case(case2, [i % 2 for i in range(8)])
+    cfg = case["cfg"]
+    got, counters = _run_with_counters(case)
+    miss = counters["p1_window_miss" if cfg.pairwise else "unary_window_miss"]
+    assert miss > 0, counters
+    cols = sorted(set(range(0, cfg.realcols, 16)) | {1, 77, 130, 203, 258, 333, 410, 511})
+    for img in (0, 5):
+        joined = got["joined"][img]
+        for c in cols:
+            ref = helpers.run_oracle(case, image=img, col_range=(c, c + 1), joined=joined)
+            errs = helpers.compare(ref, got, img, cfg, cols=[c])
+            assert not errs, f"image {img} column {c}:\n" + "\n".join(errs[:5])
+    for img in range(2, 8):     # the repeats inside the batch agree with their first copies
+        assert helpers.sections_equal(got["sections"][img], got["sections"][img % 2])
+        assert np.array_equal(got["cost_table"][img].view(np.uint32), got["cost_table"][img % 2].view(np.uint32))
+
+
+# The only shape and mode the reference itself launches and publishes context numbers for: the 784x1792
+# crop with 128 disparities and invalid_disparity = 0 (/root/reference/tests/run_test.sh:84,
+# apps/run_cityscapes.cu:129-134 and :188, apps/stixels_node.cu:162-176): 224 stixel columns, P2 = 1024,
+# P2S = 128, 12.25 tiles of 64 rows (H % 64 = 16: a partial last tile at full scale).
+REF_SHAPE = (784, 1792, 128)
+
+
+@pytest.mark.parametrize("median", [False, True])
+@pytest.mark.parametrize("preset", ["drn_d_22_unary", "drn_d_38_pairwise"])
+def test_reference_operating_point_784x1792_invalid0(preset, median):
+    """The reference's own operating point, full frame, all 224 columns against the oracle: Sections,
+    instance candidates and the complete DP tables, both models, mean and median column joins."""
+    H, W, D = REF_SHAPE
+    case = helpers.build_case(preset, H, W, D, seed=31, invalid_disparity=0.0, median_join=median)
+    assert case["cfg"].realcols == 224 and case["params"].rows_power2 == 1024
+    assert case["params"].rows_power2_segmentation == 128
+    assert (case["disparity"] == 0.0).mean() > 0.03       # the 5 % holes are there
+    got = helpers.run_core(case)
+    _assert_parity(case, got)
+
+
+@pytest.mark.parametrize("preset", ["drn_d_22_unary", "drn_d_38_pairwise"])
+def test_reference_operating_point_batch_as_timed(preset, monkeypatch):
+    """The same shape and mode at the batch bench.py times it on (variants.ref_shape_784x1792): 40 frames =
+    8960 columns in one call -- the windowed HAS_INVALID instantiations of the large-batch kernels, the
+    two-column phase 2 -- four distinct frames, four of the forty against the oracle, all against their
+    first copies."""
+    for k in ("IS_P1_WIN_TILES", "IS_NO_PRUNE"):
+        monkeypatch.delenv(k, raising=False)
+    H, W, D = REF_SHAPE
+    case4 = helpers.build_case(preset, H, W, D, seed=37, n_images=4, invalid_disparity=0.0)
+    case = helpers.sub_case(case4, [i % 4 for i in range(40)])
+    got, counters = _run_with_counters(case, want_tables=False)
+    assert counters["p1_window_miss" if case["cfg"].pairwise else "unary_window_miss"] > 0, counters
+    for img in (0, 17, 22, 39):
+        ref = helpers.run_oracle(case, image=img)
+        errs = helpers.compare(ref, got, img, case["cfg"], check_tables=False)
+        assert not errs, f"image {img}:\n" + "\n".join(errs[:10])
+    for img in range(4, 40):
+        assert helpers.sections_equal(got["sections"][img], got["sections"][img % 4])
+
+
+@pytest.mark.parametrize("preset", ["drn_d_22_unary", "drn_d_38_pairwise"])
+def test_reference_operating_point_through_the_host_class(preset):
+    """... and one frame per call through Stixels::Compute, the reference's caller sequence
+    (apps/run_cityscapes.cu:328-449) at the reference's shape and mode."""
+    from instance_stixels_amd import host
+    H, W, D = REF_SHAPE
+    case = helpers.build_case(preset, H, W, D, seed=43, n_images=2, invalid_disparity=0.0)
+    cfg = case["cfg"]
+    st = host.Stixels()
+    st.SetConfig(cfg)
+    st.Initialize()
+    try:
+        for i, frame in enumerate(case["frames"]):
+            st.SetDisparityImage(frame.disparity)
+            st.SetSegmentation(frame.segmentation)
+            st.SetRoadParameters(frame.vhor_image, frame.camera_tilt, frame.camera_height, frame.alpha_ground)
+            data = st.Compute(cfg.pairwise)
+            mapping = st.GetInstanceStixels()
+            ref = helpers.run_oracle(case, image=i)
+            got = dict(joined=ref["joined"][None], sections=data.sections[None])
+            errs = helpers.compare(ref, got, 0, cfg, check_tables=False)
+            assert not errs, f"frame {i}:\n" + "\n".join(errs[:10])
+            assert len(mapping) == int(ref["inst_per_class"].sum())
+    finally:
+        st.Finish()
 
 
 @pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p) for p in GOLDEN])
