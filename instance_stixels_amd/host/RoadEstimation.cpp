@@ -22,6 +22,9 @@ void RoadEstimation::Initialize(const float camera_center_y, const float baselin
                                 const int max_dis, const float road_vdisparity_threshold) {
     m_cy = camera_center_y; /* RE.cu:37-40 */
     m_b = baseline;
+    /* re-initialisation (a new frame shape or camera, stixels_wrapper.cu:124-152) releases the stream and the
+     * buffers of the previous one first -- on THEIR device, which Finish() still knows */
+    if (m_is_initialized || m_stream) Finish();
     m_focal = focal;
     m_HoughAccumThr = 25; /* RE.cu:45-57 */
     m_binThr = road_vdisparity_threshold;
