@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--rows", type=int, default=1024)
     ap.add_argument("--cols", type=int, default=2048)
     ap.add_argument("--max-dis", type=int, default=128)
+    ap.add_argument("--invalid-disparity", type=float, default=None,
+                    help="invalid_disparity of the configuration (e.g. 0: 5 %% of the pixels invalid, the HAS_INVALID kernels)")
     ap.add_argument("--family", default="scene", help="synthetic input family (synthetic.FAMILIES)")
     ap.add_argument("--distinct", type=int, default=0,
                     help="distinct synthetic frames per rank (default 0 = --batch: every frame of the batch is its own scene)")
@@ -755,8 +757,9 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
 
     # ---- host side (C++ Stixels class) + inputs resident in HBM before the timed region
+    extra = {} if args.invalid_disparity is None else {"invalid_disparity": args.invalid_disparity}
     wl = Workload(args.preset, args.rows, args.cols, args.max_dis, args.batch, args.distinct, dev,
-                  local_rank, seed0=17 + 101 * rank, family=args.family)
+                  local_rank, seed0=17 + 101 * rank, family=args.family, **extra)
     cfg, B, H, W, C, D, S = wl.cfg, wl.B, wl.H, wl.W, wl.C, wl.D, wl.S
     core = wl.make_core()
     core.set_kernel_timing(True)

@@ -690,6 +690,9 @@ __device__ __forceinline__ void touch_round(const RowRec* rcol, const StepRec* s
 #ifndef IS_P1_DPP
 #define IS_P1_DPP 1
 #endif
+#ifndef IS_P1_DPP_INV
+#define IS_P1_DPP_INV 1 /* the DPP / scalar-operand step also with an invalid-disparity value (mean_valid_fast) */
+#endif
 #ifndef IS_P1_MY_FIRST
 #define IS_P1_MY_FIRST 0 /* 1: the lane record requested before the tile staging: measured 2 % slower (more loads in flight at once) */
 #endif
@@ -790,7 +793,7 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
             const RowRec my = load_rec(rcol + vTc + 1);
             const RowRec rb = sload_rec(rcol);
             const int h = vTc + 1;
-            const SegTerms t = eval_segment<FAST, HAS_INVALID>(my, rb, (float)h, rcp[min(h, H)], D, P.iw);
+            const SegTerms t = eval_segment<FAST, HAS_INVALID>(my, rb, (float)h, rcp[min(h, H)], D, P.iw, rcp);
             const float od = lcol[(size_t)min(vT + 1, H) * D + (unsigned)t.fni] - lcol[(unsigned)t.fni];
             const bool below = vT <= vhor;
             const float cost_g = P.dw * t.gd + P.pw * P.first_g + P.sw * t.seg_g;
@@ -1102,10 +1105,10 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
 #else
 #define IS_P1_NEXT_ROW() load_lut_row<NRW>(next_row, lrsrc, lcol, max(vB - nw, 0), D, lane4r)
 #endif
-            /* DPP record operands without an invalid-disparity value; with one (valid-count operands
-             * and an IEEE division per step: 90+ VGPRs) the scalar-load form at 8 waves per SIMD is
-             * the faster one (2375 vs 2250 frames/s with 5 % holes) */
-            constexpr bool USE_DPP = IS_P1_DPP && !HAS_INVALID;
+            /* (with an invalid-disparity value the step used to keep the scalar-load form: valid-count operands and
+             * an IEEE division per step took the DPP form to 90+ VGPRs.  Round 5: the mean of a FAST column through
+             * mean_valid_fast -- a table read and the exact-division shortcut -- so both run the same step) */
+            constexpr bool USE_DPP = IS_P1_DPP && (!HAS_INVALID || IS_P1_DPP_INV);
             /* record of vB (c_*), of vB - nw (n_*): vector loads, two steps ahead; StepRec one step
              * ahead in a second set of SGPRs */
             const int l15 = lane & 15;
@@ -1162,9 +1165,9 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
                     if (IS_P1_SREC) {                                                              \
                         if (IS_P1_SREC_LATE) pin_step(st);                                         \
                         srec_arrived(S);                                                           \
-                        t = eval_segment_mix<HAS_INVALID, WANT>(my, S, r1, (float)h, s_rcp[h], D, P.iw); \
+                        t = eval_segment_mix<HAS_INVALID, WANT>(my, S, r1, (float)h, s_rcp[h], D, P.iw, 0.0f, s_rcp); \
                     } else {                                                                       \
-                        t = eval_segment_dpp<HAS_INVALID, WANT>(my, r0, r1, (float)h, s_rcp[h], D, P.iw); \
+                        t = eval_segment_dpp<HAS_INVALID, WANT>(my, r0, r1, (float)h, s_rcp[h], D, P.iw, s_rcp); \
                     }                                                                              \
                     od = od_value(row, t.fni, vB);                                \
                     if (!IS_P1_SREC) {                                                             \
@@ -1177,7 +1180,7 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
                 } else {                                                                           \
                     const RowRec rb = sload_rec(rcol + vB);                                        \
                     st = sload_step(scol + vB);                                                    \
-                    t = eval_segment<true, HAS_INVALID>(my, rb, (float)h, s_rcp[h], D, P.iw);      \
+                    t = eval_segment<true, HAS_INVALID>(my, rb, (float)h, s_rcp[h], D, P.iw, s_rcp);      \
                     od = od_value(row, t.fni, vB);                                \
                 }                                                                                  \
                 pairwise_step<SKY, true, NOG, true>(P, st, vB, live, od, t, b);                    \
@@ -1307,7 +1310,7 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
                 n_full++;
                 const RowRec rb = sload_rec(rcol);
                 const int h = vTc + 1;
-                const SegTerms t = eval_segment<true, HAS_INVALID>(my, rb, (float)h, s_rcp[h], D, P.iw);
+                const SegTerms t = eval_segment<true, HAS_INVALID>(my, rb, (float)h, s_rcp[h], D, P.iw, s_rcp);
                 const float od = vt_value(t.fni) - lcol[(unsigned)t.fni];
                 const bool below = vT <= vhor;
                 const float cost_g = P.dw * t.gd + P.pw * P.first_g + P.sw * t.seg_g;
@@ -1337,7 +1340,7 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
         if (vB == 0) { /* first segment, :481-594 */
             const RowRec rb = sload_rec(rcol);
             const int h = vTc + 1;
-            const SegTerms t = eval_segment<FAST, HAS_INVALID>(my, rb, (float)h, s_rcp[h], D, P.iw);
+            const SegTerms t = eval_segment<FAST, HAS_INVALID>(my, rb, (float)h, s_rcp[h], D, P.iw, s_rcp);
             const float od = vt_value(t.fni) - lcol[(unsigned)t.fni];
             const bool below = vT <= vhor;
             const float cost_g = P.dw * t.gd + P.pw * P.first_g + P.sw * t.seg_g;
@@ -1356,7 +1359,7 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
                 const LutRow<NRW> row = next_row;
                 load_lut_row<NRW>(next_row, lrsrc, lcol, min(vB + nw, H), D, lane4r);
                 const int h = vTc + 1 - vB;
-                const SegTerms t = eval_segment<FAST, HAS_INVALID>(my, rb, (float)h, s_rcp[h], D, P.iw);
+                const SegTerms t = eval_segment<FAST, HAS_INVALID>(my, rb, (float)h, s_rcp[h], D, P.iw, s_rcp);
                 const float od = od_value(row, t.fni, vB);
                 pairwise_step<false, true, true>(P, st, vB, live, od, t, b);
             }
@@ -1367,7 +1370,7 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
             const LutRow<NRW> row = next_row;
             load_lut_row<NRW>(next_row, lrsrc, lcol, min(vB + nw, H), D, lane4r);
             const int h = vTc + 1 - vB;
-            const SegTerms t = eval_segment<FAST, HAS_INVALID>(my, rb, (float)h, s_rcp[h], D, P.iw);
+            const SegTerms t = eval_segment<FAST, HAS_INVALID>(my, rb, (float)h, s_rcp[h], D, P.iw, s_rcp);
             const float od = od_value(row, t.fni, vB);
             pairwise_step<false, true>(P, st, vB, live, od, t, b);
         }
@@ -1377,7 +1380,7 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
             const LutRow<NRW> row = next_row;
             load_lut_row<NRW>(next_row, lrsrc, lcol, min(vB + nw, H), D, lane4r);
             const int h = vTc + 1 - vB;
-            const SegTerms t = eval_segment<FAST, HAS_INVALID>(my, rb, (float)h, s_rcp[h], D, P.iw);
+            const SegTerms t = eval_segment<FAST, HAS_INVALID>(my, rb, (float)h, s_rcp[h], D, P.iw, s_rcp);
             const float od = od_value(row, t.fni, vB);
             pairwise_step<true, true>(P, st, vB, live, od, t, b);
         }
@@ -1416,7 +1419,7 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
 }
 
 #ifndef ISP1_OCC_INV
-#define ISP1_OCC_INV 8 /* with an invalid-disparity value: the scalar-load form of the step, 64 VGPRs */
+#define ISP1_OCC_INV (IS_P1_DPP_INV ? 6 : 8) /* with an invalid-disparity value (8: the scalar-load form of the step, 64 VGPRs) */
 #endif
 #ifndef ISP1_OCC
 #define ISP1_OCC 6 /* waves per SIMD phase 1 is compiled for: 80 VGPRs, no spills (8: 64 VGPRs + spills) */
@@ -1616,7 +1619,7 @@ __device__ __forceinline__ void pw_phase2_body(const DevParams& P, char* smem, i
             const int hc = max(vTc + 1 - r, 1);
             const bool live = (vT < H) && (vT >= r);
             ISP2_MARK(1); /* scalar loads */
-            const SegTerms t = eval_segment<FAST, HAS_INVALID>(my, rb, (float)hc, s_rcp[hc], D, P.iw);
+            const SegTerms t = eval_segment<FAST, HAS_INVALID>(my, rb, (float)hc, s_rcp[hc], D, P.iw, s_rcp);
             ISP2_MARK(2); /* eval_segment */
             const int fo = t.fni - lo;
             const bool inwin = (unsigned)fo < (unsigned)W;
@@ -1903,8 +1906,8 @@ __device__ __forceinline__ void pw_phase2x_body(const DevParams& P, char* smem, 
         const float rh = s_rcp[min(hc, IS_TILE)];
         const bool sky = !(r - 1 < vhor);
         SegTerms t;
-        if (sky) t = eval_segment_dpp<HAS_INVALID, IS_WANT_SKY>(my, R0, R1, (float)hc, rh, D, P.iw);
-        else t = eval_segment_dpp<HAS_INVALID, IS_WANT_GROUND>(my, R0, R1, (float)hc, rh, D, P.iw);
+        if (sky) t = eval_segment_dpp<HAS_INVALID, IS_WANT_SKY>(my, R0, R1, (float)hc, rh, D, P.iw, s_rcp);
+        else t = eval_segment_dpp<HAS_INVALID, IS_WANT_GROUND>(my, R0, R1, (float)hc, rh, D, P.iw, s_rcp);
         const int fo = t.fni - lo;
         const bool inwin = (unsigned)fo < (unsigned)W;
         const int foc = inwin ? fo : 0;
@@ -2354,7 +2357,7 @@ __device__ __forceinline__ void pw_phase2s_body(const DevParams& P, char* smem, 
             const RowRec rb = sload_rec_pinned(rcol + r);
             const int hc = max(vTc + 1 - r, 1);
             const bool live = (vT < H) && (vT >= r);
-            const SegTerms t = eval_segment<FAST, HAS_INVALID>(my, rb, (float)hc, s_rcp[hc], D, P.iw);
+            const SegTerms t = eval_segment<FAST, HAS_INVALID>(my, rb, (float)hc, s_rcp[hc], D, P.iw, s_rcp);
             const int fo = t.fni - lo;
             const bool inwin = (unsigned)fo < (unsigned)W;
             const int foc = inwin ? fo : 0;

@@ -43,7 +43,7 @@
 #define ISF_GS_STEPS 1 /* ground / sky-only steps once the object bound holds for the wave */
 #endif
 #ifndef ISF_OCC_INV
-#define ISF_OCC_INV 5 /* with an invalid-disparity value: 9 spilled VGPRs at 6 */
+#define ISF_OCC_INV 7 /* with an invalid-disparity value (round 5: the mean through mean_valid_fast; 5 while it was an IEEE division) */
 #endif
 #ifndef ISF_OCC
 #define ISF_OCC 7 /* waves per SIMD the kernel is compiled for: 68 VGPRs without spills; LDS keeps three workgroups = 6 per SIMD resident (7 measured 0.5-1 % faster than 6) */
@@ -94,14 +94,14 @@ __device__ __forceinline__ SegTerms fast_step(const DevParams& P, const RowRec& 
     /* FIRST (vB = 0): ground + object; otherwise the sky OR the ground candidate, or neither */
     constexpr int WANT = SKY ? IS_WANT_SKY : (NOGROUND ? 0 : IS_WANT_GROUND);
 #if ISF_SREC
-    const SegTerms t = eval_segment_mix<HAS_INVALID, WANT>(my, S, srec[16 + l15], (float)hc, r, P.D, P.iw);
+    const SegTerms t = eval_segment_mix<HAS_INVALID, WANT>(my, S, srec[16 + l15], (float)hc, r, P.D, P.iw, 0.0f, s_rcp);
 #else
     const SegTerms t = eval_segment_dpp<HAS_INVALID, WANT>(my, srec[l15], srec[16 + l15], (float)hc, r, P.D,
-                                                           P.iw);
+                                                           P.iw, s_rcp);
 #endif
 #else
     const RowRec rb = lds_rec(srec);
-    const SegTerms t = eval_segment<true, HAS_INVALID>(my, rb, (float)hc, r, P.D, P.iw);
+    const SegTerms t = eval_segment<true, HAS_INVALID>(my, rb, (float)hc, r, P.D, P.iw, s_rcp);
 #endif
     float vtv, vbv;
     if (WIN) {
@@ -625,8 +625,8 @@ __global__ __launch_bounds__(64, ISD_OCC) void k_dp_unary_diag(
             const float rh = s_rcp[min(hc, IS_TILE)];
             const bool sky = vB > vhor; /* vB - 1 >= vhor: sky + object (:729), else ground + object (:687) */
             SegTerms t;
-            if (sky) t = eval_segment_dpp<HAS_INVALID, IS_WANT_SKY>(my, R0, R1, (float)hc, rh, D, P.iw);
-            else t = eval_segment_dpp<HAS_INVALID, IS_WANT_GROUND>(my, R0, R1, (float)hc, rh, D, P.iw);
+            if (sky) t = eval_segment_dpp<HAS_INVALID, IS_WANT_SKY>(my, R0, R1, (float)hc, rh, D, P.iw, s_rcp);
+            else t = eval_segment_dpp<HAS_INVALID, IS_WANT_GROUND>(my, R0, R1, (float)hc, rh, D, P.iw, s_rcp);
             const int fo = t.fni - lo;
             const bool inwin = (unsigned)fo < (unsigned)W;
             const int foc = inwin ? fo : 0;

@@ -85,6 +85,19 @@ __device__ __forceinline__ float fast_div(float a, float h, float r) {
     return __builtin_fmaf(e0, r, q0);
 }
 
+/* ComputeMean with an invalid-disparity value (StixelsKernels.cu:47-60) in a FAST column: the divisor is the
+ * number of valid rows of the segment -- an exact integer in [0, h] (the prefix of 0 / 1 values is exact in
+ * fp32) -- so the exact-division shortcut applies with r = RN(1 / valid) from the 1/h table `rcp_tab`
+ * (entries 0 .. at least the segment's height): one table read, one multiplication and two FMAs instead of
+ * the IEEE division sequence (v_div_scale x 2, v_rcp, four FMAs, v_div_fmas, v_div_fixup), bit for bit the
+ * same quotient (tools/verify_exact_division.c covers every divisor <= 11000, not only the height).  A
+ * segment without a valid row has mean 0 (:55); the table entry of 0 is then read but never used. */
+__device__ __forceinline__ float mean_valid_fast(float sdif, float valid_dif, const float* rcp_tab) {
+    const float rv = rcp_tab[cvt_u32_sat(valid_dif)];
+    const float q = fast_div(sdif, valid_dif, rv);
+    return (valid_dif == 0) ? 0.0f : q;
+}
+
 /* wave-uniform record through the constant address space: scalar loads, values live in SGPRs */
 __device__ __forceinline__ RowRec sload_rec(const RowRec* p) {
     crec_t q = (crec_t)p;
@@ -111,9 +124,10 @@ __device__ __forceinline__ RowRec sload_rec(const RowRec* p) {
  *   FAST columns only: float(int64 difference) via exact fp32 hi/lo parts (RowRec), x / h via
  *   fast_div, and
  *   (int)floorf(max(mean,0)) = (int)fmaxf(mean,0) because the mean is finite there. */
+/* rcp_tab (HAS_INVALID, FAST columns): the 1/h table for mean_valid_fast, or null = IEEE division */
 template <bool FAST, bool HAS_INVALID>
 __device__ __forceinline__ SegTerms eval_segment(const RowRec& my, const RowRec& rb, float height,
-                                                 float r, int D, float iw) {
+                                                 float r, int D, float iw, const float* rcp_tab = nullptr) {
     SegTerms t;
     const float nic = iw * (float)(my.Fnic - rb.Fnic); /* ComputeNonInstanceOffsetCost, :62-70, :496-499 */
     float ic; /* ComputeInstanceOffsetCost, :72-86 */
@@ -166,7 +180,8 @@ __device__ __forceinline__ SegTerms eval_segment(const RowRec& my, const RowRec&
     float mean; /* ComputeMean, :47-60 */
     if (HAS_INVALID) {
         const float valid_dif = my.V - rb.V;
-        mean = (valid_dif == 0) ? 0 : (my.S - rb.S) / valid_dif;
+        if (FAST && rcp_tab != nullptr) mean = mean_valid_fast(my.S - rb.S, valid_dif, rcp_tab);
+        else mean = (valid_dif == 0) ? 0 : (my.S - rb.S) / valid_dif;
     } else if (FAST) {
         mean = fast_div(my.S - rb.S, height, r);
     } else {
@@ -589,7 +604,7 @@ __device__ __forceinline__ float seg_o_lower_bound(const SegTerms& t, float E2x3
  * otherwise be executed even where their result is never read. */
 template <bool HAS_INVALID, int WANT = IS_WANT_GROUND | IS_WANT_SKY>
 __device__ __forceinline__ SegTerms eval_segment_dpp(const RowRec& my, float R0, float R1, float height,
-                                                     float r, int D, float iw) {
+                                                     float r, int D, float iw, const float* rcp_tab = nullptr) {
     SegTerms t;
     const float nic = iw * (float)dpp_sub_i_first<3>(my.Fnic, R1);
     float f_g = 0.0f;
@@ -648,7 +663,8 @@ __device__ __forceinline__ SegTerms eval_segment_dpp(const RowRec& my, float R0,
     if (HAS_INVALID) {
         const float valid_dif = dpp_sub<7>(my.V, R1);
         const float sdif = dpp_sub<6>(my.S, R1);
-        mean = (valid_dif == 0) ? 0 : sdif / valid_dif;
+        if (rcp_tab != nullptr) mean = mean_valid_fast(sdif, valid_dif, rcp_tab);
+        else mean = (valid_dif == 0) ? 0 : sdif / valid_dif;
     } else {
         mean = fast_div(dpp_sub<6>(my.S, R1), height, r);
     }
@@ -682,7 +698,7 @@ __device__ __forceinline__ void srec_arrived(isk_f16v& S) { asm volatile("s_wait
 template <bool HAS_INVALID, int WANT = IS_WANT_GROUND | IS_WANT_SKY, bool MEAN_GIVEN = false>
 __device__ __forceinline__ SegTerms eval_segment_mix(const RowRec& my, const isk_f16v& S, float R1,
                                                      float height, float r, int D, float iw,
-                                                     float mean_in = 0.0f) {
+                                                     float mean_in = 0.0f, const float* rcp_tab = nullptr) {
     /* (MEAN_GIVEN with HAS_INVALID is instantiated but never executed: the lazy step is the DPP path) */
     SegTerms t;
     const float nic = iw * (float)dpp_sub_i_first<3>(my.Fnic, R1);
@@ -751,7 +767,8 @@ __device__ __forceinline__ SegTerms eval_segment_mix(const RowRec& my, const isk
     } else if (HAS_INVALID) {
         const float valid_dif = dpp_sub<7>(my.V, R1);
         const float sdif = dpp_sub<6>(my.S, R1);
-        mean = (valid_dif == 0) ? 0 : sdif / valid_dif;
+        if (rcp_tab != nullptr) mean = mean_valid_fast(sdif, valid_dif, rcp_tab);
+        else mean = (valid_dif == 0) ? 0 : sdif / valid_dif;
     } else {
         mean = fast_div(dpp_sub<6>(my.S, R1), height, r);
     }
