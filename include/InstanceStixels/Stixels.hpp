@@ -97,6 +97,19 @@ public:
                       const int32_t* d_segmentation, const RoadParameters* road,
                       std::vector<StixelsData>& out, void* stream = nullptr,
                       std::vector<InstanceMapping>* instance_stixels = nullptr);
+    /* Multi-GPU (an addition: the reference runs on one GPU): this rank's shard of a batch through
+     * ComputeBatch's device path, then the compacted final gather of EVERY rank's Sections on rank `dst` of
+     * `comm` over RCCL (an ncclComm_t passed as void*; plain-C++ callers create it with is_comm_unique_id /
+     * is_comm_init_rank of instance_stixels_core.h).  One process per GPU, every rank calls it.
+     *   images_per_rank  [ranks]: the shard sizes, known to every rank; n_images = its own entry
+     *   road_all         on dst: the road parameters of ALL frames in rank order (dst hands out the work,
+     *                    so it has them) for the StixelsData headers; ignored elsewhere
+     * On dst `out` holds the frames of all ranks in rank order, elsewhere it is left empty.  Sections
+     * only: the instance mappings stay with the rank that computed them (ComputeBatch). */
+    void ComputeBatchGather(bool pairwise, int n_images, const pixel_t* d_disparity_big,
+                            const int32_t* d_segmentation, const RoadParameters* road, void* comm, int dst,
+                            const int* images_per_rank, const RoadParameters* road_all,
+                            std::vector<StixelsData>& out, void* stream = nullptr);
     /* Introspection for tests / bench. */
     const StixelParameters& GetParameters() const { return m_params; }
     const std::vector<float>& GetObjectCostLUT() const { return m_obj_cost_lut; }
@@ -150,6 +163,15 @@ private:
     int m_header_rows = 0;
     int m_head_sections = 0;
     int32_t* h_instance_head = nullptr;    /* [max_batch][8 per-class counts] */
+    /* ComputeBatchGather: the packed payload of this rank and, on the destination, the landing buffers
+     * (allocated on first use, grown on demand, released by Finish) */
+    int32_t* d_pack_counts = nullptr;
+    int32_t* d_pack_offsets = nullptr;
+    Section* d_pack_sections = nullptr;
+    int32_t* d_all_counts = nullptr;
+    Section* d_all_packed = nullptr;
+    Section* d_all_sections = nullptr;
+    size_t m_all_columns_cap = 0, m_all_packed_cap = 0;
     int32_t* h_instance_packed = nullptr;
     /* every device operation of the object runs on this stream (an ordinary stream: it still
      * synchronises with work the caller queued on the legacy NULL stream, like the reference's

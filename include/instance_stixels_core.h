@@ -195,6 +195,36 @@ int is_pack_sections(const is_section* d_sections, int n_columns, int max_sectio
 int is_unpack_sections(const int32_t* d_counts, int32_t* d_offsets, const is_section* d_packed,
                        int n_columns, int max_sections, is_section* d_sections, void* stream);
 
+/* ---- multi-GPU: the final gather of a sharded batch for C / C++ callers ----------------
+ * Images are independent: every rank (one process per GPU) runs is_compute on its shard of the batch and
+ * only the OUTPUT travels, to one rank, over RCCL (/opt/rocm/include/rccl/rccl.h:700-745).  `comm` is an
+ * ncclComm_t passed as void*; a caller that has rccl.h uses its own communicator, a plain-C++ caller the
+ * four helpers below.  RCCL is loaded at run time (dlopen of librccl.so.1): IS_EHIP if it is missing.
+ * There is no reference counterpart: the reference runs on one GPU and writes its Sections to a file
+ * per frame (apps/run_cityscapes.cu:430-449). */
+int is_comm_unique_id(void* id_out, size_t id_bytes);  /* ncclGetUniqueId; id_bytes >= 128; pass the bytes to every rank */
+int is_comm_init_rank(void** comm, int nranks, const void* id, int rank); /* ncclCommInitRank on the current device */
+int is_comm_destroy(void* comm);
+int is_comm_rank(void* comm, int* rank, int* nranks);
+/* Gather of int32 payloads of different sizes on rank `dst`: rank r sends h_counts[r] elements of d_send;
+ * dst receives them into d_recv in rank order (its own part is a device copy).  h_counts has one entry per
+ * rank; a sender reads only its own.  Grouped ncclSend / ncclRecv on `stream`, asynchronous. */
+int is_gather_i32(void* comm, int dst, const int64_t* h_counts, const int32_t* d_send, int32_t* d_recv,
+                  void* stream);
+/* The compacted gather: what is_pack_sections left on every rank goes to `dst`.
+ *   h_columns      host, [nranks]: columns (n_images * realcols) of every rank's shard -- the shard sizes are
+ *                  known everywhere (contiguous blocks of the batch); the same array on every rank
+ *   d_counts, d_offsets, d_packed   this rank's is_pack_sections output (d_offsets[columns] = its total)
+ *   d_all_counts   dst: [sum of h_columns], rank order
+ *   d_all_packed   dst: [cap_sections] is_section, the ranks' sections back to back in rank order
+ *   h_totals       host, [nranks], out: on dst the sections of every rank, elsewhere only entry [own rank]
+ * Two phases on `stream`: the sizes (ncclGather) and the per-column counts, a host synchronisation, dst's
+ * go-ahead (IS_ENOMEM on EVERY rank when the total exceeds cap_sections: nothing is sent), then the payload
+ * (queued; the caller synchronises `stream`).  is_unpack_sections on dst restores the fixed-stride arrays. */
+int is_gather_sections(void* comm, int dst, const int32_t* h_columns, const int32_t* d_counts,
+                       const int32_t* d_offsets, const is_section* d_packed, int32_t* d_all_counts,
+                       is_section* d_all_packed, size_t cap_sections, int64_t* h_totals, void* stream);
+
 /* Replaces the output wrapper of the reference's CNN export ("FlipAndPad",
  * tools/CNN_training/models/wrappers.py:35-61), i.e. the producer of d_segmentation:
  *   d_cnn_out       device, [n_images][channels][rows8][cols8] float (NCHW network output)

@@ -25,6 +25,8 @@ EXPORTS = [
     "is_ctx_device", "is_set_eval_counters", "is_get_eval_counters",
     "is_pack_sections", "is_unpack_sections", "is_stream_create", "is_stream_destroy",
     "is_debug_read_object_lut", "is_debug_read_block_summaries",
+    "is_comm_unique_id", "is_comm_init_rank", "is_comm_destroy", "is_comm_rank", "is_gather_i32",
+    "is_gather_sections",
 ]
 
 
@@ -86,6 +88,12 @@ def lib():
         L.is_unpack_sections.argtypes = [vp, vp, vp, ci, ci, vp, vp]
         L.is_scratch_bytes.argtypes = [vp]
         L.is_scratch_bytes.restype = ctypes.c_size_t
+        L.is_comm_unique_id.argtypes = [vp, ctypes.c_size_t]
+        L.is_comm_init_rank.argtypes = [ctypes.POINTER(vp), ci, vp, ci]
+        L.is_comm_destroy.argtypes = [vp]
+        L.is_comm_rank.argtypes = [vp, ctypes.POINTER(ci), ctypes.POINTER(ci)]
+        L.is_gather_i32.argtypes = [vp, ci, vp, vp, vp, vp]
+        L.is_gather_sections.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp, ctypes.c_size_t, vp, vp]
         L.is_debug_read_object_lut.argtypes = [vp, ci, vp]
         try:   # (an experiment library built from an older tree may lack the newest test hook)
             L.is_debug_read_block_summaries.argtypes = [vp, ci, vp, ci, ctypes.POINTER(ci)]
@@ -273,6 +281,36 @@ class Core:
         torch.cuda.synchronize(dev)
         pk = packed.cpu().numpy()
         return lab.cpu().numpy(), pk[1:1 + 3 * int(pk[0])].reshape(-1, 3)
+
+
+def comm_unique_id():
+    """128 bytes of an ncclUniqueId (is_comm_unique_id): created by one rank, handed to all."""
+    buf = ctypes.create_string_buffer(128)
+    _check(lib().is_comm_unique_id(buf, 128), "is_comm_unique_id")
+    return buf.raw
+
+
+def comm_init_rank(nranks, uid, rank):
+    """An RCCL communicator on the current device (is_comm_init_rank) -> ncclComm_t as int."""
+    comm = ctypes.c_void_p()
+    _check(lib().is_comm_init_rank(ctypes.byref(comm), int(nranks), ctypes.c_char_p(uid), int(rank)),
+           "is_comm_init_rank")
+    return comm.value
+
+
+def comm_destroy(comm):
+    _check(lib().is_comm_destroy(ctypes.c_void_p(comm)), "is_comm_destroy")
+
+
+def gather_sections_ptr(comm, dst, columns, d_counts, d_offsets, d_packed, d_all_counts, d_all_packed,
+                        cap_sections, stream=0):
+    """is_gather_sections on raw device pointers; returns the per-rank section totals (dst: all of them)."""
+    cols = np.ascontiguousarray(columns, np.int32)
+    totals = np.zeros(cols.size, np.int64)
+    _check(lib().is_gather_sections(ctypes.c_void_p(comm), int(dst), _hp(cols), d_counts, d_offsets, d_packed,
+                                    d_all_counts, d_all_packed, int(cap_sections), _hp(totals), stream),
+           "is_gather_sections")
+    return totals
 
 
 def pack_sections_ptr(d_sections, n_columns, max_sections, d_counts, d_offsets, d_packed, stream=0):

@@ -66,6 +66,11 @@ static int fail_arg(const char* msg) {
     snprintf(g_err, sizeof(g_err), "invalid argument: %s", msg);
     return IS_EINVAL;
 }
+/* (for the other translation units of the library: is_gather.hip) */
+extern "C" int isk_fail(int code, const char* msg) {
+    snprintf(g_err, sizeof(g_err), "%s", msg);
+    return code;
+}
 #define HIP_TRY(expr)                                                    \
     do {                                                                 \
         hipError_t e__ = (expr);                                         \

@@ -141,7 +141,7 @@ static_assert(sizeof(PruneRec) == 32, "PruneRec must be 32 bytes");
 #define IS_CNT_UNARY_GS 1   /* k_dp_unary_fast: ground- / sky-only steps               */
 #define IS_CNT_P1_FULL 2    /* k_pw_phase1: full steps (incl. the first segment vB = 0) */
 #define IS_CNT_P1_GS 3      /* k_pw_phase1: ground- / sky-only candidates               */
-#define IS_CNT_P1_LAZY 4    /* k_pw_phase1: steps in which some lane read outside its fn window (IS_P1_WIN; the slot of the lazy-step experiment) */
+#define IS_CNT_P1_WINMISS 4 /* k_pw_phase1: steps in which some lane read outside its fn window (IS_P1_WIN) */
 #define IS_CNT_UNARY_WINMISS 5 /* k_dp_unary_fast (windowed tiles): steps in which some lane read outside its fn window */
 #define IS_CNT_TILE0 8    /* + 3 * tile + {0 full, 1 window misses, 2 ground / sky-only}: per phase-1 launch, tile < 64 */
 #define IS_CNT_N 200

@@ -641,9 +641,6 @@ __device__ __forceinline__ void pairwise_step(const DevParams& P, const StepVals
 #ifndef IS_P2_GATHER_MASKED
 #define IS_P2_GATHER_MASKED 1
 #endif
-#ifndef IS_P1_ROW_AHEAD
-#define IS_P1_ROW_AHEAD 1 /* steps the vB-side lutT row is fetched ahead of its use (1 or 2) */
-#endif
 #ifndef IS_P1_TOUCH_AHEAD
 #define IS_P1_TOUCH_AHEAD 2
 #endif
@@ -693,29 +690,14 @@ __device__ __forceinline__ void touch_round(const RowRec* rcol, const StepRec* s
 #ifndef IS_P1_DPP_INV
 #define IS_P1_DPP_INV 1 /* the DPP / scalar-operand step also with an invalid-disparity value (mean_valid_fast) */
 #endif
-#ifndef IS_P1_MY_FIRST
-#define IS_P1_MY_FIRST 0 /* 1: the lane record requested before the tile staging: measured 2 % slower (more loads in flight at once) */
-#endif
 #ifndef IS_P1_TILE0_DIRECT
 #define IS_P1_TILE0_DIRECT 1
 #endif
 #ifndef IS_P1_SREC_LATE
 #define IS_P1_SREC_LATE 1 /* StepRec of the next step: loaded at the end of the step, pinned (= waited for) at its use */
 #endif
-#ifndef IS_P1_SREC_FIRST
-#define IS_P1_SREC_FIRST 0
-#endif
 #ifndef IS_P1_SREC
 #define IS_P1_SREC 1 /* class-prefix half of the vB record as scalar operands (see eval_segment_mix) */
-#endif
-#ifndef IS_P1_LAZY
-#define IS_P1_LAZY 0 /* 1: transition term first, the rest of a step only when its object candidate can still win
-                       * (see IS_P1_STEP).  MEASURED (round 4, batch 64, bit-exact): 35 % of the steps stop after the
-                       * transition term, but the DP takes 16.5-16.7 instead of 15.6 ms -- a step is bound by the
-                       * latency of what it prefetches, not by its instructions, and a shorter step hides less */
-#endif
-#ifndef IS_P1_GEN_TILE
-#define IS_P1_GEN_TILE 0 /* see ISF_GEN_TILE (is_k_unary_fast.hip): -8.6 GB of reads, +4 % DP time */
 #endif
 #ifdef IS_ABL_P1PHASES
 /* debug build only: s_memtime cycles of wave 0 of every phase-1 workgroup in prologue / walk /
@@ -757,7 +739,7 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
     const int H = P.H, D = P.D;
     /* the vT-side tile: all D lutT columns of the 64 rows, or the fn window [win_lo, win_lo + IS_P1_WIN) of
      * wide tables (is_device.h) */
-    constexpr bool windowed = WIN && !IS_P1_GEN_TILE; /* (the launch picks the instantiation: tile < P.win_tiles) */
+    constexpr bool windowed = WIN; /* (the launch picks the instantiation: tile < P.win_tiles) */
     const int win_w = windowed ? IS_P1_WIN : D;
     const int DP = win_w + 1;
     float* s_tile = (float*)smem;             /* [64][win_w + 1] */
@@ -819,13 +801,6 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
     const int vB_last = min(tile_lo, H - 1);
     const int vT = tile_lo + lane;
     const int vTc = min(vT, H - 1);
-#if IS_P1_GEN_TILE
-    /* the vT-side lutT rows rebuilt in LDS (gen_lut_tile, is_kernels.h) */
-    gen_lut_tile(s_tile, lcol, joined + (size_t)colg * H, cost_T, tile_lo, H, D, wl, lane, nwl);
-    asm volatile("" ::: "memory");
-    const RowRec my = load_rec(rcol + vTc + 1);
-    stage_rcp(s_rcp, rcp, H, tid, (int)blockDim.x);
-#else
     /* What the pre-pass of the branch-and-bound reads -- the separable summaries of the lower bound
      * blocks (lemmas L7, L8: 24 floats per block) -- is requested HERE, in front of the tile staging, and
      * lands in LDS with it: one memory round trip for the whole prologue (round 3 chased a record and a
@@ -853,15 +828,9 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
         }
     }
     const int win_lo = windowed ? __builtin_amdgcn_readfirstlane(P.win_lo[(size_t)colg * P.ntiles + tile]) : 0;
-#if IS_P1_MY_FIRST
-    const RowRec my = load_rec(rcol + vTc + 1); /* requested with the tile: one memory round trip, not two */
-    if (windowed) stage_window_and_rcp(s_tile, s_rcp, lcol, rcp, tile_lo, H, D, win_lo, tid, (int)blockDim.x);
-    else stage_tile_and_rcp(s_tile, s_rcp, lcol, rcp, tile_lo, H, D, tid, (int)blockDim.x);
-#else
     if (windowed) stage_window_and_rcp(s_tile, s_rcp, lcol, rcp, tile_lo, H, D, win_lo, tid, (int)blockDim.x);
     else stage_tile_and_rcp(s_tile, s_rcp, lcol, rcp, tile_lo, H, D, tid, (int)blockDim.x);
     const RowRec my = load_rec(rcol + vTc + 1);
-#endif
     if (pre_regs) {
 #pragma unroll
         for (int j = 0; j < PRE_N; j++) {
@@ -871,8 +840,7 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
     } else if (FAST && IS_PRUNE) { /* tall frames: a plain loop */
         for (int i = tid; i < NLB * IS_P1_SUM_F; i += nthr) s_sum[i] = pre_load(i);
     }
-#endif
-    const float* my_tile = s_tile + IS_TILE_ROW(lane) * DP;
+    const float* my_tile = s_tile + lane * DP;
     const bool live = vT < H;
     /* lemma L7: per-lane thresholds (order-preserving keys, +inf) and the two survive masks */
     unsigned* s_thr = (unsigned*)(s_scr + 8 * nwl); /* [2][64] + [4] */
@@ -1079,10 +1047,6 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
             int vB = vB_last - (vB_last - w) % nw; /* the wave's largest vB */
             LutRow<NRW> next_row;
             load_lut_row<NRW>(next_row, lrsrc, lcol, vB, D, lane4r);
-#if IS_P1_ROW_AHEAD == 2
-            LutRow<NRW> next2_row; /* the row of the step after next: two rows in flight */
-            load_lut_row<NRW>(next2_row, lrsrc, lcol, max(vB - nw, 0), D, lane4r);
-#endif
             /* The bounds are sticky per type (a bound that holds at vB holds at every smaller vB:
              * the class minima only grow, the running minima q only grow, the best cost cannot
              * change any more).  The OBJECT bound -- minimum over the object classes only --
@@ -1093,18 +1057,12 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
              * no LUT access -- a fifth of the instructions of a full step; they are evaluated FOUR
              * vB at a time so that one scalar-load latency covers four steps. */
             bool done = false, o_closed = false;
-            int n_full = 0, n_gs = 0, n_lazy = 0; /* evaluation counters (wave-uniform) */
+            int n_full = 0, n_gs = 0; /* evaluation counters (wave-uniform) */
             /* lower bound of seg_o(vB', vT) for every vB' below the last fully evaluated step; before
              * the first one: on >= 0, and X = fl(fl(ic - 3 E2) + f_oi) >= -4 E2 (1 + u) since the computed
              * ic >= -E2 and f_oi >= 0 (`E2` here is 3 E2 of PruneRec: -2 * that = -6 E2) */
             float lbseg = -2.0f * E2;
-#if IS_P1_ROW_AHEAD == 2
-#define IS_P1_NEXT_ROW()                                                                           \
-            next_row = next2_row;                                                                  \
-            load_lut_row<NRW>(next2_row, lrsrc, lcol, max(vB - 2 * nw, 0), D, lane4r)
-#else
 #define IS_P1_NEXT_ROW() load_lut_row<NRW>(next_row, lrsrc, lcol, max(vB - nw, 0), D, lane4r)
-#endif
             /* (with an invalid-disparity value the step used to keep the scalar-load form: valid-count operands and
              * an IEEE division per step took the DPP form to 90+ VGPRs.  Round 5: the mean of a FAST column through
              * mean_valid_fast -- a table read and the exact-division shortcut -- so both run the same step) */
@@ -1133,9 +1091,8 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
                 const int vn = max(vB - nw, 0);                                                    \
                 const StepRec* sn = scol + vn;                                                     \
                 asm volatile("" : "+s"(sn) : "s"(__builtin_amdgcn_readfirstlane((int)(last_use))));    \
-                if (IS_P1_SREC_FIRST) srec_request_next(S, rcol + vn);                             \
                 st_next = IS_P1_SREC_LATE ? sload_step_raw(sn) : sload_step(sn);                   \
-                if (!IS_P1_SREC_FIRST) srec_request_next(S, rcol + vn);                            \
+                srec_request_next(S, rcol + vn);                                                   \
             }
 #define IS_P1_STEP(SKY, NOG)                                                                       \
             ISP1_COUNT(4);                                                                         \
@@ -1165,7 +1122,7 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
                     if (IS_P1_SREC) {                                                              \
                         if (IS_P1_SREC_LATE) pin_step(st);                                         \
                         srec_arrived(S);                                                           \
-                        t = eval_segment_mix<HAS_INVALID, WANT>(my, S, r1, (float)h, s_rcp[h], D, P.iw, 0.0f, s_rcp); \
+                        t = eval_segment_mix<HAS_INVALID, WANT>(my, S, r1, (float)h, s_rcp[h], D, P.iw, s_rcp); \
                     } else {                                                                       \
                         t = eval_segment_dpp<HAS_INVALID, WANT>(my, r0, r1, (float)h, s_rcp[h], D, P.iw, s_rcp); \
                     }                                                                              \
@@ -1326,10 +1283,10 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
             if (counters != nullptr && lane == 0) {
                 atomicAdd(counters + IS_CNT_P1_FULL, (unsigned long long)n_full);
                 atomicAdd(counters + IS_CNT_P1_GS, (unsigned long long)n_gs);
-                atomicAdd(counters + IS_CNT_P1_LAZY, (unsigned long long)(n_lazy + n_winmiss));
+                atomicAdd(counters + IS_CNT_P1_WINMISS, (unsigned long long)n_winmiss);
                 unsigned long long* ct = counters + IS_CNT_TILE0 + 3 * min(tile, 63);
                 atomicAdd(ct + 0, (unsigned long long)n_full);
-                atomicAdd(ct + 1, (unsigned long long)(n_lazy + n_winmiss));
+                atomicAdd(ct + 1, (unsigned long long)n_winmiss);
                 atomicAdd(ct + 2, (unsigned long long)n_gs);
             }
         }
@@ -2549,7 +2506,7 @@ hipError_t isk_launch_dp_pairwise(const DevParams* P, int ncols, int nwaves, con
          * 16 / 32: 1461 / 2068 / 2795 / 3178 classic, 1424 / 2010 / 2798 / 3269 windowed.  IS_P1_WIN_TILES
          * forces the window for that many tiles at any batch: tests) */
         /* (any D: the windowed instantiation keeps 64 columns of a vB row in one register per lane) */
-        const bool win_t = !IS_P1_GEN_TILE && IS_P1_WINDOWED(P->D) &&
+        const bool win_t = IS_P1_WINDOWED(P->D) &&
                            P->win_lo != nullptr && tile < P->win_tiles &&
                            (P->knob_win_tiles >= 0 || ncols >= IS_P1_WIN_MIN_COLS);
         const int nw_t = win_t ? nwaves_win : nwaves;

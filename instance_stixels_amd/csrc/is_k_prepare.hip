@@ -784,6 +784,11 @@ __device__ __forceinline__ void object_lut_body(const DevParams& P, const int co
 #pragma unroll
             for (int l = LUT_BLOCK - 1; l >= j; l--) c[l] += c[l - j];
         }
+#ifdef PREP_ABL_CARRY_ONLY /* timing-only ablation: only the carry rows 32 k are stored (what a DP that rebuilds the rest would need) */
+        if (fn_ok && i + LUT_BLOCK <= H) __builtin_nontemporal_store(c[LUT_BLOCK - 1], &lcol[(size_t)(i + LUT_BLOCK) * D + fnc]);
+        add = c[LUT_BLOCK - 1];
+        return;
+#endif
         if (full) {
 #pragma unroll
 #ifdef PREP_ABL_WRAP /* ablation: the same stores into 8 rows per column (absorbed by the L2): what do the HBM bytes cost */

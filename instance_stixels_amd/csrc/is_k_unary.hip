@@ -387,7 +387,7 @@ __global__ __launch_bounds__(IS_UNARY_WAVES * 64, IS_UNARY_OCC) void k_dp_unary(
     b.g = b.o = b.s = IS_INF;
     b.vg = b.vs = -1;
     b.vo = 0; /* index_table[vT*3+OBJECT] = OBJECT at vB = 0, :592 */
-    const float* my_tile = s_tile + IS_TILE_ROW(lane) * DP;
+    const float* my_tile = s_tile + lane * DP;
     const int vB_end = min(tile_lo + IS_TILE - 1, H - 1);
 #ifndef IS_ABL_NOLOOP
     if (FASTCOLS)

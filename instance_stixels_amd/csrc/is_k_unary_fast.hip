@@ -51,9 +51,6 @@
 #ifndef ISF_SREC
 #define ISF_SREC 1 /* the class-prefix half of the vB record as scalar operands (eval_segment_mix) */
 #endif
-#ifndef ISF_GEN_TILE
-#define ISF_GEN_TILE 0 /* 1: the vT-side lutT rows rebuilt in LDS (gen_lut_tile) instead of read back: -8.6 GB of HBM reads per 64 frames, but +9 % DP time (measured, round 3) */
-#endif
 #define ISF_THREADS (ISF_WAVES * 64)
 #ifndef ISF_WIN_WAVES
 #define ISF_WIN_WAVES 4 /* waves per workgroup of the windowed tiles */
@@ -94,7 +91,7 @@ __device__ __forceinline__ SegTerms fast_step(const DevParams& P, const RowRec& 
     /* FIRST (vB = 0): ground + object; otherwise the sky OR the ground candidate, or neither */
     constexpr int WANT = SKY ? IS_WANT_SKY : (NOGROUND ? 0 : IS_WANT_GROUND);
 #if ISF_SREC
-    const SegTerms t = eval_segment_mix<HAS_INVALID, WANT>(my, S, srec[16 + l15], (float)hc, r, P.D, P.iw, 0.0f, s_rcp);
+    const SegTerms t = eval_segment_mix<HAS_INVALID, WANT>(my, S, srec[16 + l15], (float)hc, r, P.D, P.iw, s_rcp);
 #else
     const SegTerms t = eval_segment_dpp<HAS_INVALID, WANT>(my, srec[l15], srec[16 + l15], (float)hc, r, P.D,
                                                            P.iw, s_rcp);
@@ -326,20 +323,10 @@ __global__ __launch_bounds__(ISF_THREADS, HAS_INVALID ? ISF_OCC_INV : ISF_OCC) v
         else ring_prefetch<NVR>(lcol, rcol, vq, D, my_ring + i * SLOT, my_ring + i * SLOT + ROWF, lane);
     }
     ISF_MARK(4); /* (debug build: ring requests issued) */
-#if ISF_GEN_TILE
-    /* (before this lane's record is requested: the 32 values of a block and the 32 dwords of the
-     * record together do not fit the register budget of 6 waves per SIMD) */
-    gen_lut_tile(s_tile, lcol, joined + (size_t)colg * H, cost_T, tile_lo, H, D, w, lane, ISF_WAVES);
-    asm volatile("" ::: "memory");
-    const RowRec my = load_rec(rcol + vTc + 1);
-    ISF_MARK(5); /* (debug build: record requested) */
-    stage_rcp(s_rcp, rcp, H, tid, ISF_THREADS);
-#else
     const RowRec my = load_rec(rcol + vTc + 1);
     ISF_MARK(5); /* (debug build: record requested) */
     if (WIN) stage_window_and_rcp(s_tile, s_rcp, lcol, rcp, tile_lo, H, D, win_lo, tid, (int)blockDim.x);
     else stage_tile_and_rcp(s_tile, s_rcp, lcol, rcp, tile_lo, H, D, tid, (int)blockDim.x);
-#endif
     int n_winmiss = 0;
     FastWin fwin;
     fwin.lo = win_lo;
@@ -364,7 +351,7 @@ __global__ __launch_bounds__(ISF_THREADS, HAS_INVALID ? ISF_OCC_INV : ISF_OCC) v
         b.g = cost_table[o + 0]; b.o = cost_table[o + 1]; b.s = cost_table[o + 2];
         b.vg = index_table[o + 0]; b.vo = index_table[o + 1]; b.vs = index_table[o + 2];
     }
-    const float* my_tile = s_tile + IS_TILE_ROW(lane) * DP;
+    const float* my_tile = s_tile + lane * DP;
     const bool nog = IS_SKIP_GROUND_ABOVE_HORIZON && tile_lo >= vhor;
     __syncthreads(); /* the tile and the 1/h table: the only data the waves share */
     ISF_MARK(0);
@@ -738,7 +725,7 @@ hipError_t isk_launch_dp_unary_fast(const DevParams* P, int ncols, const RowRec*
      * 20 instead of 52 KB of LDS per workgroup, seven 4-wave workgroups per CU instead of three 8-wave ones.  The
      * tiles do not depend on each other: the taller (classic) ones go first. */
     int wt = 0;
-    if (!pre_diag && !ISF_GEN_TILE && IS_P1_WINDOWED(P->D) && P->win_lo != nullptr &&
+    if (!pre_diag && IS_P1_WINDOWED(P->D) && P->win_lo != nullptr &&
         (P->knob_win_tiles >= 0 || ncols >= ISF_WIN_MIN_COLS))
         wt = P->win_tiles < P->ntiles ? P->win_tiles : P->ntiles;
     const int nw_win = ISF_WIN_WAVES;

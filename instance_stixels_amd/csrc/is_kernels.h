@@ -210,16 +210,6 @@ __device__ __forceinline__ RowRec load_rec(const RowRec* p) {
     return r;
 }
 
-/* LDS row of the vT-side tile that holds lutT row tile_lo + 1 + r.  A lane l reads column fni of ITS
- * row, i.e. bank (row(l) * (D + 1) + fni) mod 64 = (row(l) + fni) mod 64 when D is a multiple of 64.
- * On a ground ramp fni FALLS as the row rises, so with row(l) = l the sum l + fni is nearly constant
- * across the lanes: the padding skews the wrong way (38 % of the unary kernel's LDS cycles were
- * conflict cycles).  IS_TILE_FLIP stores the rows in reverse order, row(l) = 63 - l: the bank becomes
- * fni - l, which spreads. */
-#ifndef IS_TILE_FLIP
-#define IS_TILE_FLIP 0 /* measured (round 4): SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE 0.376 flipped vs 0.381, same DP time: the lanes' fni differ by far less than one per row, either skew spreads them */
-#endif
-#define IS_TILE_ROW(r) (IS_TILE_FLIP ? (IS_TILE - 1 - (r)) : (r))
 
 /* lutT rows tile_lo+1 .. tile_lo+64 of a column into the LDS tile (row stride D+1).  When the
  * workgroup covers whole rows per sweep (nthreads a multiple of D) a thread keeps its column and
@@ -249,7 +239,7 @@ __device__ __forceinline__ void stage_lut_tile(float* s_tile, const float* __res
             for (int k = 0; k < 4; k++) {
                 const int r = rb + k * dr;
                 if (r < IS_TILE) {
-                    float* d = s_tile + IS_TILE_ROW(r) * DP + f;
+                    float* d = s_tile + (r) * DP + f;
                     d[0] = x[k].x; d[1] = x[k].y; d[2] = x[k].z; d[3] = x[k].w;
                 }
             }
@@ -267,67 +257,14 @@ __device__ __forceinline__ void stage_lut_tile(float* s_tile, const float* __res
 #pragma unroll
             for (int k = 0; k < 8; k++) {
                 const int r = rb + k * dr;
-                if (r < IS_TILE) s_tile[IS_TILE_ROW(r) * DP + f] = x[k];
+                if (r < IS_TILE) s_tile[(r) * DP + f] = x[k];
             }
         }
     } else {
         for (int i = tid; i < IS_TILE * D; i += nthreads) {
             const int r = i / D, f = i - r * D;
             const int v = min(tile_lo + 1 + r, H);
-            s_tile[IS_TILE_ROW(r) * DP + f] = lcol[(size_t)v * D + f];
-        }
-    }
-}
-
-/* The vT-side tile, lutT rows tile_lo + 1 .. tile_lo + 64, REBUILT in LDS instead of read back:
- * k_object_lut chains 32-row blocks through their last row (StixelsKernels.cu:268-272), and those
- * carry rows are part of lutT, so a block's rows follow from lutT[block start] (512 B), the 32
- * disparities of the block and the L2-resident cost table -- the same Kogge-Stone network on the
- * same values in the same order (k_object_lut, is_k_prepare.hip): bit-identical rows.  A wave
- * takes one (block, 64 fn) task: 32 table loads + 129 additions + 32 LDS stores per lane against
- * 33 KB of lutT per workgroup -- the one compulsory read of the table (8.6 GB per 64 frames)
- * disappears from the DP's HBM traffic.  Rows beyond the image repeat lutT[H] like the staging
- * functions do. */
-__device__ __forceinline__ void gen_lut_tile(float* s_tile, const float* __restrict__ lcol,
-                                             const float* __restrict__ dcol,
-                                             const float* __restrict__ cost_T, int tile_lo, int H, int D,
-                                             int wave, int lane, int nwaves) {
-    constexpr int LB = 32; /* LUT_BLOCK of k_object_lut */
-    const int DP = D + 1;
-    const int fn_groups = (D + 63) >> 6;
-    for (int task = wave; task < 2 * fn_groups; task += nwaves) {
-        const int blk = task / fn_groups, fg = task - blk * fn_groups;
-        const int fn = fg * 64 + lane;
-        const bool fn_ok = fn < D;
-        const int fnc = fn_ok ? fn : D - 1;
-        const int i = tile_lo + LB * blk; /* the block's first row */
-        float* dst = s_tile + fn; /* row LB * blk + l at IS_TILE_ROW(LB * blk + l) */
-        const int row0 = LB * blk;
-        const float vH = (i + LB > H) ? lcol[(size_t)H * D + fnc] : 0.0f; /* rows beyond the image */
-        if (i >= H) {
-            if (fn_ok)
-                for (int l = 0; l < LB; l++) dst[IS_TILE_ROW(row0 + l) * DP] = vH;
-            continue;
-        }
-        const int rl = i + (lane & (LB - 1));
-        int dis_l = 0;
-        if (rl < H) dis_l = (int)dcol[rl];
-        dis_l = min(max(dis_l, 0), D - 1);
-        float c[LB];
-#pragma unroll
-        for (int l = 0; l < LB; l++) {
-            const int dis = __builtin_amdgcn_readlane(dis_l, l);
-            c[l] = cost_T[(size_t)dis * D + fnc];
-        }
-        c[0] += lcol[(size_t)i * D + fnc]; /* the carry: lutT[i][fn] */
-#pragma unroll
-        for (int j = 1; j < LB; j <<= 1) {
-#pragma unroll
-            for (int l = LB - 1; l >= j; l--) c[l] += c[l - j];
-        }
-        if (fn_ok) {
-#pragma unroll
-            for (int l = 0; l < LB; l++) dst[IS_TILE_ROW(row0 + l) * DP] = (i + l < H) ? c[l] : vH;
+            s_tile[(r) * DP + f] = lcol[(size_t)v * D + f];
         }
     }
 }
@@ -396,7 +333,7 @@ __device__ __forceinline__ void stage_tile_and_rcp(float* s_tile, float* s_rcp,
         const int r = spread ? sr : r0 + k * dr;
         const int f = spread ? (sq + 8 * k) * 4 : f0;
         if (r < IS_TILE) {
-            float* d = s_tile + IS_TILE_ROW(r) * DP + f;
+            float* d = s_tile + (r) * DP + f;
             d[0] = x[k].x; d[1] = x[k].y; d[2] = x[k].z; d[3] = x[k].w;
         }
     }
@@ -431,7 +368,7 @@ __device__ __forceinline__ void stage_window_and_rcp(float* s_tile, float* s_rcp
         for (int k = 0; k < NX; k++) {
             const int r = rb + k * dr;
             if (r < IS_TILE) {
-                float* d = s_tile + IS_TILE_ROW(r) * WPs + 4 * q;
+                float* d = s_tile + (r) * WPs + 4 * q;
                 d[0] = x[k].x; d[1] = x[k].y; d[2] = x[k].z; d[3] = x[k].w;
             }
         }
@@ -693,13 +630,10 @@ __device__ __forceinline__ void srec_request_next(isk_f16v& S, const RowRec* gre
 }
 __device__ __forceinline__ void srec_arrived(isk_f16v& S) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(S)); }
 
-/* MEAN_GIVEN: the caller has computed the raw mean (fast_div(my.S - S[vB], h, r), the first DPP read
- * of R1 in the step) already -- pairwise phase 1 evaluates the transition term before the rest */
-template <bool HAS_INVALID, int WANT = IS_WANT_GROUND | IS_WANT_SKY, bool MEAN_GIVEN = false>
+template <bool HAS_INVALID, int WANT = IS_WANT_GROUND | IS_WANT_SKY>
 __device__ __forceinline__ SegTerms eval_segment_mix(const RowRec& my, const isk_f16v& S, float R1,
                                                      float height, float r, int D, float iw,
-                                                     float mean_in = 0.0f, const float* rcp_tab = nullptr) {
-    /* (MEAN_GIVEN with HAS_INVALID is instantiated but never executed: the lazy step is the DPP path) */
+                                                     const float* rcp_tab = nullptr) {
     SegTerms t;
     const float nic = iw * (float)dpp_sub_i_first<3>(my.Fnic, R1);
     float f_g = 0.0f;
@@ -762,9 +696,7 @@ __device__ __forceinline__ SegTerms eval_segment_mix(const RowRec& my, const isk
     if (WANT & IS_WANT_GROUND) t.gd = dpp_sub<4>(my.G, R1);
     if (WANT & IS_WANT_SKY) t.sd = dpp_sub<5>(my.K, R1);
     float mean;
-    if (MEAN_GIVEN) {
-        mean = mean_in;
-    } else if (HAS_INVALID) {
+    if (HAS_INVALID) {
         const float valid_dif = dpp_sub<7>(my.V, R1);
         const float sdif = dpp_sub<6>(my.S, R1);
         if (rcp_tab != nullptr) mean = mean_valid_fast(sdif, valid_dif, rcp_tab);

@@ -25,7 +25,7 @@ EXPORTS = [
     "ish_get_parameters", "ish_get_luts", "ish_core_context", "ish_set_disparity_image",
     "ish_set_segmentation", "ish_set_road_parameters", "ish_get_ground_model", "ish_compute",
     "ish_get_instance_stixels", "ish_get_3d_vertices", "ish_save_stixels", "ish_time_compute",
-    "ish_set_device", "ish_compute_batch", "ish_time_compute_batch",
+    "ish_set_device", "ish_compute_batch", "ish_time_compute_batch", "ish_compute_batch_gather",
     "ire_create", "ire_destroy", "ire_initialize", "ire_finish", "ire_compute", "ire_get_binary",
     "ire_hough_lines", "ire_set_device", "ire_active_device", "ire_compute_device",
     "ish_get_input_disparity_on_device",
@@ -80,6 +80,7 @@ def lib():
         L.ish_time_compute.argtypes = [vp, ci, ci, ci, ctypes.POINTER(ctypes.c_double)]
         L.ish_set_device.argtypes = [vp, ci]
         L.ish_compute_batch.argtypes = [vp, ci, ci, vp, vp, vp, vp, vp, vp, ci, vp, vp]
+        L.ish_compute_batch_gather.argtypes = [vp, ci, ci, vp, vp, vp, vp, ci, vp, vp, ci, vp, vp, vp, vp]
         L.ish_time_compute_batch.argtypes = [vp, ci, ci, vp, vp, vp, ci, ci,
                                              ctypes.POINTER(ctypes.c_double)]
         L.ish_get_3d_vertices.argtypes = [vp, vp, cf, ci, vp, ci]
@@ -231,6 +232,29 @@ class Stixels:
         if with_instances:
             maps = [{(int(u), int(v)): int(l) for u, v, l in tri[i, :cnt[i]]} for i in range(n)]
         return data, maps
+
+    def ComputeBatchGather(self, pairwise, d_disparity_big, d_segmentation, road, comm, dst,
+                           images_per_rank, road_all=None, stream=0):
+        """Stixels::ComputeBatchGather: this rank's shard, then the RCCL gather of every rank's Sections on
+        rank `dst` of `comm` (an ncclComm_t as int, core.comm_init_rank).  road: this rank's tuples
+        (vhor_image, camera_tilt, camera_height, alpha_ground); road_all: those of ALL frames in rank
+        order (dst only).  Returns the list of StixelsData of all frames on dst, [] elsewhere."""
+        n = len(road)
+        C, S = self.GetRealCols(), self.GetMaxSections()
+        rp = np.ascontiguousarray(road, np.float32).reshape(n, 4)
+        ipr = np.ascontiguousarray(images_per_rank, np.int32)
+        n_all = int(ipr.sum())
+        ra = None if road_all is None else np.ascontiguousarray(road_all, np.float32).reshape(n_all, 4)
+        sec = np.zeros((n_all, C, S), SECTION_DTYPE)
+        vh = np.zeros(n_all, np.int32)
+        n_out = ctypes.c_int(0)
+        self._check(lib().ish_compute_batch_gather(
+            self._h, int(bool(pairwise)), n, d_disparity_big, d_segmentation, rp.ctypes.data,
+            ctypes.c_void_p(int(comm)), int(dst), ipr.ctypes.data, None if ra is None else ra.ctypes.data, n_all,
+            sec.ctypes.data, vh.ctypes.data, ctypes.byref(n_out), stream), "ComputeBatchGather")
+        cfg = self._cfg
+        return [StixelsData(sec[i], int(cfg.rows), int(cfg.cols), C, S, int(cfg.max_dis), int(cfg.column_step),
+                            int(cfg.n_semantic_classes), float(ra[i, 3]), int(vh[i])) for i in range(n_out.value)]
 
     def time_compute_batch(self, pairwise, d_disparity_big, d_segmentation, road, n_iter=5,
                            with_instances=False):

@@ -369,6 +369,15 @@ void Stixels::Finish() { /* Stixels.cu:250-283 */
     IS_CHECK_RETURN(is_device_free(d_instance_core_candidates));
     IS_CHECK_RETURN(is_device_free(d_instance_labels));
     IS_CHECK_RETURN(is_device_free(d_instance_packed));
+    IS_CHECK_RETURN(is_device_free(d_pack_counts));
+    IS_CHECK_RETURN(is_device_free(d_pack_offsets));
+    IS_CHECK_RETURN(is_device_free(d_pack_sections));
+    IS_CHECK_RETURN(is_device_free(d_all_counts));
+    IS_CHECK_RETURN(is_device_free(d_all_packed));
+    IS_CHECK_RETURN(is_device_free(d_all_sections));
+    d_pack_counts = d_pack_offsets = d_all_counts = nullptr;
+    d_pack_sections = d_all_packed = d_all_sections = nullptr;
+    m_all_columns_cap = m_all_packed_cap = 0;
     IS_CHECK_RETURN(is_host_free(h_stixels));
     IS_CHECK_RETURN(is_host_free(h_stixels_head));
     h_stixels_head = nullptr; d_stixels_block = nullptr;
@@ -567,6 +576,105 @@ void Stixels::ComputeBatch(bool pairwise, int n_images, const pixel_t* d_big,
     /* a following GetInstanceStixels() returns the mapping of frame 0 (slice 0 of the arrays) */
     for (int k = 0; k < m_instance_classes; k++) m_instances_per_class[k] = h_instance_head[k];
     m_labels_on_host = false;
+}
+
+/* The shard of this rank, then the compacted gather of every rank's Sections on `dst` (the
+ * C ABI underneath: is_pack_sections -> is_gather_sections -> is_unpack_sections). */
+void Stixels::ComputeBatchGather(bool pairwise, int n_images, const pixel_t* d_big, const int32_t* d_seg,
+                                 const RoadParameters* road, void* comm, int dst, const int* images_per_rank,
+                                 const RoadParameters* road_all, std::vector<StixelsData>& out, void* stream) {
+    if (n_images < 1 || n_images > m_max_batch)
+        throw std::invalid_argument("n_images outside [1, max_batch] of InitializeBatch().");
+    if (comm == nullptr || images_per_rank == nullptr)
+        throw std::invalid_argument("ComputeBatchGather needs a communicator and the shard sizes.");
+    const DeviceGuard guard(m_ctx_device);
+    if (stream == nullptr) stream = m_stream;
+    int rank = 0, nranks = 0;
+    IS_CHECK_RETURN(is_comm_rank(comm, &rank, &nranks));
+    if (images_per_rank[rank] != n_images)
+        throw std::invalid_argument("images_per_rank[rank] differs from n_images.");
+    if (rank == dst && road_all == nullptr)
+        throw std::invalid_argument("the destination rank needs road_all (the headers of every frame).");
+    const size_t per = (size_t)m_realcols * m_max_sections;
+    const int my_cols = n_images * m_realcols;
+
+    /* ---- this rank's shard: ground model on the host, JoinColumns + DP + back-trace on the device */
+    std::vector<float> gf((size_t)n_images * m_rows), ng(gf.size()), ig(gf.size());
+    std::vector<int> vh(n_images);
+    for (int i = 0; i < n_images; i++) {
+        GroundModel g;
+        vh[i] = m_rows - road[i].vhor - 1;
+        PrecomputeGround(vh[i], road[i].camera_tilt, road[i].camera_height, road[i].alpha_ground, g);
+        std::copy(g.function.begin(), g.function.end(), gf.begin() + (size_t)i * m_rows);
+        std::copy(g.normalization.begin(), g.normalization.end(), ng.begin() + (size_t)i * m_rows);
+        std::copy(g.inv_sigma2.begin(), g.inv_sigma2.end(), ig.begin() + (size_t)i * m_rows);
+    }
+    IS_CHECK_RETURN(is_join_columns(m_ctx, d_big, m_cols, m_median_join ? 1 : 0, d_disparity, n_images, stream));
+    IS_CHECK_RETURN(is_compute(m_ctx, d_disparity, d_seg, gf.data(), ng.data(), ig.data(), vh.data(),
+                               pairwise ? 1 : 0, n_images, d_stixels, nullptr, nullptr, nullptr, stream));
+
+    /* ---- pack: per-column counts + the used sections (10-40 of the 200 slots of a column) */
+    if (d_pack_counts == nullptr) {
+        const size_t cols = (size_t)m_max_batch * m_realcols;
+        IS_CHECK_RETURN(is_device_malloc((void**)&d_pack_counts, cols * sizeof(int32_t)));
+        IS_CHECK_RETURN(is_device_malloc((void**)&d_pack_offsets, (cols + 1) * sizeof(int32_t)));
+        IS_CHECK_RETURN(is_device_malloc((void**)&d_pack_sections, cols * (m_max_sections - 1) * sizeof(Section)));
+    }
+    IS_CHECK_RETURN(is_pack_sections((const is_section*)d_stixels, my_cols, m_max_sections, d_pack_counts,
+                                     d_pack_offsets, (is_section*)d_pack_sections, stream));
+
+    /* ---- gather on dst.  Landing buffers: counts for every column, sections for 64 per column at first
+     * (synthetic and real scenes use 10-60); when a batch needs more, EVERY rank sees IS_ENOMEM from the
+     * gather (dst's go-ahead), dst grows to the worst case and all ranks repeat the call */
+    std::vector<int32_t> columns(nranks);
+    size_t all_cols = 0;
+    int all_images = 0;
+    for (int r = 0; r < nranks; r++) {
+        columns[r] = images_per_rank[r] * m_realcols;
+        all_cols += (size_t)columns[r];
+        all_images += images_per_rank[r];
+    }
+    std::vector<int64_t> totals(nranks, 0);
+    if (rank == dst && (m_all_columns_cap < all_cols || d_all_counts == nullptr)) {
+        IS_CHECK_RETURN(is_stream_synchronize(stream));
+        IS_CHECK_RETURN(is_device_free(d_all_counts));
+        IS_CHECK_RETURN(is_device_free(d_all_sections));
+        IS_CHECK_RETURN(is_device_malloc((void**)&d_all_counts, (all_cols + 1) * sizeof(int32_t) * 2));
+        IS_CHECK_RETURN(is_device_malloc((void**)&d_all_sections, all_cols * m_max_sections * sizeof(Section)));
+        m_all_columns_cap = all_cols;
+    }
+    for (int attempt = 0;; attempt++) {
+        if (rank == dst) {
+            const size_t want = attempt == 0 ? all_cols * 64 : all_cols * (size_t)(m_max_sections - 1);
+            if (m_all_packed_cap < want) {
+                IS_CHECK_RETURN(is_stream_synchronize(stream));
+                IS_CHECK_RETURN(is_device_free(d_all_packed));
+                IS_CHECK_RETURN(is_device_malloc((void**)&d_all_packed, want * sizeof(Section)));
+                m_all_packed_cap = want;
+            }
+        }
+        const int rc = is_gather_sections(comm, dst, columns.data(), d_pack_counts, d_pack_offsets,
+                                          (const is_section*)d_pack_sections, d_all_counts,
+                                          (is_section*)d_all_packed, m_all_packed_cap, totals.data(), stream);
+        if (rc == IS_ENOMEM && attempt == 0) continue; /* (every rank takes this branch together) */
+        IS_CHECK_RETURN(rc);
+        break;
+    }
+    out.clear();
+    if (rank != dst) {
+        IS_CHECK_RETURN(is_stream_synchronize(stream)); /* the payload has left before the buffers are reused */
+        return;
+    }
+    /* ---- dst: back to fixed-stride Section arrays (terminators restored), one copy to the host per frame */
+    int32_t* d_all_offsets = d_all_counts + (all_cols + 1);
+    IS_CHECK_RETURN(is_unpack_sections(d_all_counts, d_all_offsets, (const is_section*)d_all_packed, (int)all_cols,
+                                       m_max_sections, (is_section*)d_all_sections, stream));
+    out.resize(all_images);
+    for (int i = 0; i < all_images; i++) {
+        FillHeader(out[i], road_all[i].alpha_ground, m_rows - road_all[i].vhor - 1);
+        IS_CHECK_RETURN(is_memcpy_d2h(out[i].sections.data(), d_all_sections + per * i, per * sizeof(Section), stream));
+    }
+    IS_CHECK_RETURN(is_stream_synchronize(stream));
 }
 
 /* ---------------------------------------------------------------- instances */

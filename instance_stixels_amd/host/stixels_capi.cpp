@@ -200,6 +200,36 @@ int ish_compute_batch(void* h, int pairwise, int n_images, const float* d_big, c
     });
 }
 
+/* ComputeBatchGather(): this rank's shard + the RCCL gather of every rank's Sections on `dst`.
+ * road: [n][4] of this rank; images_per_rank: [ranks]; road_all: [sum][4] (dst only, else null);
+ * sections_all: [sum][realcols*max_sections] on dst; *n_out: frames written (0 on the other ranks). */
+int ish_compute_batch_gather(void* h, int pairwise, int n_images, const float* d_big, const int32_t* d_seg,
+                             const float* road, void* comm, int dst, const int* images_per_rank,
+                             const float* road_all, int n_all, Section* sections_all, int* vhor_all,
+                             int* n_out, void* stream) {
+    return guard([&] {
+        Stixels* s = (Stixels*)h;
+        auto conv = [](const float* r, int n) {
+            std::vector<Stixels::RoadParameters> rp(n);
+            for (int i = 0; i < n; i++)
+                rp[i] = Stixels::RoadParameters{(int)r[4 * i], r[4 * i + 1], r[4 * i + 2], r[4 * i + 3]};
+            return rp;
+        };
+        const std::vector<Stixels::RoadParameters> rp = conv(road, n_images);
+        const std::vector<Stixels::RoadParameters> ra = road_all ? conv(road_all, n_all)
+                                                                 : std::vector<Stixels::RoadParameters>();
+        std::vector<StixelsData> out;
+        s->ComputeBatchGather(pairwise != 0, n_images, d_big, d_seg, rp.data(), comm, dst, images_per_rank,
+                              road_all ? ra.data() : nullptr, out, stream);
+        *n_out = (int)out.size();
+        for (size_t i = 0; i < out.size(); i++) {
+            std::memcpy(sections_all + i * out[i].sections.size(), out[i].sections.data(),
+                        out[i].sections.size() * sizeof(Section));
+            vhor_all[i] = out[i].vhor;
+        }
+    });
+}
+
 /* Times n_iter ComputeBatch() calls of n_images frames (inputs resident on the device), with or
  * without the per-frame instance mappings.  -> seconds per call. */
 int ish_time_compute_batch(void* h, int pairwise, int n_images, const float* d_big, const int32_t* d_seg,

@@ -982,6 +982,20 @@ def test_bench_force_dist_child_process_runs_the_rccl_gather(gather):
     assert line["gather"]["kind"] == gather and line["gather"]["bytes_per_rank_per_step"]
 
 
+def test_capi_rccl_gather_one_rank():
+    """The C-ABI gather for C++ callers (is_comm_*, is_gather_sections, Stixels::ComputeBatchGather) in a FRESH
+    child process on a one-rank RCCL communicator: ncclGather of the sizes and counts, the grouped
+    point-to-point payload path, dst's go-ahead (an undersized buffer is refused with IS_ENOMEM), the unpack,
+    and the host class against ComputeBatch and the oracle (tests/capi_gather_child.py)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "capi_gather_child.py")],
+                         capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert out.returncode == 0 and "GATHER_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
 def test_pack_sections_kernels_match_host_logic():
     """is_pack_sections / is_unpack_sections (the compacted payload of the multi-GPU gather,
     SURVEY.md 8e) on the device against the torch restatement the gloo tests use: counts, packed
