@@ -44,6 +44,7 @@ hipError_t isk_set_lds_unary(const DevParams*);
 hipError_t isk_set_lds_pairwise(const DevParams*, int);
 hipError_t isk_set_lds_backtrace(const DevParams*);
 int isk_debug_occupancy(const DevParams*, int);
+int isk_unary_uses_carry(const DevParams*, int);
 hipError_t isk_launch_cluster(int, float, int, int, const is_instance_buffers*,
                               const is_instance_buffers*, int32_t*, hipStream_t);
 size_t isk_phase2_lds_bytes(const DevParams* P);
@@ -314,6 +315,7 @@ static int ctx_init(is_ctx* c, const is_stixel_params* p, const float* obj_cost_
         d.knob_unary_diag = knob("IS_UNARY_DIAG") == 1; /* (experiment: off unless asked for) */
         d.knob_win_tiles = knob("IS_P1_WIN_TILES");
         d.knob_pw_waves = knob("IS_PW_WAVES");
+        d.knob_lut_carry = knob("IS_LUT_CARRY"); /* carry-only lutT (is_device.h): opt-in */
     }
     {
         /* branch-and-bound constants (PruneRec, is_device.h).  gamma_d bounds the relative error of
@@ -658,15 +660,16 @@ static int compute_enqueue(is_ctx* c, const float* d_joined, const int32_t* d_se
     float* ct = d_cost_table ? d_cost_table : c->d_cost_table;
     int32_t* it = d_index_table ? d_index_table : c->d_index_table;
 
+    DevParams Pw = P; /* (+ this call's windowed / classic tile split and the form of lutT) */
+    Pw.win_tiles = call_win_tiles(P, c->h_vhor_pinned[slot], n_images, pairwise);
+    Pw.lut_carry = (!pairwise && isk_unary_uses_carry(&Pw, ncols)) ? 1 : 0;
     if (timing) HIP_TRY(hipEventRecord(c->ev[0], stream));
     /* (d_n_generic is zero here: cleared at creation and by k_backtrace at the end of every call) */
-    HIP_TRY(isk_launch_prepare(&P, ncols, d_joined, d_seg, c->d_ground, c->d_vhor,
+    HIP_TRY(isk_launch_prepare(&Pw, ncols, d_joined, d_seg, c->d_ground, c->d_vhor,
                                c->d_obj_cost_lut, c->d_recs, c->d_lutT, c->d_col_flags, c->d_sv,
                                c->d_prune, c->d_n_generic, stream, c->aux_stream, c->ev_fork, c->ev_join));
     if (pairwise) HIP_TRY(isk_launch_priors(&P, c->d_ground, c->d_priors, n_images, stream));
     if (timing) HIP_TRY(hipEventRecord(c->ev[1], stream));
-    DevParams Pw = P; /* (+ this call's windowed / classic tile split) */
-    Pw.win_tiles = call_win_tiles(P, c->h_vhor_pinned[slot], n_images, pairwise);
     if (pairwise)
         HIP_TRY(isk_launch_dp_pairwise(&Pw, ncols, c->nwaves_pairwise, c->d_recs, c->d_lutT,
                                        d_joined, c->d_priors, c->d_odr, c->d_rcp, c->d_sv, c->d_vhor,

@@ -185,6 +185,10 @@ struct DevParams {
     int* win_lo;
     int win_tiles; /* the tiles 0 .. win_tiles - 1 of this call stage a window (set per call: unary every tile,
                     * pairwise phase 1 the tiles that start below every horizon of the batch) */
+    int knob_lut_carry; /* IS_LUT_CARRY=1: carry rows only wherever the DP can rebuild the rest (unary calls whose every
+                         * tile runs the windowed ring kernel); default: lutT is materialised (measured faster) */
+    int lut_carry;      /* set per call: k_object_lut stores only the rows 32 k of lutT (the carries of its 32-row
+                         * blocks, 1/32 of the table); the DP rebuilds the rows it reads (is_k_unary_fast.hip, GEN) */
 };
 
 /* fn windows (k_dp_unary_fast, k_pw_phase1).  A (column, tile) workgroup keeps lutT[vT + 1][*] of its 64 rows in

@@ -723,6 +723,11 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_columns(
 #ifndef PREP_LUT_NT
 #define PREP_LUT_NT 1
 #endif
+/* carry_only (DevParams::lut_carry): only the rows 32 k -- the carries the 32-row blocks are chained through,
+ * StixelsKernels.cu:268-272 -- are stored: 1/32 of the bytes.  The windowed unary ring kernel rebuilds the rows
+ * it reads from them (the same network on the same values: bit-identical), generic columns get their whole table
+ * from k_object_lut_generic afterwards. */
+template <bool CARRY_ONLY>
 __device__ __forceinline__ void object_lut_body(const DevParams& P, const int colg, const int fn_block,
                                                 const int lane, const float* __restrict__ joined,
                                                 const float* __restrict__ cost_T /*[dis][fn]*/,
@@ -784,12 +789,9 @@ __device__ __forceinline__ void object_lut_body(const DevParams& P, const int co
 #pragma unroll
             for (int l = LUT_BLOCK - 1; l >= j; l--) c[l] += c[l - j];
         }
-#ifdef PREP_ABL_CARRY_ONLY /* timing-only ablation: only the carry rows 32 k are stored (what a DP that rebuilds the rest would need) */
-        if (fn_ok && i + LUT_BLOCK <= H) __builtin_nontemporal_store(c[LUT_BLOCK - 1], &lcol[(size_t)(i + LUT_BLOCK) * D + fnc]);
-        add = c[LUT_BLOCK - 1];
-        return;
-#endif
-        if (full) {
+        if (CARRY_ONLY) {
+            if (fn_ok && i + LUT_BLOCK <= H) __builtin_nontemporal_store(c[LUT_BLOCK - 1], &lcol[(size_t)(i + LUT_BLOCK) * D + fn]);
+        } else if (full) {
 #pragma unroll
 #ifdef PREP_ABL_WRAP /* ablation: the same stores into 8 rows per column (absorbed by the L2): what do the HBM bytes cost */
             for (int l = 0; l < LUT_BLOCK; l++) lcol[(size_t)((i + l + 1) & 7) * D + fnc] = c[l];
@@ -818,7 +820,22 @@ __global__ __launch_bounds__(64) void k_object_lut(const DevParams P,
                                                    const float* __restrict__ joined,
                                                    const float* __restrict__ cost_T,
                                                    float* __restrict__ lutT) {
-    object_lut_body(P, (int)blockIdx.x, (int)blockIdx.y, (int)threadIdx.x, joined, cost_T, lutT);
+    object_lut_body<false>(P, (int)blockIdx.x, (int)blockIdx.y, (int)threadIdx.x, joined, cost_T, lutT);
+}
+
+/* After a carry-only prepare: the complete table of the GENERIC columns (k_dp_unary reads it as it is).  A small
+ * grid that leaves at once when the prepare kernel counted no generic column -- the normal case. */
+__global__ __launch_bounds__(64) void k_object_lut_generic(const DevParams P, int ncols, const float* __restrict__ joined,
+                                                           const float* __restrict__ cost_T, float* __restrict__ lutT,
+                                                           const int* __restrict__ col_flags,
+                                                           const int* __restrict__ n_generic) {
+    if (__builtin_amdgcn_readfirstlane(*n_generic) == 0) return;
+    const int fn_blocks = (P.D + 63) / 64;
+    for (int u = (int)blockIdx.x; u < ncols * fn_blocks; u += (int)gridDim.x) {
+        const int colg = u / fn_blocks;
+        if (__builtin_amdgcn_readfirstlane(col_flags[colg]) == 0) continue;
+        object_lut_body<false>(P, colg, u - colg * fn_blocks, (int)threadIdx.x, joined, cost_T, lutT);
+    }
 }
 
 /* Both preparation kernels in ONE launch: a 256-thread workgroup is either one column of
@@ -872,8 +889,12 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prepare_fused(
     if (is_lut) {
         const int fn_blocks = (P.D + 63) / 64;
         const int unit = lut_b * (PREP_THREADS / 64) + (int)(threadIdx.x >> 6);
-        if (unit < ncols * fn_blocks)
-            object_lut_body(P, unit / fn_blocks, unit % fn_blocks, (int)(threadIdx.x & 63), joined, cost_T, lutT);
+        if (unit < ncols * fn_blocks) {
+            if (P.lut_carry)
+                object_lut_body<true>(P, unit / fn_blocks, unit % fn_blocks, (int)(threadIdx.x & 63), joined, cost_T, lutT);
+            else
+                object_lut_body<false>(P, unit / fn_blocks, unit % fn_blocks, (int)(threadIdx.x & 63), joined, cost_T, lutT);
+        }
     } else {
         prepare_columns_body(P, col_b, smem, joined, seg, ground, vhor_arr, recs,
                              col_flags, sv_arr, prune, n_generic);
@@ -937,6 +958,11 @@ hipError_t isk_launch_prepare(const DevParams* P, int ncols, const float* joined
         hipLaunchKernelGGL(k_prepare_fused, dim3(ncols + n_lut), dim3(PREP_THREADS),
                            isk_prepare_lds_bytes(P), stream, *P, ncols, n_lut, joined, seg, ground, vhor,
                            cost_T, recs, lutT, col_flags, sv_arr, prune, n_generic);
+        if (P->lut_carry) {
+            const int g = units < 2048 ? units : 2048;
+            hipLaunchKernelGGL(k_object_lut_generic, dim3(g), dim3(64), 0, stream, *P, ncols, joined, cost_T, lutT,
+                               col_flags, n_generic);
+        }
         return hipGetLastError();
     }
     hipStream_t lut_stream = stream;

@@ -48,6 +48,9 @@
 #ifndef ISF_OCC
 #define ISF_OCC 7 /* waves per SIMD the kernel is compiled for: 68 VGPRs without spills; LDS keeps three workgroups = 6 per SIMD resident (7 measured 0.5-1 % faster than 6) */
 #endif
+#ifndef ISF_OCC_GEN
+#define ISF_OCC_GEN 5 /* the carry-only instantiation: the 32-value network of a rebuild next to the lane's 32-register record (7: 35 spilled VGPRs, the walk 3.6 x slower) */
+#endif
 #ifndef ISF_SREC
 #define ISF_SREC 1 /* the class-prefix half of the vB record as scalar operands (eval_segment_mix) */
 #endif
@@ -75,8 +78,197 @@ struct FastWin {
     const float* grow; /* lutT row vT + 1 of this lane in global memory */
     const float* gcol; /* lutT of the column (row vB: gcol + vB * D) */
     int* misses;       /* wave-uniform count of steps with a lane outside */
+    /* GEN (carry-only lutT): what lut_entry_exact needs, and the slack of the lazy test */
+    const float* dcol;   /* joined disparities of the column */
+    const float* cost_T; /* [dis][fn] object data costs */
+    int vT1;             /* min(vT + 1, H): the lutT row of this lane */
+    float E1o;           /* PruneRec.E1o: fl(dw od) >= -E1o for every segment of the column */
 };
-template <bool HAS_INVALID, bool SKY, bool DIAG, bool FIRST, bool NOGROUND, bool WIN = false>
+
+/* ====================================================================================== */
+/* GEN: the lutT rows the walk reads, REBUILT from the carry rows (DevParams::lut_carry)     */
+/* ====================================================================================== */
+/* k_object_lut chains 32-row blocks: block k takes the per-row costs x[l] = cost_T[(int)d[32 k + l]][fn], adds
+ * its carry lutT[32 k][fn] into x[0] and runs the 32-element Kogge-Stone network c[l] += c[l - j], j = 1, 2, 4,
+ * 8, 16 (StixelsKernels.cu:249-272; object_lut_body, is_k_prepare.hip); c[l] is lutT[32 k + l + 1][fn] and c[31]
+ * the next carry.  In carry-only calls the prepare kernel stores just the rows 32 k -- 1/32 of its 8.6 GB per 64
+ * frames -- and this kernel recomputes the rows it reads with the SAME additions on the same values in the same
+ * association: bit-identical rows.
+ *   - the vT-side tile (rows tile_lo + 1 .. tile_lo + 64 = the outputs of the blocks 2 t and 2 t + 1, the 32
+ *     window columns): wave 0 in the prologue, block 2 t in lanes 0-31, block 2 t + 1 in lanes 32-63;
+ *   - the vB side: a wave visits vB = vB_top - 4 m, i.e. the rows l = (vB - 1) mod 32 of ONE residue class mod 4
+ *     of every block below its tile.  It rebuilds those 8 rows of TWO blocks at a time (lanes 0-31: block k,
+ *     lanes 32-63: block k - 1) into a private LDS cache that serves its next 16 steps: of the network only the
+ *     nodes those 8 outputs depend on (48 additions instead of 129);
+ *   - a lane whose floor(mean) falls outside the window needs an entry nobody rebuilt: first the lazy test (the
+ *     candidate cannot win whatever its data term is: skipped, exactly), else lut_entry_exact. */
+#ifndef ISF_GEN
+#define ISF_GEN 1
+#endif
+#define ISF_GEN_HALF_F (8 * IS_P1_WIN + 32) /* floats of one half's 8 cached rows; + 32: the halves' stores hit disjoint banks */
+#define ISF_GEN_CACHE_F (2 * ISF_GEN_HALF_F) /* per wave; its first 64 words double as the staging of the row offsets */
+
+/* A wave-uniform pointer that arrives in VGPRs (arguments of a called function do) back into SGPRs: loads through
+ * it then take the scalar-base form again. */
+template <typename T>
+__device__ __forceinline__ T* uniform_ptr(T* p) {
+    const unsigned long long a = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    return (T*)(((unsigned long long)hi << 32) | lo);
+}
+
+/* byte offset of row `row` of the column in cost_T: (int)d clamped like object_lut_body does; rows beyond the
+ * image use dis = 0 (:244-247) */
+__device__ __forceinline__ int gen_row_offset(const float* __restrict__ dcol, int row, int H, int D) {
+    int dis = (row >= 0 && row < H) ? (int)dcol[row] : 0;
+    dis = min(max(dis, 0), D - 1);
+    return dis * D * (int)sizeof(float);
+}
+
+/* The outputs c[l], l = RHO, RHO + 4, .., RHO + 28, of the network on x[0..31] (x[0] already holds the carry):
+ * only the nodes they depend on.  Level j keeps the positions the next level reads. */
+template <int RHO>
+__device__ __forceinline__ void gen_rows_of_residue(const float (&x)[32], float (&out)[8]) {
+    constexpr int P1 = RHO & 1;
+    float c1[16]; /* positions P1 + 2 i */
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const int p = P1 + 2 * i;
+        c1[i] = (p >= 1) ? x[p] + x[p - 1] : x[p];
+    }
+    float c2[8]; /* positions RHO + 4 i: c1[p] + c1[p - 2] */
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int p = RHO + 4 * i;
+        c2[i] = (p >= 2) ? c1[(p - P1) / 2] + c1[(p - 2 - P1) / 2] : c1[(p - P1) / 2];
+    }
+    float c3[8]; /* c2[p] + c2[p - 4] */
+#pragma unroll
+    for (int i = 0; i < 8; i++) c3[i] = (RHO + 4 * i >= 4) ? c2[i] + c2[i - 1] : c2[i];
+    float c4[8]; /* c3[p] + c3[p - 8] */
+#pragma unroll
+    for (int i = 0; i < 8; i++) c4[i] = (RHO + 4 * i >= 8) ? c3[i] + c3[i - 2] : c3[i];
+#pragma unroll
+    for (int i = 0; i < 8; i++) out[i] = (RHO + 4 * i >= 16) ? c4[i] + c4[i - 4] : c4[i];
+}
+
+/* The rows of residue RHO of the blocks k (lanes 0-31) and k - 1 (lanes 32-63), window columns win_lo + (lane &
+ * 31), into the wave's cache: row j of a half at cache[half * ISF_GEN_HALF_F + j * IS_P1_WIN + column].  The
+ * block's 32 row offsets go through the first 64 words of the cache (every row of it is dead when a rebuild
+ * starts: the walk only descends), so that a lane reads the offsets of ITS half's block with plain LDS loads. */
+/* (inlined: as CALLED functions the rebuilds made the compiler keep 70 values of the walk in scratch for good -- what
+ * lives across a call must sit in the 32 callee-saved VGPRs of a 72-register budget)*/
+template <int RHO>
+__device__ __forceinline__ void gen_rebuild_rows(float* cache, const float* lcol_, const float* dcol_, const float* cost_T_,
+                                              int k, int win_lo, int H, int D) {
+    const float* __restrict__ lcol = uniform_ptr(lcol_);
+    const float* __restrict__ dcol = uniform_ptr(dcol_);
+    const float* __restrict__ cost_T = uniform_ptr(cost_T_);
+    k = __builtin_amdgcn_readfirstlane(k); win_lo = __builtin_amdgcn_readfirstlane(win_lo);
+    H = __builtin_amdgcn_readfirstlane(H); D = __builtin_amdgcn_readfirstlane(D);
+    const int lane = (int)(threadIdx.x & 63);
+    const int half = lane >> 5, c = lane & 31;
+    const int kh = max(k - half, 0); /* (block -1 does not exist: recomputes block 0, never read) */
+    int* s_off = (int*)cache;
+    s_off[lane] = gen_row_offset(dcol, 32 * kh + c, H, D);
+    const int fn = min(win_lo + c, D - 1);
+    const unsigned fn4 = (unsigned)fn * 4u; /* (uniform base + 32-bit lane offset: one integer addition per load) */
+    const float carry = lcol[(size_t)(32 * kh) * D + fn];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* (one wave: its own LDS stores are visible to its loads) */
+    float x[32];
+#pragma unroll
+    for (int p = 0; p < 32; p++)
+        x[p] = *(const float*)((const char*)cost_T + (size_t)((unsigned)s_off[half * 32 + p] + fn4));
+    x[0] += carry; /* :249-251 */
+    float out[8];
+    gen_rows_of_residue<RHO>(x, out);
+    asm volatile("" ::: "memory");
+    float* dst = cache + half * ISF_GEN_HALF_F + c;
+#pragma unroll
+    for (int j = 0; j < 8; j++) dst[j * IS_P1_WIN] = out[j];
+}
+
+/* The vT-side tile of a carry-only call: lutT rows tile_lo + 1 .. tile_lo + 64, window columns, by ONE wave (block
+ * 2 t in lanes 0-31, block 2 t + 1 in lanes 32-63); s_off: 64 words of scratch.  Rows beyond the image hold
+ * values no live lane reads. */
+__device__ __forceinline__ void gen_window_tile(float* s_tile, int* s_off, const float* lcol_, const float* dcol_,
+                                             const float* cost_T_, int tile_lo, int win_lo, int H, int D) {
+    const float* __restrict__ lcol = uniform_ptr(lcol_);
+    const float* __restrict__ dcol = uniform_ptr(dcol_);
+    const float* __restrict__ cost_T = uniform_ptr(cost_T_);
+    tile_lo = __builtin_amdgcn_readfirstlane(tile_lo); win_lo = __builtin_amdgcn_readfirstlane(win_lo);
+    H = __builtin_amdgcn_readfirstlane(H); D = __builtin_amdgcn_readfirstlane(D);
+    const int lane = (int)(threadIdx.x & 63);
+    constexpr int WPs = IS_P1_WIN + 1;
+    const int half = lane >> 5, c = lane & 31;
+    const int i0 = tile_lo + 32 * half; /* the block's first row (a multiple of 32) */
+    s_off[lane] = gen_row_offset(dcol, i0 + c, H, D);
+    const int fn = min(win_lo + c, D - 1);
+    const unsigned fn4 = (unsigned)fn * 4u;
+    const float carry = lcol[(size_t)min(i0, (H / 32) * 32) * D + fn]; /* (a block that starts beyond the image is never read) */
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    float x[32];
+#pragma unroll
+    for (int p = 0; p < 32; p++)
+        x[p] = *(const float*)((const char*)cost_T + (size_t)((unsigned)s_off[half * 32 + p] + fn4));
+    x[0] += carry;
+#pragma unroll
+    for (int j = 1; j < 32; j <<= 1) {
+#pragma unroll
+        for (int l = 31; l >= j; l--) x[l] += x[l - j];
+    }
+    float* dst = s_tile + (32 * half) * WPs + c;
+#pragma unroll
+    for (int l = 0; l < 32; l++) dst[l * WPs] = x[l];
+}
+
+/* lutT[v][fn] of the column for ANY (v, fn), per lane, from the carry rows: the slow, exact path of the lanes
+ * outside every window.  v = 32 k + l + 1: position l of block k; with y[q] = x[l - q] the network's value at
+ * position l is a fixed binary tree over y[0..31] in which a node whose right half would start below position 0
+ * keeps its left half (c[p] += c[p - j] only for p >= j): node i of level j covers y[i 2^j .. (i + 1) 2^j - 1] and
+ * joins its halves when the left half's top position l - i 2^j is at least 2^(j - 1).  Evaluated depth first, four
+ * leaves at a time: a handful of registers, but up to eight dependent pairs of loads (measured: with all 64 loads
+ * in flight the function needs 40 registers more, and what lives across a CALL must sit in callee-saved
+ * registers -- 36 spilled VGPRs of the walk, 11.9 instead of 8.1 ms; inlined into the seven step variants: 224). */
+__device__ __noinline__ float lut_entry_exact(const float* __restrict__ lcol, const float* __restrict__ dcol,
+                                              const float* __restrict__ cost_T, int v, int fn, int H, int D) {
+    if ((v & 31) == 0) return lcol[(size_t)v * D + fn]; /* a carry row: materialised */
+    const int k = (v - 1) >> 5, l = (v - 1) & 31;
+    const float carry = lcol[(size_t)(32 * k) * D + fn];
+    const char* tbase = (const char*)(cost_T + fn);
+    auto y = [&](int q) -> float { /* x[l - q]; positions below 0 are read (clamped) but never used */
+        const int p = l - q;
+        const float xv = *(const float*)(tbase + gen_row_offset(dcol, 32 * k + max(p, 0), H, D));
+        return (p == 0) ? xv + carry : xv; /* :249-251, the carry enters at position 0 */
+    };
+    float t5 = 0.0f;
+#pragma unroll 1
+    for (int i4 = 0; i4 < 2; i4++) {
+        float t4 = 0.0f;
+        if (i4 == 1 && !(l >= 16)) break;
+#pragma unroll 1
+        for (int i3 = 0; i3 < 2; i3++) {
+            const int b3 = 16 * i4 + 8 * i3;
+            if (i3 == 1 && !(l - 16 * i4 >= 8)) break;
+            float t3 = 0.0f;
+#pragma unroll
+            for (int i2 = 0; i2 < 2; i2++) {
+                const int b2 = b3 + 4 * i2;
+                if (i2 == 1 && !(l - b3 >= 4)) break;
+                const float y0 = y(b2), y1 = y(b2 + 1), y2 = y(b2 + 2), y3 = y(b2 + 3);
+                const float t1a = (l - b2 >= 1) ? y0 + y1 : y0;
+                const float t1b = (l - b2 - 2 >= 1) ? y2 + y3 : y2;
+                const float t2 = (l - b2 >= 2) ? t1a + t1b : t1a;
+                t3 = (i2 == 0) ? t2 : t3 + t2;
+            }
+            t4 = (i3 == 0) ? t3 : t4 + t3;
+        }
+        t5 = (i4 == 0) ? t4 : t5 + t4;
+    }
+    return t5;
+}
+template <bool HAS_INVALID, bool SKY, bool DIAG, bool FIRST, bool NOGROUND, bool WIN = false, bool GEN = false>
 __device__ __forceinline__ SegTerms fast_step(const DevParams& P, const RowRec& my, const float* srec,
                                               const float* lrow, const float* my_tile,
                                               const float* s_rcp, int vT, int vTc, int vhor, int vB,
@@ -108,13 +300,32 @@ __device__ __forceinline__ SegTerms fast_step(const DevParams& P, const RowRec& 
          * fetches the SAME window of every vB row: 128 instead of 512 bytes per step) */
         vtv = my_tile[inw ? fo : 0];
         vbv = lrow[inw ? fo : 0];
-        if (__builtin_amdgcn_ballot_w64(live && !inw) != 0ull) { /* (the dead lanes of a diagonal step hold no segment) */
-            if (live && !inw) {
-                vtv = win.grow[(unsigned)t.fni];
-                vbv = (win.gcol + (size_t)vB * P.D)[(unsigned)t.fni];
+        bool need = live && !inw; /* (the dead lanes of a diagonal step hold no segment) */
+        if (GEN) {
+            /* the lazy test: whatever its data term is, fl(dw od) >= -E1o (lemma L3), so by monotone rounding
+             * cost_o >= fl(fl(-E1o + pw / h) + fl(sw seg_o)); a candidate whose bound already exceeds the lane's best
+             * object cost cannot pass the `<=` update: it needs no table entry (its od is set to +inf below, the
+             * update then fails the same way).  E1o = +inf (pruning off for the column): never skipped. */
+            const float lazy = (P.pw * r - win.E1o) + P.sw * t.seg_o;
+            need = need && !(lazy > b.o);
+        }
+        if (__builtin_amdgcn_ballot_w64(need) != 0ull) {
+            if (need) {
+                if (GEN) {
+#ifdef ISF_GEN_ABL_NOSLOW /* timing-only ablation (wrong results): what do the exact entries cost */
+                    vtv = 1.0f; vbv = 0.0f;
+#else
+                    vtv = lut_entry_exact(win.gcol, win.dcol, win.cost_T, win.vT1, t.fni, P.H, P.D);
+                    vbv = lut_entry_exact(win.gcol, win.dcol, win.cost_T, vB, t.fni, P.H, P.D);
+#endif
+                } else {
+                    vtv = win.grow[(unsigned)t.fni];
+                    vbv = (win.gcol + (size_t)vB * P.D)[(unsigned)t.fni];
+                }
             }
             (*win.misses)++;
         }
+        if (GEN && live && !inw && !need) vtv = IS_INF, vbv = 0.0f; /* skipped: cost_o = +inf, never taken (b.o is finite: lazy > b.o) */
     } else {
         vtv = my_tile[t.fni];
         vbv = lrow[t.fni];
@@ -257,10 +468,16 @@ __device__ __forceinline__ void ring_prefetch_win(const float* __restrict__ lcol
     dma_dword(g, lds_addr(slot));
 }
 
+/* GEN: the slot is the record alone (32 lanes) */
+__device__ __forceinline__ void ring_prefetch_rec(const RowRec* __restrict__ rcol, int vB, float* slot, int lane) {
+    if (lane < ISF_REC_F) dma_dword((const float*)(rcol + vB) + lane, lds_addr(slot));
+}
+
 /* PRE_DIAG: the instantiation that starts from the minima k_dp_unary_diag left in the tables (an
  * instantiation of its own: as a run-time flag the path cost the unpruned walk 1.8 %) */
-template <bool HAS_INVALID, int NVR, bool PRE_DIAG = false, bool WIN = false>
-__global__ __launch_bounds__(ISF_THREADS, HAS_INVALID ? ISF_OCC_INV : ISF_OCC) void k_dp_unary_fast(
+/* GEN (with WIN): lutT holds only its carry rows (DevParams::lut_carry); the tile and the vB-side rows are rebuilt */
+template <bool HAS_INVALID, int NVR, bool PRE_DIAG = false, bool WIN = false, bool GEN = false>
+__global__ __launch_bounds__(ISF_THREADS, GEN ? ISF_OCC_GEN : (HAS_INVALID ? ISF_OCC_INV : ISF_OCC)) void k_dp_unary_fast(
     const DevParams P, int ncols, const RowRec* __restrict__ recs, const float* __restrict__ lutT,
     const float* __restrict__ rcp, const int* __restrict__ vhor_arr,
     const int* __restrict__ col_flags, const PruneRec* __restrict__ prune,
@@ -272,9 +489,10 @@ __global__ __launch_bounds__(ISF_THREADS, HAS_INVALID ? ISF_OCC_INV : ISF_OCC) v
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int H = P.H, D = P.D;
     const int DP = (WIN ? IS_P1_WIN : D) + 1; /* WIN: the tile holds an fn window of its rows (is_device.h) */
-    const int nwv = (int)(blockDim.x >> 6);   /* waves of the workgroup: 8, or 4 for the windowed tiles */
+    const int nwv = (int)(blockDim.x >> 6);   /* waves of the workgroup: 8, or 4 for the windowed tiles (GEN: 4, the stride its row residues assume) */
     constexpr int K = ISF_RING;
-    constexpr int ROWF = WIN ? IS_P1_WIN : 64 * NVR; /* floats of a row slot (WIN: the fn window of the row) */
+    static_assert(!GEN || (WIN && !PRE_DIAG), "the rebuilt rows are window rows");
+    constexpr int ROWF = GEN ? 0 : (WIN ? IS_P1_WIN : 64 * NVR); /* floats of a row slot (WIN: the fn window of the row; GEN: none, the rows are rebuilt) */
     constexpr int NV = WIN ? 1 : NVR + 1;            /* VMEM instructions per slot fill */
     constexpr int SLOT = ROWF + ISF_REC_F;     /* floats of a ring slot */
     float* s_rcp = (float*)smem;                        /* [H+1 -> x4]                       */
@@ -283,6 +501,8 @@ __global__ __launch_bounds__(ISF_THREADS, HAS_INVALID ? ISF_OCC_INV : ISF_OCC) v
     const int merge_f = 2 * nwv * 3 * 64 + 2 * 3 * 64;
     const int tile_f = max((IS_TILE * DP + 3) & ~3, merge_f);
     float* s_ring = s_tile + tile_f;                    /* [8 waves][K][SLOT]                */
+    float* s_cache = s_ring + (size_t)nwv * K * SLOT;   /* GEN: [waves][ISF_GEN_CACHE_F] rebuilt vB-side rows */
+    float* s_zero = s_cache + (size_t)nwv * ISF_GEN_CACHE_F; /* GEN: [IS_P1_WIN] lutT row 0 */
 
     /* XCD-aware order: blocks b, b+8, ... share an XCD/L2; the tiles of a column stay on one XCD
      * (they fetch the same lutT rows) and the tallest tiles start first */
@@ -319,13 +539,20 @@ __global__ __launch_bounds__(ISF_THREADS, HAS_INVALID ? ISF_OCC_INV : ISF_OCC) v
     for (int i = 0; i < K; i++)
     {
         const int vq = max(vB_top - nwv * i, 0);
-        if (WIN) ring_prefetch_win(lcol, rcol, vq, D, win_lo, my_ring + i * SLOT, lane);
+        if (GEN) ring_prefetch_rec(rcol, vq, my_ring + i * SLOT, lane);
+        else if (WIN) ring_prefetch_win(lcol, rcol, vq, D, win_lo, my_ring + i * SLOT, lane);
         else ring_prefetch<NVR>(lcol, rcol, vq, D, my_ring + i * SLOT, my_ring + i * SLOT + ROWF, lane);
     }
     ISF_MARK(4); /* (debug build: ring requests issued) */
     const RowRec my = load_rec(rcol + vTc + 1);
     ISF_MARK(5); /* (debug build: record requested) */
-    if (WIN) stage_window_and_rcp(s_tile, s_rcp, lcol, rcp, tile_lo, H, D, win_lo, tid, (int)blockDim.x);
+    float* my_cache = s_cache + (size_t)w * ISF_GEN_CACHE_F;
+    if (GEN) {
+        /* wave 0 rebuilds the tile (its cache is the scratch of the row offsets), the others stage the 1/h table */
+        if (w == 0) gen_window_tile(s_tile, (int*)my_cache, lcol, joined + (size_t)colg * H, cost_T, tile_lo, win_lo, H, D);
+        else stage_rcp(s_rcp, rcp, H, tid - 64, (int)blockDim.x - 64);
+        if (tid < IS_P1_WIN) s_zero[tid] = 0.0f; /* lutT[0][*] = 0, :283-285 */
+    } else if (WIN) stage_window_and_rcp(s_tile, s_rcp, lcol, rcp, tile_lo, H, D, win_lo, tid, (int)blockDim.x);
     else stage_tile_and_rcp(s_tile, s_rcp, lcol, rcp, tile_lo, H, D, tid, (int)blockDim.x);
     int n_winmiss = 0;
     FastWin fwin;
@@ -333,6 +560,9 @@ __global__ __launch_bounds__(ISF_THREADS, HAS_INVALID ? ISF_OCC_INV : ISF_OCC) v
     fwin.grow = lcol + (size_t)(vTc + 1) * D;
     fwin.gcol = lcol;
     fwin.misses = &n_winmiss;
+    fwin.dcol = joined + (size_t)colg * H;
+    fwin.cost_T = cost_T;
+    fwin.vT1 = min(vT + 1, H);
     ISF_MARK(6); /* (debug build: tile + 1/h table staged; mark 0 then = the barrier) */
 
     PruneValsF pv;
@@ -342,6 +572,7 @@ __global__ __launch_bounds__(ISF_THREADS, HAS_INVALID ? ISF_OCC_INV : ISF_OCC) v
         pv.dead = ~__builtin_amdgcn_ballot_w64(row_ok);
         pv.gdead = pv.dead | __builtin_amdgcn_ballot_w64(my.G == IS_INF);
     }
+    fwin.E1o = pv.E1o;
     UnaryBestF b;
     b.g = b.o = b.s = IS_INF;
     b.vg = b.vs = -1;
@@ -358,6 +589,17 @@ __global__ __launch_bounds__(ISF_THREADS, HAS_INVALID ? ISF_OCC_INV : ISF_OCC) v
 
     /* ---- the wave's walk, vB downwards; slot i % K holds step i */
     int slot = 0;
+    int gen_k = -100; /* GEN: the cache holds the rows of this wave's residue of the blocks gen_k and gen_k - 1 */
+    auto gen_rebuild = [&](int kb, int rho) { /* (one residue per wave: vB steps by the 4 waves of the workgroup) */
+        const float* dcol = joined + (size_t)colg * H;
+        switch (rho) {
+        case 0: gen_rebuild_rows<0>(my_cache, lcol, dcol, cost_T, kb, win_lo, H, D); break;
+        case 1: gen_rebuild_rows<1>(my_cache, lcol, dcol, cost_T, kb, win_lo, H, D); break;
+        case 2: gen_rebuild_rows<2>(my_cache, lcol, dcol, cost_T, kb, win_lo, H, D); break;
+        default: gen_rebuild_rows<3>(my_cache, lcol, dcol, cost_T, kb, win_lo, H, D); break;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* the cache rows are written before they are read */
+    };
     bool o_closed = false;
     int n_full = 0, n_gs = 0; /* steps below the diagonal block (wave-uniform: SALU only) */
     isk_f16v S; /* the class prefixes of the record of vB as scalars, requested one step ahead */
@@ -373,6 +615,20 @@ __global__ __launch_bounds__(ISF_THREADS, HAS_INVALID ? ISF_OCC_INV : ISF_OCC) v
         const float* rb = s_row + ROWF; /* the record of vB in the ring slot */
         const float* lrow = s_row;
         const bool diag = vB > tile_lo;
+        if (GEN && !(ISF_GS_STEPS && o_closed && vB != 0)) { /* (a ground / sky-only step reads no table entry) */
+            if (diag) {
+                lrow = s_tile + (vB - tile_lo - 1) * DP; /* a row of the tile itself */
+            } else if (vB == 0) {
+                lrow = s_zero;
+            } else {
+                const int kb = (vB - 1) >> 5; /* row vB = output (vB - 1) mod 32 of block kb */
+                if (kb != gen_k && kb != gen_k - 1) {
+                    gen_rebuild(kb, (vB - 1) & 3);
+                    gen_k = kb;
+                }
+                lrow = my_cache + (gen_k - kb) * ISF_GEN_HALF_F + (((vB - 1) & 31) >> 2) * IS_P1_WIN;
+            }
+        }
         bool done = false;
         int ok = 0;
         if (ISF_GS_STEPS && o_closed && vB != 0) { /* (closed in a full step: the diagonal is over) */
@@ -387,30 +643,30 @@ __global__ __launch_bounds__(ISF_THREADS, HAS_INVALID ? ISF_OCC_INV : ISF_OCC) v
         n_full += diag ? 0 : 1;
         if (vB == 0) { /* first segment (:481-594): ground + object */
             if (diag)
-                fast_step<HAS_INVALID, false, true, true, false, WIN>(P, my, rb, lrow, my_tile, s_rcp, vT, vTc, vhor,
+                fast_step<HAS_INVALID, false, true, true, false, WIN, GEN>(P, my, rb, lrow, my_tile, s_rcp, vT, vTc, vhor,
                                                                       0, row_ok, b, S, fwin);
             else
-                fast_step<HAS_INVALID, false, false, true, false, WIN>(P, my, rb, lrow, my_tile, s_rcp, vT, vTc,
+                fast_step<HAS_INVALID, false, false, true, false, WIN, GEN>(P, my, rb, lrow, my_tile, s_rcp, vT, vTc,
                                                                        vhor, 0, row_ok, b, S, fwin);
         } else if (vB > vhor) { /* vB - 1 >= vhor: sky + object (:729) */
             if (diag) {
-                fast_step<HAS_INVALID, true, true, false, false, WIN>(P, my, rb, lrow, my_tile, s_rcp, vT, vTc, vhor,
+                fast_step<HAS_INVALID, true, true, false, false, WIN, GEN>(P, my, rb, lrow, my_tile, s_rcp, vT, vTc, vhor,
                                                                       vB, row_ok, b, S, fwin);
             } else {
-                const SegTerms t = fast_step<HAS_INVALID, true, false, false, false, WIN>(
+                const SegTerms t = fast_step<HAS_INVALID, true, false, false, false, WIN, GEN>(
                     P, my, rb, lrow, my_tile, s_rcp, vT, vTc, vhor, vB, row_ok, b, S, fwin);
                 if (IS_PRUNE) ok = fast_bounds<true, false>(P, pv, t, b);
             }
         } else { /* ground + object (:687) */
             if (diag) {
-                fast_step<HAS_INVALID, false, true, false, false, WIN>(P, my, rb, lrow, my_tile, s_rcp, vT, vTc, vhor,
+                fast_step<HAS_INVALID, false, true, false, false, WIN, GEN>(P, my, rb, lrow, my_tile, s_rcp, vT, vTc, vhor,
                                                                        vB, row_ok, b, S, fwin);
             } else if (nog) {
-                const SegTerms t = fast_step<HAS_INVALID, false, false, false, true, WIN>(
+                const SegTerms t = fast_step<HAS_INVALID, false, false, false, true, WIN, GEN>(
                     P, my, rb, lrow, my_tile, s_rcp, vT, vTc, vhor, vB, row_ok, b, S, fwin);
                 if (IS_PRUNE) ok = fast_bounds<false, true>(P, pv, t, b);
             } else {
-                const SegTerms t = fast_step<HAS_INVALID, false, false, false, false, WIN>(
+                const SegTerms t = fast_step<HAS_INVALID, false, false, false, false, WIN, GEN>(
                     P, my, rb, lrow, my_tile, s_rcp, vT, vTc, vhor, vB, row_ok, b, S, fwin);
                 if (IS_PRUNE) ok = fast_bounds<false, false>(P, pv, t, b);
             }
@@ -422,7 +678,8 @@ __global__ __launch_bounds__(ISF_THREADS, HAS_INVALID ? ISF_OCC_INV : ISF_OCC) v
         if (done) break; /* nothing below can win any more */
         /* refill the slot just consumed (its reads have returned: their values were used) */
         asm volatile("" ::: "memory");
-        if (WIN) ring_prefetch_win(lcol, rcol, max(vB - nwv * K, 0), D, win_lo, s_row, lane);
+        if (GEN) ring_prefetch_rec(rcol, max(vB - nwv * K, 0), s_row, lane);
+        else if (WIN) ring_prefetch_win(lcol, rcol, max(vB - nwv * K, 0), D, win_lo, s_row, lane);
         else ring_prefetch<NVR>(lcol, rcol, max(vB - nwv * K, 0), D, s_row, s_row + ROWF, lane);
 #if ISF_SREC
         srec_request(S, rcol + max(vB - nwv, 0));
@@ -660,11 +917,12 @@ static int isf_nvr(const DevParams* P) {
     return 0;
 }
 
-static size_t isf_lds_bytes(const DevParams* P, int nvr, int nwaves, bool windowed) {
+static size_t isf_lds_bytes(const DevParams* P, int nvr, int nwaves, bool windowed, bool gen = false) {
     const size_t DP = (size_t)(windowed ? IS_P1_WIN : P->D) + 1;
     const size_t rcp = ((size_t)P->H + 1 + 3) & ~(size_t)3;
     size_t tile = ((size_t)IS_TILE * DP + 3) & ~(size_t)3;
-    const size_t ring = (size_t)nwaves * ISF_RING * ((windowed ? (size_t)IS_P1_WIN : 64 * (size_t)nvr) + ISF_REC_F);
+    size_t ring = (size_t)nwaves * ISF_RING * ((gen ? 0 : (windowed ? (size_t)IS_P1_WIN : 64 * (size_t)nvr)) + ISF_REC_F);
+    if (gen) ring += (size_t)nwaves * ISF_GEN_CACHE_F + IS_P1_WIN; /* the rebuilt rows + the zero row */
     const size_t merge = (size_t)nwaves * 3 * 64 * 2 + 2 * 3 * 64; /* lives in the tile's space */
     if (tile < merge) tile = merge;
     return sizeof(float) * (rcp + tile + ring) + 16;
@@ -699,6 +957,20 @@ hipError_t isk_set_lds_unary_fast(const DevParams* P) {
     return e;
 }
 
+/* 1 when this call's FAST columns all run the carry-only (GEN) instantiation: every tile windowed, four waves per
+ * workgroup (the row residues of the rebuild), the ring kernel in use.  The prepare launch then stores the carry
+ * rows of lutT only (DevParams::lut_carry). */
+int isk_unary_uses_carry(const DevParams* P, int ncols) {
+    /* opt-in (IS_LUT_CARRY=1): MEASURED on MI355X, 64 frames of 1024x2048x128, unary, bit-exact: the prepare launch
+     * 2.61 -> 1.39 ms, but this kernel 4.57 -> 8.09 ms (5.69 with the exact entries stubbed out): 6575 instead of 8816
+     * images/s.  See DESIGN.md section 6, "carry rows only". */
+    if (!ISF_GEN || P->knob_lut_carry != 1 || ISF_WIN_WAVES != 4 || IS_P1_WIN != 32) return 0;
+    if (isk_unary_fast_chunk_rows(P) == 0 || P->knob_ring_kernel == 0 || P->knob_unary_diag != 0) return 0;
+    if (!IS_P1_WINDOWED(P->D) || P->win_lo == nullptr) return 0;
+    if (!(P->knob_win_tiles >= 0 || ncols >= ISF_WIN_MIN_COLS)) return 0;
+    return P->win_tiles >= P->ntiles ? 1 : 0;
+}
+
 /* FAST columns of the batch; the caller runs k_dp_unary<.., false> for the generic ones. */
 hipError_t isk_launch_dp_unary_fast(const DevParams* P, int ncols, const RowRec* recs,
                                     const float* lutT, const float* rcp, const int* vhor,
@@ -730,7 +1002,9 @@ hipError_t isk_launch_dp_unary_fast(const DevParams* P, int ncols, const RowRec*
         wt = P->win_tiles < P->ntiles ? P->win_tiles : P->ntiles;
     const int nw_win = ISF_WIN_WAVES;
     const size_t lds = isk_unary_fast_lds_bytes(P, nvr);
-    const size_t lds_win = isf_lds_bytes(P, nvr, nw_win, true);
+    const bool gen = P->lut_carry != 0; /* (set by the caller only when isk_unary_uses_carry() holds) */
+    if (gen && wt < P->ntiles) return hipErrorInvalidValue;
+    const size_t lds_win = isf_lds_bytes(P, nvr, nw_win, true, gen);
 #define ISF_LAUNCH(INV, NVR)                                                                      \
     do {                                                                                          \
         if (pre_diag)                                                                             \
@@ -744,7 +1018,12 @@ hipError_t isk_launch_dp_unary_fast(const DevParams* P, int ncols, const RowRec*
                                    dim3(ISF_THREADS), lds, stream, *P,                             \
                                    ncols, recs, lutT, rcp, vhor, col_flags, prune, cost_table, index_table, \
                                    counters, joined, cost_T, pre_diag, wt, P->ntiles - wt);        \
-            if (wt > 0)                                                                           \
+            if (wt > 0 && gen)                                                                    \
+                hipLaunchKernelGGL((k_dp_unary_fast<INV, NVR, false, true, true>), dim3(groups * 8 * wt), \
+                                   dim3(nw_win * 64), lds_win, stream, *P,                         \
+                                   ncols, recs, lutT, rcp, vhor, col_flags, prune, cost_table, index_table, \
+                                   counters, joined, cost_T, pre_diag, 0, wt);                     \
+            else if (wt > 0)                                                                      \
                 hipLaunchKernelGGL((k_dp_unary_fast<INV, NVR, false, true>), dim3(groups * 8 * wt), \
                                    dim3(nw_win * 64), lds_win, stream, *P,                         \
                                    ncols, recs, lutT, rcp, vhor, col_flags, prune, cost_table, index_table, \

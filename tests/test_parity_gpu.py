@@ -1281,6 +1281,59 @@ def test_phase1_fn_windows_change_nothing(preset, rows, cols, D, family, inv, mo
         _assert_parity(case, b)
 
 
+@pytest.mark.parametrize("k", range(8))
+def test_carry_only_lut_hostile_and_random_inputs(k, monkeypatch):
+    """Carry-only lutT (DevParams::lut_carry: the prepare kernel stores only the rows 32 k of the object data-cost
+    prefix table, the windowed unary ring kernel rebuilds what it reads -- the tile, the vB-side rows, and single
+    entries outside the windows through lut_entry_exact; StixelsKernels.cu:236-296, 959-978 is the association
+    that must be kept) against the materialised table (IS_LUT_CARRY=0) and the oracle: random shapes and weights,
+    invalid disparities, median joins, AND hostile columns -- generic-encoding columns get their complete table
+    from k_object_lut_generic, columns whose pruning is off (E1o = +inf) never skip an entry.  Windows forced for
+    every tile (IS_P1_WIN_TILES=99), which is what switches the carry-only form on at any batch size."""
+    preset, rows, cols, D, ov = _random_case(k)
+    preset = preset.replace("pairwise", "unary")
+    D = max(D, 64) if k % 2 else D          # (D <= 32 has no window: the mode must then stay off by itself)
+    case = helpers.build_case(preset, rows, cols, D, seed=8100 + k, n_images=2, **ov)
+    if k >= 4:
+        case = helpers.make_hostile(case, seed=8200 + k)
+    monkeypatch.setenv("IS_P1_WIN_TILES", "99")
+    outs = {}
+    for carry in ("1", "0"):
+        monkeypatch.setenv("IS_LUT_CARRY", carry)
+        outs[carry] = helpers.run_core(case)
+    a, b = outs["1"], outs["0"]
+    assert np.array_equal(a["cost_table"].view(np.uint32), b["cost_table"].view(np.uint32))
+    assert np.array_equal(a["index_table"], b["index_table"])
+    for img in range(2):
+        assert helpers.sections_equal(a["sections"][img], b["sections"][img])
+    _assert_parity(case, a)
+
+
+@pytest.mark.parametrize("inv", [-1.0, 0.0])
+def test_carry_only_lut_full_frames(inv, monkeypatch):
+    """The carry-only form at the geometry it was measured on: eight full 1024x2048x128 frames per call (2048 columns,
+    unary, every tile windowed without any knob but IS_LUT_CARRY=1), against the materialised table bit for bit
+    (complete tables), one frame against the oracle; the counters show how many steps needed an entry outside
+    their window after the lazy test."""
+    monkeypatch.delenv("IS_P1_WIN_TILES", raising=False)
+    ov = dict(invalid_disparity=inv) if inv >= 0 else {}
+    case2 = helpers.build_case("drn_d_22_unary", 1024, 2048, 128, seed=57, n_images=2, **ov)
+    case = helpers.sub_case(case2, [i % 2 for i in range(8)])
+    outs = {}
+    for carry in ("1", "0"):
+        monkeypatch.setenv("IS_LUT_CARRY", carry)
+        outs[carry], counters = _run_with_counters(case)
+        print("IS_LUT_CARRY", carry, {k: v for k, v in counters.items() if k != "p1_per_tile"})
+    a, b = outs["1"], outs["0"]
+    assert np.array_equal(a["cost_table"].view(np.uint32), b["cost_table"].view(np.uint32))
+    assert np.array_equal(a["index_table"], b["index_table"])
+    for img in range(8):
+        assert helpers.sections_equal(a["sections"][img], b["sections"][img])
+    ref = helpers.run_oracle(case, image=1)
+    errs = helpers.compare(ref, a, 1, case["cfg"])
+    assert not errs, "\n".join(errs[:10])
+
+
 @pytest.mark.parametrize("knob,value", [("IS_GRAPH", "1"), ("IS_PREPARE_OVERLAP", "0"),
                                          ("IS_PREPARE_OVERLAP", "1"), ("IS_UNARY_DIAG", "1")])
 @pytest.mark.parametrize("preset", ["drn_d_22_unary", "drn_d_38_pairwise"])
