@@ -75,7 +75,6 @@ struct UnaryBestF {
  * vmcnt(0) for it also drains the ring's prefetches: correct, and rare below the horizon). */
 struct FastWin {
     int lo;
-    const float* grow; /* lutT row vT + 1 of this lane in global memory */
     const float* gcol; /* lutT of the column (row vB: gcol + vB * D) */
     int* misses;       /* wave-uniform count of steps with a lane outside */
     /* GEN (carry-only lutT): what lut_entry_exact needs, and the slack of the lazy test */
@@ -319,7 +318,7 @@ __device__ __forceinline__ SegTerms fast_step(const DevParams& P, const RowRec& 
                     vbv = lut_entry_exact(win.gcol, win.dcol, win.cost_T, vB, t.fni, P.H, P.D);
 #endif
                 } else {
-                    vtv = win.grow[(unsigned)t.fni];
+                    vtv = (win.gcol + (size_t)win.vT1 * P.D)[(unsigned)t.fni]; /* (the address on the spot: a per-lane pointer held through the walk cost two VGPRs, a spill reloaded in every step) */
                     vbv = (win.gcol + (size_t)vB * P.D)[(unsigned)t.fni];
                 }
             }
@@ -388,37 +387,71 @@ __device__ __forceinline__ int fast_bounds(const DevParams& P, const PruneValsF&
     return (ok_o ? 1 : 0) | (ok_x ? 2 : 0);
 }
 
-/* A step after the object type has been closed for the wave (its bound is sticky: the class
- * minima only grow and the best cost cannot change any more): only the ground or the sky
- * candidate of vB is left -- two class differences, no instance term, no mean, no LUT value; a
- * fifth of the instructions of fast_step, same operand order (cost = dw * data + pw / h +
- * sw * (f + nic)).  rec: the record of vB in the ring slot.  Returns true when the bound of the
- * type holds too: the wave is done. */
+/* The ground- / sky-only candidates of a wave whose object type is closed, SIXTEEN vB per memory round trip.  One
+ * at a time through the ring, such a step cost ~150 issue cycles for ~20 instructions of arithmetic (slot
+ * bookkeeping, a scalar record request nobody reads, three LDS reads, the ring's DMA): the homogeneous family --
+ * long road / sky stretches in which every split is a near-optimal candidate, 29 % of all pairs are such steps --
+ * ran 25 % below the scene.  Here lane l fetches the four dwords a step reads of the record of vB - nwv (l & 15),
+ * the next batch is requested before this one is walked, and step j takes its operands out of lane j with
+ * v_readlane (a ROLLED loop: unrolled with DPP operands the sixteen steps of both types cost the walk's loop 30
+ * spilled SGPRs, scene -7 %).  A candidate is two class differences, no instance term, no mean, no LUT value: a
+ * fifth of the instructions of fast_step, same operand order (cost = dw * data + pw / h + sw * (f + nic)); the
+ * object bound is sticky (the class minima only grow and the best cost cannot change any more).  Returns true when the type's
+ * bound holds (the wave is done), else vB < lo.  lo = 0 includes the first segment: with the object type closed it
+ * is a ground candidate like the others (record 0 is all zeros), for the lanes first_ok. */
 template <bool SKY>
-__device__ __forceinline__ bool fast_step_gs(const DevParams& P, const PruneValsF& pv, const RowRec& my,
-                                             const float* rec, const float* s_rcp, int vTc, int vB,
-                                             UnaryBestF& b) {
-    const float r = s_rcp[vTc + 1 - vB];
-    const float4 q = *reinterpret_cast<const float4*>(rec + 16); /* Foi[6], Foi[7], Fsky, Fnic */
-    const float2 gk = *reinterpret_cast<const float2*>(rec + 20); /* G, K */
-    const float nic = P.iw * (float)(my.Fnic - __float_as_int(q.w));
-    const float pwih = P.pw * r;
-    if (SKY) {
-        const float f = my.Fsky - q.z;
-        const float seg = f + nic;
-        const float cost = P.dw * (my.K - gk.y) + pwih + P.sw * seg;
-        take_if_le(b.s, b.vs, cost, vB);
-        const float lb = P.sw * seg - pv.E1s;
-        return (__builtin_amdgcn_ballot_w64(lb > b.s) | pv.dead) == ~0ull;
-    } else {
-        const float2 g01 = *reinterpret_cast<const float2*>(rec);
-        const float f = __builtin_fminf(my.Fg0 - g01.x, my.Fg1 - g01.y);
-        const float seg = f + nic;
-        const float cost = P.dw * (my.G - gk.x) + pwih + P.sw * seg;
-        take_if_le(b.g, b.vg, cost, vB);
-        const float lb = P.sw * seg - pv.E1g;
-        return (__builtin_amdgcn_ballot_w64(lb > b.g) | pv.gdead) == ~0ull;
+__device__ __forceinline__ bool gs_walk(const DevParams& P, const PruneValsF& pv, const RowRec& my,
+                                        const RowRec* __restrict__ rcol, const float* s_rcp, int vTc, int& vB,
+                                        const int lo, const int nwv, UnaryBestF& b, int& n_gs,
+                                        const bool first_ok /* may this lane take the first segment (vB = 0)? */) {
+    const int j16 = (int)(threadIdx.x & 15);
+    /* SKY: Fsky (dword 18), Fnic (19), K (21); ground: Fg0 (0), Fg1 (1), Fnic (19), G (20) */
+    auto fetch = [&](int v0, float& A, float& Bq, float& C, float& Dq) {
+        const float* q = (const float*)(rcol + max(v0 - nwv * j16, lo)); /* (clamped: the loads are unconditional) */
+        if (SKY) { A = q[18]; Bq = q[19]; C = q[21]; Dq = 0.0f; }
+        else { A = q[0]; Bq = q[1]; C = q[19]; Dq = q[20]; }
+    };
+    float a0, a1, a2, a3, n0, n1, n2, n3;
+    fetch(vB, a0, a1, a2, a3);
+    while (vB >= lo) {
+        fetch(vB - 16 * nwv, n0, n1, n2, n3);
+        const int n_here = min(16, (vB - lo) / nwv + 1);
+        bool closed = false;
+        int jj = 0;
+#pragma unroll 1
+        for (; jj < n_here && !closed; jj++) {
+            const int v = vB - jj * nwv;
+            const float r = s_rcp[vTc + 1 - v];
+            const float pwih = P.pw * r;
+            const float q0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a0), jj));
+            const float q1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a1), jj));
+            const float q2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a2), jj));
+            if (SKY) {
+                const float f = my.Fsky - q0;
+                const float nic = P.iw * (float)(my.Fnic - __float_as_int(q1));
+                const float seg = f + nic;
+                const float cost = P.dw * (my.K - q2) + pwih + P.sw * seg;
+                take_if_le(b.s, b.vs, cost, v);
+                const float lb = P.sw * seg - pv.E1s;
+                closed = (__builtin_amdgcn_ballot_w64(lb > b.s) | pv.dead) == ~0ull;
+            } else {
+                const float q3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a3), jj));
+                const float f = __builtin_fminf(my.Fg0 - q0, my.Fg1 - q1);
+                const float nic = P.iw * (float)(my.Fnic - __float_as_int(q2));
+                const float seg = f + nic;
+                float cost = P.dw * (my.G - q3) + pwih + P.sw * seg;
+                if (v == 0 && !first_ok) cost = IS_INF; /* :509: the first segment is ground only up to the horizon */
+                take_if_le(b.g, b.vg, cost, v);
+                const float lb = P.sw * seg - pv.E1g;
+                closed = (__builtin_amdgcn_ballot_w64(lb > b.g) | pv.gdead) == ~0ull;
+            }
+        }
+        n_gs += jj;
+        if (closed) return true;
+        vB -= n_here * nwv;
+        a0 = n0; a1 = n1; a2 = n2; a3 = n3;
     }
+    return false;
 }
 
 #ifdef IS_ABL_PHASES
@@ -557,7 +590,6 @@ __global__ __launch_bounds__(ISF_THREADS, GEN ? ISF_OCC_GEN : (HAS_INVALID ? ISF
     int n_winmiss = 0;
     FastWin fwin;
     fwin.lo = win_lo;
-    fwin.grow = lcol + (size_t)(vTc + 1) * D;
     fwin.gcol = lcol;
     fwin.misses = &n_winmiss;
     fwin.dcol = joined + (size_t)colg * H;
@@ -601,6 +633,7 @@ __global__ __launch_bounds__(ISF_THREADS, GEN ? ISF_OCC_GEN : (HAS_INVALID ? ISF
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* the cache rows are written before they are read */
     };
     bool o_closed = false;
+    int vB_gs = -1; /* first vB of the batched ground / sky-only walk (gs_walk), -1: none */
     int n_full = 0, n_gs = 0; /* steps below the diagonal block (wave-uniform: SALU only) */
     isk_f16v S; /* the class prefixes of the record of vB as scalars, requested one step ahead */
 #if ISF_SREC
@@ -615,7 +648,7 @@ __global__ __launch_bounds__(ISF_THREADS, GEN ? ISF_OCC_GEN : (HAS_INVALID ? ISF
         const float* rb = s_row + ROWF; /* the record of vB in the ring slot */
         const float* lrow = s_row;
         const bool diag = vB > tile_lo;
-        if (GEN && !(ISF_GS_STEPS && o_closed && vB != 0)) { /* (a ground / sky-only step reads no table entry) */
+        if (GEN && !(ISF_GS_STEPS && o_closed && vB != 0)) { /* (the ground / sky-only walk reads no table entry) */
             if (diag) {
                 lrow = s_tile + (vB - tile_lo - 1) * DP; /* a row of the tile itself */
             } else if (vB == 0) {
@@ -632,13 +665,8 @@ __global__ __launch_bounds__(ISF_THREADS, GEN ? ISF_OCC_GEN : (HAS_INVALID ? ISF
         bool done = false;
         int ok = 0;
         if (ISF_GS_STEPS && o_closed && vB != 0) { /* (closed in a full step: the diagonal is over) */
-            n_gs++;
-            if (vB > vhor)
-                done = fast_step_gs<true>(P, pv, my, rb, s_rcp, vTc, vB, b);
-            else if (nog)
-                done = true; /* only +inf ground candidates are left */
-            else
-                done = fast_step_gs<false>(P, pv, my, rb, s_rcp, vTc, vB, b);
+            vB_gs = vB; /* the rest of the walk holds ground / sky candidates only: gs_walk, behind the loop */
+            break;
         } else {
         n_full += diag ? 0 : 1;
         if (vB == 0) { /* first segment (:481-594): ground + object */
@@ -676,13 +704,14 @@ __global__ __launch_bounds__(ISF_THREADS, GEN ? ISF_OCC_GEN : (HAS_INVALID ? ISF
                                    * (it does not carry over from the sky range to the ground range) */
         }
         if (done) break; /* nothing below can win any more */
+
         /* refill the slot just consumed (its reads have returned: their values were used) */
         asm volatile("" ::: "memory");
         if (GEN) ring_prefetch_rec(rcol, max(vB - nwv * K, 0), s_row, lane);
         else if (WIN) ring_prefetch_win(lcol, rcol, max(vB - nwv * K, 0), D, win_lo, s_row, lane);
         else ring_prefetch<NVR>(lcol, rcol, max(vB - nwv * K, 0), D, s_row, s_row + ROWF, lane);
 #if ISF_SREC
-        srec_request(S, rcol + max(vB - nwv, 0));
+        srec_request_next(S, rcol + max(vB - nwv, 0)); /* (in-out: the loop-carried value keeps its registers, no copy while the request is in flight) */
 #endif
         slot = (slot + 1 == K) ? 0 : slot + 1;
     }
@@ -690,6 +719,17 @@ __global__ __launch_bounds__(ISF_THREADS, GEN ? ISF_OCC_GEN : (HAS_INVALID ? ISF
     srec_arrived(S); /* a walk that ran to vB = 0 leaves a request in flight: it must not land in
                       * registers that hold something else by then */
 #endif
+    if (vB_gs >= 1) {
+        /* Sixteen candidates per round trip instead of one per ring slot (placed behind the loop: inside it its eight
+         * operand registers cost the walk a spilled pointer, reloaded in every step).  A sky range below the tile
+         * means that the whole tile lies above the horizon: once it is exhausted only +inf ground candidates and the
+         * closed first-segment object candidate are left.  The ground range runs down to vB = 0: with the object
+         * type closed, the first segment (:481-594) is its ground candidate alone -- the same expression on the
+         * all-zero record 0, for the lanes vT <= vhor. */
+        int v = vB_gs;
+        if (v > vhor) (void)gs_walk<true>(P, pv, my, rcol, s_rcp, vTc, v, max(vhor + 1, 1), nwv, b, n_gs, true);
+        else if (!nog) (void)gs_walk<false>(P, pv, my, rcol, s_rcp, vTc, v, 0, nwv, b, n_gs, vT <= vhor);
+    }
     ISF_MARK(1);
     if (counters != nullptr && lane == 0) {
         atomicAdd(counters + IS_CNT_UNARY_FULL, (unsigned long long)n_full);
