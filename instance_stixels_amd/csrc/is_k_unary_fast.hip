@@ -20,7 +20,7 @@
  *     per-lane ds_read_b32; no barrier inside the loop: the waves of a workgroup only share the
  *     tile's lutT rows (vT side), the 1/h table and the final merge;
  *   - a wave whose bound says that nothing below can win leaves its loop; once the object bound
- *     holds, its steps evaluate only the ground or the sky candidate (fast_step_gs).
+ *     holds, the rest of its walk evaluates only the ground or the sky candidates, sixteen per round trip (gs_walk).
  *
  * LDS per workgroup at 1024 x 128: 4 KB (1/h) + 33 KB (vT tile, reused by the merge) + 8 waves x 3
  * slots x (512 + 128) B (rings) = 52 KB: three workgroups = 24 waves per CU at 74 VGPRs, no scratch.
