@@ -157,7 +157,7 @@ def committed_traffic(cfg, B, H, W, D):
 def committed_profile(cfg, B, H, W, D):
     """The newest profiles/rNN_traffic.json entry of this mode / shape / batch (or None)."""
     prof = os.path.join(ROOT, "profiles")
-    for name in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json"):
+    for name in ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json"):
         try:
             with open(os.path.join(prof, name)) as fh:
                 t = json.load(fh).get("pairwise" if cfg.pairwise else "unary")

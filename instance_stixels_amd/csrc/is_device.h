@@ -206,5 +206,22 @@ struct DevParams {
 #define IS_P1_WIN 32
 #endif
 #define IS_P1_WINDOWED(D) (IS_P1_WIN > 0 && (D) > IS_P1_WIN && ((D) & 3) == 0)
+/* Round 5: the window is TWO halves of IS_P1_WIN / 2 columns, each anywhere (a multiple of 4): win_lo[column][tile]
+ * = first column of half A | first column of half B << 16.  A tile of one disparity cluster gets B = A + 16 -- the
+ * contiguous window of round 4 --, a tile above the horizon that holds sky (d ~ 0) AND an object one half per
+ * cluster (k_prepare picks whichever of the three forms holds most of the tile's rows).  Staged column c (0 ..
+ * IS_P1_WIN - 1) is lutT column IS_WIN_COL(w, c); IS_WIN_FIND(w, fn) is the staged column of fn, or negative. */
+#ifndef IS_WIN_SPLIT
+#define IS_WIN_SPLIT 1 /* 0: contiguous fn windows only (round 4) */
+#endif
+#define IS_WIN_HALF (IS_P1_WIN / 2)
+#define IS_WIN_A(w) ((int)((unsigned)(w) & 0xFFFFu))
+#define IS_WIN_B(w) ((int)((unsigned)(w) >> 16))
+#define IS_WIN_PACK(a, b) ((int)((unsigned)(a) | ((unsigned)(b) << 16)))
+#define IS_WIN_COL(w, c) ((c) < IS_WIN_HALF ? IS_WIN_A(w) + (c) : IS_WIN_B(w) + (c) - IS_WIN_HALF)
+#define IS_WIN_FIND(w, fn)                                                                     \
+    ((unsigned)((fn) - IS_WIN_A(w)) < (unsigned)IS_WIN_HALF                                     \
+         ? (fn) - IS_WIN_A(w)                                                                   \
+         : ((unsigned)((fn) - IS_WIN_B(w)) < (unsigned)IS_WIN_HALF ? (fn) - IS_WIN_B(w) + IS_WIN_HALF : -1))
 
 #endif /* IS_DEVICE_H_ */

@@ -856,17 +856,17 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
     const __amdgpu_buffer_rsrc_t lrsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void*)lcol, 0, (H + 1) * D * (int)sizeof(float), 0x00020000);
     const int lane4 = lane * 4;
-    /* WIN: ONE 64-lane load fetches the 64 lutT columns from win_lo on of a vB row (the row registers cover
-     * twice the tile's window); classic: NR loads, the whole row */
+    /* WIN: ONE load fetches the window columns of a vB row (lane l: staged column l & 31 -- both ends of a segment
+     * read the SAME lutT column, so the row needs what the tile holds); classic: NR loads, the whole row */
     constexpr int NRW = windowed ? 1 : NR;
-    const int lane4r = lane4 + (windowed ? win_lo * 4 : 0);
+    const int lane4r = windowed ? IS_WIN_COL(win_lo, lane & (IS_P1_WIN - 1)) * 4 : lane4;
     const unsigned scr = lds_addr(s_scr + 8 * wl);
     /* lutT[vT + 1][fni] of this lane: from the staged tile / window; outside the window from global memory */
     int n_winmiss = 0; /* steps in which some lane read outside the window (evaluation counters) */
     auto vt_value = [&](int fni) -> float {
         if (!windowed) return my_tile[fni];
-        const int fo = fni - win_lo;
-        const bool inw = (unsigned)fo < (unsigned)win_w;
+        const int fo = IS_WIN_FIND(win_lo, fni);
+        const bool inw = fo >= 0;
         float v = my_tile[inw ? fo : 0];
         if (__builtin_amdgcn_ballot_w64(!inw) != 0ull) { /* (never without a window: fni < D) */
             n_winmiss++;
@@ -877,11 +877,11 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
     /* lutT[vT + 1][fni] - lutT[vB][fni]: `row` = the registers of row vB */
     auto od_value = [&](const LutRow<NRW>& row, int fni, int vB_row) -> float {
         if (!windowed) return my_tile[fni] - pick_lut<NRW>(row, fni);
-        const int fo = fni - win_lo;
-        const bool in_t = (unsigned)fo < (unsigned)win_w; /* the tile's window  */
-        const bool in_r = (unsigned)fo < 64u;              /* the row registers */
+        const int fo = IS_WIN_FIND(win_lo, fni);
+        const bool in_t = fo >= 0; /* the tile's window = the row registers' */
+        const bool in_r = in_t;
         float vt = my_tile[in_t ? fo : 0];
-        float vb = pick_lut<NRW>(row, in_r ? fo : 0);
+        float vb = pick_lut<NRW>(row, in_t ? fo : 0);
         if (__builtin_amdgcn_ballot_w64(!in_t) != 0ull) {
             n_winmiss++;
             if (!in_t) vt = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(lrsrc, ((vTc + 1) * D + fni) * 4, 0, 0));

@@ -227,20 +227,29 @@ __device__ __forceinline__ void prepare_columns_body(
                 d = __builtin_fminf(d, __shfl_xor(d, m, 64));
                 dx = __builtin_fmaxf(dx, __shfl_xor(dx, m, 64));
             }
-            /* two candidates: the window that starts at the tile's smallest disparity (the segments of a lane
-             * start below its row -- nearer, larger disparities) and the one that ends at its largest; a tile
-             * above the horizon can hold sky (d ~ 0) AND an object: the window goes where more of its rows are */
-            int lo_a = 0, lo_b = 0;
+            /* three candidates: the contiguous window that starts at the tile's smallest disparity (the segments of
+             * a lane start below its row -- nearer, larger disparities), the contiguous one that ends at its largest,
+             * and the SPLIT one: half A from the smallest disparity on, half B up to the largest -- a tile above the
+             * horizon can hold sky (d ~ 0) AND an object.  Whichever holds most of the tile's rows (ties: contiguous). */
+            constexpr int HW = IS_WIN_HALF;
+            int lo_a = 0, lo_b = 0, hi_b = 0;
             if (d < IS_INF) {
                 lo_a = (int)__builtin_fminf(__builtin_fmaxf(d, 1.0f), (float)P.D) - 1;
                 lo_b = (int)__builtin_fminf(__builtin_fmaxf(dx, 0.0f), (float)(P.D - 1)) + 2 - IS_P1_WIN;
+                hi_b = (int)__builtin_fminf(__builtin_fmaxf(dx, 0.0f), (float)(P.D - 1)) + 2 - HW;
             }
             lo_a = min(max(lo_a, 0) & ~3, P.D - IS_P1_WIN);
             lo_b = min(max(lo_b, 0) & ~3, P.D - IS_P1_WIN);
+            hi_b = min(max(hi_b, 0) & ~3, P.D - HW);
+            const int w_a = IS_WIN_PACK(lo_a, lo_a + HW), w_b = IS_WIN_PACK(lo_b, lo_b + HW);
+            const int w_s = IS_WIN_PACK(lo_a, max(hi_b, lo_a + HW)); /* (never overlapping halves) */
             const int fl = (int)__builtin_fminf(__builtin_fmaxf(mine, 0.0f), (float)(P.D - 1));
-            const int n_a = __builtin_popcountll(__builtin_amdgcn_ballot_w64(ok && (unsigned)(fl - lo_a) < (unsigned)IS_P1_WIN));
-            const int n_b = __builtin_popcountll(__builtin_amdgcn_ballot_w64(ok && (unsigned)(fl - lo_b) < (unsigned)IS_P1_WIN));
-            if (lane == 0) P.win_lo[(size_t)colg * P.ntiles + t] = n_b > n_a ? lo_b : lo_a;
+            const int n_a = __builtin_popcountll(__builtin_amdgcn_ballot_w64(ok && IS_WIN_FIND(w_a, fl) >= 0));
+            const int n_b = __builtin_popcountll(__builtin_amdgcn_ballot_w64(ok && IS_WIN_FIND(w_b, fl) >= 0));
+            const int n_s = __builtin_popcountll(__builtin_amdgcn_ballot_w64(ok && IS_WIN_FIND(w_s, fl) >= 0));
+            int w_best = n_b > n_a ? w_b : w_a;
+            if (IS_WIN_SPLIT && n_s > max(n_a, n_b)) w_best = w_s;
+            if (lane == 0) P.win_lo[(size_t)colg * P.ntiles + t] = w_best;
         }
     }
 

@@ -171,7 +171,7 @@ __device__ __forceinline__ void gen_rebuild_rows(float* cache, const float* lcol
     const int kh = max(k - half, 0); /* (block -1 does not exist: recomputes block 0, never read) */
     int* s_off = (int*)cache;
     s_off[lane] = gen_row_offset(dcol, 32 * kh + c, H, D);
-    const int fn = min(win_lo + c, D - 1);
+    const int fn = min(IS_WIN_COL(win_lo, c), D - 1);
     const unsigned fn4 = (unsigned)fn * 4u; /* (uniform base + 32-bit lane offset: one integer addition per load) */
     const float carry = lcol[(size_t)(32 * kh) * D + fn];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* (one wave: its own LDS stores are visible to its loads) */
@@ -203,7 +203,7 @@ __device__ __forceinline__ void gen_window_tile(float* s_tile, int* s_off, const
     const int half = lane >> 5, c = lane & 31;
     const int i0 = tile_lo + 32 * half; /* the block's first row (a multiple of 32) */
     s_off[lane] = gen_row_offset(dcol, i0 + c, H, D);
-    const int fn = min(win_lo + c, D - 1);
+    const int fn = min(IS_WIN_COL(win_lo, c), D - 1);
     const unsigned fn4 = (unsigned)fn * 4u;
     const float carry = lcol[(size_t)min(i0, (H / 32) * 32) * D + fn]; /* (a block that starts beyond the image is never read) */
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -293,8 +293,8 @@ __device__ __forceinline__ SegTerms fast_step(const DevParams& P, const RowRec& 
 #endif
     float vtv, vbv;
     if (WIN) {
-        const int fo = t.fni - win.lo;
-        const bool inw = (unsigned)fo < (unsigned)IS_P1_WIN;
+        const int fo = IS_WIN_FIND(win.lo, t.fni);
+        const bool inw = fo >= 0;
         /* both ends from the windows: the lane's row in the tile, the row of vB in the ring slot (the ring
          * fetches the SAME window of every vB row: 128 instead of 512 bytes per step) */
         vtv = my_tile[inw ? fo : 0];
@@ -494,11 +494,23 @@ __device__ __forceinline__ void ring_prefetch(const float* __restrict__ lcol,
 
 /* The windowed ring slot: [IS_P1_WIN floats of lutT row vB from column lo][the 32 dwords of the record of vB] --
  * ONE LDS-DMA instruction, lanes 0-31 the row window, lanes 32-63 the record. */
-__device__ __forceinline__ void ring_prefetch_win(const float* __restrict__ lcol, const RowRec* __restrict__ rcol,
-                                                  int vB, int D, int lo, float* slot, int lane) {
+/* (gbase / gstride: this lane's address at vB = 0 and its bytes per vB -- the lutT column IS_WIN_COL(win, lane) with
+ * a row of D floats, or dword lane - 32 of the records of 128 bytes: three registers held through the walk, one
+ * multiply-add per fill) */
+struct WinLane {
+    const char* gbase;
+    unsigned gstride;
+};
+__device__ __forceinline__ WinLane win_lane(const float* __restrict__ lcol, const RowRec* __restrict__ rcol, int D, int win,
+                                            int lane) {
     static_assert(IS_P1_WIN == 32 && ISF_REC_F == 32, "one 64-lane DMA = window + record");
-    const float* g = lane < 32 ? lcol + (size_t)vB * D + lo + lane : (const float*)(rcol + vB) + (lane - 32);
-    dma_dword(g, lds_addr(slot));
+    WinLane w;
+    w.gbase = lane < 32 ? (const char*)(lcol + IS_WIN_COL(win, lane)) : (const char*)((const float*)rcol + (lane - 32));
+    w.gstride = lane < 32 ? (unsigned)D * 4u : (unsigned)sizeof(RowRec);
+    return w;
+}
+__device__ __forceinline__ void ring_prefetch_win(const WinLane& wl, int vB, float* slot) {
+    dma_dword((const float*)(wl.gbase + (size_t)vB * wl.gstride), lds_addr(slot));
 }
 
 /* GEN: the slot is the record alone (32 lanes) */
@@ -568,12 +580,13 @@ __global__ __launch_bounds__(ISF_THREADS, GEN ? ISF_OCC_GEN : (HAS_INVALID ? ISF
      * the 1/h table and this lane's record.  The wave's steps: vB_top, vB_top - 8, ... >= 0
      * (H >= 8 = the number of waves, so vB_top >= 0). */
     const int vB_top = (pre ? tile_lo : vB_end) - w; /* (pre: may be negative = no step for this wave) */
+    const WinLane wlane = win_lane(lcol, rcol, D, win_lo, lane);
 #pragma unroll
     for (int i = 0; i < K; i++)
     {
         const int vq = max(vB_top - nwv * i, 0);
         if (GEN) ring_prefetch_rec(rcol, vq, my_ring + i * SLOT, lane);
-        else if (WIN) ring_prefetch_win(lcol, rcol, vq, D, win_lo, my_ring + i * SLOT, lane);
+        else if (WIN) ring_prefetch_win(wlane, vq, my_ring + i * SLOT);
         else ring_prefetch<NVR>(lcol, rcol, vq, D, my_ring + i * SLOT, my_ring + i * SLOT + ROWF, lane);
     }
     ISF_MARK(4); /* (debug build: ring requests issued) */
@@ -708,7 +721,7 @@ __global__ __launch_bounds__(ISF_THREADS, GEN ? ISF_OCC_GEN : (HAS_INVALID ? ISF
         /* refill the slot just consumed (its reads have returned: their values were used) */
         asm volatile("" ::: "memory");
         if (GEN) ring_prefetch_rec(rcol, max(vB - nwv * K, 0), s_row, lane);
-        else if (WIN) ring_prefetch_win(lcol, rcol, max(vB - nwv * K, 0), D, win_lo, s_row, lane);
+        else if (WIN) ring_prefetch_win(wlane, max(vB - nwv * K, 0), s_row);
         else ring_prefetch<NVR>(lcol, rcol, max(vB - nwv * K, 0), D, s_row, s_row + ROWF, lane);
 #if ISF_SREC
         srec_request_next(S, rcol + max(vB - nwv, 0)); /* (in-out: the loop-carried value keeps its registers, no copy while the request is in flight) */

@@ -339,13 +339,13 @@ __device__ __forceinline__ void stage_tile_and_rcp(float* s_tile, float* s_rcp,
     }
 }
 
-/* The fn window [lo, lo + IS_P1_WIN) of lutT rows tile_lo + 1 .. tile_lo + 64 (row stride IS_P1_WIN + 1) and the
- * 1/h table behind one memory round trip.  lo is a multiple of 4: sixteen lanes fetch the 256 bytes of one
- * row's window with 16-byte loads, a wave four rows; the dword stores of a wave then hit banks
- * (row + 4 q + j) mod 64, q = 0 .. 15, four consecutive rows: all different. */
+/* The fn window `win` (two halves of IS_P1_WIN / 2 columns, is_device.h) of lutT rows tile_lo + 1 .. tile_lo + 64 (row
+ * stride IS_P1_WIN + 1) and the 1/h table behind one memory round trip.  The halves start at multiples of 4: eight
+ * lanes fetch the 128 bytes of one half with 16-byte loads, sixteen a row's window, a wave four rows; the dword
+ * stores of a wave then hit banks (row + 4 q + j) mod 64, q = 0 .. 15, four consecutive rows: all different. */
 __device__ __forceinline__ void stage_window_and_rcp(float* s_tile, float* s_rcp, const float* __restrict__ lcol,
                                                      const float* __restrict__ rcp, int tile_lo, int H, int D,
-                                                     int lo, int tid, int nthreads) {
+                                                     int win, int tid, int nthreads) {
     constexpr int WQ = IS_P1_WIN / 4; /* 16-byte chunks per row */
     constexpr int WPs = IS_P1_WIN + 1;
     constexpr int NX = 4;             /* chunks per thread and batch */
@@ -362,7 +362,7 @@ __device__ __forceinline__ void stage_window_and_rcp(float* s_tile, float* s_rcp
 #pragma unroll
         for (int k = 0; k < NX; k++) {
             const int r = min(rb + k * dr, IS_TILE - 1);
-            x[k] = *reinterpret_cast<const float4*>(lcol + (size_t)min(tile_lo + 1 + r, H) * D + lo + 4 * q);
+            x[k] = *reinterpret_cast<const float4*>(lcol + (size_t)min(tile_lo + 1 + r, H) * D + IS_WIN_COL(win, 4 * q));
         }
 #pragma unroll
         for (int k = 0; k < NX; k++) {
