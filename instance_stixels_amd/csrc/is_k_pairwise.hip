@@ -1765,9 +1765,12 @@ __device__ __forceinline__ void pw_phase2x_body(const DevParams& P, char* smem, 
     float* s_odr = (float*)(s_logc + IS_LOG_TABLE_SIZE); /* [D -> x4] */
     float* s_rcp = s_odr + ((D + 3) & ~3);               /* [IS_TILE+1 -> x4] */
     float* s_win = s_rcp + ((IS_TILE + 1 + 3) & ~3);     /* [2][65][ISP2X_WS] lutT windows */
-    constexpr int NSV = HAS_INVALID ? 2 : 1;             /* (the valid-count prefixes only with an invalid value) */
-    float* s_SV = s_win + 2 * ISP2X_WF;                  /* [2][NSV][66] S / V prefixes of the tile's rows */
-    float* s_st = s_SV + 2 * NSV * 66;                   /* [2][16] StepRec handed from phase L to phase U */
+    /* [2][66] S prefixes of the tile's rows; with an invalid value also [2][68] BYTES: the valid-count prefixes as
+     * offsets from the count at the tile's first row (0 .. 64, exact) -- as floats they cost the kernel its 16th
+     * wave per CU (10.3 instead of 9.9 KB of LDS per wave) */
+    float* s_SV = s_win + 2 * ISP2X_WF;
+    unsigned char* s_Vb = (unsigned char*)(s_SV + 2 * 66);
+    float* s_st = s_SV + 2 * 66 + (HAS_INVALID ? 36 : 0); /* [2][16] StepRec handed from phase L to phase U */
     const int tile_lo = tile * IS_TILE;
     const int colg = col0 + half;
     const RowRec* rcol = recs + (size_t)colg * (H + 1);
@@ -1777,8 +1780,9 @@ __device__ __forceinline__ void pw_phase2x_body(const DevParams& P, char* smem, 
     const float* sv = sv_arr + (size_t)colg * 2 * (H + 1);
     const int n_rows = min(IS_TILE, H - tile_lo);
     float* my_winbase = s_win + half * ISP2X_WF;
-    float* my_S = s_SV + half * NSV * 66;
-    float* my_V = my_S + (HAS_INVALID ? 66 : 0); /* (never read without an invalid value) */
+    float* my_S = s_SV + half * 66;
+    unsigned char* my_Vb = s_Vb + half * 68; /* (never touched without an invalid value) */
+    float* my_Vbase = s_SV + 2 * 66 + 34 + half; /* the count at the tile's first row (an exact integer), kept in LDS: a register held through the walk spilled */
 
     /* ---- prologue: per column the fn window [lo, lo + W) of the tile's rows (pw_phase2_body) */
     int lo, W;
@@ -1818,7 +1822,11 @@ __device__ __forceinline__ void pw_phase2x_body(const DevParams& P, char* smem, 
     for (int j = li; j <= IS_TILE; j += 32) { /* S / V prefixes at tile_lo + j */
         const RowRec* q = rcol + min(tile_lo + j, H);
         my_S[j] = q->S;
-        if (HAS_INVALID) my_V[j] = q->V;
+        if (HAS_INVALID) {
+            const float vb0 = rcol[min(tile_lo, H)].V;
+            my_Vb[j] = (unsigned char)(int)(q->V - vb0);
+            if (j == 0) *my_Vbase = vb0;
+        }
     }
     if (lane == 0) is_log_tables(s_invc, s_logc);
     for (int i = lane; i < D; i += 64) s_odr[i] = odr[i];
@@ -1897,7 +1905,7 @@ __device__ __forceinline__ void pw_phase2x_body(const DevParams& P, char* smem, 
         }
         const int oi = min(max(ob - tile_lo, 0), IS_TILE);
         S_ob = below ? S_obc : my_S[oi];
-        if (HAS_INVALID) V_ob = below ? V_obc : my_V[oi];
+        if (HAS_INVALID) V_ob = below ? V_obc : *my_Vbase + (float)my_Vb[oi];
         st = make_step<HAS_INVALID, true>(P, S_r1, V_r1, S_ob, V_ob, s_odr, s_invc, s_logc, &pv, vhor, r, cG,
                                           cO, cS, ob);
         const float m8 = min_raw(min3_raw(st.p1_hi, st.p1_lo, st.p1_mid),
@@ -2392,7 +2400,7 @@ size_t isk_phase2_lds_bytes(const DevParams* P) {
 size_t isk_phase2x_lds_bytes(const DevParams* P) {
     const size_t x = sizeof(double) * 2 * IS_LOG_TABLE_SIZE +
                      sizeof(float) * (((P->D + 3) & ~3) + ((IS_TILE + 1 + 3) & ~3) + 2 * (size_t)ISP2X_WF +
-                                      2 * (P->invalid >= 0 ? 2 : 1) * 66 + 2 * 16) + 32;
+                                      2 * 66 + (P->invalid >= 0 ? 36 : 0) + 2 * 16) + 32;
     const size_t one = isk_phase2_lds_bytes(P); /* the one-column fallback inside the kernel */
     return x > one ? x : one;
 }
