@@ -448,7 +448,7 @@ def measure_in_flight(wl, counts, steps=12):
 
 
 EXTRA_FAMILIES = ("iid_noise", "low_confidence", "flat_disparity", "homogeneous", "many_thin_objects",
-                  "noisy_disparity")
+                  "noisy_disparity", "cityscapes_like")
 
 
 def measure_families(preset, H, W, D, B, dev, local_rank, distinct=2):
@@ -479,7 +479,8 @@ def measure_families(preset, H, W, D, B, dev, local_rank, distinct=2):
                    "flat_disparity = the scene's segmentation over constant + U(0,1) disparity; "
                    "homogeneous = road below the horizon, sky above, no object, confident CNN (logit +8..9); "
                    "many_thin_objects = sixty slabs 8..24 px wide; noisy_disparity = the scene with N(0,3) "
-                   "disparity noise; mixed = frame i of the batch from family i mod 7, every frame its own "
+                   "disparity noise; cityscapes_like = spatially correlated CNN errors, a building band, 0.25 px "
+                   "disparity noise (see synthetic.make_frame); mixed = frame i of the batch from family i mod 8, every frame its own "
                    "seed; the others: 2 distinct frames repeated to the batch (value_spread has whole "
                    "batches of distinct frames for the scene and floor families)")
     return fam
@@ -667,9 +668,19 @@ def measure_variants(args, wl, dev, local_rank):
             "what": "Stixels::Compute + GetInstanceStixels per frame (host ground model, device clustering, "
                     "D2H of the sections), timed inside the C++ library"}
         one.free(); del one
-        rs["pairwise" if wr.cfg.pairwise else "unary"] = m
         wr.free(); del wr
         torch.cuda.empty_cache()
+        # the same shape and mode on the cityscapes_like family: sky and occlusion bands invalid as REGIONS,
+        # ~3400 / 2500 stixels per frame (the reference's pins on real data: 2278 / 1421)
+        wc = Workload(preset, 784, 1792, 128, B, min(B, 8), dev, local_rank, seed0=311, family="cityscapes_like",
+                      invalid_disparity=0.0)
+        core = wc.make_core()
+        dtc = wc.time_steps(core, 3)
+        m["cityscapes_like"] = {"images_per_s": B / dtc, "verify": wc.verify(wc.d_sections, images=[B - 1]),
+                                "evaluated_frac": wc.prune_stats(core)["evaluated_frac"]}
+        core.close(); wc.free(); del wc
+        torch.cuda.empty_cache()
+        rs["pairwise" if m["preset_pairwise"] else "unary"] = m
     rs["what"] = ("the only shape / mode the reference itself launches: 784x1792 crop (224 stixel columns, 12.25 "
                   "tiles), 128 disparities, invalid_disparity = 0 with 5 % holes; 16 distinct frames per batch of "
                   "64.  Context, not a baseline for this metric: BASELINE.md quotes ~19 fps for the reference's "

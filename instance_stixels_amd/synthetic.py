@@ -38,8 +38,9 @@ def rows_power2_segmentation(rows: int) -> int:  # Stixels.cu:132-133
     return int(2 ** math.ceil(math.log2(rows // 8 + 1)))
 
 
+CITY_NOISE = 0.6   # amplitude of the correlated logit noise of the "cityscapes_like" family
 FAMILIES = ("scene", "iid_noise", "low_confidence", "flat_disparity", "homogeneous", "many_thin_objects",
-            "noisy_disparity")
+            "noisy_disparity", "cityscapes_like")
 
 
 def make_frame(cfg: StixelConfig, seed: int = 0, n_slabs: int = 6, hole_fraction: float = 0.05,
@@ -56,6 +57,17 @@ def make_frame(cfg: StixelConfig, seed: int = 0, n_slabs: int = 6, hole_fraction
     "many_thin_objects" -- about sixty object slabs 8 .. 24 px wide (a crowd / pole scene: hardly a
     column without an object, many short segments); "noisy_disparity" -- the scene with
     N(0, 3) disparity noise on every pixel (a poor stereo matcher: the data terms carry little).
+    "cityscapes_like" -- statistics closer to what the reference reports on real data (there is no CNN
+    output and no stereo pair in this image): a confident CNN whose errors are SPATIALLY CORRELATED
+    (true-class logit +7 .. 8 over low-pass filtered noise of amplitude 0.6, so that the arg-max holds
+    over runs of rows instead of flipping per 8x8 cell), a building / vegetation band behind the
+    objects above the horizon, disparity noise of 0.25 px, and -- with an invalid-disparity value -- the
+    sky and an occlusion band left of every object invalid as a REGION next to 3 % pixel holes.
+    On the reference's own shape (784x1792, invalid_disparity = 0) it yields ~3430 stixels per frame in the
+    unary and ~2510 in the pairwise model (median 12 per column), where the reference's regression pins are
+    2278 and 1421 stixels per Cityscapes image (tests/run_test.sh:124,93); the iid-noise "scene" family
+    yields ~9950 / 8270.  The count is set by the models' own splitting of long uniform regions, not by the
+    CNN noise (amplitudes 0.3 .. 0.6 give the same count).
     The value range of the class channels is that of the reference's CNN wrapper,
     8 * -log_softmax (wrappers.py:50-60).
 
@@ -93,6 +105,20 @@ def make_frame(cfg: StixelConfig, seed: int = 0, n_slabs: int = 6, hole_fraction
     obj_classes = [2, 5, 8, 11, 13, 12, 17, 18, 14, 3]
     if family not in FAMILIES:
         raise ValueError(f"unknown input family {family!r}")
+    city = family == "cityscapes_like"
+    if city:   # a band of buildings / vegetation above the horizon, behind everything else
+        band_top = max(0, vhor_img - H // 4)
+        x = 0
+        while x < W:
+            w = int(rng.integers(W // 16, W // 5))
+            cls_b = 2 if rng.random() < 0.6 else 8
+            top_b = int(rng.integers(max(0, band_top - H // 10), band_top + H // 10 + 1))
+            d_b = float(rng.uniform(2.0, 6.0))
+            label[top_b:vhor_img + 1, x:x + w] = cls_b
+            disp[top_b:vhor_img + 1, x:x + w] = d_b + 0.5 * rng.random((vhor_img + 1 - top_b, min(w, W - x)),
+                                                                      dtype=np.float32)
+            x += w
+        n_slabs = 10
     if family == "homogeneous":
         n_slabs = 0
     elif family == "many_thin_objects":
@@ -116,9 +142,17 @@ def make_frame(cfg: StixelConfig, seed: int = 0, n_slabs: int = 6, hole_fraction
         disp = np.float32(D // 3) + (disp - np.floor(disp))
     if family == "noisy_disparity":
         disp = disp + rng.normal(0.0, 3.0, (H, W)).astype(np.float32)
+    if city:
+        disp = disp - (disp - np.floor(disp)) + 0.5 + rng.normal(0.0, 0.25, (H, W)).astype(np.float32)
     disp = np.clip(disp, 0.0, D - 1.01).astype(np.float32)
     if cfg.invalid_disparity >= 0 and hole_fraction > 0:
-        holes = rng.random((H, W)) < hole_fraction
+        holes = rng.random((H, W)) < (0.03 if city else hole_fraction)
+        if city:   # no match in the sky, and an occlusion band left of every object
+            holes |= label == 10
+            obj = (label >= 11) | (label == 5)
+            edge = obj & ~np.roll(obj, 1, axis=1)
+            for k in range(1, 13):
+                holes |= np.roll(edge, -k + 1 - 12, axis=1) & ~obj
         disp[holes] = np.float32(cfg.invalid_disparity)
 
     seg = np.zeros((C, CH, P2S), np.int32)
@@ -130,8 +164,13 @@ def make_frame(cfg: StixelConfig, seed: int = 0, n_slabs: int = 6, hole_fraction
         xs = np.minimum(xs, W - 1)
         lab = label[np.ix_(ys, xs)]                                     # [Hs][C]
         logits = rng.normal(0.0, 1.0, (Hs, C, K)).astype(np.float32)
+        if city:   # spatially correlated errors: low-pass filtered noise (a separable box filter, twice)
+            from scipy.ndimage import uniform_filter1d
+            for ax, n in ((0, 9), (1, 5), (0, 9), (1, 5)):
+                logits = uniform_filter1d(logits, size=n, axis=ax, mode="nearest")
+            logits = (logits / max(float(logits.std()), 1e-6) * CITY_NOISE).astype(np.float32)
         if family != "iid_noise":
-            true_logit = {"low_confidence": 1.0, "homogeneous": 8.0}.get(family, 4.0)
+            true_logit = {"low_confidence": 1.0, "homogeneous": 8.0, "cityscapes_like": 7.0}.get(family, 4.0)
             np.put_along_axis(logits, lab[..., None],
                               np.float32(true_logit) + rng.random((Hs, C, 1), dtype=np.float32), axis=2)
         logits -= logits.max(axis=2, keepdims=True)

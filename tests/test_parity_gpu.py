@@ -209,7 +209,7 @@ def test_pruning_changes_nothing_at_full_size(preset, monkeypatch):
 
 @pytest.mark.parametrize("preset", ["drn_d_38_pairwise", "drn_d_22_unary"])
 @pytest.mark.parametrize("family", ["homogeneous", "many_thin_objects", "iid_noise", "low_confidence",
-                                    "flat_disparity", "noisy_disparity"])
+                                    "flat_disparity", "noisy_disparity", "cityscapes_like"])
 def test_pruning_changes_nothing_on_the_input_families(family, preset, monkeypatch):
     """The same property on the other input families of bench.py (synthetic.make_frame(family=...)), both
     models, 9 full frames = 2304 columns (the two-column phase 2 and the unsplit phase 1 of large batches;
@@ -381,6 +381,28 @@ def test_reference_operating_point_784x1792_invalid0(preset, median):
     assert case["params"].rows_power2_segmentation == 128
     assert (case["disparity"] == 0.0).mean() > 0.03       # the 5 % holes are there
     got = helpers.run_core(case)
+    _assert_parity(case, got)
+
+
+@pytest.mark.parametrize("preset", ["drn_d_22_unary", "drn_d_38_pairwise"])
+def test_reference_operating_point_invalid_regions(preset):
+    """The reference's shape and mode on the cityscapes_like family: the sky and an occlusion band left of every
+    object are invalid as REGIONS (21 % of the joined column entries: segments without a single valid row, valid
+    counts far below the height -- the divisor of mean_valid_fast), next to 3 % pixel holes.  Two full frames in one
+    call, all 224 columns against the oracle with the complete tables."""
+    from instance_stixels_amd import synthetic
+    H, W, D = REF_SHAPE
+    case = helpers.build_case(preset, H, W, D, seed=53, n_images=2, invalid_disparity=0.0)
+    cfg = case["cfg"]
+    frames = [synthetic.make_frame(cfg, seed=900 + i, family="cityscapes_like") for i in range(2)]
+    ground = [oracle_mod().host_ground(cfg, f.vhor_image, f.camera_tilt, f.camera_height, f.alpha_ground)
+              for f in frames]
+    case.update(frames=frames, gf=np.stack([g[0] for g in ground]), ng=np.stack([g[1] for g in ground]),
+                ig=np.stack([g[2] for g in ground]), vhor=np.array([g[3] for g in ground], np.int32),
+                disparity=np.stack([f.disparity for f in frames]),
+                segmentation=np.stack([f.segmentation for f in frames]))
+    got = helpers.run_core(case)
+    assert (got["joined"] == 0.0).mean() > 0.1
     _assert_parity(case, got)
 
 
