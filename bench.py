@@ -557,15 +557,16 @@ def measure_variants(args, wl, dev, local_rank):
     del keep, ibs
     core.close()
 
-    # ---- pairwise: the column groups of the DP on three streams of ONE context (IS_PW_GROUPS=3; default 1: beside
-    # an RCCL gather pipeline the groups cost 5 %, and per-kernel durations of overlapping launches say less)
+    # ---- pairwise: ONE column group instead of the default three (IS_PW_GROUPS=1: what a caller that pipelines an
+    # RCCL gather beside the next step's compute uses -- there the groups cost 5 % --, and the setting under which the
+    # per-kernel durations of a profile are not those of overlapping launches)
     if wl.cfg.pairwise:
-        core = wl.make_core(env={"IS_PW_GROUPS": "3"})
+        core = wl.make_core(env={"IS_PW_GROUPS": "1"})
         dt_g = wl.time_steps(core, 3)
-        out["column_groups_3"] = {"images_per_s": B / dt_g, "steps": 3,
-                                  "what": "IS_PW_GROUPS=3: the phase-1 / phase-2 chains of three column groups on "
-                                          "three streams of the context (launch tails and the latency-bound phases "
-                                          "of one group beside the launches of the others)"}
+        out["column_groups_1"] = {"images_per_s": B / dt_g, "steps": 3,
+                                  "what": "IS_PW_GROUPS=1: the phase-1 / phase-2 chain of all columns on one stream "
+                                          "(default: three column groups on three streams of the context, the "
+                                          "latency-bound phase 2 of one group beside the launches of the others)"}
         core.close()
 
     # ---- two / three batches in flight: one context and one stream each, batches alternate (what a
@@ -772,7 +773,8 @@ def main():
     wl = Workload(args.preset, args.rows, args.cols, args.max_dis, args.batch, args.distinct, dev,
                   local_rank, seed0=17 + 101 * rank, family=args.family, **extra)
     cfg, B, H, W, C, D, S = wl.cfg, wl.B, wl.H, wl.W, wl.C, wl.D, wl.S
-    core = wl.make_core()
+    # (beside the pipelined RCCL gather the pairwise DP runs as ONE column group: measured, is_device.h)
+    core = wl.make_core(env={"IS_PW_GROUPS": "1"} if (use_dist and not args.no_gather and cfg.pairwise) else None)
     core.set_kernel_timing(True)
     # N > 1: the stixel outputs of every step are gathered on rank 0 (RCCL over xGMI); the gather
     # of step k overlaps the compute of step k+1 (double-buffered outputs)

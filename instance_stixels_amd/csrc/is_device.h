@@ -48,7 +48,7 @@
 #define IS_PW_SPLIT_MAX_COLS 512     /* up to that many columns: two phase-1 workgroups per (column, tile) */
 #endif
 #define IS_PAIRWISE_SPLIT_MIN_COLS 1024 /* columns per group before the pairwise DP uses one more stream */
-#define IS_PAIRWISE_MAX_GROUPS 1       /* column groups (streams) of the pairwise DP; IS_PW_GROUPS overrides.  Round 4 (small workgroups): 1 / 2 / 3 / 4 groups 3920 / 4070 / 4150 / 4090 frames/s at batch 64 (+7 ... +10 % at batch 8-32), but 3680 instead of 3860 beside the RCCL gather pipeline (round 3: +0.4 % / -9 %): the default stays 1, bench.py reports `variants.column_groups_3` */
+#define IS_PAIRWISE_MAX_GROUPS 3       /* column groups (streams of the context) of the pairwise DP; IS_PW_GROUPS overrides.  The latency-bound phase 2 of one group runs beside the launches of the others.  Round 5, frames/s with 1 / 2 / 3 / 4 groups: batch 64 4116 / 4283 / 4333 / 4227, batch 32 3776 / 3909 / 4009 / 3992, batch 16 2937 / 3120 / 3147 / 3219 (profiles/r05_ab_groups.log).  Beside a PIPELINED RCCL gather of the previous step's output (bench.py --gpus N, parallel.py) the groups cost 5 % instead (round 4: 3680 against 3860): such callers create their context with IS_PW_GROUPS=1, as bench.py does */
 #define IS_P2_SPLIT_MAX_COLS 2048     /* up to eight 2048-px frames: phase 2 of the pairwise DP as chain + evaluator wave per column */
 #define IS_BACKTRACE_STAGE_MAX_COLS 2048 /* up to eight 2048-px frames: the back-trace chases in LDS */
 #define IS_AUX_STREAMS 7               /* auxiliary streams a context owns */

@@ -8,6 +8,7 @@ OUT=gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
 echo "python3 bench.py $ARGS" > $OUT/command.txt
 export TMPDIR=/tmp
+export IS_PW_GROUPS=1   # one column group: per-kernel durations of launches that do not overlap
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py $ARGS > $OUT/bench_trace.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA --output-format csv -d $OUT/pmc1 -- python3 bench.py $ARGS > $OUT/bench_pmc1.log 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS --output-format csv -d $OUT/pmc2 -- python3 bench.py $ARGS > $OUT/bench_pmc2.log 2>&1
