@@ -26,6 +26,20 @@ def test_core_library_exports_every_declared_symbol():
     assert int(re.search(r"#define IS_CNT_N (\d+)", dev).group(1)) == core.EVAL_COUNTERS
 
 
+def test_gather_entry_points_reject_bad_arguments_without_a_gpu():
+    """The C-ABI gather (is_gather.hip) validates its arguments before it touches RCCL or the device: null
+    communicator / null sizes -> IS_EINVAL with a message (no GPU, no RCCL needed)."""
+    import ctypes
+    L = core.lib()
+    assert L.is_gather_i32(None, 0, None, None, None, None) == -1
+    assert b"null pointer" in L.is_last_error()
+    tot = (ctypes.c_int64 * 1)()
+    assert L.is_gather_sections(None, 0, None, None, None, None, None, None, 0, tot, None) == -1
+    assert L.is_comm_destroy(None) == 0
+    buf = ctypes.create_string_buffer(16)
+    assert L.is_comm_unique_id(buf, 16) == -1          # the id needs 128 bytes
+
+
 def test_host_library_exports():
     L = host.lib()
     for name in host.EXPORTS:
