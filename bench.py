@@ -264,7 +264,8 @@ class Workload:
                          None, None, self.stream)
 
     def time_steps(self, core, steps, **kw):
-        self.step(core, **kw)
+        for _ in range(2):   # (two warm-up steps: the first one of a fresh context also loads code objects)
+            self.step(core, **kw)
         self.torch.cuda.synchronize(self.dev)
         t0 = time.perf_counter()
         for _ in range(steps):

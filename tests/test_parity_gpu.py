@@ -982,6 +982,20 @@ def test_plain_cpp_caller_runs():
         assert abs(hor - int(0.45 * 256)) <= 8
 
 
+def test_plain_cpp_gather_caller_runs():
+    """examples/gather_batch.cpp: a g++-built caller (no HIP header, no Python, no torch in the process) creates an
+    RCCL communicator through the C ABI, runs its shard through Stixels::ComputeBatchGather and compares what
+    rank 0 received with ComputeBatch -- as one rank here (the box has one GPU)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "gather_batch")
+    if not os.path.exists(exe):
+        pytest.skip("examples/gather_batch not built (run __graft_entry__.build())")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0 and "gathered == computed: yes" in out.stdout, out.stdout + out.stderr
+
+
 @pytest.mark.parametrize("gather", ["compact", "fixed"])
 def test_bench_force_dist_child_process_runs_the_rccl_gather(gather):
     """bench.py --force-dist in a FRESH child process (never a re-exec of this one): RCCL (backend
