@@ -40,6 +40,20 @@ def test_gather_entry_points_reject_bad_arguments_without_a_gpu():
     assert L.is_comm_unique_id(buf, 16) == -1          # the id needs 128 bytes
 
 
+def test_scene_family_of_the_generator_is_stable():
+    """Throughput numbers are compared across rounds on the "scene" family: a later family added to
+    synthetic.make_frame must not consume random numbers of the scene's stream (numpy 2.2, PCG64: the image's)."""
+    import hashlib
+    from instance_stixels_amd import synthetic
+    cfg = make_config("drn_d_22_unary", 128, 256, 32)
+    f = synthetic.make_frame(cfg, seed=17)
+    assert hashlib.md5(f.disparity.tobytes() + f.segmentation.tobytes()).hexdigest() == "781312762ea81d7c7875b63d1cb66298"
+    for fam in synthetic.FAMILIES:     # every family builds, in the reference's tensor format
+        g = synthetic.make_frame(make_config("drn_d_22_unary", 64, 128, 32, invalid_disparity=0.0), seed=3, family=fam)
+        assert g.disparity.shape == (64, 128) and g.segmentation.shape == (16, 21, 16) and g.segmentation.dtype == np.int32
+        assert g.disparity.min() >= 0.0 and g.disparity.max() < 32
+
+
 def test_host_library_exports():
     L = host.lib()
     for name in host.EXPORTS:
