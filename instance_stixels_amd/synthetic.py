@@ -110,7 +110,7 @@ def make_frame(cfg: StixelConfig, seed: int = 0, n_slabs: int = 6, hole_fraction
         band_top = max(0, vhor_img - H // 4)
         x = 0
         while x < W:
-            w = int(rng.integers(W // 16, W // 5))
+            w = int(rng.integers(max(1, W // 16), max(2, W // 5)))
             cls_b = 2 if rng.random() < 0.6 else 8
             top_b = int(rng.integers(max(0, band_top - H // 10), band_top + H // 10 + 1))
             d_b = float(rng.uniform(2.0, 6.0))
@@ -125,7 +125,7 @@ def make_frame(cfg: StixelConfig, seed: int = 0, n_slabs: int = 6, hole_fraction
         n_slabs = 60
     for s in range(n_slabs):
         if family == "many_thin_objects":
-            w = int(rng.integers(8, 25))
+            w = min(int(rng.integers(8, 25)), W)
         else:
             w = int(rng.integers(max(8, W // 40), max(9, W // 8)))
         x0 = int(rng.integers(0, max(1, W - w)))
