@@ -269,7 +269,9 @@ int is_device_synchronize(void);
 /* Test hook (A4, ComputeObjectLUT): copies the object data-cost prefix table of ONE stixel column
  * (0 <= column < n_images * realcols) as the last is_compute call on this context left it into
  * host memory, h_out[(rows + 1) * max_dis] = lutT[v][fn] -- the transpose of the reference's
- * d_object_lut[fn][v] (Stixels.cu:159-160, StixelsKernels.cu:959-978).  Synchronises the device. */
+ * d_object_lut[fn][v] (Stixels.cu:159-160, StixelsKernels.cu:959-978).  Synchronises the device.  (A context
+ * created with IS_LUT_CARRY=1 materialises only the rows 32 k of unary calls whose every tile is windowed: the
+ * other rows then hold what an earlier call left there.) */
 int is_debug_read_object_lut(is_ctx* ctx, int column, float* h_out);
 
 /* Test hook: the bound-block summaries the pairwise DP of the last is_compute call left for one stixel
