@@ -570,6 +570,16 @@ def measure_variants(args, wl, dev, local_rank):
                                           "latency-bound phase 2 of one group beside the launches of the others)"}
         core.close()
 
+    # ---- unary: the LUT units of the prepare launch as workgroups of the DP launch (IS_LUT_FUSED=1, opt-in)
+    if not wl.cfg.pairwise:
+        core = wl.make_core(env={"IS_LUT_FUSED": "1"})
+        dt_f = wl.time_steps(core, 5)
+        out["lut_fused_1"] = {"images_per_s": B / dt_f, "steps": 5,
+                              "verify": wl.verify(wl.d_sections, images=[0, B - 1]),
+                              "what": "IS_LUT_FUSED=1: the write-bound object-LUT units run inside the issue-bound "
+                                      "k_dp_unary_fast launch (a counter per column orders them); default off"}
+        core.close()
+
     # ---- two / three batches in flight: one context and one stream each, batches alternate (what a
     # double-buffered caller does; the kernels of one batch fill the launch gaps and tails of another)
     out["in_flight"] = measure_in_flight(wl, (2, 3))

@@ -292,7 +292,8 @@ size_t is_scratch_bytes(const is_ctx* ctx);
  *   out[0] unary full steps, out[1] unary ground/sky-only steps,
  *   out[2] pairwise phase-1 full steps, out[3] pairwise phase-1 ground/sky-only candidates,
  *   out[4] pairwise phase-1 steps in which some lane read OUTSIDE its fn window (window misses),
- *   out[5] the same for the unary ring kernel;
+ *   out[5] the same for the unary ring kernel; out[6] / out[7]: the fused LUT units of the unary launch (polls of
+ *   waiting DP workgroups / shader clocks the units lived);
  *   out[8 + 3 t + j], t < 64: the phase-1 launch of 64-row tile t alone, j = 0 full, 1 window
  *   misses, 2 ground/sky-only.  n <= IS_EVAL_COUNTERS.  Both calls synchronise the device. */
 #define IS_EVAL_COUNTERS 200

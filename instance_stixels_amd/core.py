@@ -157,6 +157,7 @@ class Core:
             _check(lib().is_get_eval_counters(self._ctx, _hp(out), 8), "is_get_eval_counters")
         return dict(unary_full=int(out[0]), unary_gs=int(out[1]), p1_full=int(out[2]), p1_gs=int(out[3]),
                     p1_window_miss=int(out[4]), unary_window_miss=int(out[5]),
+                    lutf_spins=int(out[6]), lutf_unit_cycles=int(out[7]),
                     # per phase-1 launch (tile): [full, window misses, ground / sky-only]
                     p1_per_tile=[[int(out[8 + 3 * t + j]) for j in range(3)] for t in range(64)])
 

@@ -45,6 +45,7 @@ hipError_t isk_set_lds_pairwise(const DevParams*, int);
 hipError_t isk_set_lds_backtrace(const DevParams*);
 int isk_debug_occupancy(const DevParams*, int);
 int isk_unary_uses_carry(const DevParams*, int);
+int isk_unary_uses_fused_lut(const DevParams*, int);
 hipError_t isk_launch_cluster(int, float, int, int, const is_instance_buffers*,
                               const is_instance_buffers*, int32_t*, hipStream_t);
 size_t isk_phase2_lds_bytes(const DevParams* P);
@@ -316,6 +317,7 @@ static int ctx_init(is_ctx* c, const is_stixel_params* p, const float* obj_cost_
         d.knob_win_tiles = knob("IS_P1_WIN_TILES");
         d.knob_pw_waves = knob("IS_PW_WAVES");
         d.knob_lut_carry = knob("IS_LUT_CARRY"); /* carry-only lutT (is_device.h): opt-in */
+        d.knob_lut_fused = knob("IS_LUT_FUSED"); /* the LUT units inside the unary DP launch (is_k_unary_fast.hip, LUTF) */
     }
     {
         /* branch-and-bound constants (PruneRec, is_device.h).  gamma_d bounds the relative error of
@@ -384,6 +386,8 @@ static int ctx_init(is_ctx* c, const is_stixel_params* p, const float* obj_cost_
     ALLOC(c->d_part_idx, sizeof(int) * part_slots * 3 * 64);
     ALLOC(c->d_sv, sizeof(float) * B * C * 2 * (H + 1));
     ALLOC(c->d_t8row, sizeof(float) * B * C * H);
+    ALLOC(c->dp.lut_ready, sizeof(int) * B * C);
+    HIP_TRY(hipMemset(c->dp.lut_ready, 0, sizeof(int) * B * C));
     ALLOC(c->dp.win_lo, sizeof(int) * B * C * (size_t)c->dp.ntiles);
     HIP_TRY(hipMemset(c->dp.win_lo, 0, sizeof(int) * B * C * (size_t)c->dp.ntiles));
     ALLOC(c->d_blksum, sizeof(float) * B * C * ((size_t)d.ntiles * IS_QPT + 1) * 24);
@@ -457,7 +461,7 @@ int is_ctx_destroy(is_ctx* c) {
         free(c->graph_cache);
     }
     (void)hipFree(c->d_obj_cost_lut); (void)hipFree(c->d_odr); (void)hipFree(c->d_rcp); (void)hipFree(c->d_col_flags); (void)hipFree(c->d_prune); (void)hipFree(c->d_n_generic); (void)hipFree(c->d_stage);
-    (void)hipFree(c->d_recs); (void)hipFree(c->d_lutT); (void)hipFree(c->d_priors); (void)hipFree(c->d_steps); (void)hipFree(c->d_part_cost); (void)hipFree(c->d_part_idx); (void)hipFree(c->d_sv); (void)hipFree(c->d_blksum); (void)hipFree(c->d_t8row); (void)hipFree(c->dp.win_lo);
+    (void)hipFree(c->d_recs); (void)hipFree(c->d_lutT); (void)hipFree(c->d_priors); (void)hipFree(c->d_steps); (void)hipFree(c->d_part_cost); (void)hipFree(c->d_part_idx); (void)hipFree(c->d_sv); (void)hipFree(c->d_blksum); (void)hipFree(c->d_t8row); (void)hipFree(c->dp.win_lo); (void)hipFree(c->dp.lut_ready);
     (void)hipFree(c->d_cost_table); (void)hipFree(c->d_index_table); (void)hipFree(c->d_cluster_scratch);
     (void)hipFree(c->d_inst_cnt); (void)hipFree(c->d_counters);
     for (int i = 0; i < IS_STAGE_SLOTS; i++) {
@@ -663,6 +667,7 @@ static int compute_enqueue(is_ctx* c, const float* d_joined, const int32_t* d_se
     DevParams Pw = P; /* (+ this call's windowed / classic tile split and the form of lutT) */
     Pw.win_tiles = call_win_tiles(P, c->h_vhor_pinned[slot], n_images, pairwise);
     Pw.lut_carry = (!pairwise && isk_unary_uses_carry(&Pw, ncols)) ? 1 : 0;
+    Pw.lut_fused = (!pairwise && !capturing && isk_unary_uses_fused_lut(&Pw, ncols)) ? 1 : 0;
     if (timing) HIP_TRY(hipEventRecord(c->ev[0], stream));
     /* (d_n_generic is zero here: cleared at creation and by k_backtrace at the end of every call) */
     HIP_TRY(isk_launch_prepare(&Pw, ncols, d_joined, d_seg, c->d_ground, c->d_vhor,

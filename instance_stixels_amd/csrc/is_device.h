@@ -143,6 +143,8 @@ static_assert(sizeof(PruneRec) == 32, "PruneRec must be 32 bytes");
 #define IS_CNT_P1_GS 3      /* k_pw_phase1: ground- / sky-only candidates               */
 #define IS_CNT_P1_WINMISS 4 /* k_pw_phase1: steps in which some lane read outside its fn window (IS_P1_WIN) */
 #define IS_CNT_UNARY_WINMISS 5 /* k_dp_unary_fast (windowed tiles): steps in which some lane read outside its fn window */
+#define IS_CNT_LUTF_SPINS 6       /* k_dp_unary_fast (LUTF): polls of DP workgroups that found their column's LUT units unfinished */
+#define IS_CNT_LUTF_UNIT_CYCLES 7 /* k_dp_unary_fast (LUTF): shader clocks the fused LUT units lived, summed */
 #define IS_CNT_TILE0 8    /* + 3 * tile + {0 full, 1 window misses, 2 ground / sky-only}: per phase-1 launch, tile < 64 */
 #define IS_CNT_N 200
 
@@ -185,6 +187,11 @@ struct DevParams {
     int* win_lo;
     int win_tiles; /* the tiles 0 .. win_tiles - 1 of this call stage a window (set per call: unary every tile,
                     * pairwise phase 1 the tiles that start below every horizon of the batch) */
+    /* LUT units INSIDE the unary DP launch (is_k_unary_fast.hip, LUTF): device counters [columns] of finished
+     * (column, 64 fn) units, zeroed by k_prepare_columns; lut_fused is set per call */
+    int* lut_ready;
+    int knob_lut_fused; /* IS_LUT_FUSED: 1 = the LUT units run inside the unary DP launch where they can (measured +2 %; opt-in) */
+    int lut_fused;
     int knob_lut_carry; /* IS_LUT_CARRY=1: carry rows only wherever the DP can rebuild the rest (unary calls whose every
                          * tile runs the windowed ring kernel); default: lutT is materialised (measured faster) */
     int lut_carry;      /* set per call: k_object_lut stores only the rows 32 k of lutT (the carries of its 32-row

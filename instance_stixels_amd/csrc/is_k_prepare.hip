@@ -152,6 +152,7 @@ __device__ __forceinline__ void prepare_columns_body(
     const int* __restrict__ vhor_arr, RowRec* __restrict__ recs, int* __restrict__ col_flags,
     float* __restrict__ sv_arr, PruneRec* __restrict__ prune, int* __restrict__ n_generic) {
     const int H = P.H, P2 = P.P2, P2S = P.P2S, CH = P.CH, K = P.K;
+    if (P.lut_ready != nullptr && threadIdx.x == 0) P.lut_ready[colg] = 0; /* (the fused LUT units of the DP launch count up) */
     /* LDS stride of a segmentation channel: only its first H/8 + 1 entries matter (an exclusive
      * prefix at index <= H/8 never sees the zero padding up to P2S), and 21 channels of P2S = 256
      * entries were 21.5 of the kernel's 46 KB of LDS: with 132 the CU holds four workgroups, not three */
@@ -960,6 +961,11 @@ hipError_t isk_launch_prepare(const DevParams* P, int ncols, const float* joined
      * 1: two launches on two streams (did not overlap in practice), 2: the default. */
     const bool side_by_side = aux != nullptr && P->knob_prepare_overlap == 1;
     hipError_t e;
+    if (P->lut_fused) { /* the LUT units run inside the unary DP launch (k_dp_unary_fast, LUTF): records only here */
+        hipLaunchKernelGGL(k_prepare_columns, dim3(ncols), dim3(PREP_THREADS), isk_prepare_lds_bytes(P), stream, *P,
+                           joined, seg, ground, vhor, recs, col_flags, sv_arr, prune, n_generic);
+        return hipGetLastError();
+    }
     const bool fused = P->knob_prepare_overlap == 2 || P->knob_prepare_overlap < 0;
     if (fused) {
         const int units = ncols * ((P->D + 63) / 64);

@@ -520,9 +520,94 @@ __device__ __forceinline__ void ring_prefetch_rec(const RowRec* __restrict__ rco
 
 /* PRE_DIAG: the instantiation that starts from the minima k_dp_unary_diag left in the tables (an
  * instantiation of its own: as a run-time flag the path cost the unpruned walk 1.8 %) */
+/* ====================================================================================== */
+/* LUTF: the LUT units of the prepare launch INSIDE the DP launch                            */
+/* ====================================================================================== */
+/* k_prepare_fused's LUT blocks are bound by their HBM writes (8.6 GB per 64 frames, 1.6 ms alone), this kernel by
+ * VALU issue: side by side on the SAME CUs the two use different resources.  Two streams do not get there (a
+ * second kernel only receives the CUs the first one leaves: measured, rounds 2 and 4) and a CU partition does not
+ * either (a CU that runs prepare blocks cannot lend its VALU: round 5), so the LUT units become workgroups of
+ * THIS launch, interleaved in block order with the DP workgroups: block IDs are dispatched in order (per XCD:
+ * block b runs on XCD b mod 8), so a DP workgroup that waits for its column's units -- a counter per column,
+ * release / acquire -- only ever waits for workgroups that were dispatched before it.
+ *   block order: [8 LEAD LUT blocks] then per super-group s of cpb = 4 / fn_blocks column groups: [8 LUT blocks of
+ *   super-group s + LEAD] [cpb 8 ntl DP blocks of super-group s].  LUT block r of a super-group holds the units of
+ *   its cpb columns with column mod 8 = r: they run on the XCD whose L2 the DP workgroups of those columns use.
+ * The unit is object_lut_body (is_k_prepare.hip) without its software prefetch: 45 instead of 97 VGPRs, the kernel
+ * keeps its 72-register budget, and the DP waves of the CU hide the unit's latency.
+ * MEASURED (64 frames, `tools/run_variants.sh`, rocprofv3 averages): this launch 5.6 ms against 4.45 ms for the DP
+ * alone -- of the 1.6 ms the LUT blocks take in the prepare launch 0.45 ms disappear; with the units EMPTY
+ * (timing-only) 4.55 ms: the block interleaving and the waits cost nothing; with one store per block instead of
+ * 32 (timing-only) 4.95 ms: it is the 8.6 GB write stream that slows the DP workgroups down (their prologues are
+ * chains of memory round trips, and the round trips get longer), not the units' instructions -- a form of the
+ * unit with scalar-loaded row offsets and a third of the VALU instructions ran no faster, nor did the prefetching
+ * form at 6 or 5 waves per SIMD, a ring of 4 slots, or 8 / 128 / 512 super-groups of lead (8: 7.1 ms, the DP waits). */
+#ifndef ISF_OCC_LUTF
+#define ISF_OCC_LUTF 7
+#endif
+#ifndef ISF_LUTF_LEAD
+#define ISF_LUTF_LEAD 32 /* super-groups of LUT blocks dispatched ahead of the first DP block (8192 DP blocks at 1024 rows) */
+#endif
+__device__ __forceinline__ void lut_unit_fused(const DevParams& P, const int colg, const int fn_block, const int lane,
+                                               const float* __restrict__ joined, const float* __restrict__ cost_T,
+                                               float* __restrict__ lutT, int* __restrict__ ready) {
+    constexpr int LB = 32; /* LUT_BLOCK of k_object_lut */
+    const int H = P.H, D = P.D;
+    const int fn = fn_block * 64 + lane;
+    const bool fn_ok = fn < D;
+    const int fnc = fn_ok ? fn : D - 1;
+    const float* dcol = joined + (size_t)colg * H;
+    float* lcol = lutT + (size_t)colg * (H + 1) * D;
+    if (fn_ok) lcol[fn] = 0.0f; /* arr[0] = 0, :283-285 */
+    float add = 0.0f;
+    /* (full blocks store unconditionally -- a lane beyond D holds lane D - 1's values and writes them to its address
+     * again --: the same number of memory operations on every path, like object_lut_body) */
+    auto block = [&](const int i, const bool full) {
+        const int rl = i + (lane & (LB - 1));
+        int dis_l = (rl < H) ? (int)dcol[rl] : 0; /* rows beyond the image use dis = 0, :244-247 */
+        dis_l = min(max(dis_l, 0), D - 1);
+        float c[LB];
+#pragma unroll
+        for (int l = 0; l < LB; l++) c[l] = cost_T[(size_t)__builtin_amdgcn_readlane(dis_l, l) * D + fnc];
+        c[0] += add; /* :249-251 */
+#pragma unroll
+        for (int j = 1; j < LB; j <<= 1) {
+#pragma unroll
+            for (int l = LB - 1; l >= j; l--) c[l] += c[l - j];
+        }
+        float* dst = lcol + (size_t)(i + 1) * D + fnc;
+        if (full) {
+#ifdef ISF_ABL_LUTF_NOSTORE /* timing-only ablation: one row per block is stored (the network stays alive) */
+            __builtin_nontemporal_store(c[LB - 1], dst + (size_t)(LB - 1) * D);
+#else
+#pragma unroll
+            for (int l = 0; l < LB; l++) __builtin_nontemporal_store(c[l], dst + (size_t)l * D);
+#endif
+        } else if (fn_ok) {
+#pragma unroll
+            for (int l = 0; l < LB; l++)
+                if (i + l < H) dst[(size_t)l * D] = c[l];
+        }
+        add = c[LB - 1]; /* :268-272 */
+    };
+#ifndef ISF_ABL_LUTF_EMPTY /* timing-only ablation: the units do nothing (the table of an earlier IS_LUT_FUSED=0 call is still there) */
+    int i = 0;
+#pragma unroll 1
+    for (; i + LB <= H; i += LB) block(i, true);
+    if (i < H) block(i, false);
+#endif
+    /* The unit's rows are visible before its count is: the stores have been acknowledged by the L2 (vmcnt(0)) that
+     * the column's DP workgroups read through -- LUT block and DP workgroups of a column share their XCD (block ID mod
+     * 8) -- and the count is an L2 atomic.  (An agent-scope release fence is a write-back of the whole L2 on
+     * gfx950, an agent-scope acquire an invalidation: at one per unit / workgroup the launch took 10.6 ms.) */
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) __hip_atomic_fetch_add(ready + colg, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 /* GEN (with WIN): lutT holds only its carry rows (DevParams::lut_carry); the tile and the vB-side rows are rebuilt */
-template <bool HAS_INVALID, int NVR, bool PRE_DIAG = false, bool WIN = false, bool GEN = false>
-__global__ __launch_bounds__(ISF_THREADS, GEN ? ISF_OCC_GEN : (HAS_INVALID ? ISF_OCC_INV : ISF_OCC)) void k_dp_unary_fast(
+template <bool HAS_INVALID, int NVR, bool PRE_DIAG = false, bool WIN = false, bool GEN = false, bool LUTF = false>
+__global__ __launch_bounds__(ISF_THREADS, GEN ? ISF_OCC_GEN : (LUTF ? ISF_OCC_LUTF : (HAS_INVALID ? ISF_OCC_INV : ISF_OCC))) void k_dp_unary_fast(
     const DevParams P, int ncols, const RowRec* __restrict__ recs, const float* __restrict__ lutT,
     const float* __restrict__ rcp, const int* __restrict__ vhor_arr,
     const int* __restrict__ col_flags, const PruneRec* __restrict__ prune,
@@ -552,7 +637,38 @@ __global__ __launch_bounds__(ISF_THREADS, GEN ? ISF_OCC_GEN : (HAS_INVALID ? ISF
     /* XCD-aware order: blocks b, b+8, ... share an XCD/L2; the tiles of a column stay on one XCD
      * (they fetch the same lutT rows) and the tallest tiles start first */
     const int nxcd = 8;
-    const int xcd = blockIdx.x % nxcd, q = blockIdx.x / nxcd;
+    int dpb = (int)blockIdx.x; /* index of this workgroup among the DP workgroups */
+    if (LUTF) {
+        static_assert(!LUTF || (WIN && !GEN && !PRE_DIAG), "the fused LUT units belong to the windowed launch of every tile");
+        const int fnb = (D + 63) >> 6, cpb = 4 / fnb; /* (column, 64 fn) units and columns per LUT block: 4 waves */
+        const int nSG = ((ncols + 7) / 8 + cpb - 1) / cpb, dp_per = cpb * 8 * ntl;
+        const int lead = min(ISF_LUTF_LEAD, nSG);
+        int b = (int)blockIdx.x, sg = -1;
+        if (b < 8 * lead) {
+            sg = b >> 3;
+        } else {
+            b -= 8 * lead;
+            const int nfull = nSG - lead, per = 8 + dp_per;
+            if (b < nfull * per) {
+                const int s_ = b / per, o = b - s_ * per;
+                if (o < 8) sg = s_ + lead;
+                else dpb = s_ * dp_per + (o - 8);
+            } else {
+                dpb = nfull * dp_per + (b - nfull * per);
+            }
+        }
+        if (sg >= 0) { /* a LUT block: wave w takes unit w of the columns (sg cpb + k) 8 + r, r = this block's XCD */
+            const int wv = (int)(threadIdx.x >> 6), r = (int)blockIdx.x & 7;
+            const int col = ((sg * cpb + wv / fnb) * 8) + r;
+            const unsigned long long t0 = counters != nullptr ? __builtin_readcyclecounter() : 0ull;
+            if (col < ncols) lut_unit_fused(P, col, wv % fnb, (int)(threadIdx.x & 63), joined, cost_T, const_cast<float*>(lutT), P.lut_ready);
+            if (counters != nullptr && (threadIdx.x & 63) == 0) /* (measurements only: the unit's life in shader clocks) */
+                atomicAdd(counters + IS_CNT_LUTF_UNIT_CYCLES, __builtin_readcyclecounter() - t0);
+            return;
+        }
+    }
+    const unsigned long long t_wg0 = (LUTF && counters != nullptr) ? __builtin_readcyclecounter() : 0ull;
+    const int xcd = dpb % nxcd, q = dpb / nxcd;
     const int tile = __builtin_amdgcn_readfirstlane(tile0 + ntl - 1 - q % ntl);
     const int colg = __builtin_amdgcn_readfirstlane((q / ntl) * nxcd + xcd);
     if (colg >= ncols) return;
@@ -566,6 +682,20 @@ __global__ __launch_bounds__(ISF_THREADS, GEN ? ISF_OCC_GEN : (HAS_INVALID ? ISF
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (LUTF) {
+        /* this column's LUT units: workgroups of this launch with smaller block IDs, i.e. dispatched already (they
+         * wait for nothing).  The bound on the spin only keeps a broken assumption from hanging the device: the
+         * workgroup then goes on and the tests see wrong tables. */
+        if (tid == 0) {
+            const int need = (D + 63) >> 6;
+            int spins = 0;
+            while (__hip_atomic_load(P.lut_ready + colg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need && ++spins < (1 << 22))
+                __builtin_amdgcn_s_sleep(32);
+            if (counters != nullptr && spins > 0) atomicAdd(counters + IS_CNT_LUTF_SPINS, (unsigned long long)spins);
+        }
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
     const RowRec* rcol = recs + (size_t)colg * (H + 1);
     const float* lcol = lutT + (size_t)colg * (H + 1) * D;
     const int tile_lo = tile * IS_TILE;
@@ -744,6 +874,8 @@ __global__ __launch_bounds__(ISF_THREADS, GEN ? ISF_OCC_GEN : (HAS_INVALID ? ISF
         else if (!nog) (void)gs_walk<false>(P, pv, my, rcol, s_rcp, vTc, v, 0, nwv, b, n_gs, vT <= vhor);
     }
     ISF_MARK(1);
+    if (LUTF && counters != nullptr && tid == 0) /* (measurements only: a DP workgroup's life up to here, same clock as the units') */
+        atomicAdd(counters + IS_CNT_P1_FULL, __builtin_readcyclecounter() - t_wg0);
     if (counters != nullptr && lane == 0) {
         atomicAdd(counters + IS_CNT_UNARY_FULL, (unsigned long long)n_full);
         atomicAdd(counters + IS_CNT_UNARY_GS, (unsigned long long)n_gs);
@@ -1024,6 +1156,18 @@ int isk_unary_uses_carry(const DevParams* P, int ncols) {
     return P->win_tiles >= P->ntiles ? 1 : 0;
 }
 
+/* 1 when this call's LUT units run inside the DP launch (LUTF): every tile windowed in ONE launch of 4-wave
+ * workgroups, 1, 2 or 4 units per column (a LUT block is four waves). */
+int isk_unary_uses_fused_lut(const DevParams* P, int ncols) {
+    const int fnb = (P->D + 63) / 64;
+    if (P->knob_lut_fused != 1 || P->lut_ready == nullptr || ISF_WIN_WAVES != 4 || (fnb != 1 && fnb != 2 && fnb != 4)) return 0;
+    if (P->knob_lut_carry == 1) return 0;
+    if (isk_unary_fast_chunk_rows(P) == 0 || P->knob_ring_kernel == 0 || P->knob_unary_diag != 0) return 0;
+    if (!IS_P1_WINDOWED(P->D) || P->win_lo == nullptr) return 0;
+    if (!(P->knob_win_tiles >= 0 || ncols >= ISF_WIN_MIN_COLS)) return 0;
+    return P->win_tiles >= P->ntiles ? 1 : 0;
+}
+
 /* FAST columns of the batch; the caller runs k_dp_unary<.., false> for the generic ones. */
 hipError_t isk_launch_dp_unary_fast(const DevParams* P, int ncols, const RowRec* recs,
                                     const float* lutT, const float* rcp, const int* vhor,
@@ -1055,6 +1199,14 @@ hipError_t isk_launch_dp_unary_fast(const DevParams* P, int ncols, const RowRec*
         wt = P->win_tiles < P->ntiles ? P->win_tiles : P->ntiles;
     const int nw_win = ISF_WIN_WAVES;
     const size_t lds = isk_unary_fast_lds_bytes(P, nvr);
+    /* LUTF: 8 LUT blocks + cpb 8 ntiles DP blocks per super-group of cpb = 4 / fn_blocks column groups */
+    unsigned fused_grid = 0;
+    if (P->lut_fused) {
+        if (wt < P->ntiles) return hipErrorInvalidValue;
+        const int fnb = (P->D + 63) / 64, cpb = 4 / fnb;
+        const int nSG = (groups + cpb - 1) / cpb;
+        fused_grid = (unsigned)nSG * (8u + (unsigned)(cpb * 8 * P->ntiles));
+    }
     const bool gen = P->lut_carry != 0; /* (set by the caller only when isk_unary_uses_carry() holds) */
     if (gen && wt < P->ntiles) return hipErrorInvalidValue;
     const size_t lds_win = isf_lds_bytes(P, nvr, nw_win, true, gen);
@@ -1073,6 +1225,11 @@ hipError_t isk_launch_dp_unary_fast(const DevParams* P, int ncols, const RowRec*
                                    counters, joined, cost_T, pre_diag, wt, P->ntiles - wt);        \
             if (wt > 0 && gen)                                                                    \
                 hipLaunchKernelGGL((k_dp_unary_fast<INV, NVR, false, true, true>), dim3(groups * 8 * wt), \
+                                   dim3(nw_win * 64), lds_win, stream, *P,                         \
+                                   ncols, recs, lutT, rcp, vhor, col_flags, prune, cost_table, index_table, \
+                                   counters, joined, cost_T, pre_diag, 0, wt);                     \
+            else if (wt > 0 && P->lut_fused)                                                      \
+                hipLaunchKernelGGL((k_dp_unary_fast<INV, NVR, false, true, false, true>), dim3(fused_grid), \
                                    dim3(nw_win * 64), lds_win, stream, *P,                         \
                                    ncols, recs, lutT, rcp, vhor, col_flags, prune, cost_table, index_table, \
                                    counters, joined, cost_T, pre_diag, 0, wt);                     \

@@ -1370,6 +1370,60 @@ def test_carry_only_lut_full_frames(inv, monkeypatch):
     assert not errs, "\n".join(errs[:10])
 
 
+@pytest.mark.parametrize("k", range(8))
+def test_fused_lut_units_hostile_and_random_inputs(k, monkeypatch):
+    """IS_LUT_FUSED=1: the LUT units of the prepare launch run as workgroups of the unary DP launch
+    (k_dp_unary_fast, LUTF), the DP workgroups of a column wait for that column's count -- against the ordinary
+    order of launches bit for bit and against the oracle: random shapes and weights, invalid disparities, median
+    joins and hostile (generic-encoding) columns, whose table the same units build for k_dp_unary.  Windows forced
+    for every tile, which is what lets the fused form run at any batch size."""
+    preset, rows, cols, D, ov = _random_case(k)
+    preset = preset.replace("pairwise", "unary")
+    D = max(D, 64) if k % 2 else D
+    case = helpers.build_case(preset, rows, cols, D, seed=8300 + k, n_images=2, **ov)
+    if k >= 4:
+        case = helpers.make_hostile(case, seed=8400 + k)
+    monkeypatch.setenv("IS_P1_WIN_TILES", "99")
+    outs = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("IS_LUT_FUSED", fused)
+        outs[fused] = helpers.run_core(case)
+    a, b = outs["1"], outs["0"]
+    assert np.array_equal(a["cost_table"].view(np.uint32), b["cost_table"].view(np.uint32))
+    assert np.array_equal(a["index_table"], b["index_table"])
+    for img in range(2):
+        assert helpers.sections_equal(a["sections"][img], b["sections"][img])
+    _assert_parity(case, a)
+
+
+@pytest.mark.parametrize("shape", [(1024, 2048, 128, -1.0), (1024, 2048, 128, 0.0), (784, 1792, 128, 0.0),
+                                   (1024, 4096, 256, -1.0)])
+def test_fused_lut_units_full_frames(shape, monkeypatch):
+    """The fused form at the geometries of the bench line: eight full frames per call (headline shape with and
+    without an invalid value, the reference's 784x1792 crop with its partial last tile, configs[4] with four units
+    per column), complete tables against the ordinary launches, one frame against the oracle; the counters show that
+    the units ran (their summed life) and how often a DP workgroup had to poll."""
+    rows, cols, D, inv = shape
+    monkeypatch.delenv("IS_P1_WIN_TILES", raising=False)
+    ov = dict(invalid_disparity=inv) if inv >= 0 else {}
+    case2 = helpers.build_case("drn_d_22_unary", rows, cols, D, seed=59, n_images=2, **ov)
+    case = helpers.sub_case(case2, [i % 2 for i in range(16 if cols < 2048 else 8)])
+    outs = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("IS_LUT_FUSED", fused)
+        outs[fused], counters = _run_with_counters(case)
+        print("IS_LUT_FUSED", fused, {k: v for k, v in counters.items() if k.startswith("lutf")})
+        assert (counters["lutf_unit_cycles"] > 0) == (fused == "1"), counters
+    a, b = outs["1"], outs["0"]
+    assert np.array_equal(a["cost_table"].view(np.uint32), b["cost_table"].view(np.uint32))
+    assert np.array_equal(a["index_table"], b["index_table"])
+    for img in range(len(a["sections"])):
+        assert helpers.sections_equal(a["sections"][img], b["sections"][img])
+    ref = helpers.run_oracle(case, image=1)
+    errs = helpers.compare(ref, a, 1, case["cfg"])
+    assert not errs, "\n".join(errs[:10])
+
+
 @pytest.mark.parametrize("knob,value", [("IS_GRAPH", "1"), ("IS_PREPARE_OVERLAP", "0"),
                                          ("IS_PREPARE_OVERLAP", "1"), ("IS_UNARY_DIAG", "1")])
 @pytest.mark.parametrize("preset", ["drn_d_22_unary", "drn_d_38_pairwise"])
