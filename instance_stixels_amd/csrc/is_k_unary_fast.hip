@@ -518,6 +518,144 @@ __device__ __forceinline__ void ring_prefetch_rec(const RowRec* __restrict__ rco
     if (lane < ISF_REC_F) dma_dword((const float*)(rcol + vB) + lane, lds_addr(slot));
 }
 
+/* ====================================================================================== */
+/* QDIAG: the diagonal block of a windowed tile in 16-lane quarters                            */
+/* ====================================================================================== */
+/* A wave of the windowed launch owns the vB = tile_lo + a of one residue class mod 4, a = a0, a0 - 4, ... >= 1 with
+ * a0 = 63 - w: sixteen diagonal steps in which only the lanes vT >= vB hold a segment (32.5 of 64 on average), more
+ * than half of a pruned walk's steps.  The rows 16 q .. 16 q + 15 of the tile (quarter q) need only the a <= 16 q + 15,
+ * i.e. the list entries 4 (3 - q) .. 15: 16 + 12 + 8 + 4 = 40 quarter-steps.  A 16-lane row of the wave takes its vB
+ * operands as DPP row_newbcast of ITS OWN two dwords (eval_segment_dpp), so the four quarters of a wave can each
+ * walk their own vB: TEN steps with all four quarters busy instead of sixteen --
+ *     lanes 48-63: rows of quarter 3, entries 0 .. 9            (all ten steps)
+ *     lanes 32-47: rows of quarter 2, entries 4 .. 13
+ *     lanes 16-31: rows of quarter 2, entries 14, 15 (steps 0, 1), then their own rows, entries 8 .. 15
+ *     lanes  0-15: rows of quarter 3, entries 10 .. 15 (steps 0 .. 5), then their own rows, entries 12 .. 15
+ * (entry 15 does not exist for w = 3: a dead quarter-step).  A quarter that changes rows hands its partial minima to
+ * the lanes that own those rows (ds_bpermute + the merge rule of the waves: smaller cost, ties -> smaller vB) and
+ * loads its own rows' record.  Everything a step reads is in the tile (both lutT windows: vB > tile_lo is a row of
+ * the tile itself) or one cache line of the column's records, fetched a step ahead; candidates, operand order and the
+ * `<=` update of a descending walk are fast_step's.  The tile that contains the horizon keeps the uniform steps (its
+ * vB change from ground to sky candidates on the way).  Afterwards every lane holds its own row again and the wave
+ * goes on below the tile. */
+#ifndef ISF_QDIAG
+#define ISF_QDIAG 1
+#endif
+template <bool HAS_INVALID, bool SKY>
+__device__ __forceinline__ void diag_quarters(const DevParams& P, RowRec& my, UnaryBestF& b,
+                                              const RowRec* __restrict__ rcol, const float* __restrict__ lcol,
+                                              const float* s_tile, const float* s_rcp, const int tile_lo, const int w,
+                                              const int win_lo, int& n_winmiss) {
+    const int H = P.H, D = P.D;
+    constexpr int DPW = IS_P1_WIN + 1;
+    const int lane = (int)(threadIdx.x & 63), l15 = lane & 15, q = lane >> 4;
+    const int a0 = IS_TILE - 1 - w;
+    /* per lane, between two changes of rows: r the row of the tile it works for, hr = vTc + 1 - tile_lo, lim: the
+     * candidate a holds a segment of the row iff 1 <= a <= lim (0 for a row beyond the image), trow its window row */
+    int r, hr, a;
+    unsigned lim;
+    const float* trow;
+    auto init_best = [&]() {
+        b.g = b.o = b.s = IS_INF;
+        b.vg = b.vs = -1;
+        b.vo = 0;
+    };
+    /* dwords l15 and 16 + l15 of the record of vB = tile_lo + max(aa, 1) (never beyond record H) */
+    const unsigned rbase = (unsigned)tile_lo * (unsigned)sizeof(RowRec) + (unsigned)l15 * 4u;
+    const unsigned rmax = (unsigned)H * (unsigned)sizeof(RowRec) + (unsigned)l15 * 4u;
+    auto rec_dw = [&](int aa, float& r0, float& r1) {
+#ifdef ISF_ABL_QD_SAMEREC /* timing-only ablation (wrong results): every entry reads the same (L1-resident) record */
+        const unsigned off = min(rbase + 128u, rmax) + 0u * (unsigned)aa;
+#else
+        const unsigned off = min(((unsigned)max(aa, 1) << 7) + rbase, rmax);
+#endif
+        const float* p = (const float*)((const char*)rcol + off);
+        r0 = p[0];
+        r1 = p[16];
+    };
+    static_assert(sizeof(RowRec) == 128, "record offsets are shifts");
+    auto take_rows = [&](const int row, const int entry) {
+        r = row;
+        const int vTc = min(tile_lo + r, H - 1);
+        hr = vTc + 1 - tile_lo;
+        lim = (tile_lo + r < H) ? (unsigned)(hr - 1) : 0u;
+        trow = s_tile + r * DPW;
+        a = a0 - 4 * entry;
+        my = load_rec(rcol + vTc + 1);
+        init_best();
+    };
+    /* the partial minima of the lanes `delta` below, which worked for the same rows, merged into the lanes `mine` */
+    auto hand_over = [&](const int delta, const bool mine) {
+        const int src = (mine ? lane - delta : lane) << 2;
+        auto one = [&](float& c, int& vb) {
+            const float c2 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, c)));
+            const int vb2 = __builtin_amdgcn_ds_bpermute(src, vb);
+            const bool take = mine && ((c2 < c) || (c2 == c && vb2 >= 0 && (vb < 0 || vb2 < vb)));
+            c = take ? c2 : c;
+            vb = take ? vb2 : vb;
+        };
+        one(b.g, b.vg);
+        one(b.o, b.vo);
+        one(b.s, b.vs);
+    };
+    take_rows((q == 0) ? 48 + l15 : ((q == 1) ? 32 + l15 : lane), (q == 3) ? 0 : ((q == 2) ? 4 : ((q == 1) ? 14 : 10)));
+    float R0, R1;
+    rec_dw(a, R0, R1);
+#pragma unroll 1
+    for (int j = 0; j < 10; j++) {
+        if (j == 2 || j == 6) { /* quarter 1 (j = 2) / quarter 0 (j = 6) goes back to its own rows */
+            hand_over(j == 2 ? 16 : 48, q == (j == 2 ? 2 : 3));
+            if (q == (j == 2 ? 1 : 0)) {
+                take_rows(lane, j == 2 ? 8 : 12);
+                rec_dw(a, R0, R1);
+            }
+        }
+        float N0, N1;
+        rec_dw(a - 4, N0, N1); /* the next entry (a quarter that changes rows fetches its own after the change; two
+                                * entries ahead: 6 spilled VGPRs, the kernel 12 % slower) */
+        const int ac = max(a, 1);
+        const bool live = (unsigned)(a - 1) < lim;
+        const int hc = max(hr - ac, 1);
+        const float rh = s_rcp[hc];
+        constexpr int WANT = SKY ? IS_WANT_SKY : IS_WANT_GROUND;
+        const SegTerms t = eval_segment_dpp<HAS_INVALID, WANT>(my, R0, R1, (float)hc, rh, D, P.iw, s_rcp);
+        const int fo = IS_WIN_FIND(win_lo, t.fni);
+        const bool inw = fo >= 0;
+        const int foc = inw ? fo : 0;
+        float vtv = trow[foc];
+        float vbv = s_tile[(int)__umul24((unsigned)(ac - 1), (unsigned)DPW) + foc];
+        const int vB = tile_lo + ac;
+        const bool need = live && !inw;
+        if (__builtin_amdgcn_ballot_w64(need) != 0ull) {
+            if (need) {
+                vtv = (lcol + (size_t)min(tile_lo + hr, H) * D)[(unsigned)t.fni];
+                vbv = (lcol + (size_t)vB * D)[(unsigned)t.fni];
+            }
+            n_winmiss++;
+        }
+        const float od = vtv - vbv;
+        const float pwih = P.pw * rh;
+        const float cost_o = P.dw * od + pwih + P.sw * t.seg_o; /* left to right, fast_step */
+        const bool uo = live && (cost_o <= b.o);
+        b.o = uo ? cost_o : b.o;
+        b.vo = uo ? vB : b.vo;
+        if (SKY) {
+            const float cost_s = P.dw * t.sd + pwih + P.sw * t.seg_s;
+            const bool us = live && (cost_s <= b.s);
+            b.s = us ? cost_s : b.s;
+            b.vs = us ? vB : b.vs;
+        } else {
+            const float cost_g = P.dw * t.gd + pwih + P.sw * t.seg_g;
+            const bool ug = live && (cost_g <= b.g);
+            b.g = ug ? cost_g : b.g;
+            b.vg = ug ? vB : b.vg;
+        }
+        a -= 4;
+        R0 = N0;
+        R1 = N1;
+    }
+}
+
 /* PRE_DIAG: the instantiation that starts from the minima k_dp_unary_diag left in the tables (an
  * instantiation of its own: as a run-time flag the path cost the unpruned walk 1.8 %) */
 /* ====================================================================================== */
@@ -709,7 +847,13 @@ __global__ __launch_bounds__(ISF_THREADS, GEN ? ISF_OCC_GEN : (LUTF ? ISF_OCC_LU
     /* ---- prologue: the wave's first K slots are requested first, then the tile's lutT rows,
      * the 1/h table and this lane's record.  The wave's steps: vB_top, vB_top - 8, ... >= 0
      * (H >= 8 = the number of waves, so vB_top >= 0). */
-    const int vB_top = (pre ? tile_lo : vB_end) - w; /* (pre: may be negative = no step for this wave) */
+    /* QDIAG: the diagonal block in quarters (diag_quarters), the walk then starts below the tile */
+    const bool qd = ISF_QDIAG && WIN && !GEN && !pre && nwv == 4 && (tile_lo >= vhor || tile_lo + IS_TILE - 1 <= vhor);
+#ifdef ISF_ABL_NODIAG /* timing-only ablation (wrong results): the walk without its diagonal block */
+    const int vB_top = tile_lo - w;
+#else
+    const int vB_top = ((pre || qd) ? tile_lo : vB_end) - w; /* (pre, qd: may be negative = no step for this wave) */
+#endif
     const WinLane wlane = win_lane(lcol, rcol, D, win_lo, lane);
 #pragma unroll
     for (int i = 0; i < K; i++)
@@ -720,7 +864,8 @@ __global__ __launch_bounds__(ISF_THREADS, GEN ? ISF_OCC_GEN : (LUTF ? ISF_OCC_LU
         else ring_prefetch<NVR>(lcol, rcol, vq, D, my_ring + i * SLOT, my_ring + i * SLOT + ROWF, lane);
     }
     ISF_MARK(4); /* (debug build: ring requests issued) */
-    const RowRec my = load_rec(rcol + vTc + 1);
+    RowRec my;
+    if (!qd) my = load_rec(rcol + vTc + 1); /* (qd: diag_quarters loads the records of the rows its quarters work for) */
     ISF_MARK(5); /* (debug build: record requested) */
     float* my_cache = s_cache + (size_t)w * ISF_GEN_CACHE_F;
     if (GEN) {
@@ -745,7 +890,7 @@ __global__ __launch_bounds__(ISF_THREADS, GEN ? ISF_OCC_GEN : (LUTF ? ISF_OCC_LU
         cprune_t pq = (cprune_t)(prune + colg);
         pv.E1o = pq->E1o; pv.E1g = pq->E1g; pv.E1s = pq->E1s; pv.E2 = 3.0f * pq->E2;
         pv.dead = ~__builtin_amdgcn_ballot_w64(row_ok);
-        pv.gdead = pv.dead | __builtin_amdgcn_ballot_w64(my.G == IS_INF);
+        pv.gdead = pv.dead; /* (completed below, once this lane's record is here) */
     }
     fwin.E1o = pv.E1o;
     UnaryBestF b;
@@ -761,6 +906,11 @@ __global__ __launch_bounds__(ISF_THREADS, GEN ? ISF_OCC_GEN : (LUTF ? ISF_OCC_LU
     const bool nog = IS_SKIP_GROUND_ABOVE_HORIZON && tile_lo >= vhor;
     __syncthreads(); /* the tile and the 1/h table: the only data the waves share */
     ISF_MARK(0);
+    if (WIN && !GEN && qd) {
+        if (tile_lo >= vhor) diag_quarters<HAS_INVALID, true>(P, my, b, rcol, lcol, s_tile, s_rcp, tile_lo, w, win_lo, n_winmiss);
+        else diag_quarters<HAS_INVALID, false>(P, my, b, rcol, lcol, s_tile, s_rcp, tile_lo, w, win_lo, n_winmiss);
+    }
+    pv.gdead = pv.dead | __builtin_amdgcn_ballot_w64(my.G == IS_INF);
 
     /* ---- the wave's walk, vB downwards; slot i % K holds step i */
     int slot = 0;
