@@ -910,6 +910,7 @@ __global__ __launch_bounds__(ISF_THREADS, GEN ? ISF_OCC_GEN : (LUTF ? ISF_OCC_LU
         if (tile_lo >= vhor) diag_quarters<HAS_INVALID, true>(P, my, b, rcol, lcol, s_tile, s_rcp, tile_lo, w, win_lo, n_winmiss);
         else diag_quarters<HAS_INVALID, false>(P, my, b, rcol, lcol, s_tile, s_rcp, tile_lo, w, win_lo, n_winmiss);
     }
+    ISF_MARK(7); /* (debug build: the diagonal quarters) */
     pv.gdead = pv.dead | __builtin_amdgcn_ballot_w64(my.G == IS_INF);
 
     /* ---- the wave's walk, vB downwards; slot i % K holds step i */
