@@ -541,11 +541,18 @@ __device__ __forceinline__ void ring_prefetch_rec(const RowRec* __restrict__ rco
 #ifndef ISF_QDIAG
 #define ISF_QDIAG 1
 #endif
+#define ISF_NAT_STRIDE 36 /* floats between the staged records of the rows 0 .. 31 (144 bytes: 16-byte aligned, two lanes per bank group) */
+#define ISF_NAT_F (32 * ISF_NAT_STRIDE)
+/* the row of the tile a lane works for first: the quarters 0 and 1 begin with rows of the quarters 3 and 2 */
+__device__ __forceinline__ int qd_first_row(const int lane) {
+    const int q = lane >> 4, l15 = lane & 15;
+    return (q == 0) ? 48 + l15 : ((q == 1) ? 32 + l15 : lane);
+}
 template <bool HAS_INVALID, bool SKY>
 __device__ __forceinline__ void diag_quarters(const DevParams& P, RowRec& my, UnaryBestF& b,
                                               const RowRec* __restrict__ rcol, const float* __restrict__ lcol,
-                                              const float* s_tile, const float* s_rcp, const int tile_lo, const int w,
-                                              const int win_lo, int& n_winmiss) {
+                                              const float* s_tile, const float* s_rcp, const float* s_nat,
+                                              const int tile_lo, const int w, const int win_lo, int& n_winmiss) {
     const int H = P.H, D = P.D;
     constexpr int DPW = IS_P1_WIN + 1;
     const int lane = (int)(threadIdx.x & 63), l15 = lane & 15, q = lane >> 4;
@@ -581,7 +588,6 @@ __device__ __forceinline__ void diag_quarters(const DevParams& P, RowRec& my, Un
         lim = (tile_lo + r < H) ? (unsigned)(hr - 1) : 0u;
         trow = s_tile + r * DPW;
         a = a0 - 4 * entry;
-        my = load_rec(rcol + vTc + 1);
         init_best();
     };
     /* the partial minima of the lanes `delta` below, which worked for the same rows, merged into the lanes `mine` */
@@ -598,7 +604,8 @@ __device__ __forceinline__ void diag_quarters(const DevParams& P, RowRec& my, Un
         one(b.o, b.vo);
         one(b.s, b.vs);
     };
-    take_rows((q == 0) ? 48 + l15 : ((q == 1) ? 32 + l15 : lane), (q == 3) ? 0 : ((q == 2) ? 4 : ((q == 1) ? 14 : 10)));
+    take_rows(qd_first_row(lane), (q == 3) ? 0 : ((q == 2) ? 4 : ((q == 1) ? 14 : 10)));
+    my = load_rec(rcol + min(tile_lo + r, H - 1) + 1);
     float R0, R1;
     rec_dw(a, R0, R1);
 #pragma unroll 1
@@ -607,6 +614,7 @@ __device__ __forceinline__ void diag_quarters(const DevParams& P, RowRec& my, Un
             hand_over(j == 2 ? 16 : 48, q == (j == 2 ? 2 : 3));
             if (q == (j == 2 ? 1 : 0)) {
                 take_rows(lane, j == 2 ? 8 : 12);
+                my = load_rec((const RowRec*)(s_nat + lane * ISF_NAT_STRIDE)); /* this row's record, staged by the prologue */
                 rec_dw(a, R0, R1);
             }
         }
@@ -770,6 +778,7 @@ __global__ __launch_bounds__(ISF_THREADS, GEN ? ISF_OCC_GEN : (LUTF ? ISF_OCC_LU
     const int tile_f = max((IS_TILE * DP + 3) & ~3, merge_f);
     float* s_ring = s_tile + tile_f;                    /* [8 waves][K][SLOT]                */
     float* s_cache = s_ring + (size_t)nwv * K * SLOT;   /* GEN: [waves][ISF_GEN_CACHE_F] rebuilt vB-side rows */
+    float* s_nat = s_cache;                             /* QDIAG (never with GEN): [32][ISF_NAT_STRIDE] the records of the rows 0 .. 31 of the tile */
     float* s_zero = s_cache + (size_t)nwv * ISF_GEN_CACHE_F; /* GEN: [IS_P1_WIN] lutT row 0 */
 
     /* XCD-aware order: blocks b, b+8, ... share an XCD/L2; the tiles of a column stay on one XCD
@@ -864,8 +873,16 @@ __global__ __launch_bounds__(ISF_THREADS, GEN ? ISF_OCC_GEN : (LUTF ? ISF_OCC_LU
         else ring_prefetch<NVR>(lcol, rcol, vq, D, my_ring + i * SLOT, my_ring + i * SLOT + ROWF, lane);
     }
     ISF_MARK(4); /* (debug build: ring requests issued) */
+    /* (qd: diag_quarters loads the record of the row this lane's quarter works for first -- requested here, in front
+     * of the tile staging, it costs the kernel 43 spilled VGPRs --; the quarters 0 and 1 take their own rows'
+     * records out of s_nat when they come back to them) */
     RowRec my;
-    if (!qd) my = load_rec(rcol + vTc + 1); /* (qd: diag_quarters loads the records of the rows its quarters work for) */
+    if (!qd) my = load_rec(rcol + vTc + 1);
+    if (WIN && !GEN && qd) { /* 32 records x 8 float4 = one per thread of the 4-wave workgroup */
+        const int row = tid >> 3, ch = tid & 7;
+        const float4 x = reinterpret_cast<const float4*>(rcol + min(tile_lo + row, H - 1) + 1)[ch];
+        *reinterpret_cast<float4*>(s_nat + row * ISF_NAT_STRIDE + 4 * ch) = x;
+    }
     ISF_MARK(5); /* (debug build: record requested) */
     float* my_cache = s_cache + (size_t)w * ISF_GEN_CACHE_F;
     if (GEN) {
@@ -907,8 +924,8 @@ __global__ __launch_bounds__(ISF_THREADS, GEN ? ISF_OCC_GEN : (LUTF ? ISF_OCC_LU
     __syncthreads(); /* the tile and the 1/h table: the only data the waves share */
     ISF_MARK(0);
     if (WIN && !GEN && qd) {
-        if (tile_lo >= vhor) diag_quarters<HAS_INVALID, true>(P, my, b, rcol, lcol, s_tile, s_rcp, tile_lo, w, win_lo, n_winmiss);
-        else diag_quarters<HAS_INVALID, false>(P, my, b, rcol, lcol, s_tile, s_rcp, tile_lo, w, win_lo, n_winmiss);
+        if (tile_lo >= vhor) diag_quarters<HAS_INVALID, true>(P, my, b, rcol, lcol, s_tile, s_rcp, s_nat, tile_lo, w, win_lo, n_winmiss);
+        else diag_quarters<HAS_INVALID, false>(P, my, b, rcol, lcol, s_tile, s_rcp, s_nat, tile_lo, w, win_lo, n_winmiss);
     }
     ISF_MARK(7); /* (debug build: the diagonal quarters) */
     pv.gdead = pv.dead | __builtin_amdgcn_ballot_w64(my.G == IS_INF);
@@ -1259,6 +1276,7 @@ static size_t isf_lds_bytes(const DevParams* P, int nvr, int nwaves, bool window
     size_t tile = ((size_t)IS_TILE * DP + 3) & ~(size_t)3;
     size_t ring = (size_t)nwaves * ISF_RING * ((gen ? 0 : (windowed ? (size_t)IS_P1_WIN : 64 * (size_t)nvr)) + ISF_REC_F);
     if (gen) ring += (size_t)nwaves * ISF_GEN_CACHE_F + IS_P1_WIN; /* the rebuilt rows + the zero row */
+    else if (windowed && ISF_QDIAG) ring += ISF_NAT_F;              /* the records of the rows 0 .. 31 (diag_quarters) */
     const size_t merge = (size_t)nwaves * 3 * 64 * 2 + 2 * 3 * 64; /* lives in the tile's space */
     if (tile < merge) tile = merge;
     return sizeof(float) * (rcp + tile + ring) + 16;
