@@ -542,7 +542,17 @@ __device__ __forceinline__ void ring_prefetch_rec(const RowRec* __restrict__ rco
 #define ISF_QDIAG 1
 #endif
 #define ISF_NAT_STRIDE 36 /* floats between the staged records of the rows 0 .. 31 (144 bytes: 16-byte aligned, two lanes per bank group) */
-#define ISF_NAT_F (32 * ISF_NAT_STRIDE)
+#ifndef ISF_NAT_ROWS
+/* 64: every record of the tile is staged -- the record of vB = tile_lo + a IS the record of row a - 1, so the vB
+ * operands, the first record of every lane and the records the quarters 0 and 1 come back to all are LDS reads:
+ * nothing in the diagonal phase waits for memory.  9.2 KB more LDS = SIX instead of seven workgroups per CU at
+ * 1024 rows, and still 3.67 against 4.00 ms for 32 (only the rows 0 .. 31, the rest from global memory) per 64
+ * frames: with the diagonal in quarters the kernel executes 16 % fewer instructions, and what was hidden behind
+ * them -- a first record per wave, two reloads, a cache line per step -- had become its critical path. */
+#define ISF_NAT_ROWS 64
+#endif
+static_assert(ISF_NAT_ROWS == 32 || ISF_NAT_ROWS == 64, "the rows 0 .. 31, or the whole tile");
+#define ISF_NAT_F (ISF_NAT_ROWS * ISF_NAT_STRIDE)
 /* the row of the tile a lane works for first: the quarters 0 and 1 begin with rows of the quarters 3 and 2 */
 __device__ __forceinline__ int qd_first_row(const int lane) {
     const int q = lane >> 4, l15 = lane & 15;
@@ -571,6 +581,12 @@ __device__ __forceinline__ void diag_quarters(const DevParams& P, RowRec& my, Un
     const unsigned rbase = (unsigned)tile_lo * (unsigned)sizeof(RowRec) + (unsigned)l15 * 4u;
     const unsigned rmax = (unsigned)H * (unsigned)sizeof(RowRec) + (unsigned)l15 * 4u;
     auto rec_dw = [&](int aa, float& r0, float& r1) {
+#if ISF_NAT_ROWS == 64
+        const float* pl = s_nat + (max(aa, 1) - 1) * ISF_NAT_STRIDE + l15; /* record tile_lo + a = the record of row a - 1 */
+        r0 = pl[0];
+        r1 = pl[16];
+        return;
+#endif
 #ifdef ISF_ABL_QD_SAMEREC /* timing-only ablation (wrong results): every entry reads the same (L1-resident) record */
         const unsigned off = min(rbase + 128u, rmax) + 0u * (unsigned)aa;
 #else
@@ -605,7 +621,11 @@ __device__ __forceinline__ void diag_quarters(const DevParams& P, RowRec& my, Un
         one(b.s, b.vs);
     };
     take_rows(qd_first_row(lane), (q == 3) ? 0 : ((q == 2) ? 4 : ((q == 1) ? 14 : 10)));
+#if ISF_NAT_ROWS == 64
+    my = load_rec((const RowRec*)(s_nat + r * ISF_NAT_STRIDE));
+#else
     my = load_rec(rcol + min(tile_lo + r, H - 1) + 1);
+#endif
     float R0, R1;
     rec_dw(a, R0, R1);
 #pragma unroll 1
@@ -879,9 +899,17 @@ __global__ __launch_bounds__(ISF_THREADS, GEN ? ISF_OCC_GEN : (LUTF ? ISF_OCC_LU
     RowRec my;
     if (!qd) my = load_rec(rcol + vTc + 1);
     if (WIN && !GEN && qd) { /* 32 records x 8 float4 = one per thread of the 4-wave workgroup */
-        const int row = tid >> 3, ch = tid & 7;
-        const float4 x = reinterpret_cast<const float4*>(rcol + min(tile_lo + row, H - 1) + 1)[ch];
-        *reinterpret_cast<float4*>(s_nat + row * ISF_NAT_STRIDE + 4 * ch) = x;
+        float4 x[ISF_NAT_ROWS / 32];
+#pragma unroll
+        for (int k = 0; k < ISF_NAT_ROWS / 32; k++) {
+            const int row = (tid >> 3) + 32 * k, ch = tid & 7;
+            x[k] = reinterpret_cast<const float4*>(rcol + min(tile_lo + row, H - 1) + 1)[ch];
+        }
+#pragma unroll
+        for (int k = 0; k < ISF_NAT_ROWS / 32; k++) {
+            const int row = (tid >> 3) + 32 * k, ch = tid & 7;
+            *reinterpret_cast<float4*>(s_nat + row * ISF_NAT_STRIDE + 4 * ch) = x[k];
+        }
     }
     ISF_MARK(5); /* (debug build: record requested) */
     float* my_cache = s_cache + (size_t)w * ISF_GEN_CACHE_F;
