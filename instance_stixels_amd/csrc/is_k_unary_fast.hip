@@ -60,7 +60,7 @@
 #endif
 static_assert(ISF_WIN_WAVES >= 3 && ISF_WIN_WAVES <= ISF_WAVES, "the merge runs on 3 x 64 threads (one wave per type)");
 #ifndef ISF_WIN_MIN_COLS
-#define ISF_WIN_MIN_COLS 2048 /* columns per call from which the windowed launch is used (frames/s windowed | classic at batch 2: 6470 | 6050, 4: 6090 | 6350, 8: 6890 | 6680, 16: 7480 | 7010, 32: 7860 | 7200) */
+#define ISF_WIN_MIN_COLS 0 /* columns per call from which the windowed launch is used.  Round 4: 2048 (frames/s windowed | classic at batch 2: 6470 | 6050, 4: 6090 | 6350, 8: 6890 | 6680, 16: 7480 | 7010, 32: 7860 | 7200); with the diagonal blocks in quarters (round 5) the windowed launch wins at every size: batch 1: 6290 | 5220, 2: 8180 | 6140, 4: 7110 | 6380, 8: 9190 | 9070 */
 #endif
 
 struct UnaryBestF {

@@ -338,7 +338,7 @@ def _run_with_counters(case, want_tables=True):
 def test_config5_batch_of_8_windowed_kernels_as_timed(preset, monkeypatch):
     """BASELINE configs[4] at the instantiation bench.py TIMES it on: eight 1024x4096x256 frames per call =
     4096 stixel columns, which is where the library switches the D = 256 kernels to their fn windows BY
-    DEFAULT (k_dp_unary_fast from 2048 columns, k_pw_phase1 from 4096; a single frame = 512 columns runs
+    DEFAULT (k_dp_unary_fast at any size since round 5, k_pw_phase1 from 4096 columns; a single frame = 512 columns ran
     the classic tiles, which is what the one-frame tests above exercise).  Two distinct frames, repeated;
     of one copy of each: every 16th column (Sections + complete tables) and the complete tables of eight
     more columns against the oracle (StixelsKernels.cu:600-839); the counters prove that the window path
@@ -1279,7 +1279,7 @@ def test_phase1_fn_windows_change_nothing(preset, rows, cols, D, family, inv, mo
     """The fn windows of the DP kernels (is_device.h, IS_P1_WIN: a (column, tile) stages 32 lutT columns of
     its 64 rows instead of all D; lanes whose floor(mean) falls outside read global memory; k_dp_unary_fast
     and k_pw_phase1) forced for EVERY tile at any batch (IS_P1_WIN_TILES=99; by default the unary kernel
-    windows every tile of calls of >= 8 frames, phase 1 the tiles below the horizon of >= 16 frames) against
+    windows every tile of every call, phase 1 the tiles below the horizon of >= 16 frames) against
     the classic tiles (IS_P1_WIN_TILES=0): complete tables and Sections bit for bit, the classic run against
     the oracle, and the counters prove that the forced run did read outside its windows."""
     from instance_stixels_amd import synthetic
@@ -1315,6 +1315,20 @@ def test_phase1_fn_windows_change_nothing(preset, rows, cols, D, family, inv, mo
         assert misses["99"] > 0, misses
     if rows <= 512:
         _assert_parity(case, b)
+
+
+@pytest.mark.parametrize("k", range(12))
+def test_classic_tiles_random_and_hostile_inputs(k, monkeypatch):
+    """The 8-wave workgroups with complete lutT tiles (IS_P1_WIN_TILES=0: k_dp_unary_fast<.., WIN = false>,
+    k_pw_phase1<.., false>), which a unary call no longer runs by default at any size since the windowed launch
+    walks its diagonal blocks in quarters: random shapes and weights, invalid disparities, median joins, hostile
+    columns, both models, two images, complete tables against the oracle."""
+    preset, rows, cols, D, ov = _random_case(k)
+    case = helpers.build_case(preset, rows, cols, D, seed=8500 + k, n_images=2, **ov)
+    if k >= 8:
+        case = helpers.make_hostile(case, seed=8600 + k)
+    monkeypatch.setenv("IS_P1_WIN_TILES", "0")
+    _assert_parity(case, helpers.run_core(case))
 
 
 @pytest.mark.parametrize("k", range(8))
