@@ -30,6 +30,11 @@
  * (128 + 128) B = 15.5 KB: SEVEN 4-wave workgroups per CU (the registers' limit), a slot fill is ONE LDS-DMA
  * instruction (lanes 0-31 the row window, 32-63 the record); a lane whose floor(mean) lies outside the window
  * reads global memory.  Every tile of calls of >= 2048 columns runs this way: DP 5.75 -> 4.57 ms per 64 frames.
+ *
+ * Round 5: the ground- / sky-only tail of a walk in batches of sixteen candidates per memory round trip (gs_walk); the
+ * diagonal block of a windowed tile in 16-lane quarters on operands staged in LDS (diag_quarters: ten steps instead
+ * of sixteen; + 9.2 KB for the tile's 64 records = 24.9 KB per workgroup, six per CU): 3.67 ms per 64 frames, and
+ * the windowed launch at every call size (ISF_WIN_MIN_COLS).
  */
 #include "is_kernels.h"
 
@@ -533,26 +538,23 @@ __device__ __forceinline__ void ring_prefetch_rec(const RowRec* __restrict__ rco
  *     lanes  0-15: rows of quarter 3, entries 10 .. 15 (steps 0 .. 5), then their own rows, entries 12 .. 15
  * (entry 15 does not exist for w = 3: a dead quarter-step).  A quarter that changes rows hands its partial minima to
  * the lanes that own those rows (ds_bpermute + the merge rule of the waves: smaller cost, ties -> smaller vB) and
- * loads its own rows' record.  Everything a step reads is in the tile (both lutT windows: vB > tile_lo is a row of
- * the tile itself) or one cache line of the column's records, fetched a step ahead; candidates, operand order and the
+ * loads its own rows' record.  Everything a step reads is in LDS: both lutT windows (vB > tile_lo is a row of the
+ * tile itself) and the records, of vB and of the lanes' rows alike (s_nat, below); candidates, operand order and the
  * `<=` update of a descending walk are fast_step's.  The tile that contains the horizon keeps the uniform steps (its
  * vB change from ground to sky candidates on the way).  Afterwards every lane holds its own row again and the wave
  * goes on below the tile. */
 #ifndef ISF_QDIAG
 #define ISF_QDIAG 1
 #endif
-#define ISF_NAT_STRIDE 36 /* floats between the staged records of the rows 0 .. 31 (144 bytes: 16-byte aligned, two lanes per bank group) */
-#ifndef ISF_NAT_ROWS
-/* 64: every record of the tile is staged -- the record of vB = tile_lo + a IS the record of row a - 1, so the vB
- * operands, the first record of every lane and the records the quarters 0 and 1 come back to all are LDS reads:
- * nothing in the diagonal phase waits for memory.  9.2 KB more LDS = SIX instead of seven workgroups per CU at
- * 1024 rows, and still 3.67 against 4.00 ms for 32 (only the rows 0 .. 31, the rest from global memory) per 64
- * frames: with the diagonal in quarters the kernel executes 16 % fewer instructions, and what was hidden behind
- * them -- a first record per wave, two reloads, a cache line per step -- had become its critical path. */
-#define ISF_NAT_ROWS 64
-#endif
-static_assert(ISF_NAT_ROWS == 32 || ISF_NAT_ROWS == 64, "the rows 0 .. 31, or the whole tile");
-#define ISF_NAT_F (ISF_NAT_ROWS * ISF_NAT_STRIDE)
+/* Every record of the tile is staged in LDS (s_nat, row stride 144 bytes: 16-byte aligned, two lanes per bank
+ * group): the record of vB = tile_lo + a IS the record of row a - 1, so the vB operands, the first record of every
+ * lane and the records the quarters 0 and 1 come back to are all LDS reads -- nothing in the diagonal phase waits
+ * for memory.  9.2 KB = SIX instead of seven workgroups per CU at 1024 rows, and still 3.67 against 4.00 ms per 64
+ * frames for staging only the rows 0 .. 31 (the rest from global memory, seven workgroups) and 4.23 ms for no
+ * staging at all: with the diagonal in quarters the kernel executes 16 % fewer instructions, and what used to hide
+ * behind them -- a first record per wave, two reloads, a cache line per step -- had become its critical path. */
+#define ISF_NAT_STRIDE 36
+#define ISF_NAT_F (IS_TILE * ISF_NAT_STRIDE)
 /* the row of the tile a lane works for first: the quarters 0 and 1 begin with rows of the quarters 3 and 2 */
 __device__ __forceinline__ int qd_first_row(const int lane) {
     const int q = lane >> 4, l15 = lane & 15;
@@ -560,7 +562,7 @@ __device__ __forceinline__ int qd_first_row(const int lane) {
 }
 template <bool HAS_INVALID, bool SKY>
 __device__ __forceinline__ void diag_quarters(const DevParams& P, RowRec& my, UnaryBestF& b,
-                                              const RowRec* __restrict__ rcol, const float* __restrict__ lcol,
+                                              const float* __restrict__ lcol,
                                               const float* s_tile, const float* s_rcp, const float* s_nat,
                                               const int tile_lo, const int w, const int win_lo, int& n_winmiss) {
     const int H = P.H, D = P.D;
@@ -577,26 +579,12 @@ __device__ __forceinline__ void diag_quarters(const DevParams& P, RowRec& my, Un
         b.vg = b.vs = -1;
         b.vo = 0;
     };
-    /* dwords l15 and 16 + l15 of the record of vB = tile_lo + max(aa, 1) (never beyond record H) */
-    const unsigned rbase = (unsigned)tile_lo * (unsigned)sizeof(RowRec) + (unsigned)l15 * 4u;
-    const unsigned rmax = (unsigned)H * (unsigned)sizeof(RowRec) + (unsigned)l15 * 4u;
+    /* dwords l15 and 16 + l15 of the record of vB = tile_lo + max(aa, 1) = the staged record of row max(aa, 1) - 1 */
     auto rec_dw = [&](int aa, float& r0, float& r1) {
-#if ISF_NAT_ROWS == 64
-        const float* pl = s_nat + (max(aa, 1) - 1) * ISF_NAT_STRIDE + l15; /* record tile_lo + a = the record of row a - 1 */
+        const float* pl = s_nat + (max(aa, 1) - 1) * ISF_NAT_STRIDE + l15;
         r0 = pl[0];
         r1 = pl[16];
-        return;
-#endif
-#ifdef ISF_ABL_QD_SAMEREC /* timing-only ablation (wrong results): every entry reads the same (L1-resident) record */
-        const unsigned off = min(rbase + 128u, rmax) + 0u * (unsigned)aa;
-#else
-        const unsigned off = min(((unsigned)max(aa, 1) << 7) + rbase, rmax);
-#endif
-        const float* p = (const float*)((const char*)rcol + off);
-        r0 = p[0];
-        r1 = p[16];
     };
-    static_assert(sizeof(RowRec) == 128, "record offsets are shifts");
     auto take_rows = [&](const int row, const int entry) {
         r = row;
         const int vTc = min(tile_lo + r, H - 1);
@@ -621,11 +609,7 @@ __device__ __forceinline__ void diag_quarters(const DevParams& P, RowRec& my, Un
         one(b.s, b.vs);
     };
     take_rows(qd_first_row(lane), (q == 3) ? 0 : ((q == 2) ? 4 : ((q == 1) ? 14 : 10)));
-#if ISF_NAT_ROWS == 64
     my = load_rec((const RowRec*)(s_nat + r * ISF_NAT_STRIDE));
-#else
-    my = load_rec(rcol + min(tile_lo + r, H - 1) + 1);
-#endif
     float R0, R1;
     rec_dw(a, R0, R1);
 #pragma unroll 1
@@ -639,8 +623,7 @@ __device__ __forceinline__ void diag_quarters(const DevParams& P, RowRec& my, Un
             }
         }
         float N0, N1;
-        rec_dw(a - 4, N0, N1); /* the next entry (a quarter that changes rows fetches its own after the change; two
-                                * entries ahead: 6 spilled VGPRs, the kernel 12 % slower) */
+        rec_dw(a - 4, N0, N1); /* the next entry (a quarter that changes rows fetches its own after the change) */
         const int ac = max(a, 1);
         const bool live = (unsigned)(a - 1) < lim;
         const int hc = max(hr - ac, 1);
@@ -899,14 +882,14 @@ __global__ __launch_bounds__(ISF_THREADS, GEN ? ISF_OCC_GEN : (LUTF ? ISF_OCC_LU
     RowRec my;
     if (!qd) my = load_rec(rcol + vTc + 1);
     if (WIN && !GEN && qd) { /* 32 records x 8 float4 = one per thread of the 4-wave workgroup */
-        float4 x[ISF_NAT_ROWS / 32];
+        float4 x[IS_TILE / 32];
 #pragma unroll
-        for (int k = 0; k < ISF_NAT_ROWS / 32; k++) {
+        for (int k = 0; k < IS_TILE / 32; k++) {
             const int row = (tid >> 3) + 32 * k, ch = tid & 7;
             x[k] = reinterpret_cast<const float4*>(rcol + min(tile_lo + row, H - 1) + 1)[ch];
         }
 #pragma unroll
-        for (int k = 0; k < ISF_NAT_ROWS / 32; k++) {
+        for (int k = 0; k < IS_TILE / 32; k++) {
             const int row = (tid >> 3) + 32 * k, ch = tid & 7;
             *reinterpret_cast<float4*>(s_nat + row * ISF_NAT_STRIDE + 4 * ch) = x[k];
         }
@@ -952,8 +935,8 @@ __global__ __launch_bounds__(ISF_THREADS, GEN ? ISF_OCC_GEN : (LUTF ? ISF_OCC_LU
     __syncthreads(); /* the tile and the 1/h table: the only data the waves share */
     ISF_MARK(0);
     if (WIN && !GEN && qd) {
-        if (tile_lo >= vhor) diag_quarters<HAS_INVALID, true>(P, my, b, rcol, lcol, s_tile, s_rcp, s_nat, tile_lo, w, win_lo, n_winmiss);
-        else diag_quarters<HAS_INVALID, false>(P, my, b, rcol, lcol, s_tile, s_rcp, s_nat, tile_lo, w, win_lo, n_winmiss);
+        if (tile_lo >= vhor) diag_quarters<HAS_INVALID, true>(P, my, b, lcol, s_tile, s_rcp, s_nat, tile_lo, w, win_lo, n_winmiss);
+        else diag_quarters<HAS_INVALID, false>(P, my, b, lcol, s_tile, s_rcp, s_nat, tile_lo, w, win_lo, n_winmiss);
     }
     ISF_MARK(7); /* (debug build: the diagonal quarters) */
     pv.gdead = pv.dead | __builtin_amdgcn_ballot_w64(my.G == IS_INF);
