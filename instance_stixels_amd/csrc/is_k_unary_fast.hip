@@ -817,7 +817,6 @@ __global__ __launch_bounds__(ISF_THREADS, GEN ? ISF_OCC_GEN : (LUTF ? ISF_OCC_LU
             return;
         }
     }
-    const unsigned long long t_wg0 = (LUTF && counters != nullptr) ? __builtin_readcyclecounter() : 0ull;
     const int xcd = dpb % nxcd, q = dpb / nxcd;
     const int tile = __builtin_amdgcn_readfirstlane(tile0 + ntl - 1 - q % ntl);
     const int colg = __builtin_amdgcn_readfirstlane((q / ntl) * nxcd + xcd);
@@ -1053,8 +1052,6 @@ __global__ __launch_bounds__(ISF_THREADS, GEN ? ISF_OCC_GEN : (LUTF ? ISF_OCC_LU
         else if (!nog) (void)gs_walk<false>(P, pv, my, rcol, s_rcp, vTc, v, 0, nwv, b, n_gs, vT <= vhor);
     }
     ISF_MARK(1);
-    if (LUTF && counters != nullptr && tid == 0) /* (measurements only: a DP workgroup's life up to here, same clock as the units') */
-        atomicAdd(counters + IS_CNT_P1_FULL, __builtin_readcyclecounter() - t_wg0);
     if (counters != nullptr && lane == 0) {
         atomicAdd(counters + IS_CNT_UNARY_FULL, (unsigned long long)n_full);
         atomicAdd(counters + IS_CNT_UNARY_GS, (unsigned long long)n_gs);
