@@ -570,15 +570,19 @@ def measure_variants(args, wl, dev, local_rank):
                                           "latency-bound phase 2 of one group beside the launches of the others)"}
         core.close()
 
-    # ---- unary: the LUT units of the prepare launch as workgroups of the DP launch (IS_LUT_FUSED=1, opt-in)
+    # ---- unary: the object-LUT units back in the prepare launch (IS_LUT_FUSED=0; by default they run as workgroups
+    # of the DP launch in calls of >= 2048 columns), and the repair path of the fused form forced (IS_LUT_FUSED=2)
     if not wl.cfg.pairwise:
-        core = wl.make_core(env={"IS_LUT_FUSED": "1"})
-        dt_f = wl.time_steps(core, 5)
-        out["lut_fused_1"] = {"images_per_s": B / dt_f, "steps": 5,
-                              "verify": wl.verify(wl.d_sections, images=[0, B - 1]),
-                              "what": "IS_LUT_FUSED=1: the write-bound object-LUT units run inside the issue-bound "
-                                      "k_dp_unary_fast launch (a counter per column orders them); default off"}
-        core.close()
+        for knob, key, what in (("0", "lut_fused_0", "IS_LUT_FUSED=0: the object-LUT units in the prepare launch (k_prepare_fused), "
+                                 "as in every round before 5; default: inside the k_dp_unary_fast launch"),
+                                ("2", "lut_fused_repair_forced", "IS_LUT_FUSED=2: the fused launch publishes a wrong XCC id, every DP "
+                                 "workgroup distrusts the hand-over and the repair launches (ordinary LUT kernel + ordinary DP "
+                                 "launch) redo the call: the price of the safety net when it fires")):
+            core = wl.make_core(env={"IS_LUT_FUSED": knob})
+            dt_f = wl.time_steps(core, 5)
+            out[key] = {"images_per_s": B / dt_f, "steps": 5, "verify": wl.verify(wl.d_sections, images=[0, B - 1]),
+                        "what": what}
+            core.close()
 
     # ---- two / three batches in flight: one context and one stream each, batches alternate (what a
     # double-buffered caller does; the kernels of one batch fill the launch gaps and tails of another)

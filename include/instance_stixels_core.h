@@ -274,6 +274,15 @@ int is_device_synchronize(void);
  * other rows then hold what an earlier call left there.) */
 int is_debug_read_object_lut(is_ctx* ctx, int column, float* h_out);
 
+/* Test hook: did the last unary is_compute call on this context run its repair launches?  A unary call whose every
+ * tile is windowed builds the object data-cost table INSIDE its DP launch (the units of a column ahead of the
+ * column's DP workgroups, which wait for a per-column count); a DP workgroup that cannot trust the hand-over -- its
+ * column's units ran on another XCD than itself, or did not finish within the bound of its poll -- sets a word, and
+ * the two launches queued behind (the ordinary table kernel and the ordinary DP launch, which otherwise leave at once)
+ * do the call again.  *repaired = that word (0 in normal operation; IS_LUT_FUSED=2 forces 1 for tests, IS_LUT_FUSED=0
+ * keeps the table in the prepare launch).  Synchronises the device. */
+int is_debug_lut_fused_state(is_ctx* ctx, int* repaired);
+
 /* Test hook: the bound-block summaries the pairwise DP of the last is_compute call left for one stixel
  * column (lemmas L7 / L8): h_out[n_blocks][24], returns n_blocks through *n_blocks. */
 int is_debug_read_block_summaries(is_ctx* ctx, int column, float* h_out, int cap_floats, int* n_blocks);

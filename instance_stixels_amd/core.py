@@ -24,7 +24,7 @@ EXPORTS = [
     "is_cluster_instances", "is_host_malloc", "is_host_free", "is_get_device", "is_set_device",
     "is_ctx_device", "is_set_eval_counters", "is_get_eval_counters",
     "is_pack_sections", "is_unpack_sections", "is_stream_create", "is_stream_destroy",
-    "is_debug_read_object_lut", "is_debug_read_block_summaries",
+    "is_debug_read_object_lut", "is_debug_read_block_summaries", "is_debug_lut_fused_state",
     "is_comm_unique_id", "is_comm_init_rank", "is_comm_destroy", "is_comm_rank", "is_gather_i32",
     "is_gather_sections",
 ]
@@ -95,6 +95,7 @@ def lib():
         L.is_gather_i32.argtypes = [vp, ci, vp, vp, vp, vp]
         L.is_gather_sections.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp, ctypes.c_size_t, vp, vp]
         L.is_debug_read_object_lut.argtypes = [vp, ci, vp]
+        L.is_debug_lut_fused_state.argtypes = [vp, ctypes.POINTER(ci)]
         try:   # (an experiment library built from an older tree may lack the newest test hook)
             L.is_debug_read_block_summaries.argtypes = [vp, ci, vp, ci, ctypes.POINTER(ci)]
         except AttributeError:
@@ -160,6 +161,12 @@ class Core:
                     lutf_spins=int(out[6]), lutf_unit_cycles=int(out[7]),
                     # per phase-1 launch (tile): [full, window misses, ground / sky-only]
                     p1_per_tile=[[int(out[8 + 3 * t + j]) for j in range(3)] for t in range(64)])
+
+    def lut_fused_repaired(self):
+        """1 when the last unary call ran its repair launches (test hook, see instance_stixels_core.h)."""
+        out = ctypes.c_int(-1)
+        _check(lib().is_debug_lut_fused_state(self._ctx, ctypes.byref(out)), "is_debug_lut_fused_state")
+        return int(out.value)
 
     def read_object_lut(self, column):
         """lutT[v][fn] of one stixel column as the last compute call left it (test hook, A4)."""

@@ -388,6 +388,8 @@ static int ctx_init(is_ctx* c, const is_stixel_params* p, const float* obj_cost_
     ALLOC(c->d_t8row, sizeof(float) * B * C * H);
     ALLOC(c->dp.lut_ready, sizeof(int) * B * C);
     HIP_TRY(hipMemset(c->dp.lut_ready, 0, sizeof(int) * B * C));
+    ALLOC(c->dp.lutf_bad, sizeof(int));
+    HIP_TRY(hipMemset(c->dp.lutf_bad, 0, sizeof(int)));
     ALLOC(c->dp.win_lo, sizeof(int) * B * C * (size_t)c->dp.ntiles);
     HIP_TRY(hipMemset(c->dp.win_lo, 0, sizeof(int) * B * C * (size_t)c->dp.ntiles));
     ALLOC(c->d_blksum, sizeof(float) * B * C * ((size_t)d.ntiles * IS_QPT + 1) * 24);
@@ -461,7 +463,7 @@ int is_ctx_destroy(is_ctx* c) {
         free(c->graph_cache);
     }
     (void)hipFree(c->d_obj_cost_lut); (void)hipFree(c->d_odr); (void)hipFree(c->d_rcp); (void)hipFree(c->d_col_flags); (void)hipFree(c->d_prune); (void)hipFree(c->d_n_generic); (void)hipFree(c->d_stage);
-    (void)hipFree(c->d_recs); (void)hipFree(c->d_lutT); (void)hipFree(c->d_priors); (void)hipFree(c->d_steps); (void)hipFree(c->d_part_cost); (void)hipFree(c->d_part_idx); (void)hipFree(c->d_sv); (void)hipFree(c->d_blksum); (void)hipFree(c->d_t8row); (void)hipFree(c->dp.win_lo); (void)hipFree(c->dp.lut_ready);
+    (void)hipFree(c->d_recs); (void)hipFree(c->d_lutT); (void)hipFree(c->d_priors); (void)hipFree(c->d_steps); (void)hipFree(c->d_part_cost); (void)hipFree(c->d_part_idx); (void)hipFree(c->d_sv); (void)hipFree(c->d_blksum); (void)hipFree(c->d_t8row); (void)hipFree(c->dp.win_lo); (void)hipFree(c->dp.lut_ready); (void)hipFree(c->dp.lutf_bad);
     (void)hipFree(c->d_cost_table); (void)hipFree(c->d_index_table); (void)hipFree(c->d_cluster_scratch);
     (void)hipFree(c->d_inst_cnt); (void)hipFree(c->d_counters);
     for (int i = 0; i < IS_STAGE_SLOTS; i++) {
@@ -577,6 +579,14 @@ int is_debug_read_object_lut(is_ctx* c, int column, float* h_out) {
     return IS_OK;
 }
 
+int is_debug_lut_fused_state(is_ctx* c, int* repaired) {
+    if (!c || !repaired) return fail_arg("null pointer");
+    ON_CTX_DEVICE(c);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(repaired, c->dp.lutf_bad, sizeof(int), hipMemcpyDeviceToHost));
+    return IS_OK;
+}
+
 int is_debug_read_block_summaries(is_ctx* c, int column, float* h_out, int cap_floats, int* n_blocks) {
     if (!c || !h_out || !n_blocks) return fail_arg("null pointer");
     if (column < 0 || column >= c->max_batch * c->dp.C) return fail_arg("column outside the context's scratch");
@@ -667,7 +677,7 @@ static int compute_enqueue(is_ctx* c, const float* d_joined, const int32_t* d_se
     DevParams Pw = P; /* (+ this call's windowed / classic tile split and the form of lutT) */
     Pw.win_tiles = call_win_tiles(P, c->h_vhor_pinned[slot], n_images, pairwise);
     Pw.lut_carry = (!pairwise && isk_unary_uses_carry(&Pw, ncols)) ? 1 : 0;
-    Pw.lut_fused = (!pairwise && !capturing && isk_unary_uses_fused_lut(&Pw, ncols)) ? 1 : 0;
+    Pw.lut_fused = (!pairwise && !capturing) ? isk_unary_uses_fused_lut(&Pw, ncols) : 0;
     if (timing) HIP_TRY(hipEventRecord(c->ev[0], stream));
     /* (d_n_generic is zero here: cleared at creation and by k_backtrace at the end of every call) */
     HIP_TRY(isk_launch_prepare(&Pw, ncols, d_joined, d_seg, c->d_ground, c->d_vhor,

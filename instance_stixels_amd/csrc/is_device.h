@@ -190,8 +190,14 @@ struct DevParams {
     /* LUT units INSIDE the unary DP launch (is_k_unary_fast.hip, LUTF): device counters [columns] of finished
      * (column, 64 fn) units, zeroed by k_prepare_columns; lut_fused is set per call */
     int* lut_ready;
-    int knob_lut_fused; /* IS_LUT_FUSED: 1 = the LUT units run inside the unary DP launch where they can (measured +2 %; opt-in) */
-    int lut_fused;
+    /* ... and one word per context that a DP workgroup sets when it cannot trust what it waited for: its column's units
+     * ran on another XCD than itself (the hand-over goes through the XCD's L2: the units publish their XCC id with
+     * their count) or did not finish within the bound of the poll.  The launches behind the fused one -- the ordinary
+     * LUT kernel and the ordinary DP launch, which leave at once while the word is 0 -- then do the call again. */
+    int* lutf_bad;
+    int knob_lut_fused; /* IS_LUT_FUSED: -1 / 1 = the LUT units run inside the unary DP launch where they can, 0 = never,
+                         * 2 = (tests) fused with a WRONG XCC id published: every workgroup distrusts, the repair launches run */
+    int lut_fused;      /* set per call: 0, 1, or 2 (the test mode) */
     int knob_lut_carry; /* IS_LUT_CARRY=1: carry rows only wherever the DP can rebuild the rest (unary calls whose every
                          * tile runs the windowed ring kernel); default: lutT is materialised (measured faster) */
     int lut_carry;      /* set per call: k_object_lut stores only the rows 32 k of lutT (the carries of its 32-row

@@ -152,7 +152,10 @@ __device__ __forceinline__ void prepare_columns_body(
     const int* __restrict__ vhor_arr, RowRec* __restrict__ recs, int* __restrict__ col_flags,
     float* __restrict__ sv_arr, PruneRec* __restrict__ prune, int* __restrict__ n_generic) {
     const int H = P.H, P2 = P.P2, P2S = P.P2S, CH = P.CH, K = P.K;
-    if (P.lut_ready != nullptr && threadIdx.x == 0) P.lut_ready[colg] = 0; /* (the fused LUT units of the DP launch count up) */
+    if (P.lut_ready != nullptr && threadIdx.x == 0) {
+        P.lut_ready[colg] = 0; /* (the fused LUT units of the DP launch count up) */
+        if (colg == 0 && P.lutf_bad != nullptr) *P.lutf_bad = 0;
+    }
     /* LDS stride of a segmentation channel: only its first H/8 + 1 entries matter (an exclusive
      * prefix at index <= H/8 never sees the zero padding up to P2S), and 21 channels of P2S = 256
      * entries were 21.5 of the kernel's 46 KB of LDS: with 132 the CU holds four workgroups, not three */
@@ -833,6 +836,19 @@ __global__ __launch_bounds__(64) void k_object_lut(const DevParams P,
     object_lut_body<false>(P, (int)blockIdx.x, (int)blockIdx.y, (int)threadIdx.x, joined, cost_T, lutT);
 }
 
+/* Behind a fused LUT + DP launch (k_dp_unary_fast, LUTF) whose workgroups could not trust the hand-over: the complete
+ * table again, by the ordinary units.  Leaves at once while the word is 0 -- the normal case. */
+__global__ __launch_bounds__(64) void k_object_lut_repair(const DevParams P, int ncols, const float* __restrict__ joined,
+                                                          const float* __restrict__ cost_T, float* __restrict__ lutT,
+                                                          const int* __restrict__ run_if) {
+    if (__builtin_amdgcn_readfirstlane(*run_if) == 0) return;
+    const int fn_blocks = (P.D + 63) / 64;
+    for (int u = (int)blockIdx.x; u < ncols * fn_blocks; u += (int)gridDim.x) {
+        const int colg = u / fn_blocks;
+        object_lut_body<false>(P, colg, u - colg * fn_blocks, (int)threadIdx.x, joined, cost_T, lutT);
+    }
+}
+
 /* After a carry-only prepare: the complete table of the GENERIC columns (k_dp_unary reads it as it is).  A small
  * grid that leaves at once when the prepare kernel counted no generic column -- the normal case. */
 __global__ __launch_bounds__(64) void k_object_lut_generic(const DevParams P, int ncols, const float* __restrict__ joined,
@@ -948,6 +964,14 @@ size_t isk_prepare_lds_bytes(const DevParams* P) {
            + PREP_LDS_PAD
 #endif
         ;
+}
+
+hipError_t isk_launch_lut_repair(const DevParams* P, int ncols, const float* joined, const float* cost_T, float* lutT,
+                                 hipStream_t stream) {
+    const int units = ncols * ((P->D + 63) / 64);
+    hipLaunchKernelGGL(k_object_lut_repair, dim3(units < 8192 ? units : 8192), dim3(64), 0, stream, *P, ncols, joined,
+                       cost_T, lutT, P->lutf_bad);
+    return hipGetLastError();
 }
 
 hipError_t isk_launch_prepare(const DevParams* P, int ncols, const float* joined,

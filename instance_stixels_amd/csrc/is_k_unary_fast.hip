@@ -694,9 +694,18 @@ __device__ __forceinline__ void diag_quarters(const DevParams& P, RowRec& my, Un
 #ifndef ISF_OCC_LUTF
 #define ISF_OCC_LUTF 7
 #endif
+#ifndef ISF_LUTF_MIN_COLS
+#define ISF_LUTF_MIN_COLS 2048 /* columns per call from which the LUT units run inside the DP launch by default */
+#endif
 #ifndef ISF_LUTF_LEAD
 #define ISF_LUTF_LEAD 32 /* super-groups of LUT blocks dispatched ahead of the first DP block (8192 DP blocks at 1024 rows) */
 #endif
+/* the XCD (its L2) this wave runs on */
+__device__ __forceinline__ int xcc_id() {
+    unsigned x;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+    return (int)(x & 0xfu);
+}
 __device__ __forceinline__ void lut_unit_fused(const DevParams& P, const int colg, const int fn_block, const int lane,
                                                const float* __restrict__ joined, const float* __restrict__ cost_T,
                                                float* __restrict__ lutT, int* __restrict__ ready) {
@@ -747,11 +756,15 @@ __device__ __forceinline__ void lut_unit_fused(const DevParams& P, const int col
 #endif
     /* The unit's rows are visible before its count is: the stores have been acknowledged by the L2 (vmcnt(0)) that
      * the column's DP workgroups read through -- LUT block and DP workgroups of a column share their XCD (block ID mod
-     * 8) -- and the count is an L2 atomic.  (An agent-scope release fence is a write-back of the whole L2 on
+     * 8: OBSERVED placement, not a contract, so the unit publishes its XCC id and a reader that does not share it sets
+     * DevParams::lutf_bad, which makes the launches behind this one do the call again) -- and the count is an L2 atomic.  (An agent-scope release fence is a write-back of the whole L2 on
      * gfx950, an agent-scope acquire an invalidation: at one per unit / workgroup the launch took 10.6 ms.) */
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    if (lane == 0) __hip_atomic_fetch_add(ready + colg, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    /* count + 256 x the XCC id of this unit (lut_fused == 2, tests: a wrong one): the readers check that they share it */
+    if (lane == 0)
+        __hip_atomic_fetch_add(ready + colg, 1 + (((xcc_id() + (P.lut_fused == 2 ? 1 : 0)) & 15) << 8), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
 }
 
 /* GEN (with WIN): lutT holds only its carry rows (DevParams::lut_carry); the tile and the vB-side rows are rebuilt */
@@ -764,8 +777,10 @@ __global__ __launch_bounds__(ISF_THREADS, GEN ? ISF_OCC_GEN : (LUTF ? ISF_OCC_LU
     unsigned long long* __restrict__ counters /* null, or the evaluation counters (is_device.h) */,
     const float* __restrict__ joined, const float* __restrict__ cost_T,
     int pre_diag /* k_dp_unary_diag has run: the tables hold the minima over the vB inside the tiles */,
-    int tile0, int ntl /* this launch walks the tiles tile0 .. tile0 + ntl - 1 */) {
+    int tile0, int ntl /* this launch walks the tiles tile0 .. tile0 + ntl - 1 */,
+    const int* __restrict__ run_if /* null, or a word: the launch leaves at once while it is 0 (the repair launch behind a fused one) */) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (run_if != nullptr && __builtin_amdgcn_readfirstlane(*run_if) == 0) return;
     const int H = P.H, D = P.D;
     const int DP = (WIN ? IS_P1_WIN : D) + 1; /* WIN: the tile holds an fn window of its rows (is_device.h) */
     const int nwv = (int)(blockDim.x >> 6);   /* waves of the workgroup: 8, or 4 for the windowed tiles (GEN: 4, the stride its row residues assume) */
@@ -833,13 +848,18 @@ __global__ __launch_bounds__(ISF_THREADS, GEN ? ISF_OCC_GEN : (LUTF ? ISF_OCC_LU
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (LUTF) {
         /* this column's LUT units: workgroups of this launch with smaller block IDs, i.e. dispatched already (they
-         * wait for nothing).  The bound on the spin only keeps a broken assumption from hanging the device: the
-         * workgroup then goes on and the tests see wrong tables. */
+         * wait for nothing) and, block ID mod 8 being equal, on this workgroup's XCD.  Both are what the dispatcher is
+         * OBSERVED to do, neither is a contract: the poll is bounded, the units publish their XCC id, and a workgroup
+         * that runs out of polls or finds another id than its own sets lutf_bad -- the repair launches behind this
+         * one then redo the call from the table of the ordinary LUT kernel (what this workgroup writes is overwritten). */
         if (tid == 0) {
             const int need = (D + 63) >> 6;
-            int spins = 0;
-            while (__hip_atomic_load(P.lut_ready + colg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need && ++spins < (1 << 22))
+            int spins = 0, seen;
+            while (((seen = __hip_atomic_load(P.lut_ready + colg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & 255) < need &&
+                   ++spins < (1 << 22))
                 __builtin_amdgcn_s_sleep(32);
+            if ((seen & 255) < need || (seen >> 8) != need * xcc_id())
+                __hip_atomic_fetch_or(P.lutf_bad, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (counters != nullptr && spins > 0) atomicAdd(counters + IS_CNT_LUTF_SPINS, (unsigned long long)spins);
         }
         __syncthreads();
@@ -1271,6 +1291,9 @@ __global__ __launch_bounds__(64, ISD_OCC) void k_dp_unary_diag(
 
 extern "C" {
 
+hipError_t isk_launch_lut_repair(const DevParams* P, int ncols, const float* joined, const float* cost_T, float* lutT,
+                                 hipStream_t stream); /* is_k_prepare.hip */
+
 /* NVR = 64-lane loads per lutT row; 0 = the shape cannot use this kernel */
 static int isf_nvr(const DevParams* P) {
     if (P->D <= 128) return 2;
@@ -1337,12 +1360,18 @@ int isk_unary_uses_carry(const DevParams* P, int ncols) {
  * workgroups, 1, 2 or 4 units per column (a LUT block is four waves). */
 int isk_unary_uses_fused_lut(const DevParams* P, int ncols) {
     const int fnb = (P->D + 63) / 64;
-    if (P->knob_lut_fused != 1 || P->lut_ready == nullptr || ISF_WIN_WAVES != 4 || (fnb != 1 && fnb != 2 && fnb != 4)) return 0;
+    if (P->knob_lut_fused == 0 || P->lut_ready == nullptr || P->lutf_bad == nullptr || ISF_WIN_WAVES != 4 ||
+        (fnb != 1 && fnb != 2 && fnb != 4))
+        return 0;
     if (P->knob_lut_carry == 1) return 0;
     if (isk_unary_fast_chunk_rows(P) == 0 || P->knob_ring_kernel == 0 || P->knob_unary_diag != 0) return 0;
     if (!IS_P1_WINDOWED(P->D) || P->win_lo == nullptr) return 0;
     if (!(P->knob_win_tiles >= 0 || ncols >= ISF_WIN_MIN_COLS)) return 0;
-    return P->win_tiles >= P->ntiles ? 1 : 0;
+    if (P->win_tiles < P->ntiles) return 0;
+    /* by itself only where it pays (frames/s fused | prepare launch at 1 / 4 / 8 / 12 / 16 / 64 frames per call: 4730 |
+     * 6240, 7070 | 7100, 9300 | 9060, 9930 | 9440, 9610 | 9100, 11 030 | 10 160); IS_LUT_FUSED=1 / 2: at any size */
+    if (P->knob_lut_fused < 0 && ncols < ISF_LUTF_MIN_COLS) return 0;
+    return P->knob_lut_fused == 2 ? 2 : 1;
 }
 
 /* FAST columns of the batch; the caller runs k_dp_unary<.., false> for the generic ones. */
@@ -1393,28 +1422,36 @@ hipError_t isk_launch_dp_unary_fast(const DevParams* P, int ncols, const RowRec*
             hipLaunchKernelGGL((k_dp_unary_fast<INV, NVR, true>), dim3(groups * 8 * P->ntiles), dim3(ISF_THREADS), \
                                lds, stream, *P,                                                    \
                                ncols, recs, lutT, rcp, vhor, col_flags, prune, cost_table, index_table, \
-                               counters, joined, cost_T, pre_diag, 0, P->ntiles);                  \
+                               counters, joined, cost_T, pre_diag, 0, P->ntiles, nullptr);                  \
         else {                                                                                    \
             if (wt < P->ntiles)                                                                   \
                 hipLaunchKernelGGL((k_dp_unary_fast<INV, NVR, false>), dim3(groups * 8 * (P->ntiles - wt)), \
                                    dim3(ISF_THREADS), lds, stream, *P,                             \
                                    ncols, recs, lutT, rcp, vhor, col_flags, prune, cost_table, index_table, \
-                                   counters, joined, cost_T, pre_diag, wt, P->ntiles - wt);        \
+                                   counters, joined, cost_T, pre_diag, wt, P->ntiles - wt, nullptr);        \
             if (wt > 0 && gen)                                                                    \
                 hipLaunchKernelGGL((k_dp_unary_fast<INV, NVR, false, true, true>), dim3(groups * 8 * wt), \
                                    dim3(nw_win * 64), lds_win, stream, *P,                         \
                                    ncols, recs, lutT, rcp, vhor, col_flags, prune, cost_table, index_table, \
-                                   counters, joined, cost_T, pre_diag, 0, wt);                     \
-            else if (wt > 0 && P->lut_fused)                                                      \
+                                   counters, joined, cost_T, pre_diag, 0, wt, nullptr);                     \
+            else if (wt > 0 && P->lut_fused) {                                                    \
                 hipLaunchKernelGGL((k_dp_unary_fast<INV, NVR, false, true, false, true>), dim3(fused_grid), \
                                    dim3(nw_win * 64), lds_win, stream, *P,                         \
                                    ncols, recs, lutT, rcp, vhor, col_flags, prune, cost_table, index_table, \
-                                   counters, joined, cost_T, pre_diag, 0, wt);                     \
+                                   counters, joined, cost_T, pre_diag, 0, wt, nullptr);            \
+                /* the repair launches: they leave at once unless a workgroup above set lutf_bad */  \
+                const hipError_t er = isk_launch_lut_repair(P, ncols, joined, cost_T, const_cast<float*>(lutT), stream); \
+                if (er != hipSuccess) return er;                                                  \
+                hipLaunchKernelGGL((k_dp_unary_fast<INV, NVR, false, true>), dim3(groups * 8 * wt), \
+                                   dim3(nw_win * 64), lds_win, stream, *P,                         \
+                                   ncols, recs, lutT, rcp, vhor, col_flags, prune, cost_table, index_table, \
+                                   nullptr, joined, cost_T, pre_diag, 0, wt, P->lutf_bad);         \
+            }                                                                                     \
             else if (wt > 0)                                                                      \
                 hipLaunchKernelGGL((k_dp_unary_fast<INV, NVR, false, true>), dim3(groups * 8 * wt), \
                                    dim3(nw_win * 64), lds_win, stream, *P,                         \
                                    ncols, recs, lutT, rcp, vhor, col_flags, prune, cost_table, index_table, \
-                                   counters, joined, cost_T, pre_diag, 0, wt);                     \
+                                   counters, joined, cost_T, pre_diag, 0, wt, nullptr);                     \
         }                                                                                         \
     } while (0)
     if (P->invalid >= 0) {

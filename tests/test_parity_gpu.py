@@ -319,7 +319,8 @@ def test_config5_ultrawide_1024x4096x256_column_subset():
 
 
 def _run_with_counters(case, want_tables=True):
-    """One is_compute call of the whole case with the evaluation counters on: (outputs, counters)."""
+    """One is_compute call of the whole case with the evaluation counters on: (outputs, counters); the counters
+    also say whether a unary call ran its repair launches (`lutf_repaired`, see is_debug_lut_fused_state)."""
     from instance_stixels_amd.core import Core
     cfg = case["cfg"]
     core = Core(case["params"], case["lut"], case["odr"], max_batch=len(case["frames"]))
@@ -329,7 +330,9 @@ def _run_with_counters(case, want_tables=True):
                        ground_function=case["gf"], normalization_ground=case["ng"],
                        inv_sigma2_ground=case["ig"], vhor=case["vhor"], pairwise=bool(cfg.pairwise),
                        median_join=bool(cfg.median_join), want_tables=want_tables, want_instances=False)
-        return out, core.eval_counters()
+        counters = core.eval_counters()
+        counters["lutf_repaired"] = core.lut_fused_repaired()
+        return out, counters
     finally:
         core.close()
 
@@ -1386,28 +1389,35 @@ def test_carry_only_lut_full_frames(inv, monkeypatch):
 
 @pytest.mark.parametrize("k", range(8))
 def test_fused_lut_units_hostile_and_random_inputs(k, monkeypatch):
-    """IS_LUT_FUSED=1: the LUT units of the prepare launch run as workgroups of the unary DP launch
-    (k_dp_unary_fast, LUTF), the DP workgroups of a column wait for that column's count -- against the ordinary
-    order of launches bit for bit and against the oracle: random shapes and weights, invalid disparities, median
-    joins and hostile (generic-encoding) columns, whose table the same units build for k_dp_unary.  Windows forced
-    for every tile, which is what lets the fused form run at any batch size."""
+    """The LUT units of the prepare launch as workgroups of the unary DP launch (k_dp_unary_fast, LUTF: the default of
+    every unary call whose tiles are all windowed; the DP workgroups of a column wait for that column's count) --
+    against the ordinary order of launches (IS_LUT_FUSED=0) bit for bit and against the oracle: random shapes and
+    weights, invalid disparities, median joins and hostile (generic-encoding) columns, whose table the same units
+    build for k_dp_unary.  And the REPAIR path (IS_LUT_FUSED=2: the units publish a wrong XCC id, so every DP
+    workgroup distrusts the hand-over and sets the word that makes the ordinary LUT kernel and the ordinary DP launch
+    behind the fused one do the call again): the same bits."""
     preset, rows, cols, D, ov = _random_case(k)
     preset = preset.replace("pairwise", "unary")
     D = max(D, 64) if k % 2 else D
     case = helpers.build_case(preset, rows, cols, D, seed=8300 + k, n_images=2, **ov)
     if k >= 4:
         case = helpers.make_hostile(case, seed=8400 + k)
-    monkeypatch.setenv("IS_P1_WIN_TILES", "99")
-    outs = {}
-    for fused in ("1", "0"):
+    outs, ran = {}, None
+    for fused in ("1", "2", "0"):
         monkeypatch.setenv("IS_LUT_FUSED", fused)
-        outs[fused] = helpers.run_core(case)
-    a, b = outs["1"], outs["0"]
-    assert np.array_equal(a["cost_table"].view(np.uint32), b["cost_table"].view(np.uint32))
-    assert np.array_equal(a["index_table"], b["index_table"])
-    for img in range(2):
-        assert helpers.sections_equal(a["sections"][img], b["sections"][img])
-    _assert_parity(case, a)
+        outs[fused], counters = _run_with_counters(case)
+        if fused == "1":   # (the fused form needs windowed tiles -- D > 32, a multiple of 4 -- and 1, 2 or 4 units per column)
+            ran = counters["lutf_unit_cycles"] > 0
+            assert ran or D not in (64, 128, 256), (D, counters)
+        assert (counters["lutf_unit_cycles"] > 0) == (fused != "0" and ran), (fused, counters)
+        assert counters["lutf_repaired"] == (1 if fused == "2" and ran else 0), (fused, counters)
+    b = outs["0"]
+    for a in (outs["1"], outs["2"]):
+        assert np.array_equal(a["cost_table"].view(np.uint32), b["cost_table"].view(np.uint32))
+        assert np.array_equal(a["index_table"], b["index_table"])
+        for img in range(2):
+            assert helpers.sections_equal(a["sections"][img], b["sections"][img])
+    _assert_parity(case, outs["1"])
 
 
 @pytest.mark.parametrize("shape", [(1024, 2048, 128, -1.0), (1024, 2048, 128, 0.0), (784, 1792, 128, 0.0),
@@ -1415,26 +1425,32 @@ def test_fused_lut_units_hostile_and_random_inputs(k, monkeypatch):
 def test_fused_lut_units_full_frames(shape, monkeypatch):
     """The fused form at the geometries of the bench line: eight full frames per call (headline shape with and
     without an invalid value, the reference's 784x1792 crop with its partial last tile, configs[4] with four units
-    per column), complete tables against the ordinary launches, one frame against the oracle; the counters show that
-    the units ran (their summed life) and how often a DP workgroup had to poll."""
+    per column), BY DEFAULT (no knob), complete tables against the ordinary launches (IS_LUT_FUSED=0) and against the
+    repair path (IS_LUT_FUSED=2), one frame against the oracle; the counters show that the units ran (their summed
+    life), how often a DP workgroup had to poll, and that no repair was needed unless forced."""
     rows, cols, D, inv = shape
     monkeypatch.delenv("IS_P1_WIN_TILES", raising=False)
     ov = dict(invalid_disparity=inv) if inv >= 0 else {}
     case2 = helpers.build_case("drn_d_22_unary", rows, cols, D, seed=59, n_images=2, **ov)
     case = helpers.sub_case(case2, [i % 2 for i in range(16 if cols < 2048 else 8)])
     outs = {}
-    for fused in ("1", "0"):
-        monkeypatch.setenv("IS_LUT_FUSED", fused)
+    for fused in ("default", "2", "0"):
+        if fused == "default":
+            monkeypatch.delenv("IS_LUT_FUSED", raising=False)
+        else:
+            monkeypatch.setenv("IS_LUT_FUSED", fused)
         outs[fused], counters = _run_with_counters(case)
         print("IS_LUT_FUSED", fused, {k: v for k, v in counters.items() if k.startswith("lutf")})
-        assert (counters["lutf_unit_cycles"] > 0) == (fused == "1"), counters
-    a, b = outs["1"], outs["0"]
-    assert np.array_equal(a["cost_table"].view(np.uint32), b["cost_table"].view(np.uint32))
-    assert np.array_equal(a["index_table"], b["index_table"])
-    for img in range(len(a["sections"])):
-        assert helpers.sections_equal(a["sections"][img], b["sections"][img])
+        assert (counters["lutf_unit_cycles"] > 0) == (fused != "0"), counters
+        assert counters["lutf_repaired"] == (1 if fused == "2" else 0), counters
+    b = outs["0"]
+    for a in (outs["default"], outs["2"]):
+        assert np.array_equal(a["cost_table"].view(np.uint32), b["cost_table"].view(np.uint32))
+        assert np.array_equal(a["index_table"], b["index_table"])
+        for img in range(len(a["sections"])):
+            assert helpers.sections_equal(a["sections"][img], b["sections"][img])
     ref = helpers.run_oracle(case, image=1)
-    errs = helpers.compare(ref, a, 1, case["cfg"])
+    errs = helpers.compare(ref, outs["default"], 1, case["cfg"])
     assert not errs, "\n".join(errs[:10])
 
 
