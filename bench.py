@@ -366,7 +366,9 @@ class Workload:
 
 def dp_kernel_name(cfg):
     return ("k_pw_phase1 + k_pw_phase2, all 64-row tiles of the step" if cfg.pairwise
-            else "k_dp_unary_fast (FAST columns; k_dp_unary takes generic columns: none here)")
+            else "k_dp_unary_fast (FAST columns; k_dp_unary takes generic columns: none here); in calls of >= 2048 "
+                 "columns the launch also holds the object-LUT units of the prepare step (their 8.6 GB of writes per 64 "
+                 "frames are part of `traffic`, their time part of kernel_ms)")
 
 
 def measure_mode(wl, steps=3, with_pruning_off=True, with_verify=True, with_prune=True, with_single=False):
