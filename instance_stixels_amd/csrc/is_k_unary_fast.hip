@@ -1370,7 +1370,7 @@ int isk_unary_uses_fused_lut(const DevParams* P, int ncols) {
     if (P->win_tiles < P->ntiles) return 0;
     /* by itself only where it pays (frames/s fused | prepare launch at 1 / 4 / 8 / 12 / 16 / 64 frames per call: 4730 |
      * 6240, 7070 | 7100, 9300 | 9060, 9930 | 9440, 9610 | 9100, 11 030 | 10 160); IS_LUT_FUSED=1 / 2: at any size */
-    if (P->knob_lut_fused < 0 && ncols < ISF_LUTF_MIN_COLS) return 0;
+    if (P->knob_lut_fused < 0 && (ncols < ISF_LUTF_MIN_COLS || fnb > 2)) return 0; /* (D = 256, four units per column, 32 frames of 1024x4096: 3940 | 4040) */
     return P->knob_lut_fused == 2 ? 2 : 1;
 }
 
