@@ -693,6 +693,9 @@ __device__ __forceinline__ void diag_quarters(const DevParams& P, RowRec& my, Un
  * form at 6 or 5 waves per SIMD, a ring of 4 slots, or 8 / 128 / 512 super-groups of lead (8: 7.1 ms, the DP waits). */
 #ifndef ISF_OCC_LUTF
 #define ISF_OCC_LUTF 7
+#ifndef ISF_OCC_LUTF_INV
+#define ISF_OCC_LUTF_INV 6 /* with an invalid-disparity value: 80 VGPRs (the 24.9 KB of LDS admit six workgroups = 6 waves per SIMD at 1024 rows anyway); at 7: 6 spilled VGPRs, 9670 against 10 340 frames/s */
+#endif
 #endif
 #ifndef ISF_LUTF_MIN_COLS
 #define ISF_LUTF_MIN_COLS 2048 /* columns per call from which the LUT units run inside the DP launch by default */
@@ -769,7 +772,7 @@ __device__ __forceinline__ void lut_unit_fused(const DevParams& P, const int col
 
 /* GEN (with WIN): lutT holds only its carry rows (DevParams::lut_carry); the tile and the vB-side rows are rebuilt */
 template <bool HAS_INVALID, int NVR, bool PRE_DIAG = false, bool WIN = false, bool GEN = false, bool LUTF = false>
-__global__ __launch_bounds__(ISF_THREADS, GEN ? ISF_OCC_GEN : (LUTF ? ISF_OCC_LUTF : (HAS_INVALID ? ISF_OCC_INV : ISF_OCC))) void k_dp_unary_fast(
+__global__ __launch_bounds__(ISF_THREADS, GEN ? ISF_OCC_GEN : (LUTF ? (HAS_INVALID ? ISF_OCC_LUTF_INV : ISF_OCC_LUTF) : (HAS_INVALID ? ISF_OCC_INV : ISF_OCC))) void k_dp_unary_fast(
     const DevParams P, int ncols, const RowRec* __restrict__ recs, const float* __restrict__ lutT,
     const float* __restrict__ rcp, const int* __restrict__ vhor_arr,
     const int* __restrict__ col_flags, const PruneRec* __restrict__ prune,
