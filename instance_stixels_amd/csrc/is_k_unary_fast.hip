@@ -771,7 +771,8 @@ __device__ __forceinline__ void lut_unit_fused(const DevParams& P, const int col
 }
 
 /* GEN (with WIN): lutT holds only its carry rows (DevParams::lut_carry); the tile and the vB-side rows are rebuilt */
-template <bool HAS_INVALID, int NVR, bool PRE_DIAG = false, bool WIN = false, bool GEN = false, bool LUTF = false>
+template <bool HAS_INVALID, int NVR, bool PRE_DIAG = false, bool WIN = false, bool GEN = false, bool LUTF = false,
+          bool REPAIR = false>
 __global__ __launch_bounds__(ISF_THREADS, GEN ? ISF_OCC_GEN : (LUTF ? (HAS_INVALID ? ISF_OCC_LUTF_INV : ISF_OCC_LUTF) : (HAS_INVALID ? ISF_OCC_INV : ISF_OCC))) void k_dp_unary_fast(
     const DevParams P, int ncols, const RowRec* __restrict__ recs, const float* __restrict__ lutT,
     const float* __restrict__ rcp, const int* __restrict__ vhor_arr,
@@ -781,9 +782,13 @@ __global__ __launch_bounds__(ISF_THREADS, GEN ? ISF_OCC_GEN : (LUTF ? (HAS_INVAL
     const float* __restrict__ joined, const float* __restrict__ cost_T,
     int pre_diag /* k_dp_unary_diag has run: the tables hold the minima over the vB inside the tiles */,
     int tile0, int ntl /* this launch walks the tiles tile0 .. tile0 + ntl - 1 */,
-    const int* __restrict__ run_if /* null, or a word: the launch leaves at once while it is 0 (the repair launch behind a fused one) */) {
+    const int* __restrict__ run_if /* REPAIR: a word; the launch leaves at once while it is 0 */) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    if (run_if != nullptr && __builtin_amdgcn_readfirstlane(*run_if) == 0) return;
+    static_assert(!REPAIR || (WIN && !GEN && !LUTF && !PRE_DIAG), "the repair launch is the plain windowed one");
+    /* REPAIR (the launch behind a fused LUT + DP launch, DevParams::lutf_bad): a SMALL grid whose workgroups walk the
+     * (column, tile) items of the plain launch one after the other -- 262144 workgroups that only read a word and
+     * leave took 62 us per call. */
+    if (REPAIR && __builtin_amdgcn_readfirstlane(*run_if) == 0) return;
     const int H = P.H, D = P.D;
     const int DP = (WIN ? IS_P1_WIN : D) + 1; /* WIN: the tile holds an fn window of its rows (is_device.h) */
     const int nwv = (int)(blockDim.x >> 6);   /* waves of the workgroup: 8, or 4 for the windowed tiles (GEN: 4, the stride its row residues assume) */
@@ -835,11 +840,14 @@ __global__ __launch_bounds__(ISF_THREADS, GEN ? ISF_OCC_GEN : (LUTF ? (HAS_INVAL
             return;
         }
     }
+    if (REPAIR) dpb = (int)blockIdx.x;
+next_item: /* (REPAIR: the next (column, tile) item of this workgroup) */
+    {
     const int xcd = dpb % nxcd, q = dpb / nxcd;
     const int tile = __builtin_amdgcn_readfirstlane(tile0 + ntl - 1 - q % ntl);
     const int colg = __builtin_amdgcn_readfirstlane((q / ntl) * nxcd + xcd);
-    if (colg >= ncols) return;
-    if (__builtin_amdgcn_readfirstlane(col_flags[colg]) != 0) return; /* generic column: k_dp_unary */
+    if (colg >= ncols) goto item_done;
+    if (__builtin_amdgcn_readfirstlane(col_flags[colg]) != 0) goto item_done; /* generic column: k_dp_unary */
     const int vhor = __builtin_amdgcn_readfirstlane(vhor_arr[colg / P.C]);
     /* WIN: first lutT column of the fn window of this (column, tile) (k_prepare writes it; requested with the flags) */
     const int win_lo = WIN ? __builtin_amdgcn_readfirstlane(P.win_lo[(size_t)colg * P.ntiles + tile]) : 0;
@@ -1122,6 +1130,13 @@ __global__ __launch_bounds__(ISF_THREADS, GEN ? ISF_OCC_GEN : (LUTF ? (HAS_INVAL
     }
     wait_vmcnt<0>(); /* no LDS-DMA may land after the workgroup has gone (its LDS is reassigned) */
     ISF_MARK(3);
+    }
+item_done:
+    if (REPAIR) {
+        __syncthreads(); /* (the item's LDS is free) */
+        dpb += (int)gridDim.x;
+        if (dpb < ((ncols + nxcd - 1) / nxcd) * nxcd * ntl) goto next_item;
+    }
 }
 
 /* ====================================================================================== */
@@ -1445,7 +1460,8 @@ hipError_t isk_launch_dp_unary_fast(const DevParams* P, int ncols, const RowRec*
                 /* the repair launches: they leave at once unless a workgroup above set lutf_bad */  \
                 const hipError_t er = isk_launch_lut_repair(P, ncols, joined, cost_T, const_cast<float*>(lutT), stream); \
                 if (er != hipSuccess) return er;                                                  \
-                hipLaunchKernelGGL((k_dp_unary_fast<INV, NVR, false, true>), dim3(groups * 8 * wt), \
+                hipLaunchKernelGGL((k_dp_unary_fast<INV, NVR, false, true, false, false, true>),   \
+                                   dim3(groups * 8 * wt < 1536 ? groups * 8 * wt : 1536),          \
                                    dim3(nw_win * 64), lds_win, stream, *P,                         \
                                    ncols, recs, lutT, rcp, vhor, col_flags, prune, cost_table, index_table, \
                                    nullptr, joined, cost_T, pre_diag, 0, wt, P->lutf_bad);         \
