@@ -18,7 +18,7 @@ import sys
 
 DP_KERNELS = {"unary": ("k_dp_unary",), "pairwise": ("k_pw_phase1", "k_pw_phase2")}  # (k_pw_phase2 matches k_pw_phase2x and k_pw_phase2_generic too)
 # the kernel whose VALU issue is reported (bench.py `valu.issue_frac`): ISA file, mangled-name pattern
-VALU_KERNEL = {"unary": ("is_k_unary_fast", "k_dp_unary_fastILb0ELi2ELb0ELb1ELb0ELb1EE", "k_dp_unary_fast<false, 2, false, true, false, true>"),   # <false, 2, false, WIN, !GEN, LUTF>: the instantiation batch 64 runs (the repair launch behind it, <.., false>, leaves at once and is not averaged in)
+VALU_KERNEL = {"unary": ("is_k_unary_fast", "k_dp_unary_fastILb0ELi2ELb0ELb1ELb0ELb1ELb0EE", "k_dp_unary_fast<false, 2, false, true, false, true, false>"),   # <false, 2, false, WIN, !GEN, LUTF, !REPAIR>: the instantiation batch 64 runs (the repair launch behind it, <.., false>, leaves at once and is not averaged in)
                "pairwise": ("is_k_pairwise", "k_pw_phase1ILb0ELi2E", "k_pw_phase1")}
 N_SIMD = 256 * 4   # MI355X: 256 CUs x 4 SIMDs
 # issue cycles per wave64 VALU instruction on gfx950, measured with tools/ubench:
