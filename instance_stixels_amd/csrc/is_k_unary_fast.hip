@@ -48,7 +48,7 @@
 #define ISF_GS_STEPS 1 /* ground / sky-only steps once the object bound holds for the wave */
 #endif
 #ifndef ISF_OCC_INV
-#define ISF_OCC_INV 7 /* with an invalid-disparity value (round 5: the mean through mean_valid_fast; 5 while it was an IEEE division) */
+#define ISF_OCC_INV 6 /* with an invalid-disparity value (round 5: the mean through mean_valid_fast; 5 while it was an IEEE division; 7 until the tile's records were staged in LDS -- 24.9 KB per windowed workgroup admit six per CU from ~700 rows on, so the 7th wave per SIMD only cost registers: one frame of 784x1792 6770 -> 6900 frames/s, four 11 510 -> 11 630) */
 #endif
 #ifndef ISF_OCC
 #define ISF_OCC 7 /* waves per SIMD the kernel is compiled for: 68 VGPRs without spills; LDS keeps three workgroups = 6 per SIMD resident (7 measured 0.5-1 % faster than 6) */
