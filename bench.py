@@ -443,6 +443,8 @@ def measure_in_flight(wl, counts, steps=12):
         dt = (time.perf_counter() - t0) / steps
         res[str(n)] = {"images_per_s": wl.B / dt, "ms_per_step": dt * 1e3, "steps": steps,
                        "outputs_equal_single_context": bool(all(torch.equal(ref, o) for o in outs))}
+        if not wl.cfg.pairwise:   # did a fused LUT + DP launch of a context ever distrust its hand-over beside the others'?
+            res[str(n)]["lut_fused_repaired_last_call"] = [c.lut_fused_repaired() for c in cores]
         for c in cores:
             c.close()
         del cores, streams, joined, outs, ref
