@@ -33,7 +33,7 @@
  *
  * Round 5: the ground- / sky-only tail of a walk in batches of sixteen candidates per memory round trip (gs_walk); the
  * diagonal block of a windowed tile in 16-lane quarters on operands staged in LDS (diag_quarters: ten steps instead
- * of sixteen; + 9.2 KB for the tile's 64 records = 24.9 KB per workgroup, six per CU): 3.67 ms per 64 frames, and
+ * of sixteen; + 8 KB for the tile's 64 records, a ring of two slots = 22.8 KB per workgroup, seven per CU): 3.67 ms per 64 frames, and
  * the windowed launch at every call size (ISF_WIN_MIN_COLS).
  */
 #include "is_kernels.h"
@@ -48,7 +48,7 @@
 #define ISF_GS_STEPS 1 /* ground / sky-only steps once the object bound holds for the wave */
 #endif
 #ifndef ISF_OCC_INV
-#define ISF_OCC_INV 6 /* with an invalid-disparity value (round 5: the mean through mean_valid_fast; 5 while it was an IEEE division; 7 until the tile's records were staged in LDS -- 24.9 KB per windowed workgroup admit six per CU from ~700 rows on, so the 7th wave per SIMD only cost registers: one frame of 784x1792 6770 -> 6900 frames/s, four 11 510 -> 11 630) */
+#define ISF_OCC_INV 6 /* with an invalid-disparity value (round 5: the mean through mean_valid_fast; 5 while it was an IEEE division; 7 until round 5: at 72 VGPRs these instantiations spill 2-6 registers; measured again with the 22.8 KB workgroups that LDS admits seven of: 6 | 7 waves per SIMD 10 600 | 10 220 frames/s at invalid_disparity = 0, 15 550 | 15 130 on the 784x1792 crop) */
 #endif
 #ifndef ISF_OCC
 #define ISF_OCC 7 /* waves per SIMD the kernel is compiled for: 68 VGPRs without spills; LDS keeps three workgroups = 6 per SIMD resident (7 measured 0.5-1 % faster than 6) */
@@ -546,14 +546,22 @@ __device__ __forceinline__ void ring_prefetch_rec(const RowRec* __restrict__ rco
 #ifndef ISF_QDIAG
 #define ISF_QDIAG 1
 #endif
-/* Every record of the tile is staged in LDS (s_nat, row stride 144 bytes: 16-byte aligned, two lanes per bank
- * group): the record of vB = tile_lo + a IS the record of row a - 1, so the vB operands, the first record of every
- * lane and the records the quarters 0 and 1 come back to are all LDS reads -- nothing in the diagonal phase waits
- * for memory.  9.2 KB = SIX instead of seven workgroups per CU at 1024 rows, and still 3.67 against 4.00 ms per 64
- * frames for staging only the rows 0 .. 31 (the rest from global memory, seven workgroups) and 4.23 ms for no
- * staging at all: with the diagonal in quarters the kernel executes 16 % fewer instructions, and what used to hide
- * behind them -- a first record per wave, two reloads, a cache line per step -- had become its critical path. */
-#define ISF_NAT_STRIDE 36
+/* Every record of the tile is staged in LDS (s_nat): the record of vB = tile_lo + a IS the record of row a - 1, so the
+ * vB operands, the first record of every lane and the records the quarters 0 and 1 come back to are all LDS reads --
+ * nothing in the diagonal phase waits for memory: 3.67 against 4.00 ms per 64 frames for staging only the rows
+ * 0 .. 31 (the rest from global memory) and 4.23 ms for no staging at all: with the diagonal in quarters the kernel
+ * executes 16 % fewer instructions, and what used to hide behind them -- a first record per wave, two reloads, a
+ * cache line per step -- had become its critical path.
+ * Row stride: 128 bytes, UNPADDED (a lane's whole-record read and the quarters' dword reads then meet in the same
+ * banks: three record loads per wave, two dwords per step).  Padded to 144 bytes the records are 9.2 KB and the
+ * workgroup 24.9 KB = six per CU at 1024 rows; unpadded, with a ring of two slots (ISF_RING), 22.8 KB = SEVEN.  With
+ * the LUT units in the prepare launch that was a wash (3.65-3.71 against 3.70-3.73 ms), with the units inside this
+ * launch -- they take workgroup slots -- the seventh slot is worth 1.2-2.4 % (11 030 -> 11 170-11 290 frames/s);
+ * the records' 16-byte chunks XOR-swizzled by the row (conflict-free at 8 KB): 4.05 ms, the per-lane chunk addresses
+ * cost 9 spilled VGPRs. */
+#ifndef ISF_NAT_STRIDE
+#define ISF_NAT_STRIDE 32
+#endif
 #define ISF_NAT_F (IS_TILE * ISF_NAT_STRIDE)
 /* the row of the tile a lane works for first: the quarters 0 and 1 begin with rows of the quarters 3 and 2 */
 __device__ __forceinline__ int qd_first_row(const int lane) {
@@ -694,7 +702,7 @@ __device__ __forceinline__ void diag_quarters(const DevParams& P, RowRec& my, Un
 #ifndef ISF_OCC_LUTF
 #define ISF_OCC_LUTF 7
 #ifndef ISF_OCC_LUTF_INV
-#define ISF_OCC_LUTF_INV 6 /* with an invalid-disparity value: 80 VGPRs (the 24.9 KB of LDS admit six workgroups = 6 waves per SIMD at 1024 rows anyway); at 7: 6 spilled VGPRs, 9670 against 10 340 frames/s */
+#define ISF_OCC_LUTF_INV 6 /* with an invalid-disparity value: 80 VGPRs; at 7: 6 spilled VGPRs (see ISF_OCC_INV) */
 #endif
 #endif
 #ifndef ISF_LUTF_MIN_COLS

@@ -713,7 +713,7 @@ __device__ __forceinline__ SegTerms eval_segment_mix(const RowRec& my, const isk
 /* Wave-private LDS rings filled by LDS-DMA (is_k_unary_fast.hip, k_pw_phase1_ring)         */
 /* ====================================================================================== */
 #ifndef ISF_RING
-#define ISF_RING 3     /* slots per wave: prefetch distance in steps (unary) */
+#define ISF_RING 2     /* slots per wave: prefetch distance in steps (unary).  3 until the diagonal quarters (round 5): the first slots are filled while the wave walks its diagonal block in LDS; two measured equal to three (3.67 / 3.68 ms per 64 frames) and, with the unpadded records, leave the LDS of a seventh windowed workgroup per CU (is_k_unary_fast.hip) */
 #endif
 #define ISF_REC_F 32   /* floats of a record slot */
 
