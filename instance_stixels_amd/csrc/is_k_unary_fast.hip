@@ -701,9 +701,9 @@ __device__ __forceinline__ void diag_quarters(const DevParams& P, RowRec& my, Un
  * form at 6 or 5 waves per SIMD, a ring of 4 slots, or 8 / 128 / 512 super-groups of lead (8: 7.1 ms, the DP waits). */
 #ifndef ISF_OCC_LUTF
 #define ISF_OCC_LUTF 7
+#endif
 #ifndef ISF_OCC_LUTF_INV
 #define ISF_OCC_LUTF_INV 6 /* with an invalid-disparity value: 80 VGPRs; at 7: 6 spilled VGPRs (see ISF_OCC_INV) */
-#endif
 #endif
 #ifndef ISF_LUTF_MIN_COLS
 #define ISF_LUTF_MIN_COLS 2048 /* columns per call from which the LUT units run inside the DP launch by default */
