@@ -10,18 +10,28 @@ region.  Rank 0 prints ONE JSON line.
 
     python bench.py [--gpus N --steps K --warmup W] [--batch B] [--preset drn_d_22_unary]
 
-The default run (N = 1) also reports, outside `value`:
+stdout carries ONE compact JSON line (< 4 KB: compact_line()); the complete object (per-kernel times,
+timed blocks, every oracle check, the --full sweeps) goes to bench_full.json next to this file (and
+under gpurun_out/ when that directory exists).
+
+The default run (N = 1, about half a minute) also reports, outside `value`:
   verify      frames of the TIMED output against the CPU oracle (bit-exact Section arrays)
   prune       what the exact branch-and-bound evaluated (device counters, separate untimed pass)
-  variants    pruning off, three more input families, the OTHER model (pairwise when the preset
-              is unary) at the same batch with its own roofline / pruning-off / verify,
-              BASELINE configs[4] (1024x4096x256) in both modes, configs[0] (512x1024x64,
-              disparity only) on the CPU and the GPU, invalid-disparity kernels, generic
-              column encoding, the C++ host class.
+  value_pruning_off / value_floor_families (the slowest known input family, cityscapes_like; with
+              --full every family) / lut_fused_repaired over the timed steps / cpu_baseline
+--full adds `variants` and `value_spread`: three more input families, the OTHER model (pairwise when
+the preset is unary) at the same batch with its own roofline / pruning-off / verify, BASELINE
+configs[4] (1024x4096x256) in both modes, configs[0] (512x1024x64, disparity only) on the CPU and
+the GPU, invalid-disparity kernels, generic column encoding, the C++ host class.
+
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE starts `python -m torch.distributed.run
+--nproc-per-node N bench.py --gpus N ...` as a CHILD process (before anything here touches the GPU)
+and relays rank 0's line as its own last line.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -53,7 +63,11 @@ def parse():
     ap.add_argument("--distinct", type=int, default=0,
                     help="distinct synthetic frames per rank (default 0 = --batch: every frame of the batch is its own scene)")
     ap.add_argument("--spread-batches", type=int, default=8,
-                    help="disjoint batches of distinct frames behind value_spread (0 = skip)")
+                    help="--full: disjoint batches of distinct frames behind value_spread (0 = skip)")
+    ap.add_argument("--full", action="store_true",
+                    help="also run the sweeps behind `variants` / `value_spread` (minutes; into bench_full.json)")
+    ap.add_argument("--out", default=None,
+                    help="where the complete result object goes (default: bench_full.json next to bench.py)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise RCCL and run the gather pipeline even with one rank (plumbing test)")
     ap.add_argument("--gather", choices=("fixed", "compact"), default="compact",
@@ -75,8 +89,9 @@ def parse():
     ap.add_argument("--no-prune-stats", action="store_true",
                     help="skip the untimed device-counter pass (profiling runs: its atomics distort per-kernel averages)")
     ap.add_argument("--no-variants", action="store_true",
-                    help="skip the extra figures (see the module docstring)")
-    ap.add_argument("--min-seconds", type=float, default=2.0,
+                    help="(kept for old command lines: the sweeps only run with --full) also skips the "
+                         "pruning-off / floor-family figures of the default run")
+    ap.add_argument("--min-seconds", type=float, default=1.0,
                     help="repeat the timed K-step block until this much time has been measured; "
                          "the MEDIAN block is reported")
     return ap.parse_args()
@@ -157,7 +172,7 @@ def committed_traffic(cfg, B, H, W, D):
 def committed_profile(cfg, B, H, W, D):
     """The newest profiles/rNN_traffic.json entry of this mode / shape / batch (or None)."""
     prof = os.path.join(ROOT, "profiles")
-    for name in ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json"):
+    for name in ("r06_traffic.json", "r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json"):
         try:
             with open(os.path.join(prof, name)) as fh:
                 t = json.load(fh).get("pairwise" if cfg.pairwise else "unary")
@@ -754,19 +769,142 @@ def measure_variants(args, wl, dev, local_rank):
     return out
 
 
+COMPACT_LIMIT = 4096   # bytes of the stdout line (the driver keeps a bounded tail of stdout)
+
+
+def _r(x, nd=3):
+    return round(x, nd) if isinstance(x, float) else x
+
+
+def compact_line(out):
+    """The ONE line that goes to stdout: the contract keys + the figures the headline has to be read
+    with, always shorter than COMPACT_LIMIT bytes.  Everything else is in bench_full.json."""
+    roof = out.get("roofline") or {}
+    cpu = out.get("cpu_baseline")
+    cfg = out.get("config") or {}
+    c = {k: out.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+                                 "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    c["value"], c["ms_per_step"] = _r(c["value"], 1), _r(c["ms_per_step"], 4)
+    c["config"] = {k: cfg.get(k) for k in ("workload", "batch_per_gpu", "rows", "cols", "max_dis", "preset",
+                                           "family", "parallelism") if k in cfg}
+    c["roofline"] = {k: _r(roof.get(k), 5) for k in (
+        "bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms", "kernel_ms_how",
+        "algorithmic_bytes_per_image", "traffic_source", "from_committed_profile", "kernel_ms_profile",
+        "frac_profile", "measured_hbm_frac", "note") if k in roof}
+    if cpu:
+        c["cpu_baseline"] = {k: _r(cpu.get(k), 4) for k in ("value", "unit", "cores", "kind", "sample")}
+    else:
+        c["cpu_baseline"] = None
+    c["verify_all_ok"] = out.get("verify_all_ok")
+    c["verified_count"] = len(out.get("verified") or [])
+    c["value_pruning_off"] = _r(out.get("value_pruning_off"), 1)
+    fl = out.get("value_floor_families")
+    c["value_floor_families"] = ({"images_per_s": _r(fl["images_per_s"], 1), "family": fl["family"],
+                                  "families_measured": len(fl["families_measured"])} if fl else None)
+    c["lut_fused_repaired"] = out.get("lut_fused_repaired")
+    for k in ("value_incl_d2h", "value_incl_instances", "value_incl_h2d_d2h"):
+        if out.get(k) is not None:
+            c[k] = _r(out[k], 1)
+    if out.get("single_frame"):
+        c["single_frame_ms"] = _r(out["single_frame"]["ms_per_frame"], 4)
+    if out.get("prune"):
+        c["evaluated_frac"] = _r(out["prune"]["evaluated_frac"], 4)
+    if out.get("valu") and out["valu"].get("issue_frac") is not None:
+        c["valu_issue_frac"] = {"value": _r(out["valu"]["issue_frac"], 3), "from_committed_profile": True}
+    if out.get("kernel_ms"):
+        c["kernel_ms"] = {k: _r(v, 4) for k, v in out["kernel_ms"].items()}
+    if out.get("gather"):
+        g = out["gather"]
+        c["gather"] = {k: _r(g[k], 4) for k in ("kind", "exposed_ms_per_step", "ms_per_step_without_gather",
+                                                "ratio_vs_fixed") if k in g}
+        if out.get("verify") and "rccl_gather" in out["verify"]:
+            c["gather"]["rank0_copy_equals_local"] = out["verify"]["rccl_gather"].get("rank0_copy_equals_local")
+    if out.get("other_model"):
+        c["other_model"] = out["other_model"]
+    c["full"] = out.get("full_json")
+    line = json.dumps(c, separators=(",", ":"))
+    # never longer than the limit: drop the optional fields, longest first, then the free-text ones
+    for k in ("other_model", "gather", "kernel_ms", "valu_issue_frac"):
+        if len(line) >= COMPACT_LIMIT and k in c:
+            del c[k]
+            line = json.dumps(c, separators=(",", ":"))
+    def clip(x, n):   # free-text fields are what can grow: clip every string, harder until the line fits
+        if isinstance(x, dict):
+            return {k: clip(v, n) for k, v in x.items()}
+        return x[:n] if isinstance(x, str) and len(x) > n else x
+    for n in (240, 120, 60, 24):
+        if len(line) < COMPACT_LIMIT:
+            break
+        line = json.dumps(clip(c, n), separators=(",", ":"))
+    assert len(line) < COMPACT_LIMIT, len(line)
+    return line
+
+
+def emit(out, path=None):
+    """Complete object -> bench_full.json (+ gpurun_out/), compact line -> stdout (the last line)."""
+    path = path or os.path.join(ROOT, "bench_full.json")
+    written = []
+    targets = [path]
+    if os.path.isdir(os.path.join(ROOT, "gpurun_out")):
+        targets.append(os.path.join(ROOT, "gpurun_out", os.path.basename(path)))
+    for t in targets:
+        try:
+            with open(t, "w") as fh:
+                json.dump(out, fh)
+            written.append(os.path.relpath(t, ROOT))
+        except OSError:
+            pass
+    out["full_json"] = written[0] if written else None
+    line = compact_line(out)
+    sys.stdout.write(line + "\n")
+    sys.stdout.flush()
+    return line
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start torch.distributed.run as a CHILD process
+    (this process has not imported torch nor touched HIP; nothing is exec'ed), pass its output through
+    and make rank 0's JSON line the last line of OUR stdout.  Returns the child's exit code.
+    IS_BENCH_CHILD_CMD (a JSON list) replaces the child command: tests/test_bench_line.py."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    if os.environ.get("IS_BENCH_CHILD_CMD"):
+        cmd = json.loads(os.environ["IS_BENCH_CHILD_CMD"])
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.pop("IS_BENCH_CHILD_CMD", None)
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env, cwd=ROOT)
+    result, last = None, None
+    for ln in child.stdout:
+        ln = ln.rstrip("\n")
+        print(ln, flush=True)
+        last = ln
+        if ln.startswith("{") and '"metric"' in ln:
+            try:
+                json.loads(ln)
+                result = ln
+            except ValueError:
+                pass
+    rc = child.wait()
+    if result is not None and last != result:
+        print(result, flush=True)
+    return rc
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world:
-        # one process per GPU: N > 1 must come from `python -m torch.distributed.run
-        # --nproc-per-node N ... bench.py --gpus N` (nothing here re-executes a process that may
-        # have touched the GPU); checked before torch is imported
-        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE is {world}: launch with "
-                         f"python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} "
-                         f"--master-addr 127.0.0.1 --master-port <P> bench.py --gpus {args.gpus} ...")
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE is {world}")
 
     import torch
     import torch.distributed as dist
@@ -821,8 +959,10 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
+    repairs0 = core.lut_fused_repairs()   # (sticky count of repaired calls of this context)
 
     local_blocks = []   # this rank's own clock of every block (before the max over ranks)
+    kt_blocks = []      # HIP-event kernel times of the last step of every timed block
 
     def timed_block(fn=None):
         """EXACTLY args.steps steps between barrier + synchronize on both sides; max over ranks."""
@@ -841,13 +981,15 @@ def main():
 
     # the K-step block is repeated until --min-seconds have been measured (every rank sees the
     # same max-reduced times, so all ranks stop together) and the MEDIAN block is reported: a
-    # 0.3 s measurement is over before a power / utilisation sampler sees the GPU busy
-    blocks = [timed_block()]
-    while sum(blocks) < args.min_seconds and len(blocks) < 200:
+    # 0.1 s measurement is over before a power / utilisation sampler sees the GPU busy
+    blocks = []
+    while not blocks or (sum(blocks) < args.min_seconds and len(blocks) < 200):
         blocks.append(timed_block())
+        kt_blocks.append(core.kernel_times_ms())   # (outside the block's clock: the events of its last step)
     dt = float(np.median(blocks))
-    # per-kernel durations of the LAST timed step, measured with HIP events on the launch stream
-    kt = core.kernel_times_ms()
+    # per-kernel durations, HIP events on the launch stream: the mean over the last steps of all timed blocks
+    kt = {k: float(np.mean([b[k] for b in kt_blocks])) for k in kt_blocks[0]}
+    repaired = core.lut_fused_repairs() - repairs0
     timed_out = wl.d_sections if pipe is None else pipe.last_local()
     gather_stats = pipe.stats() if pipe is not None else None
 
@@ -857,7 +999,7 @@ def main():
     per_rank = None
     if use_dist:
         mine = {"rank": rank, "ms_per_step_own_clock": float(np.median(local_blocks)) / args.steps * 1e3,
-                "dp_ms": kt["dp_ms"], "prepare_ms": kt["prepare_ms"]}
+                "dp_ms": kt["dp_ms"], "prepare_ms": kt["prepare_ms"], "lut_fused_repaired": repaired}
         if pipe is not None:
             n_before = len(local_blocks)
             d_plain = timed_block(lambda: wl.step(core))
@@ -868,6 +1010,7 @@ def main():
         gathered = [None] * world
         dist.all_gather_object(gathered, mine)
         per_rank = gathered
+        repaired = sum(g["lut_fused_repaired"] for g in gathered)
 
     # ---- verify (default): frames of the TIMED output (the batch geometry the value is measured on)
     verify = None
@@ -935,11 +1078,30 @@ def main():
     if not args.no_cpu_baseline and world == 1 and rank == 0:
         cpu = cpu_baseline(cfg, wl.frames[0], args.cpu_seconds)
 
-    # ---- extra figures (N = 1): other kernel variants / families / models / shapes
-    variants = None
     core.close()
+    # ---- the two floors the headline is read with (N = 1, a few steps each, outside `value`): pruning
+    # off (data-independent) and the slowest input family any full sweep has found (cityscapes_like)
+    pruning_off = floor = None
+    quick = world == 1 and rank == 0 and not args.no_variants and not args.full
+    if quick:
+        c0 = wl.make_core(env={"IS_NO_PRUNE": "1"})
+        pruning_off = B / wl.time_steps(c0, 3)
+        c0.close()
+        fam = "cityscapes_like"
+        if args.family != fam:
+            wf = Workload(args.preset, H, W, D, B, min(B, 8), dev, local_rank, family=fam, seed0=311, **extra)
+            cf = wf.make_core()
+            vf = B / wf.time_steps(cf, 3)
+            wf.verify(wf.d_sections, images=[B - 1])
+            cf.close(); wf.free(); del wf
+            head = B * args.steps / dt
+            floor = {"images_per_s": min(vf, head), "family": fam if vf < head else args.family,
+                     "families_measured": sorted({fam, args.family})}
+
+    # ---- --full (N = 1): other kernel variants / families / models / shapes
+    variants = None
     spread = None
-    if world == 1 and not args.no_variants:
+    if world == 1 and args.full:
         variants = measure_variants(args, wl, dev, local_rank)   # (frees wl's device buffers)
         if args.spread_batches > 0:
             other = OTHER_PRESET.get(args.preset)
@@ -958,10 +1120,18 @@ def main():
         dp_s = kt["dp_ms"] * 1e-3
         traffic, tfile = committed_traffic(cfg, B, H, W, D)
         roof = wl.roofline(kt["dp_ms"], dp_kernel_name(cfg), traffic, tfile)
-        roof["note"] = ("the column DP is bound by VALU issue and per-step latency, not by HBM "
-                        "(SURVEY.md H1, DESIGN.md sections 6-7): see the valu fields; traffic = "
-                        "(2*FETCH_SIZE + WRITE_SIZE) of the DP kernels per step from the committed "
-                        "rocprofv3 PMC passes")
+        roof["kernel_ms_how"] = (f"HIP events on the launch stream around the DP launches, mean over the last step of "
+                                 f"each of the {len(kt_blocks)} timed blocks")
+        prof, pname = committed_profile(cfg, B, H, W, D)
+        if prof and prof.get("rocprof_kernel_ms"):   # the rocprofv3 --kernel-trace average of the same launches
+            roof["kernel_ms_profile"] = prof["rocprof_kernel_ms"]
+            roof["frac_profile"] = (roof["algorithmic_bytes_per_image"] * B / (prof["rocprof_kernel_ms"] * 1e-3)
+                                    / 1e9 / HBM_PEAK_GBS)
+        roof["from_committed_profile"] = traffic is not None   # (of `traffic`: PMC counters cannot be read inside the timed run)
+        roof["note"] = ("VALU-issue / latency bound, not HBM bound (DESIGN.md); traffic = 2*FETCH_SIZE + WRITE_SIZE "
+                        "of the DP kernels per step, NOT measured in this run: copied from the committed "
+                        "rocprofv3 --pmc passes (traffic_source)" if traffic is not None else
+                        "VALU-issue / latency bound, not HBM bound (DESIGN.md); no committed PMC pass for this shape")
         out = {
             "metric": "images/s on 1024x2048x128-disp column DP",
             "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps,
@@ -980,6 +1150,7 @@ def main():
                                       if world > 1 else "single GPU"},
             "roofline": roof,
             "valu": {**(committed_valu(cfg, B, H, W, D) or {"issue_frac": None}),
+                     "from_committed_profile": True,
                      "pair_evals_per_s": (pairs_img * B * prune["evaluated_frac"] / dp_s) if prune else None,
                      "pair_evals_per_s_nominal": pairs_img * B / dp_s,
                      "pair_evals_per_image_nominal": pairs_img,
@@ -988,6 +1159,7 @@ def main():
                              "evaluated (prune.evaluated_frac), _nominal all C*H*(H+1)/2"},
             "prune": prune,
             "kernel_ms": kt,
+            "lut_fused_repaired": repaired,
         }
         if d2h_value is not None:
             out["value_incl_d2h"] = d2h_value
@@ -998,7 +1170,8 @@ def main():
                                                "device-resident in/out",
                                    "images_per_s": 1.0 / single, "ms_per_frame": single * 1e3}
         out["timed_blocks"] = {"count": len(blocks), "steps_per_block": args.steps,
-                               "seconds": [round(x, 5) for x in blocks], "reported": "median"}
+                               "seconds": [round(x, 5) for x in blocks], "reported": "median",
+                               "kernel_ms_per_block": kt_blocks}
         if pipe is not None:
             out["gather"] = gather_stats
         if per_rank is not None:
@@ -1007,6 +1180,10 @@ def main():
             out["verify"] = verify
         if spread is not None:
             out["value_spread"] = spread
+        if pruning_off is not None:
+            out["value_pruning_off"] = pruning_off
+        if floor is not None:
+            out["value_floor_families"] = floor
         if variants is not None:
             out["variants"] = variants
             out["value_incl_instances"] = variants["with_instances"]["images_per_s"]
@@ -1014,6 +1191,13 @@ def main():
             # input families, and the data-independent floor (pruning off), side by side with `value`
             out["value_floor_families"] = floor_over_families(value, variants["families"])
             out["value_pruning_off"] = variants["pruning_off"]["images_per_s"]
+            okey = [k for k in variants if k.endswith(f"_batch{B}")]
+            if okey:   # the OTHER model at the same batch, in the compact line too
+                o = variants[okey[0]]
+                out["other_model"] = {"preset": o["preset"], "images_per_s": _r(o["images_per_s"], 1),
+                                      "dp_ms": _r(o["dp_ms"], 3),
+                                      "pruning_off": _r(o.get("pruning_off", {}).get("images_per_s"), 1),
+                                      "single_frame_ms": _r(o.get("single_frame", {}).get("ms_per_frame"), 4)}
         if cpu is not None:
             out["cpu_baseline"] = cpu
         out["distinct_frames"] = wl.distinct
@@ -1039,7 +1223,7 @@ def main():
         dist.destroy_process_group()
     flush_c_stdio()
     if out is not None:
-        print(json.dumps(out), flush=True)
+        emit(out, args.out)
 
 
 if __name__ == "__main__":

@@ -283,6 +283,12 @@ int is_debug_read_object_lut(is_ctx* ctx, int column, float* h_out);
  * keeps the table in the prepare launch).  Synchronises the device. */
 int is_debug_lut_fused_state(is_ctx* ctx, int* repaired);
 
+/* The number of is_compute calls of this context whose repair launches have run since it was created (the reference
+ * gets the order of its two launches from the stream, Stixels.cu:535-590; the fused launch has to earn it).  After the
+ * first one the context plans its later calls with the table in the prepare launch again (unless IS_LUT_FUSED is set
+ * to 1 or 2).  Synchronises the device. */
+int is_lut_fused_repairs(is_ctx* ctx, int* calls_repaired);
+
 /* Test hook: the bound-block summaries the pairwise DP of the last is_compute call left for one stixel
  * column (lemmas L7 / L8): h_out[n_blocks][24], returns n_blocks through *n_blocks. */
 int is_debug_read_block_summaries(is_ctx* ctx, int column, float* h_out, int cap_floats, int* n_blocks);

@@ -25,6 +25,7 @@ EXPORTS = [
     "is_ctx_device", "is_set_eval_counters", "is_get_eval_counters",
     "is_pack_sections", "is_unpack_sections", "is_stream_create", "is_stream_destroy",
     "is_debug_read_object_lut", "is_debug_read_block_summaries", "is_debug_lut_fused_state",
+    "is_lut_fused_repairs",
     "is_comm_unique_id", "is_comm_init_rank", "is_comm_destroy", "is_comm_rank", "is_gather_i32",
     "is_gather_sections",
 ]
@@ -96,6 +97,7 @@ def lib():
         L.is_gather_sections.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp, ctypes.c_size_t, vp, vp]
         L.is_debug_read_object_lut.argtypes = [vp, ci, vp]
         L.is_debug_lut_fused_state.argtypes = [vp, ctypes.POINTER(ci)]
+        L.is_lut_fused_repairs.argtypes = [vp, ctypes.POINTER(ci)]
         try:   # (an experiment library built from an older tree may lack the newest test hook)
             L.is_debug_read_block_summaries.argtypes = [vp, ci, vp, ci, ctypes.POINTER(ci)]
         except AttributeError:
@@ -166,6 +168,12 @@ class Core:
         """1 when the last unary call ran its repair launches (test hook, see instance_stixels_core.h)."""
         out = ctypes.c_int(-1)
         _check(lib().is_debug_lut_fused_state(self._ctx, ctypes.byref(out)), "is_debug_lut_fused_state")
+        return int(out.value)
+
+    def lut_fused_repairs(self):
+        """Calls of this context whose fused LUT hand-over was distrusted and repaired (sticky count)."""
+        out = ctypes.c_int(-1)
+        _check(lib().is_lut_fused_repairs(self._ctx, ctypes.byref(out)), "is_lut_fused_repairs")
         return int(out.value)
 
     def read_object_lut(self, column):

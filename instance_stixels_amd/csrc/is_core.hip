@@ -140,6 +140,7 @@ struct is_ctx {
     /* scratch */
     RowRec* d_recs;          /* [max_batch*C][H+1] */
     float* d_lutT;           /* [max_batch*C][H+1][D] */
+    int* h_lutf_repairs = nullptr; /* pinned + mapped: calls whose fused LUT hand-over was repaired (DevParams::lutf_repairs) */
     PriorRec* d_priors;      /* [max_batch][H] */
     StepRec* d_steps;        /* [max_batch*C][H]   per-vB transition records of the pairwise DP (64 B) */
     float* d_part_cost;      /* [max_batch*C][3][64] merged partial minima of the current tile */
@@ -390,6 +391,9 @@ static int ctx_init(is_ctx* c, const is_stixel_params* p, const float* obj_cost_
     HIP_TRY(hipMemset(c->dp.lut_ready, 0, sizeof(int) * B * C));
     ALLOC(c->dp.lutf_bad, sizeof(int));
     HIP_TRY(hipMemset(c->dp.lutf_bad, 0, sizeof(int)));
+    HIP_TRY(hipHostMalloc((void**)&c->h_lutf_repairs, sizeof(int), hipHostMallocMapped));
+    *c->h_lutf_repairs = 0;
+    HIP_TRY(hipHostGetDevicePointer((void**)&c->dp.lutf_repairs, c->h_lutf_repairs, 0));
     ALLOC(c->dp.win_lo, sizeof(int) * B * C * (size_t)c->dp.ntiles);
     HIP_TRY(hipMemset(c->dp.win_lo, 0, sizeof(int) * B * C * (size_t)c->dp.ntiles));
     ALLOC(c->d_blksum, sizeof(float) * B * C * ((size_t)d.ntiles * IS_QPT + 1) * 24);
@@ -464,6 +468,7 @@ int is_ctx_destroy(is_ctx* c) {
     }
     (void)hipFree(c->d_obj_cost_lut); (void)hipFree(c->d_odr); (void)hipFree(c->d_rcp); (void)hipFree(c->d_col_flags); (void)hipFree(c->d_prune); (void)hipFree(c->d_n_generic); (void)hipFree(c->d_stage);
     (void)hipFree(c->d_recs); (void)hipFree(c->d_lutT); (void)hipFree(c->d_priors); (void)hipFree(c->d_steps); (void)hipFree(c->d_part_cost); (void)hipFree(c->d_part_idx); (void)hipFree(c->d_sv); (void)hipFree(c->d_blksum); (void)hipFree(c->d_t8row); (void)hipFree(c->dp.win_lo); (void)hipFree(c->dp.lut_ready); (void)hipFree(c->dp.lutf_bad);
+    if (c->h_lutf_repairs) (void)hipHostFree(c->h_lutf_repairs);
     (void)hipFree(c->d_cost_table); (void)hipFree(c->d_index_table); (void)hipFree(c->d_cluster_scratch);
     (void)hipFree(c->d_inst_cnt); (void)hipFree(c->d_counters);
     for (int i = 0; i < IS_STAGE_SLOTS; i++) {
@@ -587,6 +592,14 @@ int is_debug_lut_fused_state(is_ctx* c, int* repaired) {
     return IS_OK;
 }
 
+int is_lut_fused_repairs(is_ctx* c, int* calls_repaired) {
+    if (!c || !calls_repaired) return fail_arg("null pointer");
+    ON_CTX_DEVICE(c);
+    HIP_TRY(hipDeviceSynchronize());
+    *calls_repaired = c->h_lutf_repairs ? *(volatile int*)c->h_lutf_repairs : 0;
+    return IS_OK;
+}
+
 int is_debug_read_block_summaries(is_ctx* c, int column, float* h_out, int cap_floats, int* n_blocks) {
     if (!c || !h_out || !n_blocks) return fail_arg("null pointer");
     if (column < 0 || column >= c->max_batch * c->dp.C) return fail_arg("column outside the context's scratch");
@@ -678,6 +691,9 @@ static int compute_enqueue(is_ctx* c, const float* d_joined, const int32_t* d_se
     Pw.win_tiles = call_win_tiles(P, c->h_vhor_pinned[slot], n_images, pairwise);
     Pw.lut_carry = (!pairwise && isk_unary_uses_carry(&Pw, ncols)) ? 1 : 0;
     Pw.lut_fused = (!pairwise && !capturing) ? isk_unary_uses_fused_lut(&Pw, ncols) : 0;
+    /* a hand-over of this context has been distrusted before (another dispatcher, a partition mode, a CU mask): the
+     * fused launch stays off unless IS_LUT_FUSED asks for it by value -- a repaired call costs 2.8 x an ordinary one */
+    if (Pw.lut_fused && (P.knob_lut_fused < 0 || P.knob_lut_fused == 3) && c->h_lutf_repairs && *(volatile int*)c->h_lutf_repairs > 0) Pw.lut_fused = 0;
     if (timing) HIP_TRY(hipEventRecord(c->ev[0], stream));
     /* (d_n_generic is zero here: cleared at creation and by k_backtrace at the end of every call) */
     HIP_TRY(isk_launch_prepare(&Pw, ncols, d_joined, d_seg, c->d_ground, c->d_vhor,

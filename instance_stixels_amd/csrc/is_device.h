@@ -195,8 +195,15 @@ struct DevParams {
      * their count) or did not finish within the bound of the poll.  The launches behind the fused one -- the ordinary
      * LUT kernel and the ordinary DP launch, which leave at once while the word is 0 -- then do the call again. */
     int* lutf_bad;
+    /* ... and the number of calls of this context whose repair launches have run: a word in pinned, mapped host memory
+     * that block 0 of the repair DP launch counts up.  The host reads it (a plain load, nothing waits) when it plans a
+     * call: after the first repair the fused launch is off for the rest of the context's life unless IS_LUT_FUSED asks
+     * for it by value.  is_lut_fused_repairs() returns it. */
+    int* lutf_repairs;
     int knob_lut_fused; /* IS_LUT_FUSED: -1 / 1 = the LUT units run inside the unary DP launch where they can, 0 = never,
-                         * 2 = (tests) fused with a WRONG XCC id published: every workgroup distrusts, the repair launches run */
+                         * 2 = (tests) fused with a WRONG XCC id published: every workgroup distrusts, the repair launches run,
+                         * 3 = (tests) the default policy (-1) with the wrong id of 2: the first large call is repaired, and the
+                         * context then keeps the table in the prepare launch (DevParams::lutf_repairs) */
     int lut_fused;      /* set per call: 0, 1, or 2 (the test mode) */
     int knob_lut_carry; /* IS_LUT_CARRY=1: carry rows only wherever the DP can rebuild the rest (unary calls whose every
                          * tile runs the windowed ring kernel); default: lutT is materialised (measured faster) */

@@ -20,14 +20,24 @@
  * touch it.  `comm` is an ncclComm_t passed as void*.
  */
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>
 
 #include <dlfcn.h>
 #include <stdio.h>
 #include <string.h>
 
+#include <mutex>
 #include <vector>
 
+/* The dozen RCCL names this file needs, declared here: the library dlopens RCCL at run time and must also
+ * BUILD on a single-GPU installation without the RCCL headers (rccl.h:36-52, 461: an opaque communicator, a
+ * 128-byte id, result 0 = success, ncclInt32 = 2; tests/test_host_and_abi.py compares these values with the
+ * header where it is installed). */
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef int ncclResult_t;
+typedef int ncclDataType_t;
+static const ncclResult_t ncclSuccess = 0;
+static const ncclDataType_t ncclInt32 = 2;
 #include "instance_stixels_core.h"
 
 extern "C" int isk_fail(int code, const char* msg);
@@ -51,20 +61,23 @@ struct Rccl {
     bool ok = false;
 };
 
-Rccl& rccl() {
+void load_rccl(Rccl& r);
+Rccl& rccl() { /* (two threads may make their first is_comm_* / is_gather_* call at once) */
     static Rccl r;
-    static bool tried = false;
-    if (tried) return r;
-    tried = true;
+    static std::once_flag once;
+    std::call_once(once, [] { load_rccl(r); });
+    return r;
+}
+void load_rccl(Rccl& r) {
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     for (const char* n : names) {
         r.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
         if (r.handle) break;
     }
-    if (!r.handle) return r;
+    if (!r.handle) return;
 #define IS_SYM(field, name) \
     *(void**)(&r.field) = dlsym(r.handle, name); \
-    if (!r.field) return r
+    if (!r.field) return
     IS_SYM(GetUniqueId, "ncclGetUniqueId");
     IS_SYM(CommInitRank, "ncclCommInitRank");
     IS_SYM(CommDestroy, "ncclCommDestroy");
@@ -79,7 +92,6 @@ Rccl& rccl() {
     IS_SYM(GetErrorString, "ncclGetErrorString");
 #undef IS_SYM
     r.ok = true;
-    return r;
 }
 
 int need_rccl() {
@@ -120,6 +132,8 @@ int comm_shape(void* comm, int* rank, int* nranks) {
 int32_t* scratch_words(int nwords) {
     static int32_t* buf[64] = {nullptr};
     static int cap[64] = {0};
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
     if (cap[dev] < nwords) {
@@ -222,23 +236,28 @@ int is_gather_sections(void* comm, int dst, const int32_t* h_columns, const int3
     if (dst < 0 || dst >= nranks) return isk_fail(IS_EINVAL, "invalid argument: dst outside the communicator");
     hipStream_t stream = (hipStream_t)stream_;
     const ncclComm_t c = (ncclComm_t)comm;
-    int32_t* d_words = scratch_words(nranks + 1);
-    if (!d_words) return isk_fail(IS_ENOMEM, "is_gather_sections: no device scratch");
-    int32_t* d_tot = d_words;          /* [nranks] sections per rank (dst) */
-    int32_t* d_go = d_words + nranks;  /* [1] dst's go-ahead for the payload */
-
-    /* ---- phase A: every rank's section total (one int: ncclGather, rccl.h:745) and its per-column counts */
-    const int my_cols = h_columns[rank];
-    if (my_cols < 0) return isk_fail(IS_EINVAL, "invalid argument: negative column count");
-    NCCL_TRY(rccl().Gather(d_offsets + my_cols, d_tot, 1, ncclInt32, dst, c, stream));
+    /* EVERY local check and the scratch come before the first collective: a rank that returns after it has posted
+     * one leaves the others blocked in the next.  (h_columns is the same array on every rank, so its checks fail on
+     * all of them alike; a failure here that is this rank's alone -- a null buffer, no scratch -- is fatal for the
+     * job, as with any collective, and is reported as IS_EINVAL / IS_EHIP, never as the "grow and repeat" IS_ENOMEM
+     * that only dst's broadcast go-ahead below may produce, on all ranks at once.) */
     std::vector<int64_t> cnt(nranks);
-    bool equal = true; /* (h_columns is the same array on every rank: all take the same branch) */
+    bool equal = true; /* (all ranks take the same branch) */
     for (int r = 0; r < nranks; r++) {
         if (h_columns[r] < 0) return isk_fail(IS_EINVAL, "invalid argument: negative column count");
         cnt[r] = h_columns[r];
         equal = equal && h_columns[r] == h_columns[0];
     }
+    const int my_cols = h_columns[rank];
     if (rank == dst && !d_all_counts) return isk_fail(IS_EINVAL, "invalid argument: null d_all_counts on dst");
+    if (my_cols > 0 && !d_packed) return isk_fail(IS_EINVAL, "invalid argument: null d_packed");
+    int32_t* d_words = scratch_words(nranks + 1);
+    if (!d_words) return isk_fail(IS_EHIP, "is_gather_sections: no device scratch (hipMalloc of 4 KB failed)");
+    int32_t* d_tot = d_words;          /* [nranks] sections per rank (dst) */
+    int32_t* d_go = d_words + nranks;  /* [1] dst's go-ahead for the payload */
+
+    /* ---- phase A: every rank's section total (one int: ncclGather, rccl.h:745) and its per-column counts */
+    NCCL_TRY(rccl().Gather(d_offsets + my_cols, d_tot, 1, ncclInt32, dst, c, stream));
     if (equal) {
         if (my_cols > 0)
             NCCL_TRY(rccl().Gather(d_counts, d_all_counts, (size_t)my_cols, ncclInt32, dst, c, stream));

@@ -708,6 +708,9 @@ __device__ __forceinline__ void diag_quarters(const DevParams& P, RowRec& my, Un
 #ifndef ISF_LUTF_MIN_COLS
 #define ISF_LUTF_MIN_COLS 2048 /* columns per call from which the LUT units run inside the DP launch by default */
 #endif
+#ifndef ISF_LUTF_POLL_MAX
+#define ISF_LUTF_POLL_MAX (1 << 14) /* polls of a DP workgroup for its column's units before it distrusts the hand-over */
+#endif
 #ifndef ISF_LUTF_LEAD
 #define ISF_LUTF_LEAD 32 /* super-groups of LUT blocks dispatched ahead of the first DP block (8192 DP blocks at 1024 rows) */
 #endif
@@ -797,6 +800,8 @@ __global__ __launch_bounds__(ISF_THREADS, GEN ? ISF_OCC_GEN : (LUTF ? (HAS_INVAL
      * (column, tile) items of the plain launch one after the other -- 262144 workgroups that only read a word and
      * leave took 62 us per call. */
     if (REPAIR && __builtin_amdgcn_readfirstlane(*run_if) == 0) return;
+    if (REPAIR && blockIdx.x == 0 && threadIdx.x == 0 && P.lutf_repairs != nullptr) /* a repaired call: the host's count */
+        __hip_atomic_fetch_add(P.lutf_repairs, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     const int H = P.H, D = P.D;
     const int DP = (WIN ? IS_P1_WIN : D) + 1; /* WIN: the tile holds an fn window of its rows (is_device.h) */
     const int nwv = (int)(blockDim.x >> 6);   /* waves of the workgroup: 8, or 4 for the windowed tiles (GEN: 4, the stride its row residues assume) */
@@ -874,8 +879,12 @@ next_item: /* (REPAIR: the next (column, tile) item of this workgroup) */
         if (tid == 0) {
             const int need = (D + 63) >> 6;
             int spins = 0, seen;
+            /* bounded: ISF_LUTF_POLL_MAX polls of about 1.5 us (s_sleep 32 = 2048 clocks + the two loads), i.e. some tens
+             * of milliseconds, and a workgroup leaves at once when another one has distrusted the hand-over already --
+             * the call is redone anyway, and 262144 workgroups must not each wait out their bound */
             while (((seen = __hip_atomic_load(P.lut_ready + colg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & 255) < need &&
-                   ++spins < (1 << 22))
+                   ++spins < ISF_LUTF_POLL_MAX &&
+                   __hip_atomic_load(P.lutf_bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
                 __builtin_amdgcn_s_sleep(32);
             if ((seen & 255) < need || (seen >> 8) != need * xcc_id())
                 __hip_atomic_fetch_or(P.lutf_bad, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1351,7 +1360,12 @@ int isk_unary_fast_chunk_rows(const DevParams* P) {
 hipError_t isk_set_lds_unary_fast(const DevParams* P) {
     const int nvr = isk_unary_fast_chunk_rows(P);
     if (nvr == 0) return hipSuccess;
-    const int b = (int)isk_unary_fast_lds_bytes(P, nvr);
+    size_t bb = isk_unary_fast_lds_bytes(P, nvr);
+    for (int gen = 0; gen < 2; gen++) { /* (the windowed forms are smaller at every shape in use; not relied upon) */
+        const size_t w = isf_lds_bytes(P, nvr, ISF_WIN_WAVES, true, gen != 0);
+        if (w > bb) bb = w;
+    }
+    const int b = (int)bb;
     hipError_t e = hipSuccess;
 #define ISF_SET(INV, NVR)                                                                         \
     if (e == hipSuccess)                                                                          \
@@ -1362,6 +1376,16 @@ hipError_t isk_set_lds_unary_fast(const DevParams* P) {
                             hipFuncAttributeMaxDynamicSharedMemorySize, b);                       \
     if (e == hipSuccess)                                                                          \
     e = hipFuncSetAttribute((const void*)k_dp_unary_fast<INV, NVR, false, true>,                  \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, b);                       \
+    /* (the GEN, LUTF and REPAIR forms of the windowed launch: same LDS layout, bounded by b) */   \
+    if (e == hipSuccess)                                                                          \
+    e = hipFuncSetAttribute((const void*)k_dp_unary_fast<INV, NVR, false, true, true>,            \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, b);                       \
+    if (e == hipSuccess)                                                                          \
+    e = hipFuncSetAttribute((const void*)k_dp_unary_fast<INV, NVR, false, true, false, true>,     \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, b);                       \
+    if (e == hipSuccess)                                                                          \
+    e = hipFuncSetAttribute((const void*)k_dp_unary_fast<INV, NVR, false, true, false, false, true>, \
                             hipFuncAttributeMaxDynamicSharedMemorySize, b)
     if (nvr == 2) { ISF_SET(true, 2); ISF_SET(false, 2); } else { ISF_SET(true, 4); ISF_SET(false, 4); }
 #undef ISF_SET
@@ -1396,8 +1420,9 @@ int isk_unary_uses_fused_lut(const DevParams* P, int ncols) {
     if (P->win_tiles < P->ntiles) return 0;
     /* by itself only where it pays (frames/s fused | prepare launch at 1 / 4 / 8 / 12 / 16 / 64 frames per call: 4730 |
      * 6240, 7070 | 7100, 9300 | 9060, 9930 | 9440, 9610 | 9100, 11 030 | 10 160); IS_LUT_FUSED=1 / 2: at any size */
-    if (P->knob_lut_fused < 0 && (ncols < ISF_LUTF_MIN_COLS || fnb > 2)) return 0; /* (D = 256, four units per column, 32 frames of 1024x4096: 3940 | 4040) */
-    return P->knob_lut_fused == 2 ? 2 : 1;
+    const bool by_itself = P->knob_lut_fused < 0 || P->knob_lut_fused == 3; /* (3, tests: the default policy with a wrong XCC id published) */
+    if (by_itself && (ncols < ISF_LUTF_MIN_COLS || fnb > 2)) return 0; /* (D = 256, four units per column, 32 frames of 1024x4096: 3940 | 4040) */
+    return P->knob_lut_fused >= 2 ? 2 : 1;
 }
 
 /* FAST columns of the batch; the caller runs k_dp_unary<.., false> for the generic ones. */

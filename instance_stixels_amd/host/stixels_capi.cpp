@@ -8,9 +8,11 @@
 #include <cstring>
 #include <ctime>
 #include <exception>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
+#include "instance_stixels_core.h"
 #include "InstanceStixels/RoadEstimation.h"
 #include "InstanceStixels/Stixels.hpp"
 
@@ -215,6 +217,15 @@ int ish_compute_batch_gather(void* h, int pairwise, int n_images, const float* d
                 rp[i] = Stixels::RoadParameters{(int)r[4 * i], r[4 * i + 1], r[4 * i + 2], r[4 * i + 3]};
             return rp;
         };
+        if (road_all) { /* dst: the caller sized road_all / sections_all / vhor_all for n_all frames */
+            int rank = 0, nranks = 0;
+            if (is_comm_rank(comm, &rank, &nranks) != IS_OK)
+                throw std::runtime_error(std::string("ish_compute_batch_gather: ") + is_last_error());
+            long sum = 0;
+            for (int r = 0; r < nranks; r++) sum += images_per_rank[r];
+            if (sum != (long)n_all)
+                throw std::invalid_argument("ish_compute_batch_gather: n_all differs from the sum of images_per_rank");
+        }
         const std::vector<Stixels::RoadParameters> rp = conv(road, n_images);
         const std::vector<Stixels::RoadParameters> ra = road_all ? conv(road_all, n_all)
                                                                  : std::vector<Stixels::RoadParameters>();
@@ -222,7 +233,7 @@ int ish_compute_batch_gather(void* h, int pairwise, int n_images, const float* d
         s->ComputeBatchGather(pairwise != 0, n_images, d_big, d_seg, rp.data(), comm, dst, images_per_rank,
                               road_all ? ra.data() : nullptr, out, stream);
         *n_out = (int)out.size();
-        for (size_t i = 0; i < out.size(); i++) {
+        for (size_t i = 0; i < out.size() && i < (size_t)(n_all > 0 ? n_all : 0); i++) {
             std::memcpy(sections_all + i * out[i].sections.size(), out[i].sections.data(),
                         out[i].sections.size() * sizeof(Section));
             vhor_all[i] = out[i].vhor;

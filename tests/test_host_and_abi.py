@@ -40,6 +40,20 @@ def test_gather_entry_points_reject_bad_arguments_without_a_gpu():
     assert L.is_comm_unique_id(buf, 16) == -1          # the id needs 128 bytes
 
 
+def test_local_rccl_declarations_match_the_installed_header():
+    """is_gather.hip declares the few RCCL names it needs itself (the library dlopens RCCL and must build without the
+    headers): where rccl.h is installed its values are the ones the source hard-codes."""
+    hdr = "/opt/rocm/include/rccl/rccl.h"
+    if not os.path.exists(hdr):
+        pytest.skip("no RCCL header on this machine")
+    text = open(hdr).read()
+    src = open(os.path.join(ROOT, "instance_stixels_amd", "csrc", "is_gather.hip")).read()
+    assert "#include <rccl" not in src
+    assert re.search(r"#define NCCL_UNIQUE_ID_BYTES 128\b", text) and "char internal[128]" in src
+    assert re.search(r"ncclSuccess\s*=\s*0\b", text) and re.search(r"ncclSuccess = 0;", src)
+    assert re.search(r"ncclInt32\s*=\s*2\b", text) and re.search(r"ncclInt32 = 2;", src)
+
+
 def test_scene_family_of_the_generator_is_stable():
     """Throughput numbers are compared across rounds on the "scene" family: a later family added to
     synthetic.make_frame must not consume random numbers of the scene's stream (numpy 2.2, PCG64: the image's)."""

@@ -1000,7 +1000,7 @@ def test_plain_cpp_gather_caller_runs():
 
 
 @pytest.mark.parametrize("gather", ["compact", "fixed"])
-def test_bench_force_dist_child_process_runs_the_rccl_gather(gather):
+def test_bench_force_dist_child_process_runs_the_rccl_gather(gather, tmp_path):
     """bench.py --force-dist in a FRESH child process (never a re-exec of this one): RCCL (backend
     "nccl") initialises with one rank, the pipelined gather of either payload runs inside the timed
     region, rank 0's gathered copy equals what it computed, and the timed output equals the
@@ -1013,12 +1013,18 @@ def test_bench_force_dist_child_process_runs_the_rccl_gather(gather):
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--force-dist", "--gather", gather,
                           "--steps", "2", "--warmup", "1", "--batch", "8", "--min-seconds", "0",
                           "--no-variants", "--no-cpu-baseline", "--no-single", "--no-d2h",
-                          "--no-prune-stats"], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+                          "--no-prune-stats", "--out", str(tmp_path / "bench_full.json")],
+                         capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
-    line = json.loads(out.stdout.strip().splitlines()[-1])
-    assert line["n_gpus"] == 1 and line["value"] > 0
-    assert line["verify"]["ok"] and line["verify"]["rccl_gather"]["rank0_copy_equals_local"]
-    assert line["gather"]["kind"] == gather and line["gather"]["bytes_per_rank_per_step"]
+    last = out.stdout.strip().splitlines()[-1]
+    assert len(last) < 4096                       # the compact line (bench.compact_line)
+    line = json.loads(last)
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["verify_all_ok"]
+    assert line["gather"]["kind"] == gather and line["gather"]["rank0_copy_equals_local"]
+    full = json.load(open(os.path.join(root, line["full"])))   # the complete object beside it
+    assert full["value"] == pytest.approx(line["value"], rel=1e-3)
+    assert full["verify"]["ok"] and full["verify"]["rccl_gather"]["rank0_copy_equals_local"]
+    assert full["gather"]["kind"] == gather and full["gather"]["bytes_per_rank_per_step"]
 
 
 def test_capi_rccl_gather_one_rank():
