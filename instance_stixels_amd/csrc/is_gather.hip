@@ -23,6 +23,7 @@
 
 #include <dlfcn.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <mutex>
@@ -69,10 +70,14 @@ Rccl& rccl() { /* (two threads may make their first is_comm_* / is_gather_* call
     return r;
 }
 void load_rccl(Rccl& r) {
-    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    /* IS_RCCL_LIB: another library with the same twelve entry points (read once, here).  The tests use it to run the
+     * gather with more than one rank on a one-GPU box (tests/mock_rccl: shared memory + host staging; real RCCL
+     * refuses two ranks on one device); a deployment could name a differently installed RCCL. */
+    const char* names[] = {getenv("IS_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     for (const char* n : names) {
+        if (n == nullptr || n[0] == 0) continue;
         r.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
-        if (r.handle) break;
+        if (r.handle || n == names[0]) break; /* (a named library that does not load is an error, not a reason to fall back) */
     }
     if (!r.handle) return;
 #define IS_SYM(field, name) \

@@ -1041,6 +1041,53 @@ def test_capi_rccl_gather_one_rank():
     assert out.returncode == 0 and "GATHER_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
 
 
+def _mock_rccl():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "tests", "mock_rccl", "libmock_rccl.so")
+    if not os.path.exists(lib):
+        pytest.skip("tests/mock_rccl/libmock_rccl.so not built (run __graft_entry__.build())")
+    return root, lib
+
+
+def test_capi_gather_two_ranks_on_one_gpu(tmp_path):
+    """is_gather_sections / Stixels::ComputeBatchGather with nranks = 2: two child processes share cuda:0 and a
+    communicator of tests/mock_rccl (shared memory + host staging with the semantics of the RCCL calls; real RCCL
+    refuses two ranks on one device and the pool leases one-GPU boxes).  Uneven shards (3 + 2 frames: the grouped
+    send / receive path of the counts), equal shards (the ncclGather path), dst = 0 and dst = 1, the refusal of an
+    undersized landing buffer on EVERY rank with the collective sequence intact afterwards, the host class against
+    ComputeBatch and the oracle (tests/capi_gather_ranks_child.py).  A rank that posted a collective the others do
+    not match would time out in the mock with a message."""
+    import subprocess
+    import sys
+    root, lib = _mock_rccl()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", IS_RCCL_LIB=lib)
+    idf = str(tmp_path / "comm.id")
+    procs = [subprocess.Popen([sys.executable, os.path.join(root, "tests", "capi_gather_ranks_child.py"), str(r), "2", idf],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env, cwd=root)
+             for r in range(2)]
+    outs = [p.communicate(timeout=900)[0] for p in procs]
+    report = "\n".join(f"---- rank {r} (rc {p.returncode}):\n{o[-3000:]}" for r, (p, o) in enumerate(zip(procs, outs)))
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"RANK_OK {r}" in o, report
+
+
+def test_plain_cpp_gather_caller_two_ranks(tmp_path):
+    """examples/gather_batch (plain C++, no torch) as TWO processes on cuda:0 over the mock communicator: rank 0
+    receives rank 1's frames and compares them with ComputeBatch of the same frames regenerated from rank 1's seed."""
+    import subprocess
+    root, lib = _mock_rccl()
+    exe = os.path.join(root, "examples", "gather_batch")
+    if not os.path.exists(exe):
+        pytest.skip("examples/gather_batch not built (run __graft_entry__.build())")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", IS_RCCL_LIB=lib)
+    idf = str(tmp_path / "comm.id")
+    procs = [subprocess.Popen([exe, str(r), "2", idf, "0"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                              env=env, cwd=root) for r in range(2)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert "rank 0 holds 6 frames of 2 ranks" in outs[0] and "gathered == computed: yes" in outs[0], outs
+
+
 def test_pack_sections_kernels_match_host_logic():
     """is_pack_sections / is_unpack_sections (the compacted payload of the multi-GPU gather,
     SURVEY.md 8e) on the device against the torch restatement the gloo tests use: counts, packed
