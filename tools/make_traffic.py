@@ -99,6 +99,21 @@ def valu_section(d, mode, build_dir):
     return out
 
 
+def rocprof_kernel_ms(d, which, steps):
+    """ms per step of the DP kernels from the kernel-trace pass (trace/**/kernel_stats.csv): the sum over the mode's DP
+    kernels of calls x average duration, over the steps the command ran -- what bench.py's HIP-event `kernel_ms`
+    (roofline) has to agree with."""
+    tot, per = 0.0, {}
+    for f in glob.glob(os.path.join(d, "trace", "**", "*kernel_stats.csv"), recursive=True):
+        with open(f) as fh:
+            for r in csv.DictReader(fh):
+                if any(k in r["Name"] for k in which):
+                    ns = float(r["TotalDurationNs"])
+                    tot += ns
+                    per[r["Name"].split("(")[0][:80]] = {"calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3}
+    return (tot / steps / 1e6 if tot else None), per
+
+
 def counters(d, which):
     tot = collections.defaultdict(float)
     calls = collections.defaultdict(int)
@@ -144,6 +159,10 @@ def main():
             "tcc_hit": tot.get("TCC_HIT_sum", 0.0) / steps,
             "bytes_per_step": (2.0 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) / steps * 1024.0,
         }
+        ms, per = rocprof_kernel_ms(d, DP_KERNELS[mode], steps)
+        if ms is not None:
+            out[mode]["rocprof_kernel_ms"] = ms
+            out[mode]["rocprof_kernels"] = per
         v = valu_section(d, mode, os.path.join("instance_stixels_amd", "csrc", "build"))
         if v:
             out[mode]["valu"] = v
