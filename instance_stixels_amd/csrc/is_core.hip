@@ -46,7 +46,6 @@ hipError_t isk_set_lds_backtrace(const DevParams*);
 int isk_debug_occupancy(const DevParams*, int);
 int isk_unary_uses_carry(const DevParams*, int);
 int isk_unary_uses_fused_lut(const DevParams*, int);
-int isk_unary_lut_side(const DevParams*, int);
 hipError_t isk_launch_cluster(int, float, int, int, const is_instance_buffers*,
                               const is_instance_buffers*, int32_t*, hipStream_t);
 size_t isk_phase2_lds_bytes(const DevParams* P);
@@ -695,8 +694,6 @@ static int compute_enqueue(is_ctx* c, const float* d_joined, const int32_t* d_se
     /* a hand-over of this context has been distrusted before (another dispatcher, a partition mode, a CU mask): the
      * fused launch stays off unless IS_LUT_FUSED asks for it by value -- a repaired call costs 2.8 x an ordinary one */
     if (Pw.lut_fused && (P.knob_lut_fused < 0 || P.knob_lut_fused == 3) && c->h_lutf_repairs && *(volatile int*)c->h_lutf_repairs > 0) Pw.lut_fused = 0;
-    Pw.lut_side = Pw.lut_fused ? isk_unary_lut_side(&Pw, ncols) : 0;
-    Pw.h_side_done = (void*)c->ev_join;
     if (timing) HIP_TRY(hipEventRecord(c->ev[0], stream));
     /* (d_n_generic is zero here: cleared at creation and by k_backtrace at the end of every call) */
     HIP_TRY(isk_launch_prepare(&Pw, ncols, d_joined, d_seg, c->d_ground, c->d_vhor,

@@ -203,13 +203,8 @@ struct DevParams {
     int knob_lut_fused; /* IS_LUT_FUSED: -1 / 1 = the LUT units run inside the unary DP launch where they can, 0 = never,
                          * 2 = (tests) fused with a WRONG XCC id published: every workgroup distrusts, the repair launches run,
                          * 3 = (tests) the default policy (-1) with the wrong id of 2: the first large call is repaired, and the
-                         * context then keeps the table in the prepare launch (DevParams::lutf_repairs),
-                         * 4 = wherever possible, as the side kernel (lut_side) at every D */
+                         * context then keeps the table in the prepare launch (DevParams::lutf_repairs) */
     int lut_fused;      /* set per call: 0, 1, or 2 (the test mode) */
-    int lut_side;       /* set per call (with lut_fused): the units run as a kernel of their own (k_lut_units_side) on an
-                         * auxiliary stream BESIDE the DP launch instead of as workgroups inside it; the DP launch keeps one
-                         * workgroup slot per CU free for them (is_k_unary_fast.hip, "side kernel") */
-    void* h_side_done;  /* (host only) hipEvent_t recorded behind the side kernel; the launches behind the DP wait for it */
     int knob_lut_carry; /* IS_LUT_CARRY=1: carry rows only wherever the DP can rebuild the rest (unary calls whose every
                          * tile runs the windowed ring kernel); default: lutT is materialised (measured faster) */
     int lut_carry;      /* set per call: k_object_lut stores only the rows 32 k of lutT (the carries of its 32-row

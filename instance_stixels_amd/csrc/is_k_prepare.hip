@@ -153,7 +153,7 @@ __device__ __forceinline__ void prepare_columns_body(
     float* __restrict__ sv_arr, PruneRec* __restrict__ prune, int* __restrict__ n_generic) {
     const int H = P.H, P2 = P.P2, P2S = P.P2S, CH = P.CH, K = P.K;
     if (P.lut_ready != nullptr && threadIdx.x == 0) {
-        if (!P.lut_side) P.lut_ready[colg] = 0; /* (the fused LUT units of the DP launch count up; the side kernel runs beside this launch: cleared by a memset in front of both) */
+        P.lut_ready[colg] = 0; /* (the fused LUT units of the DP launch count up) */
         if (colg == 0 && P.lutf_bad != nullptr) *P.lutf_bad = 0;
     }
     /* LDS stride of a segmentation channel: only its first H/8 + 1 entries matter (an exclusive
@@ -974,9 +974,6 @@ hipError_t isk_launch_lut_repair(const DevParams* P, int ncols, const float* joi
     return hipGetLastError();
 }
 
-hipError_t isk_launch_lut_side(const DevParams* P, int ncols, const float* joined, const float* cost_T, float* lutT,
-                               hipStream_t stream); /* is_k_unary_fast.hip */
-
 hipError_t isk_launch_prepare(const DevParams* P, int ncols, const float* joined,
                               const int32_t* seg, const float* ground, const int* vhor,
                               const float* cost_T, RowRec* recs, float* lutT,
@@ -989,28 +986,8 @@ hipError_t isk_launch_prepare(const DevParams* P, int ncols, const float* joined
     const bool side_by_side = aux != nullptr && P->knob_prepare_overlap == 1;
     hipError_t e;
     if (P->lut_fused) { /* the LUT units run inside the unary DP launch (k_dp_unary_fast, LUTF): records only here */
-        /* ... or beside it (k_lut_units_side on the auxiliary stream).  The units need the joined disparities only, but
-         * forked in FRONT of k_prepare_columns they run beside THAT launch -- both are bound by their HBM writes and
-         * simply share the bandwidth (measured, 32 frames of 1024x4096x256: 4.3 ms for the pair, the DP then runs alone)
-         * -- so the fork comes BEHIND it: the write-bound units beside the issue-bound DP. */
-#ifndef ISP_SIDE_FORK_FIRST
-#define ISP_SIDE_FORK_FIRST 0
-#endif
-        auto fork_side = [&]() -> hipError_t {
-            hipError_t e2;
-            if (aux == nullptr) return hipErrorInvalidValue;
-            if ((e2 = hipEventRecord(ev_fork, stream)) != hipSuccess) return e2;
-            if ((e2 = hipStreamWaitEvent(aux, ev_fork, 0)) != hipSuccess) return e2;
-            if ((e2 = isk_launch_lut_side(P, ncols, joined, cost_T, lutT, aux)) != hipSuccess) return e2;
-            return hipEventRecord((hipEvent_t)P->h_side_done, aux);
-        };
-        if (P->lut_side) {
-            if ((e = hipMemsetAsync(P->lut_ready, 0, sizeof(int) * (size_t)ncols, stream)) != hipSuccess) return e;
-            if (ISP_SIDE_FORK_FIRST && (e = fork_side()) != hipSuccess) return e;
-        }
         hipLaunchKernelGGL(k_prepare_columns, dim3(ncols), dim3(PREP_THREADS), isk_prepare_lds_bytes(P), stream, *P,
                            joined, seg, ground, vhor, recs, col_flags, sv_arr, prune, n_generic);
-        if (P->lut_side && !ISP_SIDE_FORK_FIRST && (e = fork_side()) != hipSuccess) return e;
         return hipGetLastError();
     }
     const bool fused = P->knob_prepare_overlap == 2 || P->knob_prepare_overlap < 0;

@@ -685,7 +685,10 @@ __device__ __forceinline__ void diag_quarters(const DevParams& P, RowRec& my, Un
  * second kernel only receives the CUs the first one leaves: measured, rounds 2 and 4) and a CU partition does not
  * either (a CU that runs prepare blocks cannot lend its VALU: round 5), so the LUT units become workgroups of
  * THIS launch, interleaved in block order with the DP workgroups: block IDs are dispatched in order (per XCD:
- * block b runs on XCD b mod 8), so a DP workgroup that waits for its column's units -- a counter per column,
+ * block b runs on XCD (b + k) mod 8 with ONE offset k for the whole launch -- the dispatcher's round-robin is not reset
+ * between launches: measured in round 6, when the same units as a kernel of their own on a second stream landed one and
+ * three XCDs away from their readers (profiles/r06_ab_lut_side_kernel.log); only "b and b + 8 share an XCD" is used),
+ * so a DP workgroup that waits for its column's units -- a counter per column,
  * release / acquire -- only ever waits for workgroups that were dispatched before it.
  *   block order: [8 LEAD LUT blocks] then per super-group s of cpb = 4 / fn_blocks column groups: [8 LUT blocks of
  *   super-group s + LEAD] [cpb 8 ntl DP blocks of super-group s].  LUT block r of a super-group holds the units of
@@ -707,12 +710,6 @@ __device__ __forceinline__ void diag_quarters(const DevParams& P, RowRec& my, Un
 #endif
 #ifndef ISF_LUTF_MIN_COLS
 #define ISF_LUTF_MIN_COLS 2048 /* columns per call from which the LUT units run inside the DP launch by default */
-#endif
-#ifndef ISF_LUTF_SIDE_D256
-#define ISF_LUTF_SIDE_D256 1 /* D = 256 calls of >= ISF_LUTF_MIN_COLS columns: the LUT units as the side kernel by default */
-#endif
-#ifndef ISF_LUTF_SIDE_LDS
-#define ISF_LUTF_SIDE_LDS (24 * 1024) /* LDS per DP workgroup beside the side kernel: six per CU (7 x 24 KB > 160 KB) */
 #endif
 #ifndef ISF_LUTF_POLL_MAX
 #define ISF_LUTF_POLL_MAX (1 << 14) /* polls of a DP workgroup for its column's units before it distrusts the hand-over */
@@ -787,24 +784,6 @@ __device__ __forceinline__ void lut_unit_fused(const DevParams& P, const int col
                                __HIP_MEMORY_SCOPE_AGENT);
 }
 
-/* SIDE KERNEL (DevParams::lut_side): the same units as a kernel of their own on an auxiliary stream, BESIDE the DP launch.
- * Inside the DP launch a LUT block takes a whole workgroup slot (22.8 KB of LDS it does not use, 4 x 72 VGPRs) for the
- * ~0.4 ms it lives, ten DP workgroup lives: at D = 256 -- four units per column -- the blocks hold 43 % of the slots and
- * the fused launch takes what the two halves take one after the other (7.1 against 3.7 + 3.3 ms per 32 frames of
- * 1024x4096).  Here the DP launch is given 24 KB of LDS per workgroup -- six instead of seven per CU, -2 % by itself --,
- * which leaves one wave slot and 80 VGPRs per SIMD that no DP workgroup can ever take: room for one 4-wave block of this
- * kernel per CU.  It starts with k_prepare_columns (it needs the joined disparities only), walks the columns in the order
- * the DP does, block b on XCD b mod 8 = the XCD of its columns' DP workgroups (checked through the published XCC id, as
- * in the fused form), and the DP workgroups poll their column's count as before; the launches behind the DP launch wait
- * for this kernel's event, and the repair launches stand behind both. */
-__global__ __launch_bounds__(256, 6) void k_lut_units_side(const DevParams P, int ncols, const float* __restrict__ joined,
-                                                        const float* __restrict__ cost_T, float* __restrict__ lutT) {
-    const int fnb = (P.D + 63) >> 6, cpb = 4 / fnb;
-    const int wv = (int)(threadIdx.x >> 6), r = (int)blockIdx.x & 7, sg = (int)blockIdx.x >> 3;
-    const int col = ((sg * cpb + wv / fnb) * 8) + r;
-    if (col < ncols) lut_unit_fused(P, col, wv % fnb, (int)(threadIdx.x & 63), joined, cost_T, lutT, P.lut_ready);
-}
-
 /* GEN (with WIN): lutT holds only its carry rows (DevParams::lut_carry); the tile and the vB-side rows are rebuilt */
 template <bool HAS_INVALID, int NVR, bool PRE_DIAG = false, bool WIN = false, bool GEN = false, bool LUTF = false,
           bool REPAIR = false>
@@ -854,8 +833,7 @@ __global__ __launch_bounds__(ISF_THREADS, GEN ? ISF_OCC_GEN : (LUTF ? (HAS_INVAL
         const int nSG = ((ncols + 7) / 8 + cpb - 1) / cpb, dp_per = cpb * 8 * ntl;
         const int lead = min(ISF_LUTF_LEAD, nSG);
         int b = (int)blockIdx.x, sg = -1;
-        if (P.lut_side) { /* the units run beside this launch (k_lut_units_side): DP workgroups only */
-        } else if (b < 8 * lead) {
+        if (b < 8 * lead) {
             sg = b >> 3;
         } else {
             b -= 8 * lead;
@@ -911,19 +889,8 @@ next_item: /* (REPAIR: the next (column, tile) item of this workgroup) */
                    ++spins < ISF_LUTF_POLL_MAX &&
                    __hip_atomic_load(P.lutf_bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
                 __builtin_amdgcn_s_sleep(32);
-#ifdef ISF_ABL_TRUST /* timing-only ablation: the XCC ids are not compared (results may be wrong) */
-            if ((seen & 255) < need)
-#else
             if ((seen & 255) < need || (seen >> 8) != need * xcc_id())
-#endif
                 __hip_atomic_fetch_or(P.lutf_bad, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#ifdef ISF_DEBUG_HANDOVER /* (debug builds: why a hand-over was distrusted, in the two pairwise counters a unary call leaves unused) */
-            if (counters != nullptr && (seen & 255) < need) atomicAdd(counters + IS_CNT_P1_FULL, 1ull);
-            if (counters != nullptr && (seen & 255) >= need && (seen >> 8) != need * xcc_id()) {
-                atomicAdd(counters + IS_CNT_P1_GS, 1ull);
-                atomicAdd(counters + IS_CNT_TILE0 + 8 * xcc_id() + (((seen >> 8) / need) & 7), 1ull); /* [reader XCC][unit XCC] */
-            }
-#endif
             if (counters != nullptr && spins > 0) atomicAdd(counters + IS_CNT_LUTF_SPINS, (unsigned long long)spins);
         }
         __syncthreads();
@@ -1457,26 +1424,8 @@ int isk_unary_uses_fused_lut(const DevParams* P, int ncols) {
     /* by itself only where it pays (frames/s fused | prepare launch at 1 / 4 / 8 / 12 / 16 / 64 frames per call: 4730 |
      * 6240, 7070 | 7100, 9300 | 9060, 9930 | 9440, 9610 | 9100, 11 030 | 10 160); IS_LUT_FUSED=1 / 2: at any size */
     const bool by_itself = P->knob_lut_fused < 0 || P->knob_lut_fused == 3; /* (3, tests: the default policy with a wrong XCC id published) */
-    if (by_itself && ncols < ISF_LUTF_MIN_COLS) return 0;
-    if (by_itself && fnb > 2 && !ISF_LUTF_SIDE_D256) return 0; /* (D = 256, four units per column, INSIDE the launch: 3940 | 4040 frames/s per 32 frames of 1024x4096) */
-    return (P->knob_lut_fused == 2 || P->knob_lut_fused == 3) ? 2 : 1;
-}
-
-/* 1 when the units of a fused call run as the side kernel (k_lut_units_side): IS_LUT_FUSED=4 everywhere, by itself where
- * four units per column would crowd the DP workgroups out of their own launch (D = 256) */
-int isk_unary_lut_side(const DevParams* P, int ncols) {
-    (void)ncols;
-    if (P->knob_lut_fused == 4) return 1;
-    const int fnb = (P->D + 63) / 64;
-    return (P->knob_lut_fused < 0 && fnb > 2 && ISF_LUTF_SIDE_D256) ? 1 : 0;
-}
-
-hipError_t isk_launch_lut_side(const DevParams* P, int ncols, const float* joined, const float* cost_T, float* lutT,
-                               hipStream_t stream) {
-    const int fnb = (P->D + 63) / 64, cpb = 4 / fnb;
-    const int nSG = ((ncols + 7) / 8 + cpb - 1) / cpb;
-    hipLaunchKernelGGL(k_lut_units_side, dim3(8 * nSG), dim3(256), 0, stream, *P, ncols, joined, cost_T, lutT);
-    return hipGetLastError();
+    if (by_itself && (ncols < ISF_LUTF_MIN_COLS || fnb > 2)) return 0; /* (D = 256, four units per column, 32 frames of 1024x4096: 3940 | 4040) */
+    return P->knob_lut_fused >= 2 ? 2 : 1;
 }
 
 /* FAST columns of the batch; the caller runs k_dp_unary<.., false> for the generic ones. */
@@ -1517,13 +1466,10 @@ hipError_t isk_launch_dp_unary_fast(const DevParams* P, int ncols, const RowRec*
         const int fnb = (P->D + 63) / 64, cpb = 4 / fnb;
         const int nSG = (groups + cpb - 1) / cpb;
         fused_grid = (unsigned)nSG * (8u + (unsigned)(cpb * 8 * P->ntiles));
-        if (P->lut_side) fused_grid = (unsigned)groups * 8u * (unsigned)P->ntiles; /* (the units: k_lut_units_side) */
     }
     const bool gen = P->lut_carry != 0; /* (set by the caller only when isk_unary_uses_carry() holds) */
     if (gen && wt < P->ntiles) return hipErrorInvalidValue;
     const size_t lds_win = isf_lds_bytes(P, nvr, nw_win, true, gen);
-    /* beside the side kernel: one workgroup slot per CU stays free (see k_lut_units_side) */
-    const size_t lds_fused = (P->lut_fused && P->lut_side && lds_win < (size_t)ISF_LUTF_SIDE_LDS) ? (size_t)ISF_LUTF_SIDE_LDS : lds_win;
 #define ISF_LAUNCH(INV, NVR)                                                                      \
     do {                                                                                          \
         if (pre_diag)                                                                             \
@@ -1544,12 +1490,9 @@ hipError_t isk_launch_dp_unary_fast(const DevParams* P, int ncols, const RowRec*
                                    counters, joined, cost_T, pre_diag, 0, wt, nullptr);                     \
             else if (wt > 0 && P->lut_fused) {                                                    \
                 hipLaunchKernelGGL((k_dp_unary_fast<INV, NVR, false, true, false, true>), dim3(fused_grid), \
-                                   dim3(nw_win * 64), lds_fused, stream, *P,                       \
+                                   dim3(nw_win * 64), lds_win, stream, *P,                         \
                                    ncols, recs, lutT, rcp, vhor, col_flags, prune, cost_table, index_table, \
                                    counters, joined, cost_T, pre_diag, 0, wt, nullptr);            \
-                /* (the side kernel's table is complete before anything behind the DP launch runs) */ \
-                if (P->lut_side && hipStreamWaitEvent(stream, (hipEvent_t)P->h_side_done, 0) != hipSuccess) \
-                    return hipErrorInvalidValue;                                                  \
                 /* the repair launches: they leave at once unless a workgroup above set lutf_bad */  \
                 const hipError_t er = isk_launch_lut_repair(P, ncols, joined, cost_T, const_cast<float*>(lutT), stream); \
                 if (er != hipSuccess) return er;                                                  \
