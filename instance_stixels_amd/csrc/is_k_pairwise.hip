@@ -754,9 +754,16 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
     const int nw = nwl * nsplit;
     const int w = split * nwl + wl;
     const int tile_lo = tile * IS_TILE;
-    const RowRec* rcol = recs + (size_t)colg * (H + 1);
-    const float* lcol = lutT + (size_t)colg * (H + 1) * D;
-    const StepRec* scol = steps + (size_t)colg * H;
+#ifdef IS_ABL_P1HOT /* timing-only ablation for batches whose columns are all EQUAL (tools/p1_hot_probe.py): phase 1 reads the
+                     * tables of column (colg mod 8) -- the same values, from lines that stay in the XCD's L2 -- so that the
+                     * difference to the product build is what phase 1 pays for memory latency and bandwidth */
+    const int colr = colg & 7;
+#else
+    const int colr = colg;
+#endif
+    const RowRec* rcol = recs + (size_t)colr * (H + 1);
+    const float* lcol = lutT + (size_t)colr * (H + 1) * D;
+    const StepRec* scol = steps + (size_t)colr * H;
 
 #if IS_P1_TILE0_DIRECT
     /* Tile 0 has ONE candidate per row, the first segment (vB = 0, :481-594), and it belongs to wave 0
@@ -810,7 +817,7 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
     float* s_lb = s_scr + 8 * nwl + IS_P1_L7_WORDS;   /* [NLB][64 lanes] object block bounds      */
     float* s_sum = s_lb + NLB * 64;                   /* [NLB][IS_P1_SUM_F]: 24 summary floats + the instance
                                                        * prefixes (dwords 24..31) of the record at the block's TOP row */
-    const float* bcol = blksum + (size_t)colg * (P.ntiles * IS_QPT + 1) * IS_L7_F;
+    const float* bcol = blksum + (size_t)colr * (P.ntiles * IS_QPT + 1) * IS_L7_F;
     constexpr int PRE_N = 2; /* floats per thread: NLB * 32 <= PRE_N * nthreads at 1024 rows */
     float pre_v[PRE_N];
     const int nthr = (int)blockDim.x;
@@ -827,7 +834,7 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
             pre_v[j] = i < NLB * IS_P1_SUM_F ? pre_load(i) : 0.0f;
         }
     }
-    const int win_lo = windowed ? __builtin_amdgcn_readfirstlane(P.win_lo[(size_t)colg * P.ntiles + tile]) : 0;
+    const int win_lo = windowed ? __builtin_amdgcn_readfirstlane(P.win_lo[(size_t)colr * P.ntiles + tile]) : 0;
     if (windowed) stage_window_and_rcp(s_tile, s_rcp, lcol, rcp, tile_lo, H, D, win_lo, tid, (int)blockDim.x);
     else stage_tile_and_rcp(s_tile, s_rcp, lcol, rcp, tile_lo, H, D, tid, (int)blockDim.x);
     const RowRec my = load_rec(rcol + vTc + 1);
