@@ -424,7 +424,7 @@ def measure_mode(wl, steps=3, with_pruning_off=True, with_verify=True, with_prun
 
 
 def measure_in_flight(wl, counts, steps=12):
-    """The headline step with several contexts in flight (tools/two_ctx.py): context k on its own stream
+    """The headline step with several contexts in flight (tools/experiments/two_ctx.py): context k on its own stream
     takes every k-th batch; all results are compared with the single-context output."""
     torch = wl.torch
     res = {"what": "N contexts on N streams, batches alternate between them; images/s over all of them "

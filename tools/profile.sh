@@ -3,7 +3,9 @@
 # usage: tools/profile.sh <tag> [bench args...]
 set -u
 TAG=${1:-r01}; shift || true
-ARGS=${@:---batch 64 --steps 3 --warmup 1 --no-cpu-baseline --no-variants --no-single --no-d2h --no-verify --no-prune-stats --min-seconds 0}
+# (the driver's step counts: the first dispatches of a process run 5-15 % slower -- clocks, cold caches -- and 25 of them
+# dilute that in the per-kernel averages, which then agree with bench.py's HIP-event kernel_ms)
+ARGS=${@:---batch 64 --steps 20 --warmup 5 --no-cpu-baseline --no-variants --no-single --no-d2h --no-verify --no-prune-stats --min-seconds 0}
 OUT=gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
 echo "python3 bench.py $ARGS" > $OUT/command.txt
