@@ -131,6 +131,7 @@ private:
     float ComputeObjectDisparityRange(const float previous_mean) const;
     float FastLog(float v) const;
     void FillHeader(StixelsData& d, float alpha_ground, int vhor_lib) const;
+    void EnsurePackBuffers();
     is_instance_buffers InstanceBuffers(int image = 0) const;
     GroundModel m_ground; /* per-frame ground model, storage reused between frames */
     /* the road parameters m_ground was computed for: a frame with the same parameters (a fixed
@@ -172,6 +173,10 @@ private:
     Section* d_all_packed = nullptr;
     Section* d_all_sections = nullptr;
     size_t m_all_columns_cap = 0, m_all_packed_cap = 0;
+    /* ComputeBatch: the same packed payload copied to the host in two pinned pieces (offsets, used sections) */
+    int32_t* h_pack_offsets = nullptr;
+    Section* h_pack_sections = nullptr;
+    size_t m_h_pack_cap = 0; /* sections h_pack_sections holds */
     int32_t* h_instance_packed = nullptr;
     /* every device operation of the object runs on this stream (an ordinary stream: it still
      * synchronises with work the caller queued on the legacy NULL stream, like the reference's

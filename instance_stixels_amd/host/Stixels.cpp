@@ -378,6 +378,9 @@ void Stixels::Finish() { /* Stixels.cu:250-283 */
     d_pack_counts = d_pack_offsets = d_all_counts = nullptr;
     d_pack_sections = d_all_packed = d_all_sections = nullptr;
     m_all_columns_cap = m_all_packed_cap = 0;
+    if (h_pack_offsets) IS_CHECK_RETURN(is_host_free(h_pack_offsets));
+    if (h_pack_sections) IS_CHECK_RETURN(is_host_free(h_pack_sections));
+    h_pack_offsets = nullptr; h_pack_sections = nullptr; m_h_pack_cap = 0;
     IS_CHECK_RETURN(is_host_free(h_stixels));
     IS_CHECK_RETURN(is_host_free(h_stixels_head));
     h_stixels_head = nullptr; d_stixels_block = nullptr;
@@ -543,17 +546,46 @@ void Stixels::ComputeBatch(bool pairwise, int n_images, const pixel_t* d_big,
     IS_CHECK_RETURN(is_compute(m_ctx, d_disparity, d_seg, gf.data(), ng.data(), ig.data(),
                                vh.data(), pairwise ? 1 : 0, n_images, d_stixels,
                                instance_stixels ? ibs.data() : nullptr, nullptr, nullptr, stream));
-    out.resize(n_images);
+    /* Results to the host COMPACTED and through pinned memory: a column uses 10-60 of its 200 slots, and the
+     * reference's fixed-stride copy (Stixels.cu:629-633: one frame) would move 1.6 MB per frame into pageable
+     * vectors.  is_pack_sections leaves per-column offsets + the used sections; two pinned copies (the offsets, then
+     * exactly the used sections) and a scatter on the host restore the fixed-stride layout incl. each column's
+     * terminator -- what lies behind a terminator is unspecified, as in Compute(). */
     const size_t per = (size_t)m_realcols * m_max_sections;
-    for (int i = 0; i < n_images; i++) {
-        FillHeader(out[i], road[i].alpha_ground, vh[i]);
-        IS_CHECK_RETURN(is_memcpy_d2h(out[i].sections.data(), d_stixels + per * i,
-                                      per * sizeof(Section), stream));
-    }
+    const size_t ncols = (size_t)n_images * m_realcols;
+    EnsurePackBuffers();
+    IS_CHECK_RETURN(is_pack_sections((const is_section*)d_stixels, (int)ncols, m_max_sections, d_pack_counts,
+                                     d_pack_offsets, (is_section*)d_pack_sections, stream));
+    IS_CHECK_RETURN(is_memcpy_d2h(h_pack_offsets, d_pack_offsets, (ncols + 1) * sizeof(int32_t), stream));
     if (instance_stixels) /* the per-class counts of all frames: one small copy */
         IS_CHECK_RETURN(is_memcpy_d2h(h_instance_head, d_instances_per_class,
                                       (size_t)n_images * m_instance_classes * sizeof(int32_t), stream));
     IS_CHECK_RETURN(is_stream_synchronize(stream));
+    const size_t total = (size_t)h_pack_offsets[ncols];
+    if (total > m_h_pack_cap) { /* (first call: 64 per column; grown to what a batch needs) */
+        if (h_pack_sections) IS_CHECK_RETURN(is_host_free(h_pack_sections));
+        h_pack_sections = nullptr;
+        m_h_pack_cap = total + total / 4 + 1024;
+        IS_CHECK_RETURN(is_host_malloc((void**)&h_pack_sections, m_h_pack_cap * sizeof(Section)));
+    }
+    if (total > 0)
+        IS_CHECK_RETURN(is_memcpy_d2h(h_pack_sections, d_pack_sections, total * sizeof(Section), stream));
+    out.resize(n_images);
+    for (int i = 0; i < n_images; i++) FillHeader(out[i], road[i].alpha_ground, vh[i]); /* (beside the copy) */
+    IS_CHECK_RETURN(is_stream_synchronize(stream));
+    Section term;
+    std::memset(&term, 0, sizeof(term));
+    term.type = -1; /* StixelsKernels.cu:952-954 */
+    for (int i = 0; i < n_images; i++) {
+        Section* dst = out[i].sections.data();
+        for (int c = 0; c < m_realcols; c++) {
+            const size_t col = (size_t)i * m_realcols + c;
+            const size_t o = (size_t)h_pack_offsets[col], n = (size_t)h_pack_offsets[col + 1] - o;
+            if (n > 0) std::memcpy(dst + (size_t)c * m_max_sections, h_pack_sections + o, n * sizeof(Section));
+            dst[(size_t)c * m_max_sections + n] = term;
+        }
+    }
+    (void)per;
     if (!instance_stixels) return;
     /* (column, section, label) triples of every frame, sized by the counts just read */
     const size_t inst_n = (size_t)m_instance_classes * m_realcols * m_max_sections;
@@ -576,6 +608,18 @@ void Stixels::ComputeBatch(bool pairwise, int n_images, const pixel_t* d_big,
     /* a following GetInstanceStixels() returns the mapping of frame 0 (slice 0 of the arrays) */
     for (int k = 0; k < m_instance_classes; k++) m_instances_per_class[k] = h_instance_head[k];
     m_labels_on_host = false;
+}
+
+/* the packed payload of a batch (ComputeBatch, ComputeBatchGather): allocated on first use, released by Finish */
+void Stixels::EnsurePackBuffers() {
+    if (d_pack_counts != nullptr) return;
+    const size_t cols = (size_t)m_max_batch * m_realcols;
+    IS_CHECK_RETURN(is_device_malloc((void**)&d_pack_counts, cols * sizeof(int32_t)));
+    IS_CHECK_RETURN(is_device_malloc((void**)&d_pack_offsets, (cols + 1) * sizeof(int32_t)));
+    IS_CHECK_RETURN(is_device_malloc((void**)&d_pack_sections, cols * (m_max_sections - 1) * sizeof(Section)));
+    IS_CHECK_RETURN(is_host_malloc((void**)&h_pack_offsets, (cols + 1) * sizeof(int32_t)));
+    m_h_pack_cap = cols * 64;
+    IS_CHECK_RETURN(is_host_malloc((void**)&h_pack_sections, m_h_pack_cap * sizeof(Section)));
 }
 
 /* The shard of this rank, then the compacted gather of every rank's Sections on `dst` (the
@@ -614,12 +658,7 @@ void Stixels::ComputeBatchGather(bool pairwise, int n_images, const pixel_t* d_b
                                pairwise ? 1 : 0, n_images, d_stixels, nullptr, nullptr, nullptr, stream));
 
     /* ---- pack: per-column counts + the used sections (10-40 of the 200 slots of a column) */
-    if (d_pack_counts == nullptr) {
-        const size_t cols = (size_t)m_max_batch * m_realcols;
-        IS_CHECK_RETURN(is_device_malloc((void**)&d_pack_counts, cols * sizeof(int32_t)));
-        IS_CHECK_RETURN(is_device_malloc((void**)&d_pack_offsets, (cols + 1) * sizeof(int32_t)));
-        IS_CHECK_RETURN(is_device_malloc((void**)&d_pack_sections, cols * (m_max_sections - 1) * sizeof(Section)));
-    }
+    EnsurePackBuffers();
     IS_CHECK_RETURN(is_pack_sections((const is_section*)d_stixels, my_cols, m_max_sections, d_pack_counts,
                                      d_pack_offsets, (is_section*)d_pack_sections, stream));
 
