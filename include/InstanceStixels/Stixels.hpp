@@ -177,6 +177,8 @@ private:
     int32_t* h_pack_offsets = nullptr;
     Section* h_pack_sections = nullptr;
     size_t m_h_pack_cap = 0; /* sections h_pack_sections holds */
+    int32_t* h_all_counts = nullptr; /* ComputeBatchGather on dst: the per-column counts of all ranks (pinned) */
+    size_t m_h_all_counts_cap = 0;
     int32_t* h_instance_packed = nullptr;
     /* every device operation of the object runs on this stream (an ordinary stream: it still
      * synchronises with work the caller queued on the legacy NULL stream, like the reference's

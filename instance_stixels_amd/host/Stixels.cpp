@@ -380,7 +380,9 @@ void Stixels::Finish() { /* Stixels.cu:250-283 */
     m_all_columns_cap = m_all_packed_cap = 0;
     if (h_pack_offsets) IS_CHECK_RETURN(is_host_free(h_pack_offsets));
     if (h_pack_sections) IS_CHECK_RETURN(is_host_free(h_pack_sections));
-    h_pack_offsets = nullptr; h_pack_sections = nullptr; m_h_pack_cap = 0;
+    if (h_all_counts) IS_CHECK_RETURN(is_host_free(h_all_counts));
+    h_pack_offsets = nullptr; h_pack_sections = nullptr; h_all_counts = nullptr;
+    m_h_pack_cap = m_h_all_counts_cap = 0;
     IS_CHECK_RETURN(is_host_free(h_stixels));
     IS_CHECK_RETURN(is_host_free(h_stixels_head));
     h_stixels_head = nullptr; d_stixels_block = nullptr;
@@ -551,7 +553,6 @@ void Stixels::ComputeBatch(bool pairwise, int n_images, const pixel_t* d_big,
      * vectors.  is_pack_sections leaves per-column offsets + the used sections; two pinned copies (the offsets, then
      * exactly the used sections) and a scatter on the host restore the fixed-stride layout incl. each column's
      * terminator -- what lies behind a terminator is unspecified, as in Compute(). */
-    const size_t per = (size_t)m_realcols * m_max_sections;
     const size_t ncols = (size_t)n_images * m_realcols;
     EnsurePackBuffers();
     IS_CHECK_RETURN(is_pack_sections((const is_section*)d_stixels, (int)ncols, m_max_sections, d_pack_counts,
@@ -585,7 +586,6 @@ void Stixels::ComputeBatch(bool pairwise, int n_images, const pixel_t* d_big,
             dst[(size_t)c * m_max_sections + n] = term;
         }
     }
-    (void)per;
     if (!instance_stixels) return;
     /* (column, section, label) triples of every frame, sized by the counts just read */
     const size_t inst_n = (size_t)m_instance_classes * m_realcols * m_max_sections;
@@ -618,6 +618,7 @@ void Stixels::EnsurePackBuffers() {
     IS_CHECK_RETURN(is_device_malloc((void**)&d_pack_offsets, (cols + 1) * sizeof(int32_t)));
     IS_CHECK_RETURN(is_device_malloc((void**)&d_pack_sections, cols * (m_max_sections - 1) * sizeof(Section)));
     IS_CHECK_RETURN(is_host_malloc((void**)&h_pack_offsets, (cols + 1) * sizeof(int32_t)));
+    if (h_pack_sections != nullptr) return; /* (ComputeBatchGather on dst may have made it already) */
     m_h_pack_cap = cols * 64;
     IS_CHECK_RETURN(is_host_malloc((void**)&h_pack_sections, m_h_pack_cap * sizeof(Section)));
 }
@@ -677,9 +678,7 @@ void Stixels::ComputeBatchGather(bool pairwise, int n_images, const pixel_t* d_b
     if (rank == dst && (m_all_columns_cap < all_cols || d_all_counts == nullptr)) {
         IS_CHECK_RETURN(is_stream_synchronize(stream));
         IS_CHECK_RETURN(is_device_free(d_all_counts));
-        IS_CHECK_RETURN(is_device_free(d_all_sections));
         IS_CHECK_RETURN(is_device_malloc((void**)&d_all_counts, (all_cols + 1) * sizeof(int32_t) * 2));
-        IS_CHECK_RETURN(is_device_malloc((void**)&d_all_sections, all_cols * m_max_sections * sizeof(Section)));
         m_all_columns_cap = all_cols;
     }
     for (int attempt = 0;; attempt++) {
@@ -704,16 +703,46 @@ void Stixels::ComputeBatchGather(bool pairwise, int n_images, const pixel_t* d_b
         IS_CHECK_RETURN(is_stream_synchronize(stream)); /* the payload has left before the buffers are reused */
         return;
     }
-    /* ---- dst: back to fixed-stride Section arrays (terminators restored), one copy to the host per frame */
-    int32_t* d_all_offsets = d_all_counts + (all_cols + 1);
-    IS_CHECK_RETURN(is_unpack_sections(d_all_counts, d_all_offsets, (const is_section*)d_all_packed, (int)all_cols,
-                                       m_max_sections, (is_section*)d_all_sections, stream));
-    out.resize(all_images);
-    for (int i = 0; i < all_images; i++) {
-        FillHeader(out[i], road_all[i].alpha_ground, m_rows - road_all[i].vhor - 1);
-        IS_CHECK_RETURN(is_memcpy_d2h(out[i].sections.data(), d_all_sections + per * i, per * sizeof(Section), stream));
+    /* ---- dst: the packed payload of all ranks to the host through pinned memory (per-column counts + exactly the used
+     * sections), then back to fixed-stride Section arrays with each column's terminator on the host -- like
+     * ComputeBatch; is_unpack_sections is the device-side form of the same scatter for callers that keep the result
+     * on the GPU */
+    size_t total = 0;
+    for (int r = 0; r < nranks; r++) total += (size_t)totals[r];
+    if (m_h_all_counts_cap < all_cols) {
+        if (h_all_counts) IS_CHECK_RETURN(is_host_free(h_all_counts));
+        h_all_counts = nullptr;
+        IS_CHECK_RETURN(is_host_malloc((void**)&h_all_counts, all_cols * sizeof(int32_t)));
+        m_h_all_counts_cap = all_cols;
     }
+    if (total > m_h_pack_cap) {
+        if (h_pack_sections) IS_CHECK_RETURN(is_host_free(h_pack_sections));
+        h_pack_sections = nullptr;
+        m_h_pack_cap = total + total / 4 + 1024;
+        IS_CHECK_RETURN(is_host_malloc((void**)&h_pack_sections, m_h_pack_cap * sizeof(Section)));
+    }
+    IS_CHECK_RETURN(is_memcpy_d2h(h_all_counts, d_all_counts, all_cols * sizeof(int32_t), stream));
+    if (total > 0)
+        IS_CHECK_RETURN(is_memcpy_d2h(h_pack_sections, d_all_packed, total * sizeof(Section), stream));
+    out.resize(all_images);
+    for (int i = 0; i < all_images; i++) FillHeader(out[i], road_all[i].alpha_ground, m_rows - road_all[i].vhor - 1);
     IS_CHECK_RETURN(is_stream_synchronize(stream));
+    Section term;
+    std::memset(&term, 0, sizeof(term));
+    term.type = -1; /* StixelsKernels.cu:952-954 */
+    size_t o = 0;
+    for (int i = 0; i < all_images; i++) {
+        Section* dst_sec = out[i].sections.data();
+        for (int c = 0; c < m_realcols; c++) {
+            int32_t n = h_all_counts[(size_t)i * m_realcols + c];
+            n = n < 0 ? 0 : (n > m_max_sections - 1 ? m_max_sections - 1 : n);
+            if (o + (size_t)n > total) throw std::runtime_error("ComputeBatchGather: the gathered counts exceed the gathered sections.");
+            if (n > 0) std::memcpy(dst_sec + (size_t)c * m_max_sections, h_pack_sections + o, (size_t)n * sizeof(Section));
+            dst_sec[(size_t)c * m_max_sections + n] = term;
+            o += (size_t)n;
+        }
+    }
+    (void)per;
 }
 
 /* ---------------------------------------------------------------- instances */
