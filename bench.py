@@ -805,6 +805,8 @@ def compact_line(out):
     for k in ("value_incl_d2h", "value_incl_instances", "value_incl_h2d_d2h"):
         if out.get(k) is not None:
             c[k] = _r(out[k], 1)
+    if out.get("value_incl_d2h_compact"):
+        c["value_incl_d2h_compact"] = _r(out["value_incl_d2h_compact"]["images_per_s"], 1)
     if out.get("single_frame"):
         c["single_frame_ms"] = _r(out["single_frame"]["ms_per_frame"], 4)
     if out.get("prune"):
@@ -1041,7 +1043,7 @@ def main():
     # second figure, N = 1 only and outside the judged `value`: the same step
     # followed by the D2H copy of the Section output into pinned host memory (what
     # Stixels::Compute does, Stixels.cu:629-633)
-    d2h_value = None
+    d2h_value = d2h_compact = None
     if world == 1 and not args.no_d2h:
         h_sections = torch.empty(wl.d_sections.shape, dtype=wl.d_sections.dtype, pin_memory=True)
         for _ in range(2):
@@ -1054,6 +1056,35 @@ def main():
         torch.cuda.synchronize(dev)
         d2h_value = B * k / (time.perf_counter() - t1)
         del h_sections
+        # ... and the same with the output COMPACTED first (is_pack_sections: per-column offsets + the used sections
+        # only, what Stixels::ComputeBatch copies): two pinned copies per step, the second sized by the first
+        ncol = B * C
+        counts = torch.empty(ncol, dtype=torch.int32, device=dev)
+        offsets = torch.empty(ncol + 1, dtype=torch.int32, device=dev)
+        packed = torch.empty((ncol * (S - 1), 8), dtype=torch.int32, device=dev)
+        h_off = torch.empty(ncol + 1, dtype=torch.int32, pin_memory=True)
+        h_packed = torch.empty((ncol * (S - 1), 8), dtype=torch.int32, pin_memory=True)
+        from instance_stixels_amd import core as core_mod
+
+        def step_compact():
+            wl.step(core)
+            core_mod.pack_sections_ptr(wl.d_sections.data_ptr(), ncol, S, counts.data_ptr(), offsets.data_ptr(),
+                                       packed.data_ptr(), wl.stream)
+            h_off.copy_(offsets, non_blocking=True)
+            torch.cuda.synchronize(dev)
+            total = int(h_off[-1])
+            h_packed[:total].copy_(packed[:total], non_blocking=True)
+            return total
+        for _ in range(2):
+            step_compact()
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        for _ in range(k):
+            total = step_compact()
+        torch.cuda.synchronize(dev)
+        d2h_compact = {"images_per_s": B * k / (time.perf_counter() - t1), "bytes_per_step": 4 * (ncol + 1) + 32 * total,
+                       "fixed_stride_bytes_per_step": int(wl.d_sections.numel()) * 4}
+        del counts, offsets, packed, h_off, h_packed
 
     # PCIe-inclusive figure for DESIGN.md (--pcie): inputs come from pinned host memory every step
     # and the sections go back, all on the compute stream, nothing overlapped
@@ -1163,6 +1194,7 @@ def main():
         }
         if d2h_value is not None:
             out["value_incl_d2h"] = d2h_value
+            out["value_incl_d2h_compact"] = d2h_compact
         if pcie_value is not None:
             out["value_incl_h2d_d2h"] = pcie_value
         if single is not None:
