@@ -2108,13 +2108,20 @@ __global__ __launch_bounds__(64, 2) void k_pw_phase2_generic(
 
 /* wave-uniform wait until *p >= want; a bound that a correct run never reaches turns a would-be
  * hang into an abort */
-__device__ __forceinline__ void isp2s_wait_ge(volatile int* p, int want) {
+/* The flags live in LDS and are accessed through LDS-typed pointers with LDS-only fences: as plain `volatile int*`
+ * (a generic pointer) every poll was a FLAT load with sc0 sc1 behind `s_waitcnt vmcnt(0)`, and every release fence a
+ * wait for ALL vector memory of the wave -- i.e. each step of the serial chain waited for the global stores of the
+ * StepRec it had just written (round 6: one 1024x2048 pairwise frame 1.56 -> see DESIGN.md section 9). */
+typedef __attribute__((address_space(3))) int isp2s_flag_t;
+#define ISP2S_FENCE_RELEASE() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local")
+#define ISP2S_FENCE_ACQUIRE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local")
+__device__ __forceinline__ void isp2s_wait_ge(volatile isp2s_flag_t* p, int want) {
     int spins = 0;
     while (__builtin_amdgcn_readfirstlane(*p) < want) {
         __builtin_amdgcn_s_sleep(1);
         if (++spins > ISP2S_SPIN_LIMIT) __builtin_trap();
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    ISP2S_FENCE_ACQUIRE();
 }
 
 template <bool SKY>
@@ -2161,8 +2168,8 @@ __device__ __forceinline__ void pw_phase2s_body(const DevParams& P, char* smem, 
     float* s_rcp = s_odr + ((D + 3) & ~3);               /* [IS_TILE+1 -> x4] */
     float* s_win = s_rcp + ((IS_TILE + 1 + 3) & ~3);     /* [65][ISP2_WS] lutT window */
     float* s_ring = s_win + ((ISP2_ROWS * ISP2_WS + 3) & ~3); /* [ISP2S_SLOTS][ISP2S_SLOT_F] */
-    volatile int* s_seq = (volatile int*)(s_ring + ISP2S_SLOTS * ISP2S_SLOT_F); /* [SLOTS] + cons */
-    volatile int* s_cons = s_seq + ISP2S_SLOTS;
+    volatile isp2s_flag_t* s_seq = (volatile isp2s_flag_t*)(isp2s_flag_t*)(int*)(s_ring + ISP2S_SLOTS * ISP2S_SLOT_F); /* [SLOTS] + cons */
+    volatile isp2s_flag_t* s_cons = s_seq + ISP2S_SLOTS;
     const int tile_lo = tile * IS_TILE;
     const RowRec* rcol = recs + (size_t)colg * (H + 1);
     const float* lcol = lutT + (size_t)colg * (H + 1) * D;
@@ -2260,7 +2267,7 @@ __device__ __forceinline__ void pw_phase2s_body(const DevParams& P, char* smem, 
                 pv.og_hi = p1.x; pv.og_lo = p1.y; pv.og_mid = p1.z; pv.g_prev = p1.w;
                 /* the slot is free again once these reads have executed (LDS operations of a wave
                  * execute in order) */
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                ISP2S_FENCE_RELEASE();
                 if (lane == 0) *s_cons = s;
                 if (r - 1 < vhor)
                     pairwise_step_pre<false>(P, st, r, a_gs, b_gs, a_o, b_o, fn, b);
@@ -2356,7 +2363,7 @@ __device__ __forceinline__ void pw_phase2s_body(const DevParams& P, char* smem, 
                 *reinterpret_cast<float4*>(slot + 320) = make_float4(pv.pc, pv.g_from, pv.s_from_g, pv.o_from_s);
                 *reinterpret_cast<float4*>(slot + 324) = make_float4(pv.og_hi, pv.og_lo, pv.og_mid, pv.g_prev);
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            ISP2S_FENCE_RELEASE();
             if (lane == 0) s_seq[q] = s;
         }
     }
