@@ -2115,13 +2115,14 @@ __global__ __launch_bounds__(64, 2) void k_pw_phase2_generic(
 typedef __attribute__((address_space(3))) int isp2s_flag_t;
 #define ISP2S_FENCE_RELEASE() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local")
 #define ISP2S_FENCE_ACQUIRE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local")
-__device__ __forceinline__ void isp2s_wait_ge(volatile isp2s_flag_t* p, int want) {
+__device__ __forceinline__ int isp2s_wait_ge(volatile isp2s_flag_t* p, int want) { /* -> polls that found it unready */
     int spins = 0;
     while (__builtin_amdgcn_readfirstlane(*p) < want) {
         __builtin_amdgcn_s_sleep(1);
         if (++spins > ISP2S_SPIN_LIMIT) __builtin_trap();
     }
     ISP2S_FENCE_ACQUIRE();
+    return spins;
 }
 
 template <bool SKY>
@@ -2252,13 +2253,23 @@ __device__ __forceinline__ void pw_phase2s_body(const DevParams& P, char* smem, 
         st.q_o = q_o; st.q_gs = q_gs;
         int ob_cached = -1;
         float S_obc = 0.0f, V_obc = 0.0f;
+#ifdef IS_ABL_P2PHASES /* (debug build: the chain wave's sections, tools/experiments/p2s_phase_probe.py) */
+        unsigned long long acc_p2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+        ISP2_MARK_INIT();
+        ISP2_MARK(0); /* prologue */
         for (int s = 0; s < n_rows; s++) {
             const int r = tile_lo + s;
             PriorVals pv;
             if (s > 0) {
                 const int q = s % ISP2S_SLOTS;
                 const float* slot = s_ring + q * ISP2S_SLOT_F;
+#ifdef IS_ABL_P2PHASES
+                acc_p2[3] += (unsigned long long)isp2s_wait_ge(s_seq + q, s); /* (section 3: unready polls, a count) */
+#else
                 isp2s_wait_ge(s_seq + q, s);
+#endif
+                ISP2_MARK(1); /* waiting for the evaluator's slot */
                 const float a_gs = slot[lane], b_gs = slot[64 + lane], a_o = slot[128 + lane],
                             b_o = slot[192 + lane], fn = slot[256 + lane];
                 const float4 p0 = *reinterpret_cast<const float4*>(slot + 320);
@@ -2269,10 +2280,12 @@ __device__ __forceinline__ void pw_phase2s_body(const DevParams& P, char* smem, 
                  * execute in order) */
                 ISP2S_FENCE_RELEASE();
                 if (lane == 0) *s_cons = s;
+                ISP2_MARK(2); /* slot reads */
                 if (r - 1 < vhor)
                     pairwise_step_pre<false>(P, st, r, a_gs, b_gs, a_o, b_o, fn, b);
                 else
                     pairwise_step_pre<true>(P, st, r, a_gs, b_gs, a_o, b_o, fn, b);
+                ISP2_MARK(4); /* pairwise_step */
             } else {
                 pv = sload_prior(pcol + min(r + 1, H - 1));
             }
@@ -2293,8 +2306,10 @@ __device__ __forceinline__ void pw_phase2s_body(const DevParams& P, char* smem, 
                     }
                     S_ob = S_obc; V_ob = V_obc;
                 }
+                ISP2_MARK(5); /* broadcasts */
                 st = make_step<HAS_INVALID>(P, S_r1, V_r1, S_ob, V_ob, s_odr, s_invc, s_logc, &pv, vhor, r,
                                             cG, cO, cS, ob);
+                ISP2_MARK(6); /* make_step */
                 const float m8 = min_raw(min3_raw(st.p1_hi, st.p1_lo, st.p1_mid),
                                          min3_raw(min3_raw(st.p2_hi, st.p2_lo, st.p2_mid), st.p3_yes, st.p3_no));
                 if ((s & (IS_QB - 1)) == 0) q_o = q_gs = IS_INF; /* vB = r + 1 starts a bound block */
@@ -2306,8 +2321,13 @@ __device__ __forceinline__ void pw_phase2s_body(const DevParams& P, char* smem, 
                     store_step(scol + r + 1, st);
                     t8row[(size_t)colg * H + r + 1] = pwm8;
                 }
+                ISP2_MARK(7); /* running minima + store */
             }
         }
+#ifdef IS_ABL_P2PHASES
+        if (lane == 0)
+            for (int k = 0; k < 8; k++) atomicAdd(&g_p2phase[k], acc_p2[k]);
+#endif
         if (vT < H) {
             const size_t o = ((size_t)colg * H + vT) * 3;
             cost_table[o + 0] = b.g; cost_table[o + 1] = b.o; cost_table[o + 2] = b.s;
