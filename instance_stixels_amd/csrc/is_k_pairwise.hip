@@ -2103,7 +2103,7 @@ __global__ __launch_bounds__(64, 2) void k_pw_phase2_generic(
 #ifndef ISP2S_SLOTS
 #define ISP2S_SLOTS 4
 #endif
-#define ISP2S_SLOT_F (5 * 64 + 16) /* A_gs, B_gs, A_o, B_o, fn per lane + the PriorVals of vB = r + 1 */
+#define ISP2S_SLOT_F (8 * 64 + 16) /* [lane][A_gs, B_gs, A_o, B_o, fn, 3 unused] + the PriorVals of vB = r + 1 */
 #define ISP2S_SPIN_LIMIT (1 << 26)
 
 /* wave-uniform wait until *p >= want; a bound that a correct run never reaches turns a would-be
@@ -2113,6 +2113,9 @@ __global__ __launch_bounds__(64, 2) void k_pw_phase2_generic(
  * wait for ALL vector memory of the wave -- i.e. each step of the serial chain waited for the global stores of the
  * StepRec it had just written (round 6: one 1024x2048 pairwise frame 1.56 -> see DESIGN.md section 9). */
 typedef __attribute__((address_space(3))) int isp2s_flag_t;
+typedef __attribute__((address_space(3))) float isp2s_lds_f_t;
+typedef float isp2s_f4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) isp2s_f4 isp2s_lds_f4_t;
 #define ISP2S_FENCE_RELEASE() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local")
 #define ISP2S_FENCE_ACQUIRE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local")
 __device__ __forceinline__ int isp2s_wait_ge(volatile isp2s_flag_t* p, int want) { /* -> polls that found it unready */
@@ -2245,14 +2248,23 @@ __device__ __forceinline__ void pw_phase2s_body(const DevParams& P, char* smem, 
                 if ((c2 < b.s) || (c2 == b.s && c2 < IS_INF && (i2 / 3) < (b.is / 3))) { b.s = c2; b.is = i2; }
             }
         }
+        /* S (and V) prefix at the START row of this lane's best object candidate, carried beside b.io: the row that
+         * becomes final hands it to make_step through one v_readlane.  (Until round 6 the chain fetched it with a scalar
+         * load from global memory whenever the start lay below the tile -- a round trip of its own on every such row:
+         * "broadcasts" 330 of the 2030 clocks a row costs, tools/experiments/p2s_phase_probe.py.) */
+        float So, Vo = 0.0f;
+        {
+            const int ob0 = max(b.io, 0) / 3;
+            So = sv[ob0];
+            if (HAS_INVALID) Vo = sv[(H + 1) + ob0];
+        }
+        float S_vb = 0.0f, V_vb = 0.0f; /* the prefixes at index r = the start row of this step's candidates */
         StepVals st;
         st.pwmp = IS_INF; st.idx_gs = -1;
         st.g_hi_thr = st.g_lo_thr = st.p1_hi = st.p1_lo = st.p1_mid = st.o_hi_thr = st.o_lo_thr = 0.0f;
         st.p2_hi = st.p2_lo = st.p2_mid = st.p3_yes = st.p3_no = 0.0f;
         float q_o = IS_INF, q_gs = IS_INF; /* (per tile, see pw_phase2_body) */
         st.q_o = q_o; st.q_gs = q_gs;
-        int ob_cached = -1;
-        float S_obc = 0.0f, V_obc = 0.0f;
 #ifdef IS_ABL_P2PHASES /* (debug build: the chain wave's sections, tools/experiments/p2s_phase_probe.py) */
         unsigned long long acc_p2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
@@ -2263,17 +2275,30 @@ __device__ __forceinline__ void pw_phase2s_body(const DevParams& P, char* smem, 
             PriorVals pv;
             if (s > 0) {
                 const int q = s % ISP2S_SLOTS;
-                const float* slot = s_ring + q * ISP2S_SLOT_F;
+                /* flag and data are requested TOGETHER: LDS operations of a wave execute in order and the evaluator
+                 * writes the data before the flag, so data read behind a flag that says "ready" is the step's data --
+                 * one LDS round trip instead of two on the chain.  (volatile: the compiler keeps the program order of
+                 * the accesses.)  The evaluator is ahead in practice; otherwise poll, then read again. */
+                volatile isp2s_lds_f_t* vs = (volatile isp2s_lds_f_t*)(isp2s_lds_f_t*)(s_ring + q * ISP2S_SLOT_F);
+                /* slot layout: [64 lanes][8 floats: a_gs, b_gs, a_o, b_o, fn, -, -, -] then the eight PriorVals: five LDS
+                 * instructions per step (flag, b128 + b32 per lane, two broadcast b128) instead of fourteen */
+                volatile isp2s_lds_f4_t* v4 = (volatile isp2s_lds_f4_t*)(isp2s_lds_f4_t*)(s_ring + q * ISP2S_SLOT_F);
+                int seen = s_seq[q];
+                isp2s_f4 lv = v4[2 * lane];
+                float fn = vs[8 * lane + 4];
+                isp2s_f4 p0 = v4[128], p1 = v4[129];
+                if (__builtin_amdgcn_readfirstlane(seen) < s) {
 #ifdef IS_ABL_P2PHASES
-                acc_p2[3] += (unsigned long long)isp2s_wait_ge(s_seq + q, s); /* (section 3: unready polls, a count) */
+                    acc_p2[3] += 1ull + (unsigned long long)isp2s_wait_ge(s_seq + q, s); /* (section 3: a count) */
 #else
-                isp2s_wait_ge(s_seq + q, s);
+                    isp2s_wait_ge(s_seq + q, s);
 #endif
-                ISP2_MARK(1); /* waiting for the evaluator's slot */
-                const float a_gs = slot[lane], b_gs = slot[64 + lane], a_o = slot[128 + lane],
-                            b_o = slot[192 + lane], fn = slot[256 + lane];
-                const float4 p0 = *reinterpret_cast<const float4*>(slot + 320);
-                const float4 p1 = *reinterpret_cast<const float4*>(slot + 324);
+                    lv = v4[2 * lane];
+                    fn = vs[8 * lane + 4];
+                    p0 = v4[128]; p1 = v4[129];
+                }
+                ISP2_MARK(1); /* slot flag + data */
+                const float a_gs = lv.x, b_gs = lv.y, a_o = lv.z, b_o = lv.w;
                 pv.pc = p0.x; pv.g_from = p0.y; pv.s_from_g = p0.z; pv.o_from_s = p0.w;
                 pv.og_hi = p1.x; pv.og_lo = p1.y; pv.og_mid = p1.z; pv.g_prev = p1.w;
                 /* the slot is free again once these reads have executed (LDS operations of a wave
@@ -2285,6 +2310,11 @@ __device__ __forceinline__ void pw_phase2s_body(const DevParams& P, char* smem, 
                     pairwise_step_pre<false>(P, st, r, a_gs, b_gs, a_o, b_o, fn, b);
                 else
                     pairwise_step_pre<true>(P, st, r, a_gs, b_gs, a_o, b_o, fn, b);
+                { /* lanes whose object candidate of THIS step (index 3 r + type) has just become their best */
+                    const bool up = (unsigned)(b.io - 3 * r) < 3u;
+                    So = up ? S_vb : So;
+                    if (HAS_INVALID) Vo = up ? V_vb : Vo;
+                }
                 ISP2_MARK(4); /* pairwise_step */
             } else {
                 pv = sload_prior(pcol + min(r + 1, H - 1));
@@ -2293,20 +2323,13 @@ __device__ __forceinline__ void pw_phase2s_body(const DevParams& P, char* smem, 
                 const float cG = readlane_f(b.g, s), cO = readlane_f(b.o, s), cS = readlane_f(b.s, s);
                 const int ob = __builtin_amdgcn_readlane(b.io, s) / 3;
                 const float S_r1 = readlane_f(myS, s), V_r1 = HAS_INVALID ? readlane_f(myV, s) : 0.0f;
-                float S_ob, V_ob = 0.0f;
-                if (ob > tile_lo) {
-                    S_ob = readlane_f(myS, ob - 1 - tile_lo);
-                    if (HAS_INVALID) V_ob = readlane_f(myV, ob - 1 - tile_lo);
-                } else {
-                    if (ob != ob_cached) {
-                        typedef const __attribute__((address_space(4))) float* cflt_t;
-                        S_obc = *(cflt_t)(sv + ob);
-                        if (HAS_INVALID) V_obc = *(cflt_t)(sv + (H + 1) + ob);
-                        ob_cached = ob;
-                    }
-                    S_ob = S_obc; V_ob = V_obc;
-                }
+                const float S_ob = readlane_f(So, s);
+                const float V_ob = HAS_INVALID ? readlane_f(Vo, s) : 0.0f;
+                S_vb = S_r1; V_vb = V_r1; /* prefix index r + 1 = the start row of the next step's candidates */
                 ISP2_MARK(5); /* broadcasts */
+                /* (measured here in round 6, neither kept: the exact-division shortcut for chains of up to 64 rows with
+                 * its reciprocal out of a register through v_readlane -- make_step 844 -> 994 clocks, both divisions stay
+                 * in the code --, and object_disparity_range[k] out of registers instead of LDS -- no measurable change) */
                 st = make_step<HAS_INVALID>(P, S_r1, V_r1, S_ob, V_ob, s_odr, s_invc, s_logc, &pv, vhor, r,
                                             cG, cO, cS, ob);
                 ISP2_MARK(6); /* make_step */
@@ -2377,11 +2400,11 @@ __device__ __forceinline__ void pw_phase2s_body(const DevParams& P, char* smem, 
             const int q = s % ISP2S_SLOTS;
             float* slot = s_ring + q * ISP2S_SLOT_F;
             if (s >= ISP2S_SLOTS) isp2s_wait_ge(s_cons, s - ISP2S_SLOTS); /* the slot's last tenant is consumed */
-            slot[lane] = a_gs; slot[64 + lane] = b_gs; slot[128 + lane] = a_o; slot[192 + lane] = b_o;
-            slot[256 + lane] = t.mean;
+            *reinterpret_cast<float4*>(slot + 8 * lane) = make_float4(a_gs, b_gs, a_o, b_o);
+            slot[8 * lane + 4] = t.mean;
             if (lane == 0) {
-                *reinterpret_cast<float4*>(slot + 320) = make_float4(pv.pc, pv.g_from, pv.s_from_g, pv.o_from_s);
-                *reinterpret_cast<float4*>(slot + 324) = make_float4(pv.og_hi, pv.og_lo, pv.og_mid, pv.g_prev);
+                *reinterpret_cast<float4*>(slot + 512) = make_float4(pv.pc, pv.g_from, pv.s_from_g, pv.o_from_s);
+                *reinterpret_cast<float4*>(slot + 516) = make_float4(pv.og_hi, pv.og_lo, pv.og_mid, pv.g_prev);
             }
             ISP2S_FENCE_RELEASE();
             if (lane == 0) s_seq[q] = s;
