@@ -849,6 +849,8 @@ __device__ __forceinline__ void pw_phase1_body(const DevParams& P, char* smem, i
     }
     const float* my_tile = s_tile + lane * DP;
     const bool live = vT < H;
+    /* (round 6, one frame per call: the record / StepRec lines of the wave's first 3 or 5 steps touched here, in front
+     * of the barrier and the pre-pass -- 1.563-1.588 against 1.574-1.576 ms per frame: nothing, as in round 4) */
     /* lemma L7: per-lane thresholds (order-preserving keys, +inf) and the two survive masks */
     unsigned* s_thr = (unsigned*)(s_scr + 8 * nwl); /* [2][64] + [4] */
     if (tid < 2 * 64) s_thr[tid] = 0xFF800000u;
