@@ -1027,6 +1027,43 @@ def test_bench_force_dist_child_process_runs_the_rccl_gather(gather, tmp_path):
     assert full["gather"]["kind"] == gather and full["gather"]["bytes_per_rank_per_step"]
 
 
+def test_bench_default_run_prints_one_compact_line(tmp_path):
+    """The driver's contract on the GPU: `python bench.py` (here with few steps and a short CPU sample) prints ONE line
+    on stdout -- strict JSON, under 4 KB, every key of the contract, `roofline` and `cpu_baseline` filled, the timed
+    output verified against the oracle -- and writes the complete object beside it (round 5's 29 KB line could not be
+    parsed by the driver)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tests"))
+    from test_bench_line import REQUIRED, ROOFLINE
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+                          "--min-seconds", "0.2", "--cpu-seconds", "1.5", "--out", str(tmp_path / "bench_full.json")],
+                         capture_output=True, text=True, timeout=600, cwd=root,
+                         env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and len(lines[0].encode()) < 4096, (len(lines), len(lines[0]))
+    d = json.loads(lines[0])
+    for k in REQUIRED:
+        assert k in d, k
+    for k in ROOFLINE:
+        assert k in d["roofline"], k
+    assert d["metric"].startswith("images/s on 1024x2048x128") and d["unit"] == "images/s" and d["n_gpus"] == 1
+    assert d["steps"] == 3 and d["warmup"] == 1 and d["value"] > 1000 and d["vs_baseline"] is None
+    assert d["config"]["workload"] and d["verify_all_ok"] is True and d["lut_fused_repaired"] == 0
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
+    assert r["kernel_ms"] > 0 and r["algorithmic_bytes_per_image"] == 15532032
+    assert abs(r["achieved"] - 15532032 * 64 / (r["kernel_ms"] * 1e-3) / 1e9) / r["achieved"] < 1e-3
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and c["sample"]
+    assert d["value_pruning_off"] < d["value"] and d["value_floor_families"]["images_per_s"] <= d["value"] * 1.001
+    full = json.load(open(tmp_path / "bench_full.json"))
+    assert full["verify"]["ok"] and full["timed_blocks"]["count"] >= 1 and full["prune"]["evaluated_frac"] < 0.5
+
+
 def test_capi_rccl_gather_one_rank():
     """The C-ABI gather for C++ callers (is_comm_*, is_gather_sections, Stixels::ComputeBatchGather) in a FRESH
     child process on a one-rank RCCL communicator: ncclGather of the sizes and counts, the grouped
